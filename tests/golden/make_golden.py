@@ -1,0 +1,337 @@
+#!/usr/bin/env python3
+"""Record golden vectors by running the REFERENCE's own modules on CPU.
+
+Container-only: needs ``/root/reference`` (which never travels to the GPU box).  The reference's
+hot-path modules are imported unmodified from where they lie, under stand-ins for the un-vendored
+mmcv/mmdet symbols (``_ext_stub.py``), fed seeded inputs/parameters (``unibev_amd/synthetic.py``)
+and their outputs are written as small ``.npz`` fixtures next to this script.
+
+    python tests/golden/make_golden.py            # regenerate every fixture
+
+The fixtures hold data only: explicit small inputs, seeds for the large ones (with checksums of
+the regenerated arrays), and the reference's outputs.
+"""
+import importlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF_MODULES = '/root/reference/projects/UniBEV/unibev_plugin/models/modules'
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+import _ext_stub as stub                      # noqa: E402
+import cfgs                                   # noqa: E402
+from unibev_amd import synthetic as syn       # noqa: E402
+
+
+def load_reference():
+    stub.install()
+    pkg = types.ModuleType('refmods')
+    pkg.__path__ = [REF_MODULES]
+    sys.modules['refmods'] = pkg
+    mods = {}
+    for n in ('spatial_cross_attention_img', 'spatial_cross_attention_pts',
+              'encoder_unibev_detr_img', 'encoder_unibev_detr_pts', 'decoder',
+              'transformer_fusion'):
+        mods[n] = importlib.import_module('refmods.' + n)
+    # self-attn slot: the reference's vendored copy of mmcv MultiScaleDeformableAttention
+    stub.ATTENTION.register_module(name='MultiScaleDeformableAttention')(
+        mods['decoder'].CustomMSDeformableAttention)
+    # quirk q10: unregistered name used by unibev_nus_C.py:206
+    stub.ATTENTION.register_module(name='MSDeformableAttention3DUniQueryImg')(
+        mods['spatial_cross_attention_img'].MSDeformableAttention3DImg)
+    return mods
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def checksum(a):
+    a = np.asarray(a, dtype=np.float64)
+    return np.array([a.sum(), np.abs(a).sum(), float(a.size)])
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print(f'{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB')
+
+
+# --------------------------------------------------------------------------- k1 cases
+MSDA_CASES = [
+    # name, B, shapes, H, Dh, P, Nq, loc spread
+    ('c0', 2, [(6, 5)], 8, 32, 4, 37, 0.35),
+    ('c1', 1, [(8, 22)], 8, 32, 8, 50, 0.60),      # many out-of-range samples
+    ('c2', 2, [(7, 9), (4, 5), (2, 3)], 4, 16, 4, 19, 0.40),
+    ('c3', 1, [(3, 4)], 2, 8, 2, 5, 0.50),
+    ('c4', 1, [(1, 1)], 8, 16, 8, 9, 0.70),        # degenerate 1x1 map
+]
+
+
+def gen_msda():
+    out = {}
+    for name, B, shapes, H, Dh, P, Nq, spread in MSDA_CASES:
+        L = len(shapes)
+        S = sum(h * w for h, w in shapes)
+        value = syn.seeded_array(f'msda:{name}:value', (B, S, H, Dh), 1)
+        loc = 0.5 + syn.seeded_array(f'msda:{name}:loc', (B, Nq, H, L, P, 2), 1, spread)
+        logits = syn.seeded_array(f'msda:{name}:w', (B, Nq, H, L * P), 1)
+        w = torch.softmax(t(logits), -1).view(B, Nq, H, L, P).numpy()
+        gout = syn.seeded_array(f'msda:{name}:gout', (B, Nq, H * Dh), 1)
+        v_, l_, w_ = (t(value).double().requires_grad_(), t(loc).double().requires_grad_(),
+                      t(w).double().requires_grad_())
+        o = stub.multi_scale_deformable_attn_pytorch(v_, shapes, l_, w_)
+        o.backward(t(gout).double())
+        o32 = stub.multi_scale_deformable_attn_pytorch(t(value), shapes, t(loc), t(w))
+        out.update({f'{name}_shapes': np.asarray(shapes, np.int64), f'{name}_value': value,
+                    f'{name}_loc': loc.astype(np.float32), f'{name}_w': w.astype(np.float32),
+                    f'{name}_gout': gout, f'{name}_out': o32.numpy(),
+                    f'{name}_out64': o.detach().numpy(),
+                    f'{name}_gvalue': v_.grad.numpy(), f'{name}_gloc': l_.grad.numpy(),
+                    f'{name}_gw': w_.grad.numpy()})
+    save('msda', **out)
+
+
+# --------------------------------------------------------------------------- reference points
+def gen_point_sampling(mods):
+    enc = mods['encoder_unibev_detr_img'].ImgEncoder
+    ptsenc = mods['encoder_unibev_detr_pts'].PtsEncoder
+    out = {}
+    for tag, (H, W, D, bs, nc, hw) in dict(
+            small=(6, 5, 4, 2, 3, (64, 96)), mid=(20, 24, 4, 2, 6, (256, 704))).items():
+        ref3d = enc.get_reference_points(H, W, 8, D, dim='3d', bs=bs, device='cpu',
+                                         dtype=torch.float32)
+        ref2d = enc.get_reference_points(H, W, dim='2d', bs=bs, device='cpu', dtype=torch.float32)
+        metas = syn.img_metas(bs, nc, hw, jitter_seed=3)
+        self_ = types.SimpleNamespace()
+        cam, mask = enc.point_sampling(self_, ref3d, cfgs.PC_RANGE, metas)
+        rpl, m2 = ptsenc.point_sampling(self_, ref3d)
+        out.update({f'{tag}_meta': np.array([H, W, D, bs, nc, hw[0], hw[1]]),
+                    f'{tag}_lidar2img': np.asarray([m['lidar2img'] for m in metas]),
+                    f'{tag}_ref3d': ref3d.numpy(), f'{tag}_ref2d': ref2d.numpy(),
+                    f'{tag}_cam': cam.numpy(), f'{tag}_mask': mask.numpy(),
+                    f'{tag}_rpl': rpl.contiguous().numpy()})
+    # full size: per-camera visibility statistics of the synthetic rig (bs=1, 200x200, 6 cams)
+    ref3d = enc.get_reference_points(200, 200, 8, 4, dim='3d', bs=1, device='cpu',
+                                     dtype=torch.float32)
+    metas = syn.img_metas(1, 6, (256, 704))
+    cam, mask = enc.point_sampling(types.SimpleNamespace(), ref3d, cfgs.PC_RANGE, metas)
+    vis = mask[:, 0].sum(-1) > 0
+    out['full_visible_per_cam'] = vis.sum(-1).numpy()
+    out['full_visible_any'] = np.array([(vis.sum(0) > 0).sum().item(), (vis.sum(0) > 1).sum().item()])
+    out['full_mask_bits'] = np.packbits(mask.numpy().reshape(-1))
+    out['full_cam_checksum'] = checksum(cam.numpy()[mask.numpy()])
+    save('point_sampling', **out)
+
+
+# --------------------------------------------------------------------------- module-level cases
+def seeded_load(module, seed):
+    named = [(k, tuple(v.shape)) for k, v in module.state_dict().items()]
+    sd = syn.seeded_state_dict(named, seed)
+    module.load_state_dict({k: t(v) for k, v in sd.items()})
+    return named
+
+
+def gen_sca(mods):
+    out = {}
+    C, nc, bs, H, W, D = 128, 3, 2, 9, 7, 4
+    fh, fw = 5, 6
+    Nq = H * W
+    enc = mods['encoder_unibev_detr_img'].ImgEncoder
+    ref3d = enc.get_reference_points(H, W, 8, D, dim='3d', bs=bs, device='cpu', dtype=torch.float32)
+    metas = syn.img_metas(bs, nc, (64, 96), jitter_seed=5)
+    cam, mask = enc.point_sampling(types.SimpleNamespace(), ref3d, cfgs.PC_RANGE, metas)
+    sca = stub.build_attention(dict(
+        type='SpatialCrossAttentionImg', pc_range=cfgs.PC_RANGE, num_cams=nc, embed_dims=C,
+        batch_first=True,
+        deformable_attention=dict(type='MSDeformableAttention3DImg', embed_dims=C, num_points=8,
+                                  num_levels=1))).eval()
+    seeded_load(sca, 11)
+    query = syn.seeded_array('sca_img:query', (bs, Nq, C), 11)
+    value = syn.seeded_array('sca_img:value', (nc, fh * fw, bs, C), 11)
+    ss = torch.tensor([[fh, fw]])
+    with torch.no_grad():
+        o = sca(t(query), t(value), t(value), reference_points_cam=cam, bev_mask=mask,
+                spatial_shapes=ss, level_start_index=torch.tensor([0]))
+    out.update(img_meta=np.array([C, nc, bs, H, W, D, fh, fw, 64, 96]),
+               img_lidar2img=np.asarray([m['lidar2img'] for m in metas]),
+               img_cam=cam.numpy(), img_mask=mask.numpy(), img_out=o.numpy(),
+               img_query_ck=checksum(query), img_value_ck=checksum(value))
+    # pts
+    fh, fw = 8, 6
+    ptsenc = mods['encoder_unibev_detr_pts'].PtsEncoder
+    rpl, _ = ptsenc.point_sampling(types.SimpleNamespace(), ref3d)
+    scap = stub.build_attention(dict(
+        type='SpatialCrossAttentionPts', pc_range=cfgs.PC_RANGE, embed_dims=C, batch_first=True,
+        deformable_attention=dict(type='MSDeformableAttention3DPts', embed_dims=C, num_points=8,
+                                  num_levels=1))).eval()
+    seeded_load(scap, 12)
+    query = syn.seeded_array('sca_pts:query', (bs, Nq, C), 12)
+    value = syn.seeded_array('sca_pts:value', (fh * fw, bs, C), 12)
+    with torch.no_grad():
+        o = scap(t(query), t(value), t(value), reference_points_lidar=rpl,
+                 spatial_shapes=torch.tensor([[fh, fw]]), level_start_index=torch.tensor([0]))
+    out.update(pts_meta=np.array([C, bs, H, W, D, fh, fw]), pts_out=o.numpy(),
+               pts_query_ck=checksum(query), pts_value_ck=checksum(value))
+    save('sca', **out)
+
+
+# --------------------------------------------------------------------------- whole encoder+fusion
+ENCODER_CASES = {
+    # name: (cfg kwargs, bev_h, bev_w, bs, img feat hw, pts feat hw, img_hw, seed)
+    'cnw': (dict(embed_dims=128, num_layers=2, num_cams=2), 10, 12, 2, (4, 6), (9, 11), (64, 96), 21),
+    'avg': (dict(embed_dims=128, num_layers=1, num_cams=2, fusion_method='avg',
+                 feature_norm=None), 10, 12, 2, (4, 6), (9, 11), (64, 96), 22),
+    'cat': (dict(embed_dims=128, num_layers=1, num_cams=2, fusion_method='cat',
+                 feature_norm=None), 10, 12, 2, (4, 6), (9, 11), (64, 96), 23),
+    'cnw256': (dict(embed_dims=256, num_layers=1, num_cams=3), 8, 9, 1, (3, 5), (7, 8), (64, 96), 24),
+    'C': (dict(embed_dims=128, num_layers=1, num_cams=2, feature_norm=None, drop_modality=None,
+               modalities='C', img_da_type='MSDeformableAttention3DUniQueryImg'),
+          10, 12, 2, (4, 6), None, (64, 96), 25),
+    'L': (dict(embed_dims=128, num_layers=1, feature_norm=None, drop_modality=None,
+               modalities='L'), 10, 12, 2, None, (9, 11), (64, 96), 26),
+    'spatial': (dict(embed_dims=128, num_layers=1, num_cams=2, spatial_norm='SpatialNormWeights',
+                     bev_h=10, bev_w=12), 10, 12, 2, (4, 6), (9, 11), (64, 96), 27),
+}
+
+
+def encoder_inputs(name, kw, bev_h, bev_w, bs, img_hw_f, pts_hw_f, img_hw, seed):
+    C = kw['embed_dims']
+    s = 2 if kw.get('fusion_method') == 'cat' else 1
+    nc = kw.get('num_cams', 6)
+    img = None if img_hw_f is None else [syn.seeded_array(f'enc:{name}:img', (bs, nc, C) + img_hw_f, seed)]
+    pts = None if pts_hw_f is None else [syn.seeded_array(f'enc:{name}:pts', (bs, C) + pts_hw_f, seed)]
+    bev_q = syn.seeded_array(f'enc:{name}:bev_q', (bev_h * bev_w, C), seed)
+    bev_pos = syn.seeded_array(f'enc:{name}:bev_pos', (bs, C, bev_h, bev_w), seed)
+    oq = syn.seeded_array(f'enc:{name}:oq', (7, 2 * C * s), seed)
+    metas = syn.img_metas(bs, nc, img_hw, jitter_seed=seed)
+    return img, pts, bev_q, bev_pos, oq, metas
+
+
+def run_reference_transformer(mods, name, case):
+    kw, bev_h, bev_w, bs, img_hw_f, pts_hw_f, img_hw, seed = case
+    cfg = cfgs.transformer_cfg(**kw)
+    T = mods['transformer_fusion'].UniBEVTransformer
+    args = dict(cfg)
+    args.pop('type')
+    model = T(**args)
+    model.init_weights()
+    named = seeded_load(model, seed)
+    model.eval()
+    img, pts, bev_q, bev_pos, oq, metas = encoder_inputs(name, *case)
+    parts = {}
+    if hasattr(model, 'img_bev_encoder'):
+        model.img_bev_encoder.register_forward_hook(lambda m, i, o: parts.__setitem__('img', o))
+    if hasattr(model, 'pts_bev_encoder'):
+        model.pts_bev_encoder.register_forward_hook(lambda m, i, o: parts.__setitem__('pts', o))
+    with torch.no_grad():
+        fused, _, _, _ = model(
+            None if img is None else [t(x) for x in img],
+            None if pts is None else [t(x) for x in pts],
+            t(bev_q), t(oq), bev_h, bev_w, bev_pos=t(bev_pos), img_metas=metas)
+    return cfg, named, fused, parts, (img, pts, bev_q, bev_pos, metas)
+
+
+def gen_encoders(mods):
+    for name, case in ENCODER_CASES.items():
+        cfg, named, fused, parts, (img, pts, bev_q, bev_pos, metas) = \
+            run_reference_transformer(mods, name, case)
+        arrays = dict(cfg_json=np.array(json.dumps(cfg)),
+                      param_names=np.array([n for n, _ in named]),
+                      param_shapes=np.array([json.dumps(list(s)) for _, s in named]),
+                      lidar2img=np.asarray([m['lidar2img'] for m in metas]),
+                      fused=fused.numpy(), bev_q_ck=checksum(bev_q), bev_pos_ck=checksum(bev_pos))
+        if img is not None:
+            arrays['img_ck'] = checksum(img[0])
+            arrays['img_bev'] = parts['img'].numpy()
+        if pts is not None:
+            arrays['pts_ck'] = checksum(pts[0])
+            arrays['pts_bev'] = parts['pts'].numpy()
+        save('encoder_' + name, **arrays)
+
+
+def gen_fullsize(mods):
+    """cfg4 shapes at bs=1 (6 x 8x22 image feats, 180x180 LiDAR feats, 200x200 BEV, C=256, 3 layers):
+    statistics + a strided subsample of the reference's output."""
+    case = (dict(embed_dims=256, num_layers=3), 200, 200, 1, (8, 22), (180, 180), (256, 704), 31)
+    cfg, named, fused, parts, (img, pts, bev_q, bev_pos, metas) = \
+        run_reference_transformer(mods, 'full', case)
+    f = fused.numpy().reshape(-1)
+    idx = np.arange(0, f.size, 2503)
+    save('encoder_fullsize', cfg_json=np.array(json.dumps(cfg)),
+         param_names=np.array([n for n, _ in named]),
+         param_shapes=np.array([json.dumps(list(s)) for _, s in named]),
+         fused_idx=idx, fused_sub=f[idx], fused_ck=checksum(f),
+         fused_std=np.array([f.std()]),
+         img_bev_ck=checksum(parts['img'].numpy()), pts_bev_ck=checksum(parts['pts'].numpy()),
+         img_ck=checksum(img[0]), pts_ck=checksum(pts[0]))
+
+
+def gen_modality_dropout(mods):
+    """Train-mode modality-dropout flags (transformer_fusion.py:463-477, np.random driven)."""
+    T = mods['transformer_fusion'].UniBEVTransformer
+    out = {}
+    for tag, dm in dict(float=0.5, dict=dict(dropout_prob=0.6, lidar_prob=0.3)).items():
+        cfg = cfgs.transformer_cfg(embed_dims=128, num_layers=1, num_cams=2, drop_modality=dm)
+        args = dict(cfg)
+        args.pop('type')
+        model = T(**args)
+        model.init_weights()
+        model.train()
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        case = ENCODER_CASES['cnw']
+        img, pts, bev_q, bev_pos, oq, metas = encoder_inputs('cnw', *case)
+        np.random.seed(1234)
+        flags = []
+        with torch.no_grad():
+            for _ in range(12):
+                model([t(x) for x in img], [t(x) for x in pts], t(bev_q), t(oq), 10, 12,
+                      bev_pos=t(bev_pos), img_metas=metas)
+                flags.append((int(model.c_flag), int(model.l_flag)))
+        out[tag + '_flags'] = np.asarray(flags)
+    save('modality_dropout', **out)
+
+
+def gen_init(mods):
+    """init_weights() facts that do not depend on torch's RNG: the sampling_offsets bias grid."""
+    T = mods['transformer_fusion'].UniBEVTransformer
+    cfg = cfgs.transformer_cfg(embed_dims=128, num_layers=1, num_cams=2)
+    args = dict(cfg)
+    args.pop('type')
+    model = T(**args)
+    model.init_weights()
+    sd = model.state_dict()
+    pre = 'img_bev_encoder.layers.0.attentions.'
+    save('init', self_bias=sd[pre + '0.sampling_offsets.bias'].numpy(),
+         cross_bias=sd[pre + '1.deformable_attention.sampling_offsets.bias'].numpy(),
+         self_w_abs=np.array([sd[pre + '0.sampling_offsets.weight'].abs().sum().item(),
+                              sd[pre + '0.attention_weights.weight'].abs().sum().item(),
+                              sd[pre + '0.attention_weights.bias'].abs().sum().item()]))
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    mods = load_reference()
+    gen_msda()
+    gen_point_sampling(mods)
+    gen_sca(mods)
+    gen_encoders(mods)
+    gen_modality_dropout(mods)
+    gen_init(mods)
+    gen_fullsize(mods)
+
+
+if __name__ == '__main__':
+    main()
