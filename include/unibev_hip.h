@@ -1,0 +1,219 @@
+/*
+ * unibev_hip.h — C ABI of libunibev_hip.so: the MI355X (gfx950) kernels behind UniBEV's BEV-encoder
+ * hot path.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer unless the parameter name ends in `_host`.
+ *   - Tensors are dense, row-major, in the shapes written next to each parameter.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are asynchronous
+ *     and never synchronise the device.
+ *   - The caller owns every buffer.  "accumulated" outputs must be zeroed by the caller.
+ *   - Return value: 0 on success, a negative ubv_status otherwise; ubv_last_error() returns a
+ *     thread-local message for the last failure.  No call aborts the process.
+ *   - dtype codes (ubv_dtype) describe the element type of `value`-like tensors; sampling
+ *     locations, attention weights, reference points and all gradients w.r.t. them are float32.
+ *
+ * Each entry point names the reference interface it replaces.  Reference paths are relative to
+ * /root/reference/projects/UniBEV/unibev_plugin/ ("[ext]" = the un-vendored mmcv-full 1.3.17 /
+ * mmdet3d 0.18.1 symbol reached from that call site).
+ */
+#ifndef UNIBEV_HIP_H_
+#define UNIBEV_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { UBV_F32 = 0, UBV_F16 = 1, UBV_BF16 = 2 } ubv_dtype;
+
+typedef enum {
+  UBV_OK = 0,
+  UBV_ERR_INVALID = -1,      /* bad argument / unsupported shape */
+  UBV_ERR_LAUNCH = -2,       /* HIP runtime error at launch */
+  UBV_ERR_UNSUPPORTED = -3   /* valid request this build has no kernel for */
+} ubv_status;
+
+int ubv_version(void);
+const char* ubv_last_error(void);
+/* Name of the gfx target the kernels were compiled for ("gfx950"). */
+const char* ubv_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * k1 — multi-scale deformable attention sampling.
+ * Replaces [ext] mmcv `_ext.ms_deform_attn_forward` / `ms_deform_attn_backward`, loaded at
+ * models/modules/spatial_cross_attention_img.py:19-20, spatial_cross_attention_pts.py:19-20,
+ * decoder.py:29-30 and called through MultiScaleDeformableAttnFunction.apply at
+ * spatial_cross_attention_img.py:433-435, spatial_cross_attention_pts.py:440-442, decoder.py:325-327.
+ *
+ *   value            [B, S, H, Dh]        dtype
+ *   spatial_shapes   [L, 2] int64 (h, w)  (device, as in mmcv)
+ *   level_start      [L]    int64         (device)
+ *   sampling_loc     [B, Nq, H, L, P, 2]  f32, (x, y) normalised to [0, 1]
+ *   attn_weight      [B, Nq, H, L, P]     f32
+ *   out              [B, Nq, H*Dh]        dtype
+ * out[b,q,h*Dh+c] = sum_{l,p} w * bilinear(value_l[b,:,h,c], x = loc_x*W_l - 0.5, y = loc_y*H_l - 0.5),
+ * zero padding per corner (== F.grid_sample(bilinear, zeros, align_corners=False) on 2*loc-1).
+ * `im2col_step` of the mmcv signature is accepted and ignored (no batch chunking is needed).
+ */
+int ubv_ms_deform_attn_forward(const void* value, const int64_t* spatial_shapes,
+                               const int64_t* level_start, const float* sampling_loc,
+                               const float* attn_weight, void* out, int B, int S, int H, int Dh,
+                               int L, int Nq, int P, int dtype, int im2col_step, void* stream);
+
+/*   grad_out          [B, Nq, H*Dh]       dtype
+ *   grad_value        [B, S, H, Dh]       f32, ACCUMULATED (caller zeroes; cast to dtype by caller)
+ *   grad_sampling_loc [B, Nq, H, L, P, 2] f32, written
+ *   grad_attn_weight  [B, Nq, H, L, P]    f32, written
+ */
+int ubv_ms_deform_attn_backward(const void* value, const int64_t* spatial_shapes,
+                                const int64_t* level_start, const float* sampling_loc,
+                                const float* attn_weight, const void* grad_out, float* grad_value,
+                                float* grad_sampling_loc, float* grad_attn_weight, int B, int S,
+                                int H, int Dh, int L, int Nq, int P, int dtype, int im2col_step,
+                                void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused BEV query lifting (one level): offsets -> locations, logits -> softmax, sampling,
+ * per-camera accumulation and the camera mean, in one kernel; nothing but the GEMM outputs is
+ * materialised.  Replaces the tensor arithmetic of
+ *   MSDeformableAttention3DImg.forward   models/modules/spatial_cross_attention_img.py:385-435
+ *   MSDeformableAttention3DPts.forward   models/modules/spatial_cross_attention_pts.py:383-442
+ *   [ext] MultiScaleDeformableAttention (self-attn slot; vendored copy decoder.py:299-327)
+ * and, for num_cams > 1, the re-batch / scatter-add / count-divide of
+ *   SpatialCrossAttentionImg.forward     models/modules/spatial_cross_attention_img.py:141-212.
+ *
+ *   value     [B*Nc, S = fh*fw, H, Dh]  dtype   (batch-major, camera-minor)
+ *   offsets   row (b,q) at offsets + (b*Nq+q)*off_stride : [H, P, 2] f32 raw Linear output
+ *   logits    row (b,q) at logits  + (b*Nq+q)*log_stride : [H, P]    f32 raw Linear output
+ *   ref       [Nc, B, Nq, Z, 2] f32 reference points; flat point p uses anchor p % Z
+ *             (quirk q3, spatial_cross_attention_img.py:407-419)
+ *   vis0      [Nc, Nq] uint8 or NULL: camera i contributes to query q iff vis0[i,q] != 0
+ *             (visibility of BATCH ELEMENT 0, quirk q1, :141-152)
+ *   count     [B, Nq] f32 or NULL: the result is divided by count[b,q] (quirk q2, :209-212)
+ *   out       [B, Nq, H*Dh] dtype
+ *   loc = ref + offsets / (fw, fh);  w = softmax_P(logits)
+ * qgrid_w/qgrid_h: if Nq == qgrid_w*qgrid_h the queries are walked in 8x8 tiles of that grid
+ * (L2 locality); pass 0 for raster order.
+ * Supported: P in {4, 8}; H*Dh*sizeof(16 B vector)/... see ubv_fused_supported().
+ */
+int ubv_bev_lift_forward(const void* value, const float* offsets, int64_t off_stride,
+                         const float* logits, int64_t log_stride, const float* ref,
+                         const uint8_t* vis0, const float* count, void* out, int B, int Nc, int fh,
+                         int fw, int H, int Dh, int Nq, int P, int Z, int qgrid_w, int qgrid_h,
+                         int dtype, void* stream);
+
+/*   grad_out     [B, Nq, H*Dh]       dtype
+ *   grad_value   [B*Nc, S, H, Dh]    f32, ACCUMULATED
+ *   grad_offsets row (b,q) at grad_offsets + (b*Nq+q)*goff_stride : [H, P, 2] f32, written
+ *   grad_logits  row (b,q) at grad_logits  + (b*Nq+q)*glog_stride : [H, P]    f32, written
+ */
+int ubv_bev_lift_backward(const void* value, const float* offsets, int64_t off_stride,
+                          const float* logits, int64_t log_stride, const float* ref,
+                          const uint8_t* vis0, const float* count, const void* grad_out,
+                          float* grad_value, float* grad_offsets, int64_t goff_stride,
+                          float* grad_logits, int64_t glog_stride, int B, int Nc, int fh, int fw,
+                          int H, int Dh, int Nq, int P, int Z, int qgrid_w, int qgrid_h, int dtype,
+                          void* stream);
+
+/* 1 if ubv_bev_lift_* has a kernel for this shape, else 0 (callers then compose k1). */
+int ubv_bev_lift_supported(int H, int Dh, int P, int dtype);
+
+/* ------------------------------------------------------------------------------------------------
+ * Camera projection of the pillar reference points + visibility.
+ * Replaces ImgEncoder.point_sampling, models/modules/encoder_unibev_detr_img.py:112-187, and the
+ * `count` / per-camera index bookkeeping of spatial_cross_attention_img.py:141-153, 209-211.
+ *
+ *   lidar2img [B, Nc, 4, 4] f32
+ *   xs [bev_w], ys [bev_h], zs [D] f32: normalised pillar coordinates exactly as
+ *             get_reference_points builds them (encoder_unibev_detr_img.py:68-73)
+ *   pc_range_host[6], img_h/img_w: img_metas[0]['img_shape'][0] (quirk q5, :166-167)
+ *   ref_cam  [Nc, B, Nq, D, 2] f32 out      bev_mask [Nc, B, Nq, D] uint8 out
+ *   vis0     [Nc, Nq] uint8 out (any_D bev_mask[:, 0])    count [B, Nq] f32 out
+ *            count = clamp(sum_cams any_D(bev_mask), min=1)
+ */
+int ubv_point_sampling(const float* lidar2img, const float* xs, const float* ys, const float* zs,
+                       const float* pc_range_host, float img_h, float img_w, float* ref_cam,
+                       uint8_t* bev_mask, uint8_t* vis0, float* count, int B, int Nc, int bev_h,
+                       int bev_w, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Feature flattening + embedding add.
+ * Replaces UniBEVTransformer._pre_process_img_feats / _pre_process_pts_feats,
+ * models/modules/transformer_fusion.py:230-278.
+ *   in   [N, C, HW] dtype (N = bs*num_cams for images, bs for LiDAR BEV features)
+ *   embA [groups, C] f32 or NULL, row (n % groups)   (cams_embeds, groups = num_cams)
+ *   embB [C] f32 or NULL                              (level embedding of this level)
+ *   out  [N, HW, C] dtype = in^T + embA + embB
+ */
+int ubv_flatten_embed_forward(const void* in, const float* embA, int groups, const float* embB,
+                              void* out, int N, int C, int HW, int dtype, void* stream);
+/*   grad_out [N, HW, C] dtype -> grad_in [N, C, HW] dtype (written);
+ *   grad_emb [N, C] f32 ACCUMULATED (caller zeroes): per-n column sums of grad_out; the caller
+ *   reduces over n for the parameter gradients. */
+int ubv_flatten_embed_backward(const void* grad_out, void* grad_in, float* grad_emb, int N, int C,
+                               int HW, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BEV fusion epilogue.  Replaces channel_feature_norm / spatial_feature_norm /
+ * multi_modal_fusion and the final permute, models/modules/transformer_fusion.py:280-413, 549.
+ *   img, pts [B, Nq, C] dtype (either may be NULL = missing modality, treated as zeros)
+ *   cw_img, cw_pts [C] f32 per-channel factors (CNW softmax x modality flag; host-composed)
+ *   sw_img, sw_pts [Nq] f32 per-query factors or NULL (SpatialNormWeights)
+ *   cat == 0: out [Nq, B, C]   = cw_img*sw_img*img + cw_pts*sw_pts*pts
+ *   cat == 1: out [Nq, B, 2C]  = [cw_img*sw_img*img , cw_pts*sw_pts*pts]
+ */
+int ubv_bev_fuse_forward(const void* img, const void* pts, const float* cw_img,
+                         const float* cw_pts, const float* sw_img, const float* sw_pts, void* out,
+                         int B, int Nq, int C, int cat, int dtype, void* stream);
+/*   grad_out as `out`; grad_img/grad_pts [B,Nq,C] dtype (NULL to skip);
+ *   grad_cw [2, C] f32 and grad_sw [2, Nq] f32 ACCUMULATED (NULL to skip). */
+int ubv_bev_fuse_backward(const void* grad_out, const void* img, const void* pts,
+                          const float* cw_img, const float* cw_pts, const float* sw_img,
+                          const float* sw_pts, void* grad_img, void* grad_pts, float* grad_cw,
+                          float* grad_sw, int B, int Nq, int C, int cat, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LiDAR front end.
+ * Replaces [ext] mmdet3d ops built from `pts_voxel_layer` and called at
+ * models/detectors/unibev_detector.py:163-167 (Voxelization -> hard_voxelize, deterministic),
+ * :117 (HardSimpleVFE), and the SparseConvTensor.dense() scatter at the tail of SparseEncoder
+ * (configs/unibev/unibev_nus_LC_cnw_256_modality_dropout.py:194-208).
+ */
+
+/* Bytes of scratch ubv_hard_voxelize needs. */
+int64_t ubv_hard_voxelize_workspace(int N, int max_points, int max_voxels);
+
+/* points [N, F] f32 (x, y, z first).  Voxel coordinate per axis c = floor((p - min) / size) in
+ * f32, point dropped unless 0 <= c < grid; voxels are numbered by first appearance in input order;
+ * at most max_points points per voxel (input order), at most max_voxels voxels.
+ *   voxels      [max_voxels, max_points, F] f32 out, zero padded
+ *   coors       [max_voxels, 3] int32 out, (z, y, x)
+ *   num_points  [max_voxels] int32 out
+ *   voxel_num   [1] int32 out (device): number of voxels produced
+ *   voxel_size_host[3], range_host[6]: host arrays; grid = round((max-min)/size)
+ */
+int ubv_hard_voxelize(const float* points, float* voxels, int32_t* coors, int32_t* num_points,
+                      int32_t* voxel_num, void* workspace, int64_t workspace_bytes, int N, int F,
+                      const float* voxel_size_host, const float* range_host, int max_points,
+                      int max_voxels, void* stream);
+
+/* [ext] mmdet3d dynamic_voxelize: coors [N, 3] int32 (z, y, x), or (-1,-1,-1) when outside. */
+int ubv_dynamic_voxelize(const float* points, int32_t* coors, int N, int F,
+                         const float* voxel_size_host, const float* range_host, void* stream);
+
+/* [ext] HardSimpleVFE: mean [M, F] = voxels[:, :, :F].sum(1) / num_points.  M is read from the
+ * device counter `voxel_num` (rows >= *voxel_num are left untouched); max_voxels bounds the launch. */
+int ubv_voxel_mean(const float* voxels, const int32_t* num_points, const int32_t* voxel_num,
+                   float* mean, int max_voxels, int max_points, int F, void* stream);
+
+/* SparseConvTensor.dense(): dense [B, C, D, Hs, Ws] f32 (caller zeroes) <- feats [M, C] at
+ * coors [M, 4] int32 (batch, z, y, x).  M read from device counter m_dev if non-NULL else m. */
+int ubv_sparse_to_dense(const float* feats, const int32_t* coors, const int32_t* m_dev, int m,
+                        float* dense, int B, int C, int D, int Hs, int Ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNIBEV_HIP_H_ */

@@ -1,0 +1,101 @@
+"""ORACLE — test infrastructure only.  ctypes wrapper of ``oracle/_build/liboracle.so`` (plain-C
+restatements in ``msda_ref.c`` and ``voxelize_ref.c``; build with ``make -C oracle``)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, '_build', 'liboracle.so')
+_lib = None
+
+
+def build():
+    subprocess.check_call(['make', '-s', '-C', _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.oracle_hard_voxelize.restype = ctypes.c_int
+    return _lib
+
+
+def _f(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels):
+    pts = np.ascontiguousarray(points, np.float32)
+    N, F = pts.shape
+    vs = np.asarray(voxel_size, np.float32)
+    rg = np.asarray(coors_range, np.float32)
+    voxels = np.zeros((max_voxels, max_points, F), np.float32)
+    coors = np.zeros((max_voxels, 3), np.int32)
+    num = np.zeros((max_voxels,), np.int32)
+    m = lib().oracle_hard_voxelize(_f(pts), N, F, _f(vs), _f(rg), max_points, max_voxels,
+                                   _f(voxels), _f(coors), _f(num))
+    return voxels[:m], coors[:m], num[:m]
+
+
+def dynamic_voxelize(points, voxel_size, coors_range):
+    pts = np.ascontiguousarray(points, np.float32)
+    N, F = pts.shape
+    coors = np.zeros((N, 3), np.int32)
+    lib().oracle_dynamic_voxelize(_f(pts), N, F, _f(np.asarray(voxel_size, np.float32)),
+                                  _f(np.asarray(coors_range, np.float32)), _f(coors))
+    return coors
+
+
+def voxel_mean(voxels, num_points):
+    v = np.ascontiguousarray(voxels, np.float32)
+    n = np.ascontiguousarray(num_points, np.int32)
+    M, T, F = v.shape
+    mean = np.zeros((M, F), np.float32)
+    lib().oracle_voxel_mean(_f(v), _f(n), M, T, F, _f(mean))
+    return mean
+
+
+def sparse_to_dense(feats, coors, B, D, H, W):
+    f = np.ascontiguousarray(feats, np.float32)
+    c = np.ascontiguousarray(coors, np.int32)
+    M, C = f.shape
+    dense = np.zeros((B, C, D, H, W), np.float32)
+    lib().oracle_sparse_to_dense(_f(f), _f(c), M, B, C, D, H, W, _f(dense))
+    return dense
+
+
+def msda_forward(value, spatial_shapes, loc, aw):
+    v = np.ascontiguousarray(value, np.float32)
+    B, S, H, Dh = v.shape
+    ss = np.ascontiguousarray(spatial_shapes, np.int64).reshape(-1, 2)
+    L = ss.shape[0]
+    ls = np.concatenate(([0], np.cumsum(ss[:, 0] * ss[:, 1])[:-1])).astype(np.int64)
+    lo = np.ascontiguousarray(loc, np.float32)
+    w = np.ascontiguousarray(aw, np.float32)
+    Nq, P = lo.shape[1], lo.shape[4]
+    out = np.zeros((B, Nq, H * Dh), np.float32)
+    lib().oracle_msda_forward(_f(v), _f(ss), _f(ls), _f(lo), _f(w), _f(out), B, S, H, Dh, L, Nq, P)
+    return out
+
+
+def msda_backward(value, spatial_shapes, loc, aw, gout):
+    v = np.ascontiguousarray(value, np.float32)
+    B, S, H, Dh = v.shape
+    ss = np.ascontiguousarray(spatial_shapes, np.int64).reshape(-1, 2)
+    L = ss.shape[0]
+    ls = np.concatenate(([0], np.cumsum(ss[:, 0] * ss[:, 1])[:-1])).astype(np.int64)
+    lo = np.ascontiguousarray(loc, np.float32)
+    w = np.ascontiguousarray(aw, np.float32)
+    g = np.ascontiguousarray(gout, np.float32)
+    Nq, P = lo.shape[1], lo.shape[4]
+    gv = np.zeros(v.shape, np.float64)
+    gl = np.zeros(lo.shape, np.float32)
+    gw = np.zeros(w.shape, np.float32)
+    lib().oracle_msda_backward(_f(v), _f(ss), _f(ls), _f(lo), _f(w), _f(g), _f(gv), _f(gl), _f(gw),
+                               B, S, H, Dh, L, Nq, P)
+    return gv, gl, gw

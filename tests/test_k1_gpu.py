@@ -1,0 +1,148 @@
+"""k1 (ms_deform_attn) on the GPU through the C ABI vs the oracle / reference-recorded vectors."""
+import numpy as np
+import pytest
+import torch
+
+from _util import golden, t
+import make_golden as mg
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def _levels(shapes, dev):
+    ss = torch.as_tensor(np.asarray(shapes).reshape(-1, 2), dtype=torch.long, device=dev)
+    ls = torch.cat((ss.new_zeros(1), (ss[:, 0] * ss[:, 1]).cumsum(0)[:-1]))
+    return ss, ls
+
+
+@pytest.mark.parametrize('case', [c[0] for c in mg.MSDA_CASES])
+def test_k1_fp32_matches_reference_vectors(case):
+    """fp32 kernel vs the vectors recorded from the reference's CPU definition; tolerance 2e-5
+    abs/rel on forward, 1e-4 on gradients (fp32 accumulation order differs)."""
+    from unibev_amd.functional import ms_deform_attn
+    g = golden('msda')
+    v = t(g[f'{case}_value'], device=DEV).requires_grad_()
+    l = t(g[f'{case}_loc'], device=DEV).requires_grad_()
+    w = t(g[f'{case}_w'], device=DEV).requires_grad_()
+    ss, ls = _levels(g[f'{case}_shapes'], DEV)
+    out = ms_deform_attn(v, ss, ls, l, w, 64)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[f'{case}_out64'], rtol=2e-5, atol=2e-5)
+    out.backward(t(g[f'{case}_gout'], device=DEV))
+    np.testing.assert_allclose(v.grad.cpu().numpy(), g[f'{case}_gvalue'], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(l.grad.cpu().numpy(), g[f'{case}_gloc'], rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(w.grad.cpu().numpy(), g[f'{case}_gw'], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize('case', ['c0', 'c1', 'c2'])
+def test_k1_half_precision_within_tolerance(case, dtype, tol):
+    """north_star bar: within 1e-3 rel (fp16) of the fp32 reference, measured as max |err| / max |ref|;
+    bf16 (8 mantissa bits) is held to 8e-3."""
+    from unibev_amd.functional import ms_deform_attn
+    g = golden('msda')
+    v = t(g[f'{case}_value'], device=DEV).to(dtype)
+    ss, ls = _levels(g[f'{case}_shapes'], DEV)
+    out = ms_deform_attn(v, ss, ls, t(g[f'{case}_loc'], device=DEV), t(g[f'{case}_w'], device=DEV))
+    assert out.dtype == dtype
+    ref = g[f'{case}_out64']
+    err = np.abs(out.float().cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err < tol, err
+
+
+@pytest.mark.parametrize('B,shapes,H,Dh,P,Nq', [
+    (2, [(13, 17)], 8, 32, 4, 301),
+    (1, [(20, 20)], 8, 16, 8, 400),
+    (3, [(5, 7), (3, 4)], 8, 32, 4, 33),
+    (1, [(6, 6)], 4, 32, 3, 10),        # H*LP = 32: two queries per wave, odd P
+    (2, [(4, 5)], 3, 12, 2, 7),         # no lane tiling possible: fallback kernel
+    (1, [(9, 9)], 8, 64, 4, 11),
+])
+def test_k1_random_shapes_vs_c_oracle(B, shapes, H, Dh, P, Nq):
+    from oracle import c_ref
+    from unibev_amd.functional import ms_deform_attn
+    rs = np.random.RandomState(B * 1000 + Nq)
+    L = len(shapes)
+    S = sum(h * w for h, w in shapes)
+    value = rs.standard_normal((B, S, H, Dh)).astype(np.float32)
+    loc = (0.5 + 0.45 * rs.standard_normal((B, Nq, H, L, P, 2))).astype(np.float32)
+    aw = rs.random_sample((B, Nq, H, L, P)).astype(np.float32)
+    gout = rs.standard_normal((B, Nq, H * Dh)).astype(np.float32)
+    ref = c_ref.msda_forward(value, shapes, loc, aw)
+    gv, gl, gw = c_ref.msda_backward(value, shapes, loc, aw, gout)
+    v = t(value, device=DEV).requires_grad_()
+    l = t(loc, device=DEV).requires_grad_()
+    w = t(aw, device=DEV).requires_grad_()
+    ss, ls = _levels(shapes, DEV)
+    out = ms_deform_attn(v, ss, ls, l, w)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+    out.backward(t(gout, device=DEV))
+    np.testing.assert_allclose(v.grad.cpu().numpy(), gv, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(l.grad.cpu().numpy(), gl, rtol=1e-4, atol=5e-4)
+    np.testing.assert_allclose(w.grad.cpu().numpy(), gw, rtol=1e-4, atol=1e-4)
+
+
+def test_k1_edge_locations():
+    """Exactly-on-boundary, far outside, NaN and huge locations contribute what the definition
+    says (zero outside; NaN locations are 'outside')."""
+    from oracle import c_ref
+    from unibev_amd.functional import ms_deform_attn
+    shapes = [(4, 6)]
+    value = np.arange(24 * 8 * 16, dtype=np.float32).reshape(1, 24, 8, 16) / 100.0
+    pts = np.array([[0.0, 0.0], [1.0, 1.0], [-1.0 / 12, 0.5], [1.0 + 1.0 / 12, 0.5], [0.5, -0.126],
+                    [5.0, 5.0], [-7.0, 0.3], [1e30, 0.5], [0.5 / 6, 0.5 / 4], [0.999999, 0.000001]],
+                   np.float32)
+    Nq = len(pts)
+    loc = np.broadcast_to(pts[None, :, None, None, None, :], (1, Nq, 8, 1, 1, 2)).copy()
+    aw = np.ones((1, Nq, 8, 1, 1), np.float32)
+    ref = c_ref.msda_forward(value, shapes, loc, aw)
+    ss, ls = _levels(shapes, DEV)
+    out = ms_deform_attn(t(value, device=DEV), ss, ls, t(loc, device=DEV), t(aw, device=DEV))
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    loc[0, 0] = np.nan
+    out = ms_deform_attn(t(value, device=DEV), ss, ls, t(loc, device=DEV), t(aw, device=DEV))
+    assert torch.all(out[0, 0] == 0) and torch.isfinite(out).all()
+
+
+def test_k1_empty_query_set_and_bad_args():
+    from unibev_amd.functional import ms_deform_attn
+    ss, ls = _levels([(4, 4)], DEV)
+    v = torch.randn(1, 16, 8, 32, device=DEV)
+    out = ms_deform_attn(v, ss, ls, torch.zeros(1, 0, 8, 1, 4, 2, device=DEV),
+                         torch.zeros(1, 0, 8, 1, 4, device=DEV))
+    assert out.shape == (1, 0, 256)
+    with pytest.raises(ValueError):
+        ms_deform_attn(v, ss, ls, torch.zeros(1, 3, 4, 1, 4, 2, device=DEV),
+                       torch.zeros(1, 3, 8, 1, 4, device=DEV))
+    with pytest.raises(RuntimeError):
+        ms_deform_attn(v.cpu(), ss, ls, torch.zeros(1, 3, 8, 1, 4, 2), torch.zeros(1, 3, 8, 1, 4))
+
+
+def test_k1_full_size_properties():
+    """BASELINE sizes (self-attn instance: S = Nq = 40 000, H = 8, Dh = 32, P = 4): properties
+    that hold at any size — linearity in value, weights summing to one reproduce a constant map,
+    agreement with the C oracle on a strided sample of queries."""
+    from oracle import c_ref
+    from unibev_amd.functional import ms_deform_attn
+    torch.manual_seed(0)
+    B, Hq, Wq, H, Dh, P = 1, 200, 200, 8, 32, 4
+    S = Nq = Hq * Wq
+    ss, ls = _levels([(Hq, Wq)], DEV)
+    ys, xs = torch.meshgrid(torch.arange(Hq, device=DEV), torch.arange(Wq, device=DEV), indexing='ij')
+    ref = torch.stack(((xs + 0.5) / Wq, (ys + 0.5) / Hq), -1).view(1, Nq, 1, 1, 1, 2)
+    loc = (ref + 0.02 * torch.randn(B, Nq, H, 1, P, 2, device=DEV)).contiguous()
+    aw = torch.softmax(torch.randn(B, Nq, H, 1, P, device=DEV), -1)
+    v1 = torch.randn(B, S, H, Dh, device=DEV)
+    v2 = torch.randn(B, S, H, Dh, device=DEV)
+    o1 = ms_deform_attn(v1, ss, ls, loc, aw)
+    o2 = ms_deform_attn(v2, ss, ls, loc, aw)
+    o12 = ms_deform_attn(2.0 * v1 - 3.0 * v2, ss, ls, loc, aw)
+    torch.testing.assert_close(o12, 2.0 * o1 - 3.0 * o2, rtol=1e-4, atol=1e-4)
+    inner = loc.clamp(0.01, 0.99)
+    const = ms_deform_attn(torch.full_like(v1, 1.5), ss, ls, inner, aw)
+    torch.testing.assert_close(const, torch.full_like(const, 1.5), rtol=1e-5, atol=1e-5)
+    idx = torch.arange(0, Nq, 997, device=DEV)
+    sub = c_ref.msda_forward(v1.cpu().numpy(), [(Hq, Wq)], loc[:, idx].cpu().numpy(),
+                             aw[:, idx].cpu().numpy())
+    np.testing.assert_allclose(o1[:, idx].cpu().numpy(), sub, rtol=2e-5, atol=2e-5)

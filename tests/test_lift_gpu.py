@@ -1,0 +1,127 @@
+"""Fused BEV lifting (ubv_bev_lift_*) vs the oracle's unfused composition (offsets -> locations,
+softmax, k1, camera scatter-add, count divide), forward and backward."""
+import numpy as np
+import pytest
+import torch
+
+from _util import t
+from oracle import unibev_ref as R
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def oracle_lift(value, offlog, ref, vis0, count, Nc, fh, fw, H, P):
+    """value (B*Nc, S, C), offlog (B, Nq, H*P*3), ref (Nc, B, Nq, Z, 2) — CPU fp64 composition
+    following MSDeformableAttention3DImg.forward + SpatialCrossAttentionImg's accumulation."""
+    BNc, S, C = value.shape
+    B = BNc // Nc
+    Nq = offlog.shape[1]
+    Z = ref.shape[3]
+    off = offlog[..., :H * P * 2].reshape(B, Nq, H, 1, P, 2)
+    aw = offlog[..., H * P * 2:].reshape(B, Nq, H, P).softmax(-1).view(B, Nq, H, 1, P)
+    norm = torch.tensor([fw, fh], dtype=value.dtype)
+    off = (off / norm).view(B, Nq, H, 1, P // Z, Z, 2)
+    out = torch.zeros(B, Nq, C, dtype=value.dtype)
+    v = value.view(B, Nc, S, H, C // H)
+    for cam in range(Nc):
+        loc = (ref[cam][:, :, None, None, None, :, :] + off).view(B, Nq, H, 1, P, 2)
+        o = R.msda(v[:, cam], [(fh, fw)], loc, aw)
+        if vis0 is not None:
+            o = o * vis0[cam].to(value.dtype)[None, :, None]
+        out = out + o
+    if count is not None:
+        out = out / count[..., None]
+    return out
+
+
+CASES = [
+    # B, Nc, fh, fw, H, Dh, qh, qw, P, Z
+    (2, 1, 9, 11, 8, 32, 10, 12, 8, 4),      # SCA-pts shape class
+    (1, 1, 10, 12, 8, 32, 10, 12, 4, 1),     # self-attn shape class
+    (2, 3, 4, 6, 8, 32, 7, 9, 8, 4),         # SCA-img: 3 cameras, visibility + count
+    (2, 2, 5, 5, 8, 16, 6, 5, 8, 4),         # Dh = 16 (cat-128 config)
+    (1, 1, 16, 16, 8, 16, 16, 16, 4, 1),
+    (1, 6, 8, 22, 8, 32, 20, 20, 8, 4),
+]
+
+
+def make_case(case, seed, with_vis):
+    B, Nc, fh, fw, H, Dh, qh, qw, P, Z = case
+    rs = np.random.RandomState(seed)
+    Nq, C, S = qh * qw, H * Dh, fh * fw
+    value = rs.standard_normal((B * Nc, S, C))
+    offlog = np.concatenate([rs.standard_normal((B, Nq, H * P * 2)) * 1.5,
+                             rs.standard_normal((B, Nq, H * P))], -1)
+    ref = 0.5 + 0.3 * rs.standard_normal((Nc, B, Nq, Z, 2))
+    vis0 = count = None
+    if with_vis:
+        vis_b = rs.random_sample((Nc, B, Nq)) < 0.4
+        vis0 = vis_b[:, 0].astype(np.uint8)
+        count = np.maximum(vis_b.sum(0), 1).astype(np.float32)
+    gout = rs.standard_normal((B, Nq, C))
+    return value, offlog, ref, vis0, count, gout
+
+
+@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('tiled', [True, False])
+def test_lift_fp32_forward_backward(case, tiled):
+    from unibev_amd.functional import bev_lift
+    B, Nc, fh, fw, H, Dh, qh, qw, P, Z = case
+    value, offlog, ref, vis0, count, gout = make_case(case, 7, Nc > 1)
+    # oracle in float64
+    v64 = t(value).requires_grad_()
+    ol64 = t(offlog).requires_grad_()
+    o_ref = oracle_lift(v64, ol64, t(ref), None if vis0 is None else t(vis0),
+                        None if count is None else t(count).double(), Nc, fh, fw, H, P)
+    o_ref.backward(t(gout))
+    v = t(value, torch.float32, DEV).requires_grad_()
+    ol = t(offlog, torch.float32, DEV).requires_grad_()
+    out = bev_lift(v, ol, t(ref, torch.float32, DEV), Nc, (fh, fw), H, P,
+                   vis0=None if vis0 is None else t(vis0, device=DEV),
+                   count=None if count is None else t(count, device=DEV),
+                   query_grid=(qh, qw) if tiled else None)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), o_ref.detach().numpy(), rtol=3e-5, atol=3e-5)
+    out.backward(t(gout, torch.float32, DEV))
+    np.testing.assert_allclose(v.grad.cpu().numpy(), v64.grad.numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(ol.grad.cpu().numpy(), ol64.grad.numpy(), rtol=2e-4, atol=5e-4)
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
+def test_lift_half_precision(dtype, tol):
+    from unibev_amd.functional import bev_lift
+    case = CASES[2]
+    B, Nc, fh, fw, H, Dh, qh, qw, P, Z = case
+    value, offlog, ref, vis0, count, gout = make_case(case, 9, True)
+    o_ref = oracle_lift(t(value), t(offlog), t(ref), t(vis0), t(count).double(), Nc, fh, fw, H, P)
+    v = t(value, dtype, DEV).requires_grad_()
+    ol = t(offlog, torch.float32, DEV).requires_grad_()
+    out = bev_lift(v, ol, t(ref, torch.float32, DEV), Nc, (fh, fw), H, P,
+                   vis0=t(vis0, device=DEV), count=t(count, device=DEV), query_grid=(qh, qw))
+    assert out.dtype == dtype
+    err = (out.float().cpu() - o_ref.float()).abs().max() / o_ref.abs().max()
+    assert err < tol, float(err)
+    out.backward(t(gout, dtype, DEV))
+    assert v.grad.dtype == dtype and torch.isfinite(ol.grad).all()
+
+
+def test_lift_equals_k1_composition_at_full_size():
+    """200x200 queries into a 180x180 map (SCA-pts instance), fp32: the fused kernel and the k1
+    operator fed with torch-computed locations / softmax agree to fp32 round-off."""
+    from unibev_amd.functional import bev_lift, ms_deform_attn
+    torch.manual_seed(1)
+    B, fh, fw, H, Dh, P, Z, qh, qw = 1, 180, 180, 8, 32, 8, 4, 200, 200
+    Nq, C = qh * qw, H * Dh
+    value = torch.randn(B, fh * fw, C, device=DEV)
+    offlog = torch.randn(B, Nq, H * P * 3, device=DEV)
+    offlog[..., :H * P * 2] *= 3.0
+    ys, xs = torch.meshgrid(torch.arange(qh, device=DEV), torch.arange(qw, device=DEV), indexing='ij')
+    ref = torch.stack(((xs + 0.5) / qw, (ys + 0.5) / qh), -1).view(1, 1, Nq, 1, 2).expand(1, B, Nq, Z, 2)
+    fused = bev_lift(value, offlog, ref, 1, (fh, fw), H, P, query_grid=(qh, qw))
+    off = offlog[..., :H * P * 2].view(B, Nq, H, 1, P, 2) / torch.tensor([fw, fh], device=DEV)
+    loc = (ref[0][:, :, None, None, None, :, :] + off.view(B, Nq, H, 1, P // Z, Z, 2)).view(B, Nq, H, 1, P, 2)
+    aw = offlog[..., H * P * 2:].view(B, Nq, H, P).softmax(-1).view(B, Nq, H, 1, P)
+    ss = torch.tensor([[fh, fw]], device=DEV)
+    ls = torch.zeros(1, dtype=torch.long, device=DEV)
+    comp = ms_deform_attn(value.view(B, -1, H, Dh), ss, ls, loc.contiguous(), aw.contiguous())
+    torch.testing.assert_close(fused, comp, rtol=2e-5, atol=2e-5)

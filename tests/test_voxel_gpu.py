@@ -1,0 +1,121 @@
+"""LiDAR front end on the GPU vs the sequential C oracle: voxel indices bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from _util import t
+from oracle import c_ref
+from unibev_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+VS = [0.075, 0.075, 0.2]
+RG = [-54, -54, -5, 54, 54, 3]
+
+
+def run_gpu(points, T, M, vs=VS, rg=RG):
+    from unibev_amd.functional import hard_voxelize
+    voxels, coors, num, vnum = hard_voxelize(t(points, device=DEV), vs, rg, T, M)
+    m = int(vnum.item())
+    return voxels[:m].cpu().numpy(), coors[:m].cpu().numpy(), num[:m].cpu().numpy(), \
+        (voxels, coors, num, vnum)
+
+
+def check_equal(points, T, M, vs=VS, rg=RG):
+    v_ref, c_ref_, n_ref = c_ref.hard_voxelize(points, vs, rg, T, M)
+    v, c, n, raw = run_gpu(points, T, M, vs, rg)
+    assert c.dtype == np.int32 and n.dtype == np.int32
+    np.testing.assert_array_equal(c, c_ref_)
+    np.testing.assert_array_equal(n, n_ref)
+    np.testing.assert_array_equal(v, v_ref)
+    return raw
+
+
+def test_synthetic_30k_cloud_bit_exact():
+    raw = check_equal(syn.lidar_points(30000, seed=0), 10, 90000)
+    voxels, coors, num, vnum = raw
+    # rows past voxel_num stay zero
+    m = int(vnum.item())
+    assert torch.all(voxels[m:] == 0) and torch.all(num[m:] == 0)
+
+
+def test_dense_cloud_many_points_per_voxel_and_voxel_cap():
+    rs = np.random.RandomState(3)
+    pts = np.concatenate([rs.uniform(-2, 2, (60000, 2)), rs.uniform(-1.5, -0.5, (60000, 1)),
+                          rs.uniform(0, 1, (60000, 2))], 1).astype(np.float32)
+    check_equal(pts, 10, 90000)
+    check_equal(pts, 3, 500)          # voxel budget exhausted: later first-appearances dropped
+    check_equal(pts, 1, 90000)
+
+
+def test_known_answer_cloud():
+    """Hand-built cloud: duplicates, a point exactly on the max edge (dropped), on the min edge
+    (kept), NaN, outside z."""
+    vs, rg = [1.0, 1.0, 1.0], [0, 0, 0, 4, 4, 2]
+    pts = np.array([
+        [0.5, 0.5, 0.5, 1, 0], [3.5, 0.5, 0.5, 2, 0], [0.6, 0.4, 0.9, 3, 0], [4.0, 1.0, 1.0, 4, 0],
+        [0.0, 0.0, 0.0, 5, 0], [1.5, 2.5, 1.5, 6, 0], [np.nan, 1.0, 1.0, 7, 0], [1.0, 1.0, 2.0, 8, 0],
+        [1.5, 2.5, 1.2, 9, 0], [0.9, 0.9, 0.1, 10, 0], [-0.0001, 1.0, 1.0, 11, 0], [3.999, 3.999, 1.999, 12, 0],
+    ], np.float32)
+    v, c, n, _ = run_gpu(pts, 3, 10, vs, rg)
+    np.testing.assert_array_equal(c, [[0, 0, 0], [0, 0, 3], [1, 2, 1], [1, 3, 3]])
+    np.testing.assert_array_equal(n, [3, 1, 2, 1])       # voxel 0 saw 4 points, keeps the first 3
+    np.testing.assert_array_equal(v[0, :, 3], [1, 3, 5])
+    np.testing.assert_array_equal(v[2, :2, 3], [6, 9])
+    assert np.all(v[1, 1:] == 0)
+    check_equal(pts, 3, 10, vs, rg)
+
+
+def test_empty_and_all_outside():
+    v, c, n, (voxels, coors, num, vnum) = run_gpu(np.zeros((0, 5), np.float32), 10, 100)
+    assert v.shape[0] == 0 and int(vnum.item()) == 0
+    pts = np.full((100, 5), 1e4, np.float32)
+    v, c, n, _ = run_gpu(pts, 10, 100)
+    assert v.shape[0] == 0
+
+
+def test_dynamic_voxelize_mean_vfe_and_dense_scatter():
+    from unibev_amd.functional import dynamic_voxelize, voxel_mean, sparse_to_dense
+    pts = syn.lidar_points(20000, seed=2)
+    np.testing.assert_array_equal(dynamic_voxelize(t(pts, device=DEV), VS, RG).cpu().numpy(),
+                                  c_ref.dynamic_voxelize(pts, VS, RG))
+    v_ref, c_ref_, n_ref = c_ref.hard_voxelize(pts, VS, RG, 10, 90000)
+    mean = voxel_mean(t(v_ref, device=DEV), t(n_ref, device=DEV))
+    np.testing.assert_allclose(mean.cpu().numpy(), c_ref.voxel_mean(v_ref, n_ref), rtol=1e-6, atol=1e-6)
+    rs = np.random.RandomState(0)
+    M, C = 5000, 16
+    cells = rs.choice(2 * 2 * 180 * 180, M, replace=False)
+    coors = np.stack([cells // (2 * 180 * 180), (cells // (180 * 180)) % 2, (cells // 180) % 180,
+                      cells % 180], 1).astype(np.int32)
+    feats = rs.standard_normal((M, C)).astype(np.float32)
+    dense = sparse_to_dense(t(feats, device=DEV), t(coors, device=DEV), 2, (2, 180, 180))
+    np.testing.assert_array_equal(dense.cpu().numpy(), c_ref.sparse_to_dense(feats, coors, 2, 2, 180, 180))
+
+
+def test_voxelization_module_and_batch_helper():
+    from unibev_amd.modules.voxel import Voxelization, HardSimpleVFE, voxelize_batch
+    layer = Voxelization(VS, RG, 10, (90000, 120000)).eval()
+    assert layer.grid_size.tolist() == [1440, 1440, 40]
+    clouds = [syn.lidar_points(5000, seed=s) for s in (4, 5)]
+    voxels, num, coors = voxelize_batch(layer, [t(c, device=DEV) for c in clouds])
+    ref = [c_ref.hard_voxelize(c, VS, RG, 10, 120000) for c in clouds]
+    np.testing.assert_array_equal(voxels.cpu().numpy(), np.concatenate([r[0] for r in ref]))
+    np.testing.assert_array_equal(coors[:, 1:].cpu().numpy(), np.concatenate([r[1] for r in ref]))
+    np.testing.assert_array_equal(coors[:, 0].cpu().numpy(),
+                                  np.concatenate([np.full(len(r[1]), i) for i, r in enumerate(ref)]))
+    feats = HardSimpleVFE(5)(voxels, num, coors)
+    np.testing.assert_allclose(feats.cpu().numpy(),
+                               np.concatenate([c_ref.voxel_mean(r[0], r[2]) for r in ref]),
+                               rtol=1e-6, atol=1e-6)
+
+
+def test_full_sweep_cloud_idempotent_property():
+    """~300k points (10-sweep size): voxelizing the voxel contents again reproduces the voxels
+    (idempotence), and every stored point lies in its voxel's cell."""
+    pts = syn.lidar_points(300000, seed=7)
+    v, c, n, _ = run_gpu(pts, 10, 120000)
+    flat = np.concatenate([v[i, :n[i]] for i in range(0, len(v), 97)])
+    cc = c_ref.dynamic_voxelize(flat, VS, RG)
+    owner = np.concatenate([np.repeat(c[i][None], n[i], 0) for i in range(0, len(v), 97)])
+    np.testing.assert_array_equal(cc, owner)
+    check_equal(pts, 10, 120000)

@@ -1,0 +1,75 @@
+"""ctypes binding of ``libunibev_hip.so`` (C ABI declared in ``include/unibev_hip.h``).
+
+There is NO fallback: if the shared library is missing or a call fails, an exception is raised.
+The product path never routes through a CPU implementation.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libunibev_hip.so')
+
+_lib = None
+
+UBV_F32, UBV_F16, UBV_BF16 = 0, 1, 2
+
+# name -> (restype, argtypes); mirrors include/unibev_hip.h one to one
+_P = c_void_p
+SIGNATURES = {
+    'ubv_version': (c_int, []),
+    'ubv_last_error': (c_char_p, []),
+    'ubv_arch': (c_char_p, []),
+    'ubv_ms_deform_attn_forward': (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 9 + [_P]),
+    'ubv_ms_deform_attn_backward': (c_int, [_P] * 9 + [c_int] * 9 + [_P]),
+    'ubv_bev_lift_forward': (c_int, [_P, _P, c_int64, _P, c_int64, _P, _P, _P, _P]
+                             + [c_int] * 12 + [_P]),
+    'ubv_bev_lift_backward': (c_int, [_P, _P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, _P, c_int64,
+                                      _P, c_int64] + [c_int] * 12 + [_P]),
+    'ubv_bev_lift_supported': (c_int, [c_int] * 4),
+    'ubv_point_sampling': (c_int, [_P, _P, _P, _P, ctypes.POINTER(c_float), c_float, c_float,
+                                   _P, _P, _P, _P] + [c_int] * 5 + [_P]),
+    'ubv_flatten_embed_forward': (c_int, [_P, _P, c_int, _P, _P] + [c_int] * 4 + [_P]),
+    'ubv_flatten_embed_backward': (c_int, [_P, _P, _P] + [c_int] * 4 + [_P]),
+    'ubv_bev_fuse_forward': (c_int, [_P] * 7 + [c_int] * 5 + [_P]),
+    'ubv_bev_fuse_backward': (c_int, [_P] * 11 + [c_int] * 5 + [_P]),
+    'ubv_hard_voxelize_workspace': (c_int64, [c_int, c_int, c_int]),
+    'ubv_hard_voxelize': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int,
+                                  ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_int,
+                                  _P]),
+    'ubv_dynamic_voxelize': (c_int, [_P, _P, c_int, c_int, ctypes.POINTER(c_float),
+                                     ctypes.POINTER(c_float), _P]),
+    'ubv_voxel_mean': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'ubv_sparse_to_dense': (c_int, [_P, _P, _P, c_int, _P] + [c_int] * 5 + [_P]),
+}
+
+
+class UniBEVHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise loudly if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise UniBEVHipError(
+                f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; '
+                f'g.build()"` (or `make -C unibev_amd/csrc`). There is no CPU fallback.')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().ubv_last_error().decode(errors='replace')
+        raise UniBEVHipError(f'{what} failed (status {status}): {msg}')
+
+
+def float_array(values):
+    return (c_float * len(values))(*[float(v) for v in values])

@@ -1,0 +1,408 @@
+"""Autograd operators over the C ABI of ``libunibev_hip.so``.
+
+These are the operator-level drop-ins for the reference's un-vendored extension ops
+(SURVEY.md section 8(b)): same names, argument meaning and error behaviour.  Every function
+requires CUDA(HIP) tensors; there is no CPU path (``UniBEVHipError`` / ``RuntimeError``).
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._lib import check, lib
+
+_DT = {torch.float32: _lib.UBV_F32, torch.float16: _lib.UBV_F16, torch.bfloat16: _lib.UBV_BF16}
+
+# optional per-op HIP-event timing (bench.py): name -> list of (start, end) events
+_PROFILE = None
+
+
+def enable_profile(flag=True):
+    global _PROFILE
+    _PROFILE = {} if flag else None
+
+
+def profile_results():
+    """name -> list of (milliseconds, meta) per call; synchronises."""
+    out = {}
+    if _PROFILE is None:
+        return out
+    torch.cuda.synchronize()
+    for k, evs in _PROFILE.items():
+        out[k] = [(s.elapsed_time(e), m) for s, e, m in evs]
+    return out
+
+
+class _timed:
+    """HIP events on the launch stream around one C-ABI call (only while profiling is on)."""
+
+    def __init__(self, name, meta=None):
+        self.name = name
+        self.meta = meta
+
+    def __enter__(self):
+        if _PROFILE is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+    def __exit__(self, *a):
+        if _PROFILE is not None:
+            self.e.record()
+            _PROFILE.setdefault(self.name, []).append((self.s, self.e, self.meta))
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f'unsupported dtype {t.dtype}; expected float32, float16 or bfloat16')
+
+
+def _need_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('unibev_amd ops run on the GPU only (got a CPU tensor); '
+                               'there is no CPU fallback')
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ----------------------------------------------------------------------------------------------- k1
+class MultiScaleDeformableAttnFunction(Function):
+    """Drop-in for [ext] mmcv ``MultiScaleDeformableAttnFunction`` (call sites
+    spatial_cross_attention_img.py:433-435, spatial_cross_attention_pts.py:440-442,
+    decoder.py:325-327): ``apply(value, spatial_shapes, level_start_index, sampling_locations,
+    attention_weights, im2col_step)`` -> (B, Nq, H*Dh); grads (value, None, None, loc, weight, None).
+    """
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                attention_weights, im2col_step=64):
+        _need_cuda(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                   attention_weights)
+        B, S, H, Dh = value.shape
+        _, Nq, H2, L, P, two = sampling_locations.shape
+        if H2 != H or two != 2 or attention_weights.shape != (B, Nq, H, L, P):
+            raise ValueError('ms_deform_attn: inconsistent shapes '
+                             f'{tuple(value.shape)} {tuple(sampling_locations.shape)} '
+                             f'{tuple(attention_weights.shape)}')
+        value = value.contiguous()
+        ss = value_spatial_shapes.to(torch.int64).contiguous()
+        ls = value_level_start_index.to(torch.int64).contiguous()
+        loc = sampling_locations.float().contiguous()
+        aw = attention_weights.float().contiguous()
+        out = torch.empty(B, Nq, H * Dh, dtype=value.dtype, device=value.device)
+        with _timed('k1_fwd'):
+            check(lib().ubv_ms_deform_attn_forward(_p(value), _p(ss), _p(ls), _p(loc), _p(aw),
+                                                   _p(out), B, S, H, Dh, L, Nq, P, _dt(value),
+                                                   int(im2col_step), _stream()),
+                  'ms_deform_attn_forward')
+        ctx.save_for_backward(value, ss, ls, loc, aw)
+        ctx.im2col_step = int(im2col_step)
+        ctx.in_dtypes = (sampling_locations.dtype, attention_weights.dtype)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, ss, ls, loc, aw = ctx.saved_tensors
+        B, S, H, Dh = value.shape
+        _, Nq, _, L, P, _ = loc.shape
+        go = grad_output.to(value.dtype).contiguous()
+        gv = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
+        gloc = torch.empty_like(loc)
+        gaw = torch.empty_like(aw)
+        with _timed('k1_bwd'):
+            check(lib().ubv_ms_deform_attn_backward(_p(value), _p(ss), _p(ls), _p(loc), _p(aw),
+                                                    _p(go), _p(gv), _p(gloc), _p(gaw), B, S, H, Dh,
+                                                    L, Nq, P, _dt(value), ctx.im2col_step,
+                                                    _stream()),
+                  'ms_deform_attn_backward')
+        return (gv.to(value.dtype), None, None, gloc.to(ctx.in_dtypes[0]),
+                gaw.to(ctx.in_dtypes[1]), None)
+
+
+def ms_deform_attn(value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
+                   im2col_step=64):
+    return MultiScaleDeformableAttnFunction.apply(value, spatial_shapes, level_start_index,
+                                                  sampling_locations, attention_weights,
+                                                  im2col_step)
+
+
+# ----------------------------------------------------------------------------------------------- lift
+def bev_lift_supported(num_heads, head_dim, num_points, dtype):
+    return bool(lib().ubv_bev_lift_supported(num_heads, head_dim, num_points, _DT.get(dtype, -1)))
+
+
+class _BevLift(Function):
+    @staticmethod
+    def forward(ctx, value, offlog, ref, vis0, count, geom):
+        B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh = geom
+        _need_cuda(value, offlog, ref, vis0, count)
+        value = value.contiguous()
+        ol = offlog.float().contiguous()
+        ref = ref.float().contiguous()
+        row = H * P * 3
+        assert ol.shape[-1] == row and ol.numel() == B * Nq * row
+        assert value.numel() == B * Nc * fh * fw * H * Dh
+        assert ref.numel() == Nc * B * Nq * Z * 2
+        out = torch.empty(B, Nq, H * Dh, dtype=value.dtype, device=value.device)
+        base = ol.data_ptr()
+        with _timed('lift_fwd', (geom, value.element_size())):
+            check(lib().ubv_bev_lift_forward(
+                _p(value), ctypes.c_void_p(base), row, ctypes.c_void_p(base + H * P * 2 * 4), row,
+                _p(ref), _p(vis0), _p(count), _p(out), B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh,
+                _dt(value), _stream()), 'bev_lift_forward')
+        ctx.save_for_backward(value, ol, ref, vis0, count)
+        ctx.geom = geom
+        ctx.ol_dtype = offlog.dtype
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, ol, ref, vis0, count = ctx.saved_tensors
+        B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh = ctx.geom
+        row = H * P * 3
+        go = grad_output.to(value.dtype).contiguous()
+        gv = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
+        gol = torch.empty_like(ol)
+        base, gbase = ol.data_ptr(), gol.data_ptr()
+        off2 = H * P * 2 * 4
+        with _timed('lift_bwd', (ctx.geom, value.element_size())):
+            check(lib().ubv_bev_lift_backward(
+                _p(value), ctypes.c_void_p(base), row, ctypes.c_void_p(base + off2), row, _p(ref),
+                _p(vis0), _p(count), _p(go), _p(gv), ctypes.c_void_p(gbase), row,
+                ctypes.c_void_p(gbase + off2), row, B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh,
+                _dt(value), _stream()), 'bev_lift_backward')
+        return gv.to(value.dtype), gol.to(ctx.ol_dtype), None, None, None, None
+
+
+def bev_lift(value, offlog, ref, num_cams, feat_hw, num_heads, num_points, vis0=None, count=None,
+             query_grid=None):
+    """Fused single-level BEV query lifting (``ubv_bev_lift_forward``).
+
+    value  (B*num_cams, fh*fw, C)  projected features, batch-major / camera-minor
+    offlog (B, Nq, H*P*3)          [sampling_offsets | attention logits] raw Linear outputs
+    ref    (num_cams, B, Nq, Z, 2) reference points, flat point p uses anchor p % Z
+    vis0   (num_cams, Nq) uint8    visibility of batch element 0, or None
+    count  (B, Nq) float32         camera count divisor, or None
+    """
+    fh, fw = feat_hw
+    BNc, S, C = value.shape[0], value.shape[1], value.shape[-1] if value.dim() == 3 else None
+    if value.dim() == 4:
+        C = value.shape[2] * value.shape[3]
+    B = BNc // num_cams
+    Nq = offlog.shape[-2]
+    Z = ref.shape[-2]
+    Dh = C // num_heads
+    qw, qh = (query_grid[1], query_grid[0]) if query_grid is not None else (0, 0)
+    geom = (B, num_cams, fh, fw, num_heads, Dh, Nq, num_points, Z, qw, qh)
+    return _BevLift.apply(value, offlog, ref, vis0, count, geom)
+
+
+# ----------------------------------------------------------------------------------------------- geometry
+@torch.no_grad()
+def point_sampling(lidar2img, xs, ys, zs, pc_range, img_hw):
+    """Camera projection + visibility (``ubv_point_sampling``).
+
+    lidar2img (B, Nc, 4, 4) float32 cuda; xs (W,), ys (H,), zs (D,) float32 cuda.
+    Returns reference_points_cam (Nc,B,Nq,D,2) f32, bev_mask (Nc,B,Nq,D) bool, vis0 (Nc,Nq) uint8,
+    count (B,Nq) f32.
+    """
+    _need_cuda(lidar2img, xs, ys, zs)
+    B, Nc = lidar2img.shape[:2]
+    W, H, D = xs.numel(), ys.numel(), zs.numel()
+    Nq = H * W
+    dev = lidar2img.device
+    l2i = lidar2img.float().contiguous()
+    ref_cam = torch.empty(Nc, B, Nq, D, 2, dtype=torch.float32, device=dev)
+    mask = torch.empty(Nc, B, Nq, D, dtype=torch.uint8, device=dev)
+    vis0 = torch.empty(Nc, Nq, dtype=torch.uint8, device=dev)
+    count = torch.empty(B, Nq, dtype=torch.float32, device=dev)
+    check(lib().ubv_point_sampling(_p(l2i), _p(xs), _p(ys), _p(zs), _lib.float_array(pc_range),
+                                   float(img_hw[0]), float(img_hw[1]), _p(ref_cam), _p(mask),
+                                   _p(vis0), _p(count), B, Nc, H, W, D, _stream()),
+          'point_sampling')
+    return ref_cam, mask.view(torch.bool), vis0, count
+
+
+# ----------------------------------------------------------------------------------------------- flatten
+class _FlattenEmbed(Function):
+    @staticmethod
+    def forward(ctx, feat, embA, embB):
+        _need_cuda(feat, embA, embB)
+        N, C, HW = feat.shape
+        feat = feat.contiguous()
+        a = None if embA is None else embA.float().contiguous()
+        b = None if embB is None else embB.float().contiguous()
+        out = torch.empty(N, HW, C, dtype=feat.dtype, device=feat.device)
+        groups = 1 if a is None else a.shape[0]
+        check(lib().ubv_flatten_embed_forward(_p(feat), _p(a), groups, _p(b), _p(out), N, C, HW,
+                                              _dt(feat), _stream()), 'flatten_embed_forward')
+        ctx.groups = groups
+        ctx.has = (embA is not None, embB is not None)
+        ctx.emb_dtypes = (None if embA is None else embA.dtype, None if embB is None else embB.dtype)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        N, HW, C = grad_out.shape
+        go = grad_out.contiguous()
+        gin = torch.empty(N, C, HW, dtype=go.dtype, device=go.device)
+        need_emb = (ctx.has[0] and ctx.needs_input_grad[1]) or (ctx.has[1] and ctx.needs_input_grad[2])
+        gemb = torch.zeros(N, C, dtype=torch.float32, device=go.device) if need_emb else None
+        check(lib().ubv_flatten_embed_backward(_p(go), _p(gin), _p(gemb), N, C, HW, _dt(go),
+                                               _stream()), 'flatten_embed_backward')
+        ga = gb = None
+        if ctx.has[0] and ctx.needs_input_grad[1]:
+            ga = gemb.view(N // ctx.groups, ctx.groups, C).sum(0).to(ctx.emb_dtypes[0])
+        if ctx.has[1] and ctx.needs_input_grad[2]:
+            gb = gemb.sum(0).to(ctx.emb_dtypes[1])
+        return gin, ga, gb
+
+
+def flatten_embed(feat, embA=None, embB=None):
+    """(N, C, HW) -> (N, HW, C) + embA[n % groups] + embB (``ubv_flatten_embed_forward``)."""
+    return _FlattenEmbed.apply(feat, embA, embB)
+
+
+# ----------------------------------------------------------------------------------------------- fusion
+class _BevFuse(Function):
+    @staticmethod
+    def forward(ctx, img, pts, cw_img, cw_pts, sw_img, sw_pts, cat):
+        ref = img if img is not None else pts
+        _need_cuda(ref, cw_img, cw_pts)
+        B, Nq, C = ref.shape
+        img_c = None if img is None else img.contiguous()
+        pts_c = None if pts is None else pts.to(ref.dtype).contiguous()
+        cwi, cwp = cw_img.float().contiguous(), cw_pts.float().contiguous()
+        swi = None if sw_img is None else sw_img.float().contiguous()
+        swp = None if sw_pts is None else sw_pts.float().contiguous()
+        out = torch.empty(Nq, B, C * (2 if cat else 1), dtype=ref.dtype, device=ref.device)
+        check(lib().ubv_bev_fuse_forward(_p(img_c), _p(pts_c), _p(cwi), _p(cwp), _p(swi), _p(swp),
+                                         _p(out), B, Nq, C, int(cat), _dt(ref), _stream()),
+              'bev_fuse_forward')
+        ctx.save_for_backward(img_c, pts_c, cwi, cwp, swi, swp)
+        ctx.cat = int(cat)
+        ctx.shape = (B, Nq, C)
+        ctx.dt = (cw_img.dtype, cw_pts.dtype, None if sw_img is None else sw_img.dtype,
+                  None if sw_pts is None else sw_pts.dtype)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        img, pts, cwi, cwp, swi, swp = ctx.saved_tensors
+        B, Nq, C = ctx.shape
+        ref = img if img is not None else pts
+        go = grad_out.to(ref.dtype).contiguous()
+        gimg = torch.empty_like(img) if (img is not None and ctx.needs_input_grad[0]) else None
+        gpts = torch.empty_like(pts) if (pts is not None and ctx.needs_input_grad[1]) else None
+        need_cw = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        need_sw = (swi is not None and ctx.needs_input_grad[4]) or \
+                  (swp is not None and ctx.needs_input_grad[5])
+        gcw = torch.zeros(2, C, dtype=torch.float32, device=go.device) if need_cw else None
+        gsw = torch.zeros(2, Nq, dtype=torch.float32, device=go.device) if need_sw else None
+        check(lib().ubv_bev_fuse_backward(_p(go), _p(img), _p(pts), _p(cwi), _p(cwp), _p(swi),
+                                          _p(swp), _p(gimg), _p(gpts), _p(gcw), _p(gsw), B, Nq, C,
+                                          ctx.cat, _dt(ref), _stream()), 'bev_fuse_backward')
+        g = [gimg, gpts, None, None, None, None, None]
+        if need_cw:
+            g[2], g[3] = gcw[0].to(ctx.dt[0]), gcw[1].to(ctx.dt[1])
+        if need_sw:
+            if swi is not None:
+                g[4] = gsw[0].to(ctx.dt[2])
+            if swp is not None:
+                g[5] = gsw[1].to(ctx.dt[3])
+        return tuple(g)
+
+
+def bev_fuse(img, pts, cw_img, cw_pts, sw_img=None, sw_pts=None, cat=False):
+    """(B,Nq,C) x2 -> (Nq,B,C*s): per-channel / per-query weighting, add or concat, and the final
+    permute (``ubv_bev_fuse_forward``).  A missing modality is ``None`` (zeros)."""
+    return _BevFuse.apply(img, pts, cw_img, cw_pts, sw_img, sw_pts, cat)
+
+
+# ----------------------------------------------------------------------------------------------- voxels
+_WS = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+@torch.no_grad()
+def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels):
+    """Deterministic hard voxelization (``ubv_hard_voxelize``), full-capacity, sync-free form.
+
+    Returns voxels (max_voxels, max_points, F), coors (max_voxels, 3) int32 zyx,
+    num_points (max_voxels,) int32 and voxel_num (1,) int32 ON DEVICE; rows >= voxel_num are
+    zero / undefined.  ``Voxelization.forward`` slices them to the reference's shapes.
+    """
+    _need_cuda(points)
+    pts = points.float().contiguous()
+    N, F = pts.shape
+    dev = pts.device
+    voxels = torch.empty(max_voxels, max_points, F, dtype=torch.float32, device=dev)
+    coors = torch.zeros(max_voxels, 3, dtype=torch.int32, device=dev)
+    num = torch.empty(max_voxels, dtype=torch.int32, device=dev)
+    vnum = torch.empty(1, dtype=torch.int32, device=dev)
+    nbytes = lib().ubv_hard_voxelize_workspace(N, max_points, max_voxels)
+    ws = _workspace(nbytes, dev)
+    check(lib().ubv_hard_voxelize(_p(pts), _p(voxels), _p(coors), _p(num), _p(vnum), _p(ws),
+                                  ws.numel(), N, F, _lib.float_array(voxel_size),
+                                  _lib.float_array(coors_range), max_points, max_voxels, _stream()),
+          'hard_voxelize')
+    return voxels, coors, num, vnum
+
+
+@torch.no_grad()
+def dynamic_voxelize(points, voxel_size, coors_range):
+    """[ext] mmdet3d dynamic_voxelize: (N,3) int32 zyx coords, -1 outside."""
+    _need_cuda(points)
+    pts = points.float().contiguous()
+    N, F = pts.shape
+    coors = torch.empty(N, 3, dtype=torch.int32, device=pts.device)
+    check(lib().ubv_dynamic_voxelize(_p(pts), _p(coors), N, F, _lib.float_array(voxel_size),
+                                     _lib.float_array(coors_range), _stream()), 'dynamic_voxelize')
+    return coors
+
+
+@torch.no_grad()
+def voxel_mean(voxels, num_points, voxel_num=None):
+    """[ext] HardSimpleVFE: per-voxel mean of the stored points."""
+    _need_cuda(voxels, num_points)
+    M, T, F = voxels.shape
+    mean = torch.zeros(M, F, dtype=torch.float32, device=voxels.device)
+    check(lib().ubv_voxel_mean(_p(voxels.contiguous()), _p(num_points.contiguous()), _p(voxel_num),
+                               _p(mean), M, T, F, _stream()), 'voxel_mean')
+    return mean
+
+
+@torch.no_grad()
+def sparse_to_dense(feats, coors, batch_size, spatial_shape, m_dev=None):
+    """SparseConvTensor.dense(): (M,C) feats at (M,4) int32 (b,z,y,x) -> (B,C,D,H,W)."""
+    _need_cuda(feats, coors)
+    M, C = feats.shape
+    D, Hs, Ws = spatial_shape
+    dense = torch.zeros(batch_size, C, D, Hs, Ws, dtype=torch.float32, device=feats.device)
+    check(lib().ubv_sparse_to_dense(_p(feats.float().contiguous()), _p(coors.contiguous()),
+                                    _p(m_dev), M, _p(dense), batch_size, C, D, Hs, Ws, _stream()),
+          'sparse_to_dense')
+    return dense

@@ -1,0 +1,9 @@
+from .bricks import (FFN, BaseModule, BaseTransformerLayer, DetrTransformerDecoderLayer,  # noqa
+                     LearnedPositionalEncoding, MultiheadAttention, TransformerLayerSequence)
+from .deform_attn import (CustomMSDeformableAttention, MSDeformableAttention3DImg,  # noqa
+                          MSDeformableAttention3DPts, MultiScaleDeformableAttention)
+from .head import UniBEV_Head, inverse_sigmoid  # noqa
+from .encoders import ImgEncoder, ImgLayer, PtsEncoder, PtsLayer  # noqa
+from .sca import SpatialCrossAttentionImg, SpatialCrossAttentionPts  # noqa
+from .transformer import UniBEVTransformer  # noqa
+from .voxel import HardSimpleVFE, Voxelization, sparse_to_dense, voxelize_batch  # noqa

@@ -1,0 +1,251 @@
+"""Deformable-attention modules of the BEV encoder, on the HIP kernels.
+
+Registry keys / constructor kwargs / state-dict names follow the reference:
+  * ``MultiScaleDeformableAttention`` — [ext] mmcv module in the self-attn slot of every encoder
+    layer (configs/unibev/unibev_nus_LC_cnw_256_modality_dropout.py:270-273); the reference
+    vendors a verbatim copy as ``CustomMSDeformableAttention`` (models/modules/decoder.py:131-338).
+  * ``MSDeformableAttention3DImg`` / ``MSDeformableAttention3DPts`` —
+    models/modules/spatial_cross_attention_img.py:218-442, spatial_cross_attention_pts.py:209-449.
+  * alias ``MSDeformableAttention3DUniQueryImg`` (named by unibev_nus_C.py:206, registered nowhere
+    in the reference — quirk q10).
+
+Fast path (one level, 4 or 8 points): the two query Linears run as ONE GEMM whose rows
+``[offsets | logits]`` feed ``functional.bev_lift`` directly; sampling locations and softmaxed
+weights are never materialised.  Anything else composes the k1 operator exactly as the
+reference does.
+"""
+import math
+import warnings
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import functional as UF
+from ..registry import ATTENTION
+from .bricks import BaseModule, constant_init, xavier_init
+
+
+def static_hw(spatial_shapes):
+    """Host copy [(h, w), ...] of a ``spatial_shapes`` tensor without a device sync when the
+    producer attached one (``_ubv_hw``); otherwise one ``tolist()`` (sync) as in any eager use."""
+    hw = getattr(spatial_shapes, '_ubv_hw', None)
+    if hw is None:
+        hw = [tuple(int(v) for v in r) for r in spatial_shapes.tolist()]
+        try:
+            spatial_shapes._ubv_hw = hw
+        except Exception:
+            pass
+    return hw
+
+
+def shapes_tensor(hw, device):
+    """(L, 2) int64 device tensor carrying its own host copy."""
+    t = torch.as_tensor(hw, dtype=torch.long, device=device)
+    t._ubv_hw = [tuple(int(v) for v in r) for r in hw]
+    return t
+
+
+def _is_power_of_2(n):
+    if (not isinstance(n, int)) or (n < 0):
+        raise ValueError('invalid input for _is_power_of_2: {} (type: {})'.format(n, type(n)))
+    return (n & (n - 1) == 0) and n != 0
+
+
+class _DeformAttnBase(BaseModule):
+    """Parameters and initialisation shared by every deformable attention on the path."""
+
+    def __init__(self, embed_dims, num_heads, num_levels, num_points, im2col_step, batch_first,
+                 norm_cfg, init_cfg, with_output_proj):
+        super().__init__(init_cfg)
+        if embed_dims % num_heads != 0:
+            raise ValueError(f'embed_dims must be divisible by num_heads, '
+                             f'but got {embed_dims} and {num_heads}')
+        if not _is_power_of_2(embed_dims // num_heads):
+            warnings.warn("You'd better set embed_dims in MultiScaleDeformAttention to make the "
+                          'dimension of each attention head a power of 2 which is more efficient '
+                          'in our implementation.')
+        self.norm_cfg = norm_cfg
+        self.batch_first = batch_first
+        self.fp16_enabled = False
+        self.im2col_step = im2col_step
+        self.embed_dims = embed_dims
+        self.num_levels = num_levels
+        self.num_heads = num_heads
+        self.num_points = num_points
+        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.output_proj = nn.Linear(embed_dims, embed_dims) if with_output_proj else None
+        self.init_weights()
+
+    def init_weights(self):
+        """Offsets start as the 8 compass directions scaled by the point index, attention logits
+        at zero (spatial_cross_attention_img.py:293-311, decoder.py:208-226)."""
+        constant_init(self.sampling_offsets, 0.)
+        thetas = torch.arange(self.num_heads, dtype=torch.float32) * (2.0 * math.pi / self.num_heads)
+        grid_init = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid_init = (grid_init / grid_init.abs().max(-1, keepdim=True)[0]).view(
+            self.num_heads, 1, 1, 2).repeat(1, self.num_levels, self.num_points, 1)
+        for i in range(self.num_points):
+            grid_init[:, :, i, :] *= i + 1
+        self.sampling_offsets.bias.data = grid_init.view(-1).to(self.sampling_offsets.bias.device)
+        constant_init(self.attention_weights, val=0., bias=0.)
+        xavier_init(self.value_proj, distribution='uniform', bias=0.)
+        xavier_init(self.output_proj, distribution='uniform', bias=0.)
+        self._is_init = True
+
+    init_weight = init_weights
+
+    # -- pieces --------------------------------------------------------------------------------
+    def offsets_and_logits(self, query):
+        """One GEMM for both query Linears: rows [H*L*P*2 offsets | H*L*P logits]."""
+        w = torch.cat((self.sampling_offsets.weight, self.attention_weights.weight), 0)
+        b = torch.cat((self.sampling_offsets.bias, self.attention_weights.bias), 0)
+        return F.linear(query, w, b)
+
+    def can_lift(self, value):
+        return (self.num_levels == 1 and
+                UF.bev_lift_supported(self.num_heads, self.embed_dims // self.num_heads,
+                                      self.num_points, value.dtype))
+
+    def project_value(self, value, key_padding_mask=None):
+        value = self.value_proj(value)
+        if key_padding_mask is not None:
+            value = value.masked_fill(key_padding_mask[..., None], 0.0)
+        return value
+
+    def k1(self, value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
+        bs, num_value = value.shape[:2]
+        return UF.MultiScaleDeformableAttnFunction.apply(
+            value.view(bs, num_value, self.num_heads, -1), spatial_shapes, level_start_index,
+            sampling_locations, attention_weights, self.im2col_step)
+
+
+@ATTENTION.register_module(name=['MultiScaleDeformableAttention', 'CustomMSDeformableAttention'])
+class MultiScaleDeformableAttention(_DeformAttnBase):
+    """Deformable self/cross attention with output projection, dropout and residual
+    (decoder.py:230-338)."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=4, im2col_step=64,
+                 dropout=0.1, batch_first=False, norm_cfg=None, init_cfg=None):
+        super().__init__(embed_dims, num_heads, num_levels, num_points, im2col_step, batch_first,
+                         norm_cfg, init_cfg, with_output_proj=True)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None,
+                key_padding_mask=None, reference_points=None, spatial_shapes=None,
+                level_start_index=None, flag='decoder', **kwargs):
+        if 'residual' in kwargs and identity is None:         # deprecated_api_warning mapping
+            identity = kwargs.pop('residual')
+        if value is None:
+            value = query
+        if identity is None:
+            identity = query
+        if query_pos is not None:
+            query = query + query_pos
+        if not self.batch_first:
+            query = query.permute(1, 0, 2)
+            value = value.permute(1, 0, 2)
+        bs, num_query, _ = query.shape
+        bs, num_value, _ = value.shape
+        hw = static_hw(spatial_shapes)
+        assert sum(h * w for h, w in hw) == num_value
+        value = self.project_value(value, key_padding_mask)
+        H, L, P = self.num_heads, self.num_levels, self.num_points
+        if reference_points.shape[-1] == 2 and self.can_lift(value) and \
+                reference_points.shape[2] == 1:
+            grid = kwargs.get('bev_h'), kwargs.get('bev_w')
+            qgrid = grid if (grid[0] and grid[1] and grid[0] * grid[1] == num_query) else None
+            output = UF.bev_lift(value, self.offsets_and_logits(query),
+                                 reference_points.reshape(1, bs, num_query, 1, 2), 1, hw[0], H, P,
+                                 query_grid=qgrid)
+        else:
+            sampling_offsets = self.sampling_offsets(query).view(bs, num_query, H, L, P, 2)
+            attention_weights = self.attention_weights(query).view(bs, num_query, H, L * P)
+            attention_weights = attention_weights.softmax(-1).view(bs, num_query, H, L, P)
+            if reference_points.shape[-1] == 2:
+                offset_normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+                sampling_locations = reference_points[:, :, None, :, None, :] \
+                    + sampling_offsets / offset_normalizer[None, None, None, :, None, :]
+            elif reference_points.shape[-1] == 4:
+                sampling_locations = reference_points[:, :, None, :, None, :2] \
+                    + sampling_offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
+            else:
+                raise ValueError(f'Last dim of reference_points must be 2 or 4, but get '
+                                 f'{reference_points.shape[-1]} instead.')
+            output = self.k1(value, spatial_shapes, level_start_index, sampling_locations,
+                             attention_weights)
+        output = self.output_proj(output)
+        if not self.batch_first:
+            output = output.permute(1, 0, 2)
+        return self.dropout(output) + identity
+
+
+CustomMSDeformableAttention = MultiScaleDeformableAttention
+
+
+class _MSDeformableAttention3D(_DeformAttnBase):
+    """Z-anchored deformable sampling without output projection / residual
+    (spatial_cross_attention_img.py:313-442 == spatial_cross_attention_pts.py:306-449)."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=8, im2col_step=64,
+                 dropout=0.1, batch_first=True, norm_cfg=None, init_cfg=None):
+        super().__init__(embed_dims, num_heads, num_levels, num_points, im2col_step, batch_first,
+                         norm_cfg, init_cfg, with_output_proj=False)
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None,
+                key_padding_mask=None, reference_points=None, spatial_shapes=None,
+                level_start_index=None, **kwargs):
+        if value is None:
+            value = query
+        if identity is None:
+            identity = query
+        if query_pos is not None:
+            query = query + query_pos
+        if not self.batch_first:
+            query = query.permute(1, 0, 2)
+            value = value.permute(1, 0, 2)
+        bs, num_query, _ = query.shape
+        bs, num_value, _ = value.shape
+        hw = static_hw(spatial_shapes)
+        assert sum(h * w for h, w in hw) == num_value
+        value = self.project_value(value, key_padding_mask)
+        H, L, P = self.num_heads, self.num_levels, self.num_points
+        if reference_points.shape[-1] != 2:
+            if reference_points.shape[-1] == 4:
+                assert False
+            raise ValueError(f'Last dim of reference_points must be 2 or 4, but get '
+                             f'{reference_points.shape[-1]} instead.')
+        num_Z_anchors = reference_points.shape[2]
+        assert P % num_Z_anchors == 0
+        if self.can_lift(value):
+            output = UF.bev_lift(value, self.offsets_and_logits(query),
+                                 reference_points.reshape(1, bs, num_query, num_Z_anchors, 2), 1,
+                                 hw[0], H, P, query_grid=kwargs.get('query_grid'))
+        else:
+            sampling_offsets = self.sampling_offsets(query).view(bs, num_query, H, L, P, 2)
+            attention_weights = self.attention_weights(query).view(bs, num_query, H, L * P)
+            attention_weights = attention_weights.softmax(-1).view(bs, num_query, H, L, P)
+            offset_normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+            sampling_offsets = sampling_offsets / offset_normalizer[None, None, None, :, None, :]
+            sampling_offsets = sampling_offsets.view(bs, num_query, H, L, P // num_Z_anchors,
+                                                     num_Z_anchors, 2)
+            sampling_locations = reference_points[:, :, None, None, None, :, :] + sampling_offsets
+            sampling_locations = sampling_locations.view(bs, num_query, H, L, P, 2)
+            output = self.k1(value, spatial_shapes, level_start_index, sampling_locations,
+                             attention_weights)
+        if not self.batch_first:
+            output = output.permute(1, 0, 2)
+        return output
+
+
+@ATTENTION.register_module(name=['MSDeformableAttention3DImg',
+                                 'MSDeformableAttention3DUniQueryImg'])
+class MSDeformableAttention3DImg(_MSDeformableAttention3D):
+    pass
+
+
+@ATTENTION.register_module()
+class MSDeformableAttention3DPts(_MSDeformableAttention3D):
+    pass

@@ -1,0 +1,276 @@
+"""Per-modality BEV encoders: ``ImgEncoder``/``ImgLayer`` and ``PtsEncoder``/``PtsLayer``.
+
+Reference: models/modules/encoder_unibev_detr_img.py and encoder_unibev_detr_pts.py (same
+registry keys, kwargs, forward signatures and state-dict layout).  Differences are mechanical:
+the pillar reference grids are cached per shape instead of rebuilt every forward, the camera
+projection + visibility runs as one HIP kernel (``functional.point_sampling``) whose per-camera
+visibility / count by-products are handed to the cross-attention, and the (1,2) shape tensors of
+the self-attention are built once per device.
+"""
+import copy
+import warnings
+
+import numpy as np
+import torch
+
+from .. import functional as UF
+from ..registry import TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE
+from .bricks import BaseTransformerLayer, TransformerLayerSequence
+from .deform_attn import shapes_tensor
+
+
+def pillar_axes(H, W, Z, num_points_in_pillar, device, dtype=torch.float32):
+    """Normalised 1-D pillar coordinates (xs[W], ys[H], zs[D]) with the reference's arithmetic
+    (encoder_unibev_detr_img.py:68-73): ``linspace(0.5, n - 0.5, n) / n``."""
+    # built on the host (torch CPU linspace is the parity target) and moved once; callers cache
+    zs = torch.linspace(0.5, Z - 0.5, num_points_in_pillar, dtype=dtype) / Z
+    xs = torch.linspace(0.5, W - 0.5, W, dtype=dtype) / W
+    ys = torch.linspace(0.5, H - 0.5, H, dtype=dtype) / H
+    xs, ys, zs = xs.to(device), ys.to(device), zs.to(device)
+    return xs, ys, zs
+
+
+def reference_points_3d(H, W, Z=8, num_points_in_pillar=4, bs=1, device='cuda',
+                        dtype=torch.float):
+    xs, ys, zs = pillar_axes(H, W, Z, num_points_in_pillar, device, dtype)
+    D = num_points_in_pillar
+    ref = torch.stack((xs.view(1, 1, W).expand(D, H, W), ys.view(1, H, 1).expand(D, H, W),
+                       zs.view(D, 1, 1).expand(D, H, W)), -1)            # (D, H, W, 3)
+    return ref.reshape(D, H * W, 3)[None].repeat(bs, 1, 1, 1)            # (bs, D, Nq, 3)
+
+
+def reference_points_2d(H, W, bs=1, device='cuda', dtype=torch.float):
+    xs, ys, _ = pillar_axes(H, W, 1, 1, device, dtype)
+    ref = torch.stack((xs.view(1, W).expand(H, W), ys.view(H, 1).expand(H, W)), -1)
+    return ref.reshape(1, H * W, 2).repeat(bs, 1, 1).unsqueeze(2)        # (bs, Nq, 1, 2)
+
+
+class _EncoderBase(TransformerLayerSequence):
+    def __init__(self, *args, pc_range=None, return_intermediate=False, dataset_type='nuscenes',
+                 **kwargs):
+        super().__init__(*args, **kwargs)
+        self.return_intermediate = return_intermediate
+        self.pc_range = pc_range
+        self.fp16_enabled = False
+        self._ref_cache = {}
+
+    @staticmethod
+    def get_reference_points(H, W, Z=8, num_points_in_pillar=4, dim='3d', bs=1, device='cuda',
+                             dtype=torch.float):
+        """Reference points of SCA ('3d': (bs, D, Nq, 3)) and self-attention ('2d':
+        (bs, Nq, 1, 2)); encoder_unibev_detr_img.py:45-109."""
+        if dim == '3d':
+            return reference_points_3d(H, W, Z, num_points_in_pillar, bs, device, dtype)
+        if dim == '2d':
+            return reference_points_2d(H, W, bs, device, dtype)
+        return None
+
+    def _cached(self, key, fn):
+        v = self._ref_cache.get(key)
+        if v is None:
+            v = fn()
+            if len(self._ref_cache) > 8:
+                self._ref_cache.clear()
+            self._ref_cache[key] = v
+        return v
+
+    def _run_layers(self, bev_query, key, value, args, layer_kwargs):
+        intermediate = []
+        output = bev_query
+        for layer in self.layers:
+            output = layer(bev_query, key, value, *args, **layer_kwargs)
+            bev_query = output
+            if self.return_intermediate:
+                intermediate.append(output)
+        if self.return_intermediate:
+            return torch.stack(intermediate)
+        return output
+
+
+def _lidar2img_tensor(img_metas, device):
+    """(B, Nc, 4, 4) float32 on ``device``.  Accepts the reference's numpy metas
+    (encoder_unibev_detr_img.py:115-124: one H2D copy per forward) or device-resident tensors."""
+    first = img_metas[0]['lidar2img']
+    if torch.is_tensor(first):
+        return torch.stack([m['lidar2img'] for m in img_metas]).to(device=device,
+                                                                    dtype=torch.float32)
+    if isinstance(first, (list, tuple)) and len(first) and torch.is_tensor(first[0]):
+        return torch.stack([torch.stack(list(m['lidar2img'])) for m in img_metas]).to(
+            device=device, dtype=torch.float32)
+    arr = np.asarray([m['lidar2img'] for m in img_metas])
+    # reference: reference_points.new_tensor(float64 array) -> rounds to f32
+    return torch.from_numpy(np.ascontiguousarray(arr.astype(np.float32))).to(device,
+                                                                             non_blocking=True)
+
+
+@TRANSFORMER_LAYER_SEQUENCE.register_module()
+class ImgEncoder(_EncoderBase):
+    def __init__(self, *args, pc_range=None, num_points_in_pillar=4, return_intermediate=False,
+                 dataset_type='nuscenes', **kwargs):
+        super().__init__(*args, pc_range=pc_range, return_intermediate=return_intermediate,
+                         dataset_type=dataset_type, **kwargs)
+        self.num_points_in_pillar = num_points_in_pillar
+
+    def point_sampling(self, reference_points, pc_range, img_metas, with_visibility=False):
+        """encoder_unibev_detr_img.py:112-187 on the GPU.  ``reference_points`` is the (bs, D, Nq, 3)
+        grid of ``get_reference_points``; returns reference_points_cam (Nc,B,Nq,D,2) and bev_mask
+        (Nc,B,Nq,D) bool [+ (vis0, count) when ``with_visibility``]."""
+        bs, D, Nq, _ = reference_points.shape
+        rp = reference_points[0].float()
+        # recover the separable axes of the grid: x varies fastest
+        W = int((rp[0, :, 1] == rp[0, 0, 1]).sum().item()) if Nq > 1 else 1
+        xs = rp[0, :W, 0].contiguous()
+        ys = rp[0, ::W, 1].contiguous()
+        zs = rp[:, 0, 2].contiguous()
+        return self._project(xs, ys, zs, pc_range, img_metas, rp.device, with_visibility)
+
+    def _project(self, xs, ys, zs, pc_range, img_metas, device, with_visibility):
+        l2i = _lidar2img_tensor(img_metas, device)
+        shape0 = img_metas[0]['img_shape'][0]
+        cam, mask, vis0, count = UF.point_sampling(l2i, xs, ys, zs, pc_range,
+                                                   (shape0[0], shape0[1]))
+        if with_visibility:
+            return cam, mask, vis0, count
+        return cam, mask
+
+    def forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,
+                spatial_shapes=None, level_start_index=None, valid_ratios=None, **kwargs):
+        """bev_query (Nq, bs, C); key/value (num_cam, sum hw, bs, C) -> (bs, Nq, C)."""
+        bs, dev, dt = bev_query.size(1), bev_query.device, bev_query.dtype
+        Z = self.pc_range[5] - self.pc_range[2]
+        D = self.num_points_in_pillar
+        axes = self._cached(('axes', bev_h, bev_w, Z, D, dev),
+                            lambda: pillar_axes(bev_h, bev_w, Z, D, dev))
+        ref_3d = self._cached(('3d', bev_h, bev_w, Z, D, bs, dev, dt),
+                              lambda: reference_points_3d(bev_h, bev_w, Z, D, bs, dev, dt))
+        ref_2d = self._cached(('2d', bev_h, bev_w, bs, dev, dt),
+                              lambda: reference_points_2d(bev_h, bev_w, bs, dev, dt))
+        cam, mask, vis0, count = self._project(*axes, self.pc_range, kwargs['img_metas'], dev, True)
+        bev_query = bev_query.permute(1, 0, 2)
+        if bev_pos is not None:
+            bev_pos = bev_pos.permute(1, 0, 2)
+        layer_kwargs = dict(kwargs, bev_pos=bev_pos, ref_2d=ref_2d, ref_3d=ref_3d, bev_h=bev_h,
+                            bev_w=bev_w, spatial_shapes=spatial_shapes,
+                            level_start_index=level_start_index, reference_points_cam=cam,
+                            bev_mask=mask, cam_vis0=vis0, cam_count=count,
+                            query_grid=(bev_h, bev_w))
+        return self._run_layers(bev_query, key, value, args, layer_kwargs)
+
+
+@TRANSFORMER_LAYER_SEQUENCE.register_module()
+class PtsEncoder(_EncoderBase):
+    def __init__(self, *args, pc_range=None, num_points_in_pillar_lidar=1,
+                 return_intermediate=False, dataset_type='nuscenes', **kwargs):
+        super().__init__(*args, pc_range=pc_range, return_intermediate=return_intermediate,
+                         dataset_type=dataset_type, **kwargs)
+        self.num_points_in_pillar_lidar = num_points_in_pillar_lidar
+
+    def point_sampling(self, reference_points):
+        """encoder_unibev_detr_pts.py:105-127: (bs, D, Nq, 3) -> xy as (D, bs, Nq, 2) plus the
+        in-range mask the caller discards (quirk q6)."""
+        rp = reference_points.clone().permute(1, 0, 2, 3)
+        lidar = rp[..., :2]
+        mask = ((lidar[..., 1:2] > 0.0) & (lidar[..., 1:2] < 1.0)
+                & (lidar[..., 0:1] < 1.0) & (lidar[..., 0:1] > 0.0))
+        return lidar, mask.permute(1, 2, 0, 3).squeeze(-1)
+
+    def forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,
+                spatial_shapes=None, level_start_index=None, valid_ratios=None, prev_bev=None,
+                shift=0., **kwargs):
+        bs, dev, dt = bev_query.size(1), bev_query.device, bev_query.dtype
+        Z = self.pc_range[5] - self.pc_range[2]
+        D = self.num_points_in_pillar_lidar
+        ref_3d = self._cached(('3d', bev_h, bev_w, Z, D, bs, dev, dt),
+                              lambda: reference_points_3d(bev_h, bev_w, Z, D, bs, dev, dt))
+        ref_2d = self._cached(('2d', bev_h, bev_w, bs, dev, dt),
+                              lambda: reference_points_2d(bev_h, bev_w, bs, dev, dt))
+        lidar = self._cached(('lidar', bev_h, bev_w, Z, D, bs, dev, dt),
+                             lambda: self.point_sampling(ref_3d)[0].contiguous())
+        bev_query = bev_query.permute(1, 0, 2)
+        if bev_pos is not None:
+            bev_pos = bev_pos.permute(1, 0, 2)
+        layer_kwargs = dict(kwargs, bev_pos=bev_pos, ref_2d=ref_2d, ref_3d=ref_3d, bev_h=bev_h,
+                            bev_w=bev_w, spatial_shapes=spatial_shapes,
+                            level_start_index=level_start_index, reference_points_lidar=lidar,
+                            query_grid=(bev_h, bev_w))
+        return self._run_layers(bev_query, key, value, args, layer_kwargs)
+
+
+class _BevLayer(BaseTransformerLayer):
+    """Post-norm layer ('self_attn','norm','cross_attn','norm','ffn','norm'); the loop follows
+    encoder_unibev_detr_img.py:395-481 including its positional-encoding quirk q4: the
+    self-attention receives ``bev_pos``, the cross-attention (attn index 1) receives
+    ``query_pos`` = None."""
+
+    cross_kw = ()
+
+    def __init__(self, attn_cfgs, feedforward_channels, ffn_dropout=0.0, operation_order=None,
+                 act_cfg=dict(type='ReLU', inplace=True), norm_cfg=dict(type='LN'),
+                 batch_first=True, ffn_num_fcs=2, **kwargs):
+        super().__init__(attn_cfgs=attn_cfgs, feedforward_channels=feedforward_channels,
+                         ffn_dropout=ffn_dropout, operation_order=operation_order, act_cfg=act_cfg,
+                         norm_cfg=norm_cfg, ffn_num_fcs=ffn_num_fcs, batch_first=batch_first,
+                         **kwargs)
+        self.fp16_enabled = False
+        self._self_shapes = {}
+
+    def _bev_shapes(self, bev_h, bev_w, device):
+        key = (bev_h, bev_w, device)
+        v = self._self_shapes.get(key)
+        if v is None:
+            v = (shapes_tensor([(bev_h, bev_w)], device),
+                 torch.zeros(1, dtype=torch.long, device=device))
+            self._self_shapes[key] = v
+        return v
+
+    def forward(self, query, key=None, value=None, bev_pos=None, query_pos=None, key_pos=None,
+                attn_masks=None, query_key_padding_mask=None, key_padding_mask=None, ref_2d=None,
+                ref_3d=None, bev_h=None, bev_w=None, mask=None, spatial_shapes=None,
+                level_start_index=None, **kwargs):
+        norm_index = attn_index = ffn_index = 0
+        identity = query
+        if attn_masks is None:
+            attn_masks = [None for _ in range(self.num_attn)]
+        elif isinstance(attn_masks, torch.Tensor):
+            attn_masks = [copy.deepcopy(attn_masks) for _ in range(self.num_attn)]
+            warnings.warn(f'Use same attn_mask in all attentions in {self.__class__.__name__} ')
+        else:
+            assert len(attn_masks) == self.num_attn, \
+                f'The length of attn_masks {len(attn_masks)} must be equal to the number of ' \
+                f'attention in operation_order {self.num_attn}'
+        for layer in self.operation_order:
+            if layer == 'self_attn':
+                ss, lsi = self._bev_shapes(bev_h, bev_w, query.device)
+                query = self.attentions[attn_index](
+                    query, query, query, identity if self.pre_norm else None, query_pos=bev_pos,
+                    key_pos=bev_pos, attn_mask=attn_masks[attn_index],
+                    key_padding_mask=query_key_padding_mask, reference_points=ref_2d,
+                    spatial_shapes=ss, level_start_index=lsi, bev_h=bev_h, bev_w=bev_w, **kwargs)
+                attn_index += 1
+                identity = query
+            elif layer == 'norm':
+                query = self.norms[norm_index](query)
+                norm_index += 1
+            elif layer == 'cross_attn':
+                pos = (bev_pos, bev_pos) if attn_index == 0 else (query_pos, key_pos)
+                query = self.attentions[attn_index](
+                    query, key, value, identity if self.pre_norm else None, query_pos=pos[0],
+                    key_pos=pos[1], reference_points=ref_3d, mask=mask,
+                    attn_mask=attn_masks[attn_index], key_padding_mask=key_padding_mask,
+                    spatial_shapes=spatial_shapes, level_start_index=level_start_index, **kwargs)
+                attn_index += 1
+                identity = query
+            elif layer == 'ffn':
+                query = self.ffns[ffn_index](query, identity if self.pre_norm else None)
+                ffn_index += 1
+        return query
+
+
+@TRANSFORMER_LAYER.register_module()
+class ImgLayer(_BevLayer):
+    pass
+
+
+@TRANSFORMER_LAYER.register_module()
+class PtsLayer(_BevLayer):
+    pass

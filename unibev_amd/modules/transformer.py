@@ -1,0 +1,282 @@
+"""``UniBEVTransformer``: both BEV encoders, CNW / spatial normalisation and linear | avg | cat fusion.
+
+Reference: models/modules/transformer_fusion.py:49-586 (registry key, constructor kwargs,
+parameter names, forward signature and return tuple are the same).  The encoder+fusion part
+(:463-549) is the hot path; the object-query decoder (:572-582) is a consumer that is built
+when its config type is registered and skipped otherwise.
+
+MI355X form of the glue:
+  * ``_pre_process_*``: one LDS-tiled transpose kernel adds the camera / level embeddings while
+    it flattens (``functional.flatten_embed``) and writes the [bs][cam][hw][C] layout the value
+    projection reads, exposed as the reference's (num_cam, hw, bs, C) view.
+  * channel/spatial normalisation + fusion + the final (bs,Nq,C)->(Nq,bs,C*s) permute: one kernel
+    (``functional.bev_fuse``); the 2xC CNW softmax stays a tiny torch op so autograd reaches the
+    ``*_channel_weights`` parameters.
+  * modality dropout draws from ``np.random`` exactly like the reference (:227-228, 463-477), so a
+    seeded run drops the same modalities.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.init import constant_, normal_
+
+from .. import functional as UF
+from ..registry import (TRANSFORMER, TRANSFORMER_LAYER_SEQUENCE,
+                        build_transformer_layer_sequence)
+from .bricks import BaseModule, xavier_init
+from .deform_attn import _DeformAttnBase, shapes_tensor
+
+_UNSUPPORTED_NORMS = ('MLP_ChannelNormWeights', 'Leaky_ReLU_MLP_ChannelNormWeights',
+                      'ELU_MLP_ChannelNormWeights', 'Sigmoid_MLP_ChannelNormWeights',
+                      'ModalityProjection')
+
+
+@TRANSFORMER.register_module()
+class UniBEVTransformer(BaseModule):
+    def __init__(self, num_feature_levels=4, num_cams=6, two_stage_num_proposals=300,
+                 img_encoder=None, pts_encoder=None, decoder=None, embed_dims=256,
+                 use_cams_embeds=True, fusion_method='linear', drop_modality=None,
+                 feature_norm=None, spatial_norm=None, use_modal_embeds=None, bev_h=200,
+                 bev_w=200, dual_queries=False, vis_output=None, cna_constant_init=None,
+                 **kwargs):
+        super().__init__(**kwargs)
+        if img_encoder is not None:
+            self.img_bev_encoder = build_transformer_layer_sequence(img_encoder)
+        if pts_encoder is not None:
+            self.pts_bev_encoder = build_transformer_layer_sequence(pts_encoder)
+        # The decoder consumes fused_bev_embed; it is outside the hot path.
+        self.decoder = None
+        if decoder is not None and decoder.get('type') in TRANSFORMER_LAYER_SEQUENCE:
+            self.decoder = build_transformer_layer_sequence(decoder)
+        self.dual_queries = dual_queries
+        self.embed_dims = embed_dims
+        self.num_feature_levels = num_feature_levels
+        self.num_cams = num_cams
+        self.fp16_enabled = False
+        self.cna_constant_norm = cna_constant_init
+        self.bev_h = bev_h
+        self.bev_w = bev_w
+        self.use_cams_embeds = use_cams_embeds
+        self.fusion_method = fusion_method
+        if fusion_method in ('linear', 'avg'):
+            self.scale_factor = 1
+        elif fusion_method == 'cat':
+            self.scale_factor = 2
+        else:
+            raise ValueError('Unrecognizable fusion method:{}'.format(fusion_method))
+        self.drop_modality = drop_modality
+        self.feature_norm = feature_norm
+        self.spatial_norm = spatial_norm
+        self.use_modal_embeds = use_modal_embeds
+        self.two_stage_num_proposals = two_stage_num_proposals
+        self.vis_output = vis_output
+        self.l_flag = 1
+        self.c_flag = 1
+        self.init_layers()
+
+    @property
+    def with_img_bev_encoder(self):
+        return getattr(self, 'img_bev_encoder', None) is not None
+
+    @property
+    def with_pts_bev_encoder(self):
+        return getattr(self, 'pts_bev_encoder', None) is not None
+
+    def init_layers(self):
+        """Parameter names follow transformer_fusion.py:130-182 (they are checkpoint keys)."""
+        if self.feature_norm == 'ChannelNormWeights':
+            self.feature_norm_layer = nn.Softmax(dim=0)
+            self.pts_channel_weights = nn.Parameter(torch.Tensor(self.embed_dims))
+            self.img_channel_weights = nn.Parameter(torch.Tensor(self.embed_dims))
+        elif self.feature_norm in _UNSUPPORTED_NORMS:
+            raise NotImplementedError(
+                f'feature_norm={self.feature_norm!r}: experimental variant of the reference '
+                f'(transformer_fusion.py:136-155) that no shipped config selects')
+        if self.spatial_norm == 'SpatialNormWeights':
+            self.spatial_norm_layer = nn.Softmax(dim=0)
+            self.pts_spatial_weights = nn.Parameter(torch.Tensor(self.bev_h * self.bev_w))
+            self.img_spatial_weights = nn.Parameter(torch.Tensor(self.bev_h * self.bev_w))
+        if self.with_img_bev_encoder:
+            self.img_level_embeds = nn.Parameter(torch.Tensor(self.num_feature_levels,
+                                                              self.embed_dims))
+            self.cams_embeds = nn.Parameter(torch.Tensor(self.num_cams, self.embed_dims))
+        if self.with_pts_bev_encoder:
+            self.pts_level_embeds = nn.Parameter(torch.Tensor(self.num_feature_levels,
+                                                              self.embed_dims))
+        if self.use_modal_embeds is not None:
+            raise NotImplementedError('use_modal_embeds: unused by every shipped config '
+                                      '(transformer_fusion.py:172-180, 306-312)')
+        self.reference_points = nn.Linear(self.embed_dims * self.scale_factor, 3)
+
+    def init_weights(self):
+        """transformer_fusion.py:184-225."""
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, _DeformAttnBase):
+                m.init_weights()
+        if self.with_pts_bev_encoder:
+            normal_(self.pts_level_embeds)
+        if self.with_img_bev_encoder:
+            normal_(self.img_level_embeds)
+            normal_(self.cams_embeds)
+        if self.feature_norm == 'ChannelNormWeights':
+            if self.cna_constant_norm is True:
+                constant_(self.pts_channel_weights, 0.5)
+                constant_(self.img_channel_weights, 0.5)
+            else:
+                normal_(self.pts_channel_weights)
+                normal_(self.img_channel_weights)
+        if self.spatial_norm == 'SpatialNormWeights':
+            normal_(self.pts_spatial_weights)
+            normal_(self.img_spatial_weights)
+        xavier_init(self.reference_points, distribution='uniform', bias=0.)
+
+    def get_probability(self, prob):
+        return True if np.random.random() < prob else False
+
+    # -- feature flattening ---------------------------------------------------------------------
+    def _pre_process_img_feats(self, mlvl_img_feats, bev_queries):
+        """list[(bs, Nc, C, h, w)] -> ((Nc, sum hw, bs, C) view, spatial_shapes, level_start_index);
+        transformer_fusion.py:230-255."""
+        flat, shapes = [], []
+        for lvl, feat in enumerate(mlvl_img_feats):
+            bs, num_cam, c, h, w = feat.shape
+            tok = UF.flatten_embed(feat.reshape(bs * num_cam, c, h * w),
+                                   self.cams_embeds if self.use_cams_embeds else None,
+                                   self.img_level_embeds[lvl])
+            flat.append(tok.view(bs, num_cam, h * w, c))
+            shapes.append((h, w))
+        flat = flat[0] if len(flat) == 1 else torch.cat(flat, 2)
+        spatial_shapes = shapes_tensor(shapes, bev_queries.device)
+        starts = np.concatenate(([0], np.cumsum([h * w for h, w in shapes])[:-1]))
+        level_start_index = torch.as_tensor(starts, dtype=torch.long, device=bev_queries.device)
+        return flat.permute(1, 2, 0, 3), spatial_shapes, level_start_index
+
+    def _pre_process_pts_feats(self, mlvl_pts_feats, bev_queries):
+        """list[(bs, C, h, w)] -> ((sum hw, bs, C) view, ...); transformer_fusion.py:257-278.
+        The reference concatenates levels on the channel axis (:272), which only works for one
+        level; more than one level is rejected here instead of silently mis-shaped."""
+        if len(mlvl_pts_feats) != 1:
+            raise ValueError('pts features: the reference path supports exactly one level')
+        feat = mlvl_pts_feats[0]
+        bs, c, h, w = feat.shape
+        tok = UF.flatten_embed(feat.reshape(bs, c, h * w), None, self.pts_level_embeds[0])
+        spatial_shapes = shapes_tensor([(h, w)], bev_queries.device)
+        level_start_index = torch.zeros(1, dtype=torch.long, device=bev_queries.device)
+        return tok.permute(1, 0, 2), spatial_shapes, level_start_index
+
+    # -- fusion ----------------------------------------------------------------------------------
+    def _channel_factors(self, device):
+        """Per-channel factors of (img, pts): CNW softmax (transformer_fusion.py:323-337) times the
+        fusion rule's modality scalar (:282-302)."""
+        C = self.embed_dims
+        c, l = float(self.c_flag), float(self.l_flag)
+        if self.fusion_method == 'avg':
+            c, l = c / (self.c_flag + self.l_flag), l / (self.c_flag + self.l_flag)
+        if self.feature_norm == 'ChannelNormWeights':
+            fw = torch.stack((self.img_channel_weights, self.pts_channel_weights), 0)
+            if self.c_flag == 1 and self.l_flag == 1:
+                n = self.feature_norm_layer(fw)
+                iw, pw = n[0], n[1]
+            else:
+                iw = self.feature_norm_layer(fw[0:1])[0]
+                pw = self.feature_norm_layer(fw[1:2])[0]
+            return iw * c, pw * l
+        one = torch.ones(C, dtype=torch.float32, device=device)
+        return one * c, one * l
+
+    def _spatial_factors(self):
+        if self.spatial_norm != 'SpatialNormWeights':
+            return None, None
+        sw = torch.stack((self.img_spatial_weights, self.pts_spatial_weights), 0)
+        if self.c_flag == 1 and self.l_flag == 1:
+            n = self.spatial_norm_layer(sw)
+            return n[0], n[1]
+        return self.spatial_norm_layer(sw[:1])[0], self.spatial_norm_layer(sw[1:])[0]
+
+    def fuse(self, img_bev_embed, pts_bev_embed):
+        """channel_feature_norm -> spatial_feature_norm -> multi_modal_fusion -> permute
+        (transformer_fusion.py:535-549) as one kernel.  Returns (Nq, bs, C*s)."""
+        ref = img_bev_embed if img_bev_embed is not None else pts_bev_embed
+        cw_img, cw_pts = self._channel_factors(ref.device)
+        sw_img, sw_pts = self._spatial_factors()
+        return UF.bev_fuse(img_bev_embed, pts_bev_embed, cw_img, cw_pts, sw_img, sw_pts,
+                           cat=self.fusion_method == 'cat')
+
+    # -- forward ---------------------------------------------------------------------------------
+    def _draw_modality_flags(self, img_mlvl_feats, pts_mlvl_feats):
+        self.l_flag = 1
+        self.c_flag = 1
+        if self.drop_modality is not None and self.training is True:
+            if isinstance(self.drop_modality, dict):
+                dropout_prob = self.drop_modality['dropout_prob']
+                lidar_prob = self.drop_modality['lidar_prob']
+            elif isinstance(self.drop_modality, float):
+                dropout_prob = lidar_prob = self.drop_modality
+            else:
+                raise ValueError('Unrecognized type: {}'.format(type(self.drop_modality)))
+            if self.get_probability(dropout_prob):
+                self.l_flag = self.get_probability(lidar_prob) * 1
+                self.c_flag = 1 - self.l_flag
+        if img_mlvl_feats is None:
+            self.c_flag = 0
+            return pts_mlvl_feats[0].size(0)
+        if pts_mlvl_feats is None:
+            self.l_flag = 0
+        return img_mlvl_feats[0].size(0)
+
+    def encode(self, img_mlvl_feats, pts_mlvl_feats, bev_queries, bev_h, bev_w, bev_pos=None,
+               return_parts=False, **kwargs):
+        """The hot path: everything of ``forward`` up to ``fused_bev_embed`` (Nq, bs, C*s)."""
+        bs = self._draw_modality_flags(img_mlvl_feats, pts_mlvl_feats)
+        if bev_pos is not None:
+            bev_pos = bev_pos.flatten(2).permute(2, 0, 1)
+        if self.dual_queries:
+            assert isinstance(bev_queries, list)
+            q_img = bev_queries[0].unsqueeze(1).expand(-1, bs, -1)
+            q_pts = bev_queries[1].unsqueeze(1).expand(-1, bs, -1)
+        else:
+            q_img = q_pts = bev_queries.unsqueeze(1).expand(-1, bs, -1)
+        img_bev_embed = pts_bev_embed = None
+        if img_mlvl_feats is not None:
+            flat, ss, lsi = self._pre_process_img_feats(img_mlvl_feats, q_img)
+            img_bev_embed = self.img_bev_encoder(q_img, flat, flat, bev_h=bev_h, bev_w=bev_w,
+                                                 bev_pos=bev_pos, spatial_shapes=ss,
+                                                 level_start_index=lsi, **kwargs)
+        if pts_mlvl_feats is not None:
+            flat, ss, lsi = self._pre_process_pts_feats(pts_mlvl_feats, q_pts)
+            pts_bev_embed = self.pts_bev_encoder(q_pts, flat, flat, bev_h=bev_h, bev_w=bev_w,
+                                                 bev_pos=bev_pos, spatial_shapes=ss,
+                                                 level_start_index=lsi, **kwargs)
+        fused = self.fuse(img_bev_embed, pts_bev_embed)
+        if return_parts:
+            return fused, img_bev_embed, pts_bev_embed
+        return fused
+
+    def forward(self, img_mlvl_feats, pts_mlvl_feats, bev_queries, object_query_embed, bev_h,
+                bev_w, bev_pos=None, reg_branches=None, cls_branches=None, **kwargs):
+        """-> (fused_bev_embed (Nq, bs, C*s), inter_states, init_reference_out,
+        inter_references_out); transformer_fusion.py:416-586."""
+        kwargs.pop('grid_length', None) if self.decoder is None else None
+        fused_bev_embed = self.encode(img_mlvl_feats, pts_mlvl_feats, bev_queries, bev_h, bev_w,
+                                      bev_pos=bev_pos, **kwargs)
+        bs = fused_bev_embed.size(1)
+        query_pos, query = torch.split(object_query_embed, self.embed_dims * self.scale_factor,
+                                       dim=1)
+        query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)
+        query = query.unsqueeze(0).expand(bs, -1, -1)
+        reference_points = self.reference_points(query_pos).sigmoid()
+        init_reference_out = reference_points
+        if self.decoder is None:
+            return fused_bev_embed, None, init_reference_out, None
+        query = query.permute(1, 0, 2)
+        query_pos = query_pos.permute(1, 0, 2)
+        inter_states, inter_references = self.decoder(
+            query=query, key=None, value=fused_bev_embed, query_pos=query_pos,
+            reference_points=reference_points, reg_branches=reg_branches,
+            cls_branches=cls_branches,
+            spatial_shapes=shapes_tensor([(bev_h, bev_w)], query.device),
+            level_start_index=torch.zeros(1, dtype=torch.long, device=query.device), **kwargs)
+        return fused_bev_embed, inter_states, init_reference_out, inter_references
