@@ -270,8 +270,10 @@ static int k1_dispatch(const K1Args& a, int dtype, bool bwd, void* stream) {
                 "ms_deform_attn: non-positive dimension (B=%d S=%d H=%d Dh=%d L=%d Nq=%d P=%d)",
                 a.B, a.S, a.H, a.Dh, a.L, a.Nq, a.P);
   UBV_CHECK_ARG(a.L <= kMaxLevels, "ms_deform_attn: at most %d levels (got %d)", kMaxLevels, a.L);
+  if (a.Nq == 0) return UBV_OK;                 // empty query set: nothing to do, nothing to check
   UBV_CHECK_ARG(a.value && a.ss && a.ls && a.loc && a.aw, "ms_deform_attn: null input pointer");
-  if (a.Nq == 0) return UBV_OK;
+  UBV_CHECK_ARG(bwd ? (a.gout && a.gvalue && a.gloc && a.gaw) : (a.out != nullptr),
+                "ms_deform_attn: null output / gradient pointer");
   hipStream_t st = as_stream(stream);
   switch (dtype) {
     case UBV_F32: dispatch_T<float>(a, bwd, st); break;
@@ -293,7 +295,6 @@ extern "C" int ubv_ms_deform_attn_forward(const void* value, const int64_t* spat
   (void)im2col_step;
   ubv::K1Args a{value, spatial_shapes, level_start, sampling_loc, attn_weight, out, nullptr,
                 nullptr, nullptr, nullptr, B, S, H, Dh, L, Nq, P};
-  UBV_CHECK_ARG(out != nullptr, "ms_deform_attn_forward: null output");
   return ubv::k1_dispatch(a, dtype, false, stream);
 }
 
@@ -307,7 +308,5 @@ extern "C" int ubv_ms_deform_attn_backward(const void* value, const int64_t* spa
   (void)im2col_step;
   ubv::K1Args a{value, spatial_shapes, level_start, sampling_loc, attn_weight, nullptr, grad_out,
                 grad_value, grad_sampling_loc, grad_attn_weight, B, S, H, Dh, L, Nq, P};
-  UBV_CHECK_ARG(grad_out && grad_value && grad_sampling_loc && grad_attn_weight,
-                "ms_deform_attn_backward: null gradient pointer");
   return ubv::k1_dispatch(a, dtype, true, stream);
 }

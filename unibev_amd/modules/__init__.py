@@ -1,5 +1,6 @@
 from .bricks import (FFN, BaseModule, BaseTransformerLayer, DetrTransformerDecoderLayer,  # noqa
                      LearnedPositionalEncoding, MultiheadAttention, TransformerLayerSequence)
+from .decoder import DetectionTransformerDecoder  # noqa
 from .deform_attn import (CustomMSDeformableAttention, MSDeformableAttention3DImg,  # noqa
                           MSDeformableAttention3DPts, MultiScaleDeformableAttention)
 from .head import UniBEV_Head, inverse_sigmoid  # noqa

@@ -13,11 +13,7 @@ import torch.nn as nn
 
 from ..registry import HEADS, build_positional_encoding, build_transformer
 from .bricks import BaseModule
-
-
-def inverse_sigmoid(x, eps=1e-5):
-    x = x.clamp(min=0, max=1)
-    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+from .decoder import inverse_sigmoid
 
 
 @HEADS.register_module()
