@@ -112,7 +112,7 @@ def lift_bytes(name, geom, esize):
     """Algorithmic (compulsory) HBM bytes of one bev_lift launch: every input read once, every
     output written once, gathers not counted; offsets / logits / refs /
     grads f32, values `esize` bytes."""
-    B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh = geom
+    B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh = geom[:11]
     C, S = H * Dh, fh * fw
     value = B * Nc * S * C * esize
     offlog = B * Nq * H * P * 3 * 4
@@ -210,7 +210,7 @@ def main():
             for kind in ('fwd', 'bwd'):
                 groups = {}
                 for ms, (geom, esize) in prof.get('lift_' + kind, []):
-                    B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh = geom
+                    B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh = geom[:11]
                     inst = ('self-attn' if (Z == 1 and P == 4) else
                             ('SCA-img' if Nc > 1 else 'SCA-pts'))
                     key = f'bev_lift_{kind}<P={P}> {inst} (Nc={Nc}, map {fh}x{fw}, Nq={Nq}, B={B})'

@@ -96,7 +96,7 @@ int ubv_ms_deform_attn_backward(const void* value, const int64_t* spatial_shapes
  *   loc = ref + offsets / (fw, fh);  w = softmax_P(logits)
  * qgrid_w/qgrid_h: if Nq == qgrid_w*qgrid_h the queries are walked in 8x8 tiles of that grid
  * (L2 locality); pass 0 for raster order.
- * Supported: P in {4, 8}; H*Dh*sizeof(16 B vector)/... see ubv_fused_supported().
+ * Supported shapes: see ubv_bev_lift_supported() (Dh in {16, 32}, P in {4, 8}).
  */
 int ubv_bev_lift_forward(const void* value, const float* offsets, int64_t off_stride,
                          const float* logits, int64_t log_stride, const float* ref,
@@ -105,16 +105,32 @@ int ubv_bev_lift_forward(const void* value, const float* offsets, int64_t off_st
                          int dtype, void* stream);
 
 /*   grad_out     [B, Nq, H*Dh]       dtype
- *   grad_value   [B*Nc, S, H, Dh]    f32, ACCUMULATED
+ *   grad_value   [B*Nc, S, H, Dh]    f32, WRITTEN (previous content ignored; zeroed internally
+ *                                    only on the paths that accumulate)
  *   grad_offsets row (b,q) at grad_offsets + (b*Nq+q)*goff_stride : [H, P, 2] f32, written
  *   grad_logits  row (b,q) at grad_logits  + (b*Nq+q)*glog_stride : [H, P]    f32, written
+ *   ref_is_grid  1 iff Nc == 1 and ref[0,b,q,z] == ((qx+.5)/qgrid_w, (qy+.5)/qgrid_h) for every z
+ *                (BEV self-attention and SCA-pts: the references are the BEV grid itself).  Selects
+ *                the owner-tile grad_value kernel (LDS accumulation, no global atomics except for
+ *                sampling points farther than P+2 pixels from their reference).  0 is always safe.
+ *   slot_center  [H, P, 2] f32 or NULL: where each sampling slot (h, p) lands relative to its
+ *                reference when the learned offset equals the sampling_offsets bias, in pixels.
+ *                A speed hint for the owner tiles (they search a 3-pixel window around it instead
+ *                of P+2 around the reference); results do not depend on it.
+ *   workspace    scratch of at least ubv_bev_lift_backward_workspace(...) bytes (may be NULL when
+ *                that is 0): per-point records for the owner tiles / per-camera visible-query lists.
  */
+int64_t ubv_bev_lift_backward_workspace(int B, int Nc, int fh, int fw, int H, int Dh, int Nq, int P,
+                                        int qgrid_w, int qgrid_h, int ref_is_grid);
+
 int ubv_bev_lift_backward(const void* value, const float* offsets, int64_t off_stride,
                           const float* logits, int64_t log_stride, const float* ref,
-                          const uint8_t* vis0, const float* count, const void* grad_out,
-                          float* grad_value, float* grad_offsets, int64_t goff_stride,
+                          const uint8_t* vis0, const float* count, const float* slot_center,
+                          const void* grad_out, float* grad_value, float* grad_offsets,
+                          int64_t goff_stride,
                           float* grad_logits, int64_t glog_stride, int B, int Nc, int fh, int fw,
-                          int H, int Dh, int Nq, int P, int Z, int qgrid_w, int qgrid_h, int dtype,
+                          int H, int Dh, int Nq, int P, int Z, int qgrid_w, int qgrid_h,
+                          int ref_is_grid, int dtype, void* workspace, int64_t workspace_bytes,
                           void* stream);
 
 /* 1 if ubv_bev_lift_* has a kernel for this shape, else 0 (callers then compose k1). */

@@ -125,3 +125,81 @@ def test_lift_equals_k1_composition_at_full_size():
     ls = torch.zeros(1, dtype=torch.long, device=DEV)
     comp = ms_deform_attn(value.view(B, -1, H, Dh), ss, ls, loc.contiguous(), aw.contiguous())
     torch.testing.assert_close(fused, comp, rtol=2e-5, atol=2e-5)
+
+
+def grid_ref(B, qh, qw, Z):
+    ys, xs = np.meshgrid(np.arange(qh), np.arange(qw), indexing='ij')
+    r = np.stack(((xs + 0.5) / qw, (ys + 0.5) / qh), -1).reshape(1, 1, qh * qw, 1, 2).astype(np.float32)
+    return np.broadcast_to(r, (1, B, qh * qw, Z, 2)).copy()
+
+
+@pytest.mark.parametrize('case', [
+    # B, fh, fw, H, Dh, qh, qw, P, Z, offset sigma (pixels)
+    (2, 37, 41, 8, 32, 40, 45, 8, 4, 3.0),     # SCA-pts class, partial edge tiles
+    (1, 50, 50, 8, 32, 50, 50, 4, 1, 2.0),     # self-attn class
+    (2, 33, 20, 8, 32, 36, 23, 8, 4, 9.0),     # many points beyond the near radius: atomic fallback
+    (1, 48, 64, 8, 16, 52, 70, 4, 1, 4.0),     # Dh = 16
+    (1, 16, 16, 8, 32, 16, 16, 8, 4, 30.0),    # offsets larger than the map
+])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_lift_backward_owner_tiles_grid_mode(case, dtype):
+    """grad_value by LDS owner tiles (BEV-grid references) == the fp64 oracle, for offsets inside
+    and outside the near radius, and == the all-atomics kernel."""
+    from unibev_amd.functional import bev_lift
+    B, fh, fw, H, Dh, qh, qw, P, Z, sig = case
+    rs = np.random.RandomState(11)
+    Nq, C, S = qh * qw, H * Dh, fh * fw
+    value = rs.standard_normal((B, S, C))
+    # offsets scatter (sigma `sig` pixels) around a per-slot centre, like a trained
+    # sampling_offsets layer: bias + W q
+    center = (rs.standard_normal(H * P * 2) * 4.0).astype(np.float32)
+    offlog = np.concatenate([center[None, None] + rs.standard_normal((B, Nq, H * P * 2)) * sig,
+                             rs.standard_normal((B, Nq, H * P))], -1)
+    ref = grid_ref(B, qh, qw, Z)
+    gout = rs.standard_normal((B, Nq, C))
+    if dtype != torch.float32:          # make the 16-bit inputs exactly representable
+        value = t(value).to(dtype).double().numpy()
+        gout = t(gout).to(dtype).double().numpy()
+    v64, ol64 = t(value).requires_grad_(), t(offlog).requires_grad_()
+    o_ref = oracle_lift(v64, ol64, t(ref).double(), None, None, 1, fh, fw, H, P)
+    o_ref.backward(t(gout))
+    grads = {}
+    for grid in (True, 'centred', False):
+        v = t(value, dtype, DEV).requires_grad_()
+        ol = t(offlog, torch.float32, DEV).requires_grad_()
+        out = bev_lift(v, ol, t(ref, torch.float32, DEV), 1, (fh, fw), H, P, query_grid=(qh, qw),
+                       ref_is_grid=bool(grid),
+                       slot_center=t(center, device=DEV) if grid == 'centred' else None)
+        out.backward(t(gout, dtype, DEV))
+        grads[grid] = (v.grad.float().cpu().numpy(), ol.grad.cpu().numpy())
+    tol = 2e-4 if dtype == torch.float32 else 2e-2
+    scale = np.abs(v64.grad.numpy()).max()
+    for grid in (True, 'centred', False):
+        np.testing.assert_allclose(grads[grid][0], v64.grad.numpy(), rtol=tol, atol=tol * scale)
+        # d/d(offset) is discontinuous where a sampling point sits exactly on a pixel boundary
+        # (grid-centred references put points within f32 round-off of one now and then): allow a
+        # handful of such elements, everything else must agree
+        bad = ~np.isclose(grads[grid][1], ol64.grad.numpy(), rtol=2e-4, atol=1e-3)
+        assert bad.sum() <= 1e-5 * bad.size + 1, int(bad.sum())
+
+
+def test_lift_backward_camera_mode_bands_and_chunks():
+    """SCA-img maps of the three BASELINE sizes: 8x22 (one band), 25x45 and 29x50 (row bands),
+    6 cameras, visibility + count; grad_value vs the fp64 oracle."""
+    from unibev_amd.functional import bev_lift
+    for (fh, fw, Dh) in [(8, 22, 32), (25, 45, 16), (29, 50, 32)]:
+        case = (2, 6, fh, fw, 8, Dh, 30, 33, 8, 4)
+        B, Nc, fh, fw, H, Dh, qh, qw, P, Z = case
+        value, offlog, ref, vis0, count, gout = make_case(case, 13, True)
+        v64, ol64 = t(value).requires_grad_(), t(offlog).requires_grad_()
+        o_ref = oracle_lift(v64, ol64, t(ref), t(vis0), t(count).double(), Nc, fh, fw, H, P)
+        o_ref.backward(t(gout))
+        v = t(value, torch.float32, DEV).requires_grad_()
+        ol = t(offlog, torch.float32, DEV).requires_grad_()
+        out = bev_lift(v, ol, t(ref, torch.float32, DEV), Nc, (fh, fw), H, P,
+                       vis0=t(vis0, device=DEV), count=t(count, device=DEV), query_grid=(qh, qw))
+        out.backward(t(gout, torch.float32, DEV))
+        scale = np.abs(v64.grad.numpy()).max()
+        np.testing.assert_allclose(v.grad.cpu().numpy(), v64.grad.numpy(), rtol=2e-4, atol=2e-4 * scale)
+        bad = ~np.isclose(ol.grad.cpu().numpy(), ol64.grad.numpy(), rtol=2e-4, atol=1e-3)
+        assert bad.sum() <= 1e-5 * bad.size + 1, int(bad.sum())       # pixel-boundary discontinuities

@@ -19,6 +19,8 @@
 // wave64 holds 64/(H*LP) queries).  Work decomposition: a 256-thread block owns an 8x8 tile of
 // the BEV query grid (neighbouring queries sample neighbouring pixels: L1/L2 reuse), and tiles
 // are dealt to XCDs in contiguous bands so a band's value rows stay in one XCD's L2.
+#include <stdlib.h>
+
 #include "ubv_common.h"
 
 namespace ubv {
@@ -29,6 +31,10 @@ struct LiftArgs {
   void* out;                                     // fwd
   const void* gout; float* gvalue; float* goff; long goff_stride; float* glog; long glog_stride;
   int B, Nc, fh, fw, H, Nq, Z, qw, qh, tiles_x, tiles_per_sample, total_tiles, chunk;
+  int R;                                         // near radius (pixels) of the owner-tile backward
+  float4* rec;                                   // [B,Nq,H,P] (x_pix, y_pix, w/count, -) or null
+  int* cam_list; int* cam_n;                     // per-camera compacted visible queries or null
+  const float* center;                           // [H,P,2] slot centres in pixels or null
 };
 
 // Decode (b, q, valid) of the query this lane works on in iteration `it`.
@@ -130,8 +136,30 @@ __global__ __launch_bounds__(256) void lift_fwd_kernel(const LiftArgs a) {
   }
 }
 
-template <typename T, int DH, int VEC, int P>
-__global__ __launch_bounds__(256) void lift_bwd_kernel(const LiftArgs a) {
+// ------------------------------------------------------------------------------------------------
+// Backward, part 1 — per-query gradients (d offsets, d logits): the forward's gather plus dot
+// products with grad_out, reduced over the Dh lanes with wave shuffles.  ATOMICS selects who
+// scatters grad_value:
+//   kAtomAll : this kernel, one hardware f32 atomic per (corner, channel) — the mmcv scheme; kept for
+//              arbitrary reference points on large maps.
+//   kAtomFar : only corners farther than R pixels (Chebyshev) from the point's home pixel; the
+//              owner-tile kernel below takes every near corner without atomics.
+//   kAtomNone: never (the owner-tile kernel covers the whole map).
+enum { kAtomAll = 0, kAtomFar = 1, kAtomNone = 2 };
+
+__device__ __forceinline__ int home_pixel(float r, int n) {
+  return min(max((int)floorf(r * (float)n), 0), n - 1);
+}
+
+// Expected pixel of sampling slot (h, p) of a query: its home pixel shifted by the slot centre
+// (the sampling_offsets bias, i.e. where the slot samples when the learned offset is the bias).
+__device__ __forceinline__ int slot_shift(const float* __restrict__ center, int h, int P, int p,
+                                          int axis) {
+  return center ? (int)rintf(center[(h * P + p) * 2 + axis]) : 0;
+}
+
+template <typename T, int DH, int VEC, int P, int ATOMICS>
+__global__ __launch_bounds__(256) void lift_bwd_query_kernel(const LiftArgs a) {
   constexpr int LP = DH / VEC;
   const int item = xcd_remap(blockIdx.x, a.chunk);
   if (item >= a.total_tiles) return;
@@ -176,7 +204,15 @@ __global__ __launch_bounds__(256) void lift_bwd_kernel(const LiftArgs a) {
         zi = (zi + 1 == a.Z) ? 0 : zi + 1;
         const float lx = r.x + off[2 * p] / fwf;
         const float ly = r.y + off[2 * p + 1] / fhf;
-        const Footprint f = make_footprint(lx, ly, a.fh, a.fw);
+        const float xp = lx * fwf - 0.5f, yp = ly * fhf - 0.5f;
+        const Footprint f = footprint_px(xp, yp, a.fh, a.fw);
+        int hx = 0, hy = 0;
+        if (ATOMICS == kAtomFar) {
+          hx = home_pixel(r.x, a.fw) + slot_shift(a.center, h, P, p, 0);
+          hy = home_pixel(r.y, a.fh) + slot_shift(a.center, h, P, p, 1);
+          if (valid && cg == 0 && a.rec != nullptr)      // hand the point to the owner-tile kernel
+            a.rec[(bq * a.H + h) * P + p] = make_float4(xp, yp, w[p] / cnt, 0.0f);
+        }
         float dot[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -187,16 +223,21 @@ __global__ __launch_bounds__(256) void lift_bwd_kernel(const LiftArgs a) {
 #pragma unroll
           for (int i = 0; i < VEC; ++i) d = fmaf(go[i], v[i], d);
           dot[k] = d * f.m[k];
-          const float c = w[p] * f.w[k];
-          if (valid && c != 0.0f) {
+          if (ATOMICS != kAtomNone) {
+            const float c = w[p] * f.w[k];
+            bool scatter = valid && c != 0.0f;
+            if (ATOMICS == kAtomFar)
+              scatter = scatter && (abs(f.xc[k & 1] - hx) > a.R || abs(f.yc[k >> 1] - hy) > a.R);
+            if (scatter) {
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) atomic_add_f32(a.gvalue + o + i, c * go[i]);
+              for (int i = 0; i < VEC; ++i) atomic_add_f32(a.gvalue + o + i, c * go[i]);
+            }
           }
         }
-        const float hx = 1.0f - f.lx, hy = 1.0f - f.ly;
-        gw[p] += hy * hx * dot[0] + hy * f.lx * dot[1] + f.ly * hx * dot[2] + f.ly * f.lx * dot[3];
-        gx[p] += (dot[1] - dot[0]) * hy + (dot[3] - dot[2]) * f.ly;
-        gy[p] += (dot[2] - dot[0]) * hx + (dot[3] - dot[1]) * f.lx;
+        const float hx_ = 1.0f - f.lx, hy_ = 1.0f - f.ly;
+        gw[p] += hy_ * hx_ * dot[0] + hy_ * f.lx * dot[1] + f.ly * hx_ * dot[2] + f.ly * f.lx * dot[3];
+        gx[p] += (dot[1] - dot[0]) * hy_ + (dot[3] - dot[2]) * f.ly;
+        gy[p] += (dot[2] - dot[0]) * hx_ + (dot[3] - dot[1]) * f.lx;
       }
     }
     // reduce the Dh partial dot products over the LP lanes of this (query, head)
@@ -227,23 +268,446 @@ __global__ __launch_bounds__(256) void lift_bwd_kernel(const LiftArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward, part 2 — grad_value without global atomics: "owner computes", scatter as a matmul.
+//
+// A wave OWNS a pixel tile (M = 32*RB pixels) of one (sample, camera) value map for one head.  The
+// scatter  grad_value[pix, :] += w_p * bilinear_k * grad_out[q, head, :]  over the sampling points
+// that touch the tile is the product
+//        Tile[M pixels, Dh]  +=  A[M, K points]  .  G[K, Dh]
+// with a SPARSE coefficient matrix A (<= 4 non-zeros per column: the point's owned corners) and the
+// points' grad_out rows G.  Per round of 32 candidate points:
+//   * each point's lane writes its (up to) 4 coefficients into its own column of A in LDS — a
+//     conflict-free scatter, no atomics, no read-modify-write — and stages its grad_out row in LDS;
+//   * every lane reads MFMA fragments of A and G from LDS (ds_read_b128) and
+//     v_mfma_f32_32x32x16 accumulates the tile in REGISTERS (16 f32 per lane per 32 pixels);
+//   * the lanes clear the coefficients they wrote.
+// Why not LDS accumulation: ds_add_f32 retires ~1 lane per 3 cycles on gfx950 (193 cycles per wave
+// instruction measured, tools/ubench/lds_atomic.hip, 24x a plain read+write pair), and a plain
+// LDS read-modify-write per point is a ~60-instruction scalar loop bound by its LDS round trip
+// (profiles/ notes).  16-bit operands: with f16 / bf16 data the coefficients are rounded to that
+// type (the data's own precision); with f32 data both operands are split into bf16 hi + lo parts
+// and three products are accumulated (hi*hi + lo*hi + hi*lo, relative error ~2^-16), f32
+// accumulation throughout.
+//
+//   GRID   (BEV-grid reference points, one map per sample: self-attention, SCA-pts): 8x8-pixel
+//          tiles.  For each sampling slot p the candidates are the queries whose expected pixel
+//          (home pixel + slot centre, i.e. where the slot lands when the learned offset equals
+//          the sampling_offsets bias) lies within R of the tile; a corner is taken iff it is
+//          inside the tile AND within R of that expected pixel.  The complement — "far" corners —
+//          is scattered atomically by lift_bwd_query_kernel<kAtomFar>, so the two kernels
+//          partition the corners exactly for ANY learned offset.
+//   CAMERA (small per-camera maps, arbitrary projected reference points: SCA-img): the tile is a
+//          band of full rows (the whole 8x22 map in one band), candidates = a chunk of the
+//          camera's compacted visible-query list; the chunks of one camera share the map, so the
+//          flush is one f32 atomic per tile element per chunk (~10^6 instead of ~10^9 atomics).
+struct TileArgs {
+  int mode;            // 1 = GRID, 2 = CAMERA
+  int tile_w, tile_h;  // pixels
+  int tiles_x, tiles_y;
+  int chunks, chunk_q; // CAMERA: query chunks per tile
+  int total, chunk;    // tiles, blocks per XCD
+  int waves;           // waves (= tiles) per block
+};
+
+// Ordered compaction of each camera's visible queries (vis0[cam, q] != 0): list[cam, 0..n) holds the
+// query indices in ascending order.  One 1024-thread block per camera.
+__global__ __launch_bounds__(1024) void compact_visible_kernel(const uint8_t* __restrict__ vis0,
+                                                               int Nq, int* __restrict__ list,
+                                                               int* __restrict__ n_out) {
+  __shared__ int wave_cnt[16];
+  __shared__ int base_s;
+  const int cam = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  for (int q0 = 0; q0 < Nq; q0 += 1024) {
+    const int q = q0 + threadIdx.x;
+    const bool v = q < Nq && (vis0 == nullptr || vis0[(long)cam * Nq + q] != 0);
+    const unsigned long long m = __ballot(v);
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wv] = __popcll(m);
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wv; ++w) off += wave_cnt[w];
+    if (v) list[(long)cam * Nq + off + rank] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wave_cnt[w]; base_s += t; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) n_out[cam] = base_s;
+}
+
+// ---- shared pieces of the owner-tile kernel -------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+// 16-bit MFMA operand type used for pipeline element type T
+template <typename T> struct mma_traits;
+template <> struct mma_traits<bf16_t> {
+  static constexpr bool kSplit = false;
+  static __device__ __forceinline__ uint16_t enc(float v) { return (uint16_t)float_to_bf16_bits(v); }
+  static __device__ __forceinline__ float dec(uint16_t b) { return bf16_bits_to_float(b); }
+  static __device__ __forceinline__ f32x16_t mma(uint4 a, uint4 b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct mma_traits<f16_t> {
+  static constexpr bool kSplit = false;
+  static __device__ __forceinline__ uint16_t enc(float v) { return __builtin_bit_cast(uint16_t, (_Float16)v); }
+  static __device__ __forceinline__ float dec(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+  static __device__ __forceinline__ f32x16_t mma(uint4 a, uint4 b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a),
+                                                  __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct mma_traits<float> : mma_traits<bf16_t> {     // f32 data: bf16 hi + lo parts
+  static constexpr bool kSplit = true;
+};
+
+struct TileGeom {
+  int b, cam, h, ck, x0, y0, tw, th, npx;
+};
+
+__device__ __forceinline__ bool tile_decode(const LiftArgs& a, const TileArgs& t, TileGeom& g) {
+  const int item = xcd_remap(blockIdx.x, t.chunk) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+  if (item >= t.total) return false;
+  // item -> (b, cam, tile_y, tile_x, chunk, head); head fastest: neighbours share rows of grad_out
+  int r = item;
+  g.h = r % a.H; r /= a.H;
+  g.ck = r % t.chunks; r /= t.chunks;
+  const int tx = r % t.tiles_x; r /= t.tiles_x;
+  const int ty = r % t.tiles_y; r /= t.tiles_y;
+  g.cam = r % a.Nc;
+  g.b = r / a.Nc;
+  g.x0 = tx * t.tile_w; g.y0 = ty * t.tile_h;
+  g.tw = min(t.tile_w, a.fw - g.x0); g.th = min(t.tile_h, a.fh - g.y0);
+  g.npx = t.tile_w * t.tile_h;
+  return true;
+}
+
+// Ownership of the 4 corners of a footprint by tile g (and, when NEAR, nearness to the slot's
+// expected pixel (ex, ey)): fills lp (tile-local pixel index or -1) and cwt (coefficient).
+template <bool NEAR>
+__device__ __forceinline__ bool tile_own(const Footprint& f, float w, bool valid, const TileGeom& g,
+                                         int tile_w, int ex, int ey, int R, int (&lp)[4],
+                                         float (&cwt)[4]) {
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int cx = f.xc[k & 1], cy = f.yc[k >> 1];
+    bool own = valid && f.w[k] != 0.0f && cx >= g.x0 && cx < g.x0 + g.tw && cy >= g.y0 &&
+               cy < g.y0 + g.th;
+    if (NEAR) own = own && abs(cx - ex) <= R && abs(cy - ey) <= R;
+    lp[k] = own ? (cy - g.y0) * tile_w + (cx - g.x0) : -1;
+    cwt[k] = own ? w * f.w[k] : 0.0f;
+    any = any || own;
+  }
+  return any;
+}
+
+constexpr int kAStride = 40;      // u16 per A row: 32 point slots + 8 pad (80 B: conflict-free b128 reads)
+
+// Per-wave LDS carve (u16 units): A_hi[32*RB][kAStride] (+ A_lo), G_hi[32][DH] (+ G_lo)
+template <typename T, int DH, int RB>
+struct TileLds {
+  static constexpr bool kSplit = mma_traits<T>::kSplit;
+  static constexpr int kA = 32 * RB * kAStride;
+  static constexpr int kG = 32 * DH;
+  static constexpr int kWords = (kA + kG) * (kSplit ? 2 : 1);      // u16 per wave
+};
+
+// Stages a grad_out row (held raw in `v`, Dh elements) in LDS as 16-bit MFMA operands.
+template <typename T, int DH, int NV>
+__device__ __forceinline__ void stage_row(uint16_t* __restrict__ g_hi, uint16_t* __restrict__ g_lo,
+                                          int slot, const uint4 (&v)[NV]) {
+  using M = mma_traits<T>;
+  if constexpr (!M::kSplit) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) reinterpret_cast<uint4*>(g_hi + slot * DH)[i] = v[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float f[4] = {__uint_as_float(v[i].x), __uint_as_float(v[i].y), __uint_as_float(v[i].z),
+                          __uint_as_float(v[i].w)};
+      uint16_t hi[4], lo[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { hi[k] = M::enc(f[k]); lo[k] = M::enc(f[k] - M::dec(hi[k])); }
+      reinterpret_cast<uint2*>(g_hi + slot * DH)[i] =
+          make_uint2(hi[0] | ((uint32_t)hi[1] << 16), hi[2] | ((uint32_t)hi[3] << 16));
+      reinterpret_cast<uint2*>(g_lo + slot * DH)[i] =
+          make_uint2(lo[0] | ((uint32_t)lo[1] << 16), lo[2] | ((uint32_t)lo[3] << 16));
+    }
+  }
+}
+
+// The wave's pending operand tiles: up to 32 point slots filled densely by the owned points of
+// successive batches (slot = fill + rank among the batch's owned lanes); when they are full the
+// MFMA round runs over all 32 slots and the coefficient tile is cleared.
+template <typename T, int DH, int RB>
+struct TileAcc {
+  using M = mma_traits<T>;
+  using L = TileLds<T, DH, RB>;
+  uint16_t* a_hi; uint16_t* a_lo; uint16_t* g_hi; uint16_t* g_lo;
+  f32x16_t acc[RB];
+  int fill;
+
+  __device__ __forceinline__ void init(uint16_t* lds, int lane) {
+    a_hi = lds; a_lo = lds + L::kA;
+    g_hi = lds + (M::kSplit ? 2 : 1) * L::kA; g_lo = g_hi + L::kG;
+    for (int i = lane; i < L::kWords / 2; i += 64) reinterpret_cast<uint32_t*>(lds)[i] = 0u;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
+    fill = 0;
+  }
+
+  // Tile += A . G over the 32 slots, then clear A.  (One wave: its LDS operations execute in
+  // program order, so the fragment reads see the producers' writes without a barrier.)
+  __device__ __forceinline__ void flush(int lane) {
+    const int n = lane & 31, kg = lane >> 5;
+    const int nn = (DH >= 32) ? n : (n % DH);            // Dh = 16: columns 16..31 are don't-care
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      uint16_t bh[8], bl[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        bh[j] = g_hi[(kb * 16 + kg * 8 + j) * DH + nn];
+        if (M::kSplit) bl[j] = g_lo[(kb * 16 + kg * 8 + j) * DH + nn];
+      }
+      uint4 b_hi, b_lo;
+      b_hi.x = bh[0] | ((uint32_t)bh[1] << 16); b_hi.y = bh[2] | ((uint32_t)bh[3] << 16);
+      b_hi.z = bh[4] | ((uint32_t)bh[5] << 16); b_hi.w = bh[6] | ((uint32_t)bh[7] << 16);
+      if (M::kSplit) {
+        b_lo.x = bl[0] | ((uint32_t)bl[1] << 16); b_lo.y = bl[2] | ((uint32_t)bl[3] << 16);
+        b_lo.z = bl[4] | ((uint32_t)bl[5] << 16); b_lo.w = bl[6] | ((uint32_t)bl[7] << 16);
+      }
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const int ao = (rb * 32 + n) * kAStride + kb * 16 + kg * 8;
+        const uint4 f_hi = *reinterpret_cast<const uint4*>(a_hi + ao);
+        acc[rb] = M::mma(f_hi, b_hi, acc[rb]);
+        if (M::kSplit) {
+          const uint4 f_lo = *reinterpret_cast<const uint4*>(a_lo + ao);
+          acc[rb] = M::mma(f_lo, b_hi, acc[rb]);
+          acc[rb] = M::mma(f_hi, b_lo, acc[rb]);
+        }
+      }
+    }
+    constexpr int kAVec = (M::kSplit ? 2 : 1) * L::kA / 8;          // 16-byte vectors of A
+    for (int i = lane; i < kAVec; i += 64) reinterpret_cast<uint4*>(a_hi)[i] = make_uint4(0, 0, 0, 0);
+    fill = 0;
+  }
+
+  // Adds the owned points of one batch (one point per lane).
+  __device__ __forceinline__ void add(const int (&lp)[4], const float (&cwt)[4], bool any,
+                                      const T* __restrict__ grow_ptr, int lane) {
+    const unsigned long long m = __ballot(any);
+    if (m == 0ull) return;
+    // issue the grad_out row loads first: a pending MFMA round (flush) below overlaps their latency
+    constexpr int NV = DH * elem<T>::kBytes / 16;
+    uint4 grow[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      grow[i] = any ? reinterpret_cast<const uint4*>(grow_ptr)[i] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const unsigned int hm = (unsigned int)(m >> (32 * half));
+      if (hm == 0u) continue;
+      const int cnt = __popc(hm);
+      if (fill + cnt > 32) flush(lane);
+      if (any && (lane >> 5) == half) {
+        const int slot = fill + __popc(hm & ((1u << (lane & 31)) - 1u));
+        stage_row<T, DH, NV>(g_hi, g_lo, slot, grow);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (lp[k] >= 0) {
+            const uint16_t hi = M::enc(cwt[k]);
+            a_hi[lp[k] * kAStride + slot] = hi;
+            if (M::kSplit) a_lo[lp[k] * kAStride + slot] = M::enc(cwt[k] - M::dec(hi));
+          }
+        }
+      }
+      fill += cnt;
+    }
+  }
+};
+
+// MODE 1 = GRID, 2 = CAMERA.  One wave per tile, blockDim.x / 64 independent waves per block.
+template <typename T, int DH, int P, int RB, int MODE>
+__global__ __launch_bounds__(256) void lift_bwd_value_kernel(const LiftArgs a, const TileArgs t) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds_all[];
+  using L = TileLds<T, DH, RB>;
+  TileGeom g;
+  if (!tile_decode(a, t, g)) return;
+  const int lane = threadIdx.x & 63;
+  uint16_t* __restrict__ lds = lds_all + (threadIdx.x >> 6) * L::kWords;
+  int ncand_cam = 0, l0 = 0;
+  if (MODE == 2) {
+    l0 = g.ck * t.chunk_q;                                // offset into this camera's list
+    ncand_cam = min(t.chunk_q, a.cam_n[g.cam] - l0);
+    if (ncand_cam <= 0) return;                           // nothing visible in this chunk
+  }
+  TileAcc<T, DH, RB> ta;
+  ta.init(lds, lane);
+  const long row = (long)a.H * DH;
+  const T* __restrict__ gout = (const T*)a.gout;
+
+  auto rounds = [&](const int (&lp)[4], const float (&cwt)[4], bool any, int q) {
+    ta.add(lp, cwt, any, gout + ((long)g.b * a.Nq + q) * row + g.h * DH, lane);
+  };
+
+  if (MODE == 1) {
+    // ---- GRID: per sampling slot p, lane = candidate query, records from lift_bwd_query_kernel
+    const float sx = (float)a.qw / (float)a.fw, sy = (float)a.qh / (float)a.fh;
+    for (int p = 0; p < P; ++p) {
+      const int dx = slot_shift(a.center, g.h, P, p, 0), dy = slot_shift(a.center, g.h, P, p, 1);
+      // queries whose expected pixel can be within R of the tile (conservative superset)
+      const int qx_lo = max(0, (int)floorf((float)(g.x0 - a.R - dx) * sx) - 1);
+      const int qy_lo = max(0, (int)floorf((float)(g.y0 - a.R - dy) * sy) - 1);
+      const int qx_hi = min(a.qw - 1, (int)ceilf((float)(g.x0 + g.tw + a.R - dx) * sx) + 1);
+      const int qy_hi = min(a.qh - 1, (int)ceilf((float)(g.y0 + g.th + a.R - dy) * sy) + 1);
+      const int cw = qx_hi - qx_lo + 1;
+      const int ncand = cw * (qy_hi - qy_lo + 1);
+      if (cw <= 0 || ncand <= 0) continue;
+      const float inv_cw = 1.0f / (float)cw;
+      const int zi = p % a.Z;
+      auto fetch = [&](int c0, float4& rec, float2& ref, int& q) -> bool {
+        const int c = c0 + lane;
+        const bool valid = c < ncand;
+        const int cc = valid ? c : 0;
+        int cy = (int)(((float)cc + 0.5f) * inv_cw);          // cc / cw for cc < 2^22
+        cy -= (cy * cw > cc) ? 1 : 0;
+        cy += ((cy + 1) * cw <= cc) ? 1 : 0;
+        q = (qy_lo + cy) * a.qw + qx_lo + (cc - cy * cw);
+        const long bq = (long)g.b * a.Nq + q;
+        rec = a.rec[(bq * a.H + g.h) * P + p];
+        ref = *reinterpret_cast<const float2*>(a.ref + (bq * a.Z + zi) * 2);
+        return valid;
+      };
+      float4 nrec; float2 nref; int nq;
+      bool nvalid = fetch(0, nrec, nref, nq);
+      for (int c0 = 0; c0 < ncand; c0 += 64) {
+        const float4 rec = nrec; const float2 ref = nref; const int q = nq; const bool valid = nvalid;
+        if (c0 + 64 < ncand) nvalid = fetch(c0 + 64, nrec, nref, nq);
+        int lp[4];
+        float cwt[4];
+        const Footprint f = footprint_px(rec.x, rec.y, a.fh, a.fw);
+        const bool any = tile_own<true>(f, rec.z, valid, g, t.tile_w, home_pixel(ref.x, a.fw) + dx,
+                                        home_pixel(ref.y, a.fh) + dy, a.R, lp, cwt);
+        rounds(lp, cwt, any, q);
+      }
+    }
+  } else {
+    // ---- CAMERA: lane = (query slot, point); three-stage pipeline list entry -> inputs -> use
+    constexpr int QB = kWave / P;
+    const float fwf = (float)a.fw, fhf = (float)a.fh;
+    const int qi = lane / P, p = lane % P, zi = p % a.Z;
+    struct Raw { float2 off, ref; float lg, cnt; int q; bool valid; };
+    auto stage0 = [&](int c0, bool& valid) -> int {
+      const int c = c0 + qi;
+      valid = c < ncand_cam;
+      return a.cam_list[(long)g.cam * a.Nq + l0 + (valid ? c : 0)];
+    };
+    auto stage1 = [&](int q, bool valid) -> Raw {
+      Raw rw;
+      rw.q = q; rw.valid = valid;
+      const long bq = (long)g.b * a.Nq + q;
+      rw.ref = *reinterpret_cast<const float2*>(
+          a.ref + ((((long)g.cam * a.B + g.b) * a.Nq + q) * a.Z + zi) * 2);
+      rw.lg = a.logits[bq * a.log_stride + g.h * P + p];
+      rw.off = *reinterpret_cast<const float2*>(a.offsets + bq * a.off_stride + g.h * 2 * P + 2 * p);
+      rw.cnt = (a.count != nullptr) ? a.count[bq] : 1.0f;
+      return rw;
+    };
+    bool v1, v2;
+    const int q1 = stage0(0, v1);
+    Raw nxt = stage1(q1, v1);
+    int q2 = stage0(QB, v2);
+    for (int c0 = 0; c0 < ncand_cam; c0 += QB) {
+      const Raw cur = nxt;
+      nxt = stage1(q2, v2);
+      q2 = stage0(c0 + 2 * QB, v2);
+      // softmax weight of this lane's point: max / sum over the P lanes of its query
+      float m = cur.lg;
+#pragma unroll
+      for (int d = 1; d < P; d <<= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+      const float e = expf(cur.lg - m);
+      float ssum = e;
+#pragma unroll
+      for (int d = 1; d < P; d <<= 1) ssum += __shfl_xor(ssum, d, 64);
+      const float w = (e / ssum) / cur.cnt;               // (g / count) * w * bilinear
+      int lp[4];
+      float cwt[4];
+      const Footprint f = make_footprint(cur.ref.x + cur.off.x / fwf, cur.ref.y + cur.off.y / fhf,
+                                         a.fh, a.fw);
+      const bool any = tile_own<false>(f, w, cur.valid, g, t.tile_w, 0, 0, 0, lp, cwt);
+      rounds(lp, cwt, any, cur.q);
+    }
+  }
+  if (ta.fill > 0) ta.flush(lane);
+  // ---- flush the accumulators: D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  float* __restrict__ gv = a.gvalue + ((long)g.b * a.Nc + g.cam) * a.fh * a.fw * row + g.h * DH;
+  const int col = lane & 31;
+  if (col < DH) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int px = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int lx = px % t.tile_w, ly = px / t.tile_w;
+        if (px < g.npx && lx < g.tw && ly < g.th) {
+          const long o = ((long)(g.y0 + ly) * a.fw + (g.x0 + lx)) * row + col;
+          const float v = ta.acc[rb][r];
+          if (MODE == 1) gv[o] += v;      // single owner; on top of the query kernel's far corners
+          else if (v != 0.0f) atomic_add_f32(gv + o, v);   // chunks of one camera share the map
+        }
+      }
+    }
+  }
+}
+
 // ---- dispatch ----------------------------------------------------------------------------------------
 template <typename T, int DH, int P>
-static void lift_launch(const LiftArgs& a, bool bwd, hipStream_t st) {
+static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, hipStream_t st) {
   constexpr int VEC = 16 / elem<T>::kBytes;
   const int blocks = 8 * a.chunk;
-  if (!bwd)
+  if (bwd_mode < 0) {
     hipLaunchKernelGGL((lift_fwd_kernel<T, DH, VEC, P>), dim3(blocks), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((lift_bwd_kernel<T, DH, VEC, P>), dim3(blocks), dim3(256), 0, st, a);
+    return;
+  }
+  if (bwd_mode == kAtomAll) {
+    hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomAll>), dim3(blocks), dim3(256), 0, st, a);
+  } else if (bwd_mode == kAtomFar) {
+    // the query kernel leaves one record per sampling point for the owner tiles and scatters the
+    // (rare) far corners atomically into the zeroed grad_value; the owner tiles then add their
+    // exclusive pixels on top with a plain read-add-store.
+    hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomFar>), dim3(blocks), dim3(256), 0, st, a);
+    constexpr int RB = 2;
+    const size_t lds = (size_t)t.waves * TileLds<T, DH, RB>::kWords * sizeof(uint16_t);
+    hipLaunchKernelGGL((lift_bwd_value_kernel<T, DH, P, RB, 1>), dim3(8 * t.chunk), dim3(64 * t.waves),
+                       lds, st, a, t);
+  } else {
+    hipLaunchKernelGGL(compact_visible_kernel, dim3(a.Nc), dim3(1024), 0, st, a.vis0, a.Nq,
+                       a.cam_list, a.cam_n);
+    constexpr int RB = 6;
+    const size_t lds = (size_t)t.waves * TileLds<T, DH, RB>::kWords * sizeof(uint16_t);
+    hipLaunchKernelGGL((lift_bwd_value_kernel<T, DH, P, RB, 2>), dim3(8 * t.chunk), dim3(64 * t.waves),
+                       lds, st, a, t);
+    hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomNone>), dim3(blocks), dim3(256), 0, st, a);
+  }
 }
 
 template <typename T>
-static bool lift_dispatch_T(const LiftArgs& a, int Dh, int P, bool bwd, hipStream_t st) {
-  if (Dh == 32 && P == 8) { lift_launch<T, 32, 8>(a, bwd, st); return true; }
-  if (Dh == 32 && P == 4) { lift_launch<T, 32, 4>(a, bwd, st); return true; }
-  if (Dh == 16 && P == 8) { lift_launch<T, 16, 8>(a, bwd, st); return true; }
-  if (Dh == 16 && P == 4) { lift_launch<T, 16, 4>(a, bwd, st); return true; }
+static bool lift_dispatch_T(const LiftArgs& a, const TileArgs& t, int Dh, int P, int bwd_mode,
+                            hipStream_t st) {
+  if (Dh == 32 && P == 8) { lift_launch<T, 32, 8>(a, t, bwd_mode, st); return true; }
+  if (Dh == 32 && P == 4) { lift_launch<T, 32, 4>(a, t, bwd_mode, st); return true; }
+  if (Dh == 16 && P == 8) { lift_launch<T, 16, 8>(a, t, bwd_mode, st); return true; }
+  if (Dh == 16 && P == 4) { lift_launch<T, 16, 4>(a, t, bwd_mode, st); return true; }
   return false;
 }
 
@@ -255,7 +719,51 @@ static bool lift_shape_ok(int H, int Dh, int P, int dtype) {
   return lq >= 4 && lq <= 64 && (64 % lq) == 0;
 }
 
-static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, void* stream) {
+
+// Chooses who scatters grad_value (see lift_bwd_value_kernel) and lays out the owner tiles.
+static int plan_backward(const LiftArgs& a, int Dh, int P, int dtype, int ref_is_grid, TileArgs& t) {
+  t = TileArgs{};
+  if (ref_is_grid && a.Nc == 1 && a.qw > 0) {
+    t.mode = 1;
+    t.tile_w = t.tile_h = 8;                 // 64 pixels = 2 MFMA row blocks
+    t.tiles_x = (a.fw + 7) / 8;
+    t.tiles_y = (a.fh + 7) / 8;
+    t.chunks = 1;
+    t.chunk_q = 0;
+    t.waves = 4;
+  } else {
+    // CAMERA: bands of full rows, at most 6 MFMA row blocks (192 pixels) per band, and few enough
+    // bands that re-walking the visible queries once per band stays cheap
+    int band = 192 / a.fw;
+    if (band < 1) return kAtomAll;
+    if (band > a.fh) band = a.fh;
+    const int bands = (a.fh + band - 1) / band;
+    if (bands > 8) return kAtomAll;
+    t.mode = 2;
+    t.tile_w = a.fw;
+    t.tile_h = band;
+    t.tiles_x = 1;
+    t.tiles_y = bands;
+    // a chunk = 1024 entries of the camera's compacted visible-query list (device-side length:
+    // chunks past the end exit at once)
+    static const int cq = getenv("UBV_CAM_CHUNK") ? atoi(getenv("UBV_CAM_CHUNK")) : 1024;
+    t.chunk_q = cq;
+    t.chunks = (a.Nq + cq - 1) / cq;
+    t.waves = (dtype == UBV_F32) ? 2 : 4;    // f32 data carries hi + lo operand tiles: 2x the LDS
+  }
+  t.total = a.B * a.Nc * t.tiles_y * t.tiles_x * t.chunks * a.H;
+  t.chunk = ((t.total + t.waves - 1) / t.waves + 7) / 8;       // blocks per XCD
+  return t.mode == 1 ? kAtomFar : kAtomNone;
+}
+
+static size_t lift_ws_bytes(int mode, const LiftArgs& a, int P) {
+  if (mode == kAtomFar) return (size_t)a.B * a.Nq * a.H * P * sizeof(float4);
+  if (mode == kAtomNone) return ((size_t)a.Nc * a.Nq + a.Nc + 4) * sizeof(int);
+  return 0;
+}
+
+static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_grid, void* ws,
+                    int64_t ws_bytes, void* stream) {
   UBV_CHECK_ARG(a.B > 0 && a.Nc > 0 && a.fh > 0 && a.fw > 0 && a.H > 0 && a.Nq > 0 && a.Z > 0,
                 "bev_lift: non-positive dimension");
   UBV_CHECK_ARG(P % a.Z == 0, "bev_lift: num_points %d not a multiple of Z %d", P, a.Z);
@@ -281,12 +789,32 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, void* stream
   }
   a.total_tiles = a.B * a.tiles_per_sample;
   a.chunk = (a.total_tiles + 7) / 8;
+  // near radius: around the slot centre when given (offset ~ bias), else around the home pixel
+  // (learned offsets start at <= P pixels, init_weights); anything farther is still exact
+  static const int r_env = getenv("UBV_NEAR_R") ? atoi(getenv("UBV_NEAR_R")) : -1;
+  a.R = r_env >= 0 ? r_env : (a.center ? 3 : P + 2);
   hipStream_t st = as_stream(stream);
+  TileArgs t{};
+  int mode = -1;
+  if (bwd) {
+    mode = plan_backward(a, Dh, P, dtype, ref_is_grid, t);
+    const size_t need = lift_ws_bytes(mode, a, P);
+    UBV_CHECK_ARG(need == 0 || (ws != nullptr && ws_bytes >= (int64_t)need),
+                  "bev_lift_backward: workspace of %lld bytes needed, got %lld", (long long)need,
+                  (long long)ws_bytes);
+    if (mode == kAtomFar) a.rec = (float4*)ws;
+    if (mode == kAtomNone) { a.cam_list = (int*)ws; a.cam_n = (int*)ws + (size_t)a.Nc * a.Nq; }
+    const size_t bytes = (size_t)a.B * a.Nc * a.fh * a.fw * a.H * Dh * sizeof(float);
+    if (hipMemsetAsync(a.gvalue, 0, bytes, st) != hipSuccess) {
+      set_error("bev_lift_backward: memset failed");
+      return UBV_ERR_LAUNCH;
+    }
+  }
   bool ok = false;
   switch (dtype) {
-    case UBV_F32: ok = lift_dispatch_T<float>(a, Dh, P, bwd, st); break;
-    case UBV_F16: ok = lift_dispatch_T<f16_t>(a, Dh, P, bwd, st); break;
-    case UBV_BF16: ok = lift_dispatch_T<bf16_t>(a, Dh, P, bwd, st); break;
+    case UBV_F32: ok = lift_dispatch_T<float>(a, t, Dh, P, mode, st); break;
+    case UBV_F16: ok = lift_dispatch_T<f16_t>(a, t, Dh, P, mode, st); break;
+    case UBV_BF16: ok = lift_dispatch_T<bf16_t>(a, t, Dh, P, mode, st); break;
   }
   if (!ok) { set_error("bev_lift: dispatch failed"); return UBV_ERR_UNSUPPORTED; }
   UBV_CHECK_LAUNCH(bwd ? "bev_lift_backward" : "bev_lift_forward");
@@ -294,6 +822,18 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, void* stream
 }
 
 }  // namespace ubv
+
+extern "C" int64_t ubv_bev_lift_backward_workspace(int B, int Nc, int fh, int fw, int H, int Dh,
+                                                   int Nq, int P, int qgrid_w, int qgrid_h,
+                                                   int ref_is_grid) {
+  ubv::LiftArgs a{};
+  a.B = B; a.Nc = Nc; a.fh = fh; a.fw = fw; a.H = H; a.Nq = Nq;
+  a.qw = (qgrid_w > 0 && (long)qgrid_w * qgrid_h == Nq) ? qgrid_w : 0;
+  a.qh = a.qw ? qgrid_h : 0;
+  ubv::TileArgs t{};
+  const int mode = ubv::plan_backward(a, Dh, P, UBV_BF16, ref_is_grid, t);
+  return (int64_t)ubv::lift_ws_bytes(mode, a, P);
+}
 
 extern "C" int ubv_bev_lift_supported(int H, int Dh, int P, int dtype) {
   return ubv::lift_shape_ok(H, Dh, P, dtype) ? 1 : 0;
@@ -310,24 +850,27 @@ extern "C" int ubv_bev_lift_forward(const void* value, const float* offsets, int
   a.log_stride = log_stride; a.ref = ref; a.vis0 = vis0; a.count = count; a.out = out;
   a.B = B; a.Nc = Nc; a.fh = fh; a.fw = fw; a.H = H; a.Nq = Nq; a.Z = Z; a.qw = qgrid_w;
   a.qh = qgrid_h;
-  return ubv::lift_run(a, Dh, P, dtype, false, stream);
+  return ubv::lift_run(a, Dh, P, dtype, false, 0, nullptr, 0, stream);
 }
 
 extern "C" int ubv_bev_lift_backward(const void* value, const float* offsets, int64_t off_stride,
                                      const float* logits, int64_t log_stride, const float* ref,
-                                     const uint8_t* vis0, const float* count, const void* grad_out,
+                                     const uint8_t* vis0, const float* count,
+                                     const float* slot_center, const void* grad_out,
                                      float* grad_value, float* grad_offsets, int64_t goff_stride,
                                      float* grad_logits, int64_t glog_stride, int B, int Nc, int fh,
                                      int fw, int H, int Dh, int Nq, int P, int Z, int qgrid_w,
-                                     int qgrid_h, int dtype, void* stream) {
+                                     int qgrid_h, int ref_is_grid, int dtype, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
   UBV_CHECK_ARG(value && offsets && logits && ref && grad_out && grad_value && grad_offsets &&
                     grad_logits, "bev_lift_backward: null pointer");
   ubv::LiftArgs a{};
   a.value = value; a.offsets = offsets; a.off_stride = off_stride; a.logits = logits;
   a.log_stride = log_stride; a.ref = ref; a.vis0 = vis0; a.count = count; a.gout = grad_out;
+  a.center = slot_center;
   a.gvalue = grad_value; a.goff = grad_offsets; a.goff_stride = goff_stride; a.glog = grad_logits;
   a.glog_stride = glog_stride;
   a.B = B; a.Nc = Nc; a.fh = fh; a.fw = fw; a.H = H; a.Nq = Nq; a.Z = Z; a.qw = qgrid_w;
   a.qh = qgrid_h;
-  return ubv::lift_run(a, Dh, P, dtype, true, stream);
+  return ubv::lift_run(a, Dh, P, dtype, true, ref_is_grid, workspace, workspace_bytes, stream);
 }

@@ -149,12 +149,12 @@ struct Footprint {
   float w[4];      // bilinear weight of each corner, 0 when the corner is outside
   float lx, ly;    // fractional parts
   float m[4];      // 1 where the corner is inside, else 0 (for the gradient w.r.t. the location)
+  int xc[2], yc[2];  // clamped corner columns / rows: corner k sits at (xc[k & 1], yc[k >> 1])
 };
 
-__device__ __forceinline__ Footprint make_footprint(float loc_x, float loc_y, int Hh, int Ww) {
+// Footprint from pixel coordinates (x, y) = (loc_x*W - 0.5, loc_y*H - 0.5).
+__device__ __forceinline__ Footprint footprint_px(float x, float y, int Hh, int Ww) {
   Footprint f;
-  const float x = loc_x * (float)Ww - 0.5f;
-  const float y = loc_y * (float)Hh - 0.5f;
   const bool inside = (y > -1.0f) && (x > -1.0f) && (y < (float)Hh) && (x < (float)Ww);
   const float xf = floorf(x), yf = floorf(y);
   // NaN / huge locations: `inside` is false, keep the integer conversion defined.
@@ -168,6 +168,7 @@ __device__ __forceinline__ Footprint make_footprint(float loc_x, float loc_y, in
   const float my1 = (inside && y0 + 1 <= Hh - 1) ? 1.0f : 0.0f;
   const int xc0 = min(max(x0, 0), Ww - 1), xc1 = min(max(x0 + 1, 0), Ww - 1);
   const int yc0 = min(max(y0, 0), Hh - 1), yc1 = min(max(y0 + 1, 0), Hh - 1);
+  f.xc[0] = xc0; f.xc[1] = xc1; f.yc[0] = yc0; f.yc[1] = yc1;
   f.idx[0] = yc0 * Ww + xc0; f.idx[1] = yc0 * Ww + xc1;
   f.idx[2] = yc1 * Ww + xc0; f.idx[3] = yc1 * Ww + xc1;
   f.m[0] = my0 * mx0; f.m[1] = my0 * mx1; f.m[2] = my1 * mx0; f.m[3] = my1 * mx1;
@@ -175,6 +176,10 @@ __device__ __forceinline__ Footprint make_footprint(float loc_x, float loc_y, in
   f.w[0] = hy * hx * f.m[0]; f.w[1] = hy * f.lx * f.m[1];
   f.w[2] = f.ly * hx * f.m[2]; f.w[3] = f.ly * f.lx * f.m[3];
   return f;
+}
+
+__device__ __forceinline__ Footprint make_footprint(float loc_x, float loc_y, int Hh, int Ww) {
+  return footprint_px(loc_x * (float)Ww - 0.5f, loc_y * (float)Hh - 0.5f, Hh, Ww);
 }
 
 // XCD-aware block -> work-item remap: blocks are dispatched round-robin over the 8 XCDs

@@ -145,9 +145,9 @@ def bev_lift_supported(num_heads, head_dim, num_points, dtype):
 
 class _BevLift(Function):
     @staticmethod
-    def forward(ctx, value, offlog, ref, vis0, count, geom):
-        B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh = geom
-        _need_cuda(value, offlog, ref, vis0, count)
+    def forward(ctx, value, offlog, ref, vis0, count, center, geom):
+        B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh, grid = geom
+        _need_cuda(value, offlog, ref, vis0, count, center)
         value = value.contiguous()
         ol = offlog.float().contiguous()
         ref = ref.float().contiguous()
@@ -162,7 +162,10 @@ class _BevLift(Function):
                 _p(value), ctypes.c_void_p(base), row, ctypes.c_void_p(base + H * P * 2 * 4), row,
                 _p(ref), _p(vis0), _p(count), _p(out), B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh,
                 _dt(value), _stream()), 'bev_lift_forward')
-        ctx.save_for_backward(value, ol, ref, vis0, count)
+        if center is not None:
+            center = center.detach().float().contiguous()
+            assert center.numel() == H * P * 2
+        ctx.save_for_backward(value, ol, ref, vis0, count, center)
         ctx.geom = geom
         ctx.ol_dtype = offlog.dtype
         return out
@@ -170,25 +173,27 @@ class _BevLift(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
-        value, ol, ref, vis0, count = ctx.saved_tensors
-        B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh = ctx.geom
+        value, ol, ref, vis0, count, center = ctx.saved_tensors
+        B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh, grid = ctx.geom
         row = H * P * 3
         go = grad_output.to(value.dtype).contiguous()
-        gv = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
+        gv = torch.empty(value.shape, dtype=torch.float32, device=value.device)
         gol = torch.empty_like(ol)
         base, gbase = ol.data_ptr(), gol.data_ptr()
         off2 = H * P * 2 * 4
+        nws = lib().ubv_bev_lift_backward_workspace(B, Nc, fh, fw, H, Dh, Nq, P, qw, qh, int(grid))
+        ws = _workspace(nws, value.device) if nws > 0 else None
         with _timed('lift_bwd', (ctx.geom, value.element_size())):
             check(lib().ubv_bev_lift_backward(
                 _p(value), ctypes.c_void_p(base), row, ctypes.c_void_p(base + off2), row, _p(ref),
-                _p(vis0), _p(count), _p(go), _p(gv), ctypes.c_void_p(gbase), row,
+                _p(vis0), _p(count), _p(center), _p(go), _p(gv), ctypes.c_void_p(gbase), row,
                 ctypes.c_void_p(gbase + off2), row, B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh,
-                _dt(value), _stream()), 'bev_lift_backward')
-        return gv.to(value.dtype), gol.to(ctx.ol_dtype), None, None, None, None
+                int(grid), _dt(value), _p(ws), int(nws), _stream()), 'bev_lift_backward')
+        return gv.to(value.dtype), gol.to(ctx.ol_dtype), None, None, None, None, None
 
 
 def bev_lift(value, offlog, ref, num_cams, feat_hw, num_heads, num_points, vis0=None, count=None,
-             query_grid=None):
+             query_grid=None, ref_is_grid=False, slot_center=None):
     """Fused single-level BEV query lifting (``ubv_bev_lift_forward``).
 
     value  (B*num_cams, fh*fw, C)  projected features, batch-major / camera-minor
@@ -196,6 +201,9 @@ def bev_lift(value, offlog, ref, num_cams, feat_hw, num_heads, num_points, vis0=
     ref    (num_cams, B, Nq, Z, 2) reference points, flat point p uses anchor p % Z
     vis0   (num_cams, Nq) uint8    visibility of batch element 0, or None
     count  (B, Nq) float32         camera count divisor, or None
+    query_grid (qh, qw)            BEV grid the Nq queries form (tiling / owner-tile backward)
+    ref_is_grid                    ref is exactly that grid's cell centres (and num_cams == 1)
+    slot_center (H*P*2,)           the sampling_offsets bias (pixels): speed hint for backward
     """
     fh, fw = feat_hw
     BNc, S, C = value.shape[0], value.shape[1], value.shape[-1] if value.dim() == 3 else None
@@ -206,8 +214,9 @@ def bev_lift(value, offlog, ref, num_cams, feat_hw, num_heads, num_points, vis0=
     Z = ref.shape[-2]
     Dh = C // num_heads
     qw, qh = (query_grid[1], query_grid[0]) if query_grid is not None else (0, 0)
-    geom = (B, num_cams, fh, fw, num_heads, Dh, Nq, num_points, Z, qw, qh)
-    return _BevLift.apply(value, offlog, ref, vis0, count, geom)
+    grid = bool(ref_is_grid) and num_cams == 1 and qw > 0
+    geom = (B, num_cams, fh, fw, num_heads, Dh, Nq, num_points, Z, qw, qh, grid)
+    return _BevLift.apply(value, offlog, ref, vis0, count, slot_center, geom)
 
 
 # ----------------------------------------------------------------------------------------------- geometry

@@ -159,7 +159,9 @@ class MultiScaleDeformableAttention(_DeformAttnBase):
             qgrid = grid if (grid[0] and grid[1] and grid[0] * grid[1] == num_query) else None
             output = UF.bev_lift(value, self.offsets_and_logits(query),
                                  reference_points.reshape(1, bs, num_query, 1, 2), 1, hw[0], H, P,
-                                 query_grid=qgrid)
+                                 query_grid=qgrid,
+                                 ref_is_grid=bool(kwargs.get('ref_is_grid')) and qgrid is not None,
+                                 slot_center=self.sampling_offsets.bias)
         else:
             sampling_offsets = self.sampling_offsets(query).view(bs, num_query, H, L, P, 2)
             attention_weights = self.attention_weights(query).view(bs, num_query, H, L * P)
@@ -222,7 +224,9 @@ class _MSDeformableAttention3D(_DeformAttnBase):
         if self.can_lift(value):
             output = UF.bev_lift(value, self.offsets_and_logits(query),
                                  reference_points.reshape(1, bs, num_query, num_Z_anchors, 2), 1,
-                                 hw[0], H, P, query_grid=kwargs.get('query_grid'))
+                                 hw[0], H, P, query_grid=kwargs.get('query_grid'),
+                                 ref_is_grid=bool(kwargs.get('ref_is_grid')),
+                                 slot_center=self.sampling_offsets.bias)
         else:
             sampling_offsets = self.sampling_offsets(query).view(bs, num_query, H, L, P, 2)
             attention_weights = self.attention_weights(query).view(bs, num_query, H, L * P)

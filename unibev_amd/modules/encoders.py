@@ -153,7 +153,7 @@ class ImgEncoder(_EncoderBase):
                             bev_w=bev_w, spatial_shapes=spatial_shapes,
                             level_start_index=level_start_index, reference_points_cam=cam,
                             bev_mask=mask, cam_vis0=vis0, cam_count=count,
-                            query_grid=(bev_h, bev_w))
+                            query_grid=(bev_h, bev_w), ref_is_grid=True)
         return self._run_layers(bev_query, key, value, args, layer_kwargs)
 
 
@@ -192,7 +192,7 @@ class PtsEncoder(_EncoderBase):
         layer_kwargs = dict(kwargs, bev_pos=bev_pos, ref_2d=ref_2d, ref_3d=ref_3d, bev_h=bev_h,
                             bev_w=bev_w, spatial_shapes=spatial_shapes,
                             level_start_index=level_start_index, reference_points_lidar=lidar,
-                            query_grid=(bev_h, bev_w))
+                            query_grid=(bev_h, bev_w), ref_is_grid=True)
         return self._run_layers(bev_query, key, value, args, layer_kwargs)
 
 

@@ -140,6 +140,6 @@ class SpatialCrossAttentionPts(BaseModule):
         queries = self.deformable_attention(
             query=query, key=value, value=value, reference_points=reference_points_lidar,
             spatial_shapes=spatial_shapes, level_start_index=level_start_index,
-            query_grid=kwargs.get('query_grid'))
+            query_grid=kwargs.get('query_grid'), ref_is_grid=kwargs.get('ref_is_grid', False))
         queries = queries.view(bs, -1, self.embed_dims)
         return self.dropout(self.output_proj(queries)) + inp_residual
