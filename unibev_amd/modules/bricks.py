@@ -13,6 +13,7 @@ import warnings
 import torch
 import torch.nn as nn
 
+from ..linear import linear as ubv_linear
 from ..registry import (ATTENTION, FEEDFORWARD_NETWORK, POSITIONAL_ENCODING, TRANSFORMER_LAYER,
                         TRANSFORMER_LAYER_SEQUENCE, build_attention, build_feedforward_network,
                         build_transformer_layer)
@@ -80,8 +81,25 @@ class FFN(BaseModule):
         self.dropout_layer = nn.Dropout(p) if p > 0 else nn.Identity()
         self.add_identity = add_identity
 
+    def _mlp(self, x):
+        """``self.layers(x)`` with the Linear layers routed through the split-K-wgrad linear."""
+        for layer in self.layers:
+            if isinstance(layer, nn.Linear):
+                x = ubv_linear(x, layer.weight, layer.bias)
+            elif isinstance(layer, nn.Sequential):
+                for sub in layer:
+                    if isinstance(sub, nn.Linear):
+                        x = ubv_linear(x, sub.weight, sub.bias)
+                    elif isinstance(sub, nn.ReLU):
+                        x = torch.relu(x)          # out-of-place: x is the output of a custom op
+                    else:
+                        x = sub(x)
+            else:
+                x = layer(x)
+        return x
+
     def forward(self, x, identity=None):
-        out = self.layers(x)
+        out = self._mlp(x)
         if not self.add_identity:
             return self.dropout_layer(out)
         if identity is None:

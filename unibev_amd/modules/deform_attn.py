@@ -22,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import functional as UF
+from ..linear import linear as ubv_linear
 from ..registry import ATTENTION
 from .bricks import BaseModule, constant_init, xavier_init
 
@@ -102,7 +103,7 @@ class _DeformAttnBase(BaseModule):
         """One GEMM for both query Linears: rows [H*L*P*2 offsets | H*L*P logits]."""
         w = torch.cat((self.sampling_offsets.weight, self.attention_weights.weight), 0)
         b = torch.cat((self.sampling_offsets.bias, self.attention_weights.bias), 0)
-        return F.linear(query, w, b)
+        return ubv_linear(query, w, b)
 
     def can_lift(self, value):
         return (self.num_levels == 1 and
@@ -110,7 +111,7 @@ class _DeformAttnBase(BaseModule):
                                       self.num_points, value.dtype))
 
     def project_value(self, value, key_padding_mask=None):
-        value = self.value_proj(value)
+        value = ubv_linear(value, self.value_proj.weight, self.value_proj.bias)
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
         return value
@@ -178,7 +179,7 @@ class MultiScaleDeformableAttention(_DeformAttnBase):
                                  f'{reference_points.shape[-1]} instead.')
             output = self.k1(value, spatial_shapes, level_start_index, sampling_locations,
                              attention_weights)
-        output = self.output_proj(output)
+        output = ubv_linear(output, self.output_proj.weight, self.output_proj.bias)
         if not self.batch_first:
             output = output.permute(1, 0, 2)
         return self.dropout(output) + identity

@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as UF
+from ..linear import linear as ubv_linear
 from ..registry import ATTENTION, build_attention
 from .bricks import BaseModule, xavier_init
 from .deform_attn import static_hw
@@ -76,7 +77,7 @@ class SpatialCrossAttentionImg(BaseModule):
         else:
             slots = self._rebatch_path(query, value, reference_points_cam, bev_mask,
                                        spatial_shapes, level_start_index)
-        slots = self.output_proj(slots)
+        slots = ubv_linear(slots, self.output_proj.weight, self.output_proj.bias)
         return self.dropout(slots) + inp_residual
 
     def _rebatch_path(self, query, value, reference_points_cam, bev_mask, spatial_shapes,
@@ -142,4 +143,5 @@ class SpatialCrossAttentionPts(BaseModule):
             spatial_shapes=spatial_shapes, level_start_index=level_start_index,
             query_grid=kwargs.get('query_grid'), ref_is_grid=kwargs.get('ref_is_grid', False))
         queries = queries.view(bs, -1, self.embed_dims)
-        return self.dropout(self.output_proj(queries)) + inp_residual
+        out = ubv_linear(queries, self.output_proj.weight, self.output_proj.bias)
+        return self.dropout(out) + inp_residual
