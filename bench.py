@@ -108,22 +108,6 @@ def synth_inputs(workload, bs, dtype, device, rank):
     return img, pts, metas
 
 
-def lift_bytes(name, geom, esize):
-    """Algorithmic (compulsory) HBM bytes of one bev_lift launch: every input read once, every
-    output written once, gathers not counted; offsets / logits / refs /
-    grads f32, values `esize` bytes."""
-    B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh = geom[:11]
-    C, S = H * Dh, fh * fw
-    value = B * Nc * S * C * esize
-    offlog = B * Nq * H * P * 3 * 4
-    ref = Nc * B * Nq * Z * 2 * 4
-    vis = (Nc * Nq + B * Nq * 4) if Nc > 1 else 0
-    out = B * Nq * C * esize
-    if name == 'fwd':
-        return value + offlog + ref + vis + out
-    return value + B * Nc * S * C * 4 + 2 * offlog + ref + vis + out
-
-
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -135,9 +119,8 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)     # RCCL over xGMI
+    from unibev_amd import dp
+    dp.init_distributed('nccl', device)                       # RCCL over xGMI (no-op for N = 1)
 
     from unibev_amd import functional as UF
     torch.manual_seed(0)          # identical replicas
@@ -148,12 +131,8 @@ def main():
     img, pts, metas = synth_inputs(args.workload, args.bs, dtype, device, rank)
 
     head.forward = head.forward_bev           # DDP calls module.forward
-    model = head
-    if world > 1:
-        model = torch.nn.parallel.DistributedDataParallel(
-            head, device_ids=[local], broadcast_buffers=False, gradient_as_bucket_view=True,
-            bucket_cap_mb=32)
-    fwd = (lambda: model(img, pts, metas)) if world == 1 else (lambda: model(img, pts, metas))
+    model = dp.wrap_ddp(head, device_ids=[local])
+    fwd = lambda: model(img, pts, metas)       # noqa: E731
     params = [p for p in head.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.01, fused=True)
     s = 2 if WORKLOADS[args.workload][0].get('fusion_method') == 'cat' else 1
@@ -179,18 +158,15 @@ def main():
         step()
     barrier()
     if not args.no_kernel_timing:
-        UF.enable_profile(True)
+        UF.kernel_profile(True)          # HIP events around every sampling kernel, on its stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
-    prof = UF.profile_results()
-    UF.enable_profile(False)
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    prof = {} if args.no_kernel_timing else UF.kernel_profile()
+    UF.kernel_profile(False)
+    dt = dp.max_over_ranks(dt, device)
 
     if rank == 0:
         out = {
@@ -204,28 +180,19 @@ def main():
                        'step': 'fwd + bwd + grad all-reduce + clip + AdamW',
                        'parallelism': f'dp{world}'},
         }
-        # ---- roofline of the dominant sampling kernel ------------------------------------
+        # ---- roofline of the dominant sampling kernel (HIP events inside the library) -------
         detail = []
-        if prof:
-            for kind in ('fwd', 'bwd'):
-                groups = {}
-                for ms, (geom, esize) in prof.get('lift_' + kind, []):
-                    B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh = geom[:11]
-                    inst = ('self-attn' if (Z == 1 and P == 4) else
-                            ('SCA-img' if Nc > 1 else 'SCA-pts'))
-                    key = f'bev_lift_{kind}<P={P}> {inst} (Nc={Nc}, map {fh}x{fw}, Nq={Nq}, B={B})'
-                    g = groups.setdefault(key, [0, 0.0, lift_bytes(kind, geom, esize)])
-                    g[0] += 1
-                    g[1] += ms
-                for key, (calls, total_ms, nbytes) in groups.items():
-                    detail.append({'kernel': key, 'launches': calls, 'avg_us': 1e3 * total_ms / calls,
-                                   'algorithmic_bytes_per_launch': nbytes,
-                                   'achieved_GBps': nbytes * calls / (total_ms * 1e-3) / 1e9})
-            dom = max(detail, key=lambda d: d['avg_us'] * d['launches'])
+        for name, r in prof.items():
+            detail.append({'kernel': name, 'launches': r['launches'], 'avg_us': r['avg_us'],
+                           'algorithmic_bytes_per_launch': r['bytes_per_launch'],
+                           'achieved_GBps': r['bytes_per_launch'] / (r['avg_us'] * 1e-6) / 1e9})
+        detail.sort(key=lambda d: -d['avg_us'] * d['launches'])
+        if detail:
+            dom = detail[0]
             traffic = None
             tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.exists(tfile):
-                traffic = json.load(open(tfile)).get(dom['kernel'].split(' ')[0])
+                traffic = json.load(open(tfile)).get(dom['kernel'].split('<')[0])
             out['roofline'] = {'bound': 'hbm', 'achieved': dom['achieved_GBps'], 'peak': HBM_PEAK_GBS,
                                'unit': 'GB/s', 'frac': dom['achieved_GBps'] / HBM_PEAK_GBS,
                                'traffic': traffic, 'kernel': dom['kernel'],
@@ -246,7 +213,9 @@ def cpu_baseline(args, tcfg, head):
     """The oracle (CPU restatement of the reference path, oracle/unibev_ref.py) timed on the host:
     forward only, fp32, bs = 1, eval mode, 1 warm-up + 2 timed passes (~10-20 s)."""
     from oracle import unibev_ref as R
-    torch.set_num_threads(os.cpu_count() or 1)
+    # a 256-thread host oversubscribes torch's small CPU kernels (78.9 s/pass measured with all
+    # threads vs ~5 s with 16): the baseline uses at most 16 threads and says so
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
     sd = {k[len('transformer.'):]: v.detach().float().cpu() for k, v in head.state_dict().items()
           if k.startswith('transformer.')}
     img, pts, metas = synth_inputs(args.workload, 1, torch.float32, 'cpu', 0)

@@ -40,6 +40,13 @@ const char* ubv_last_error(void);
 /* Name of the gfx target the kernels were compiled for ("gfx950"). */
 const char* ubv_arch(void);
 
+/* Optional per-kernel timing: while enabled, every kernel of the sampling family is bracketed by
+ * HIP events on its launch stream.  ubv_profile_read() synchronises on them and writes one line per
+ * kernel name: "name<TAB>launches<TAB>total_ms<TAB>algorithmic_bytes_per_launch\n"; returns the
+ * number of bytes the full text needs.  ubv_profile_enable(0|1) also clears the records. */
+int ubv_profile_enable(int on);
+int64_t ubv_profile_read(char* out, int64_t capacity);
+
 /* ------------------------------------------------------------------------------------------------
  * k1 — multi-scale deformable attention sampling.
  * Replaces [ext] mmcv `_ext.ms_deform_attn_forward` / `ms_deform_attn_backward`, loaded at

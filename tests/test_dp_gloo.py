@@ -1,0 +1,80 @@
+"""The data-parallel harness on CPU: 2 processes, gloo.  Checks the sample sharding contract, that
+DDP-averaged gradients of encoder-side torch modules (FFN + LayerNorm built through the registry)
+equal the average of the per-rank gradients, and the max-over-ranks timing reduction."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from unibev_amd import dp
+    from unibev_amd.registry import build_feedforward_network
+    torch.set_num_threads(1)
+    r, w = dp.init_distributed('gloo')
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)                                   # identical replicas
+    net = torch.nn.Sequential(
+        build_feedforward_network(dict(type='FFN', embed_dims=32, feedforward_channels=64,
+                                       ffn_drop=0.0)),
+        torch.nn.LayerNorm(32))
+    ddp = dp.wrap_ddp(net)
+    data = torch.randn(7, 5, 32, generator=torch.Generator().manual_seed(1))      # 7 samples
+    mine = dp.shard_samples(7, rank, world)
+    loss = ddp(data[mine]).square().sum() / len(mine)
+    loss.backward()
+    grads = torch.cat([p.grad.flatten() for p in net.parameters()])
+    # reference: average over ranks of the per-rank gradients, computed without DDP
+    ref = torch.zeros_like(grads)
+    for rr in range(world):
+        torch.manual_seed(0)
+        net2 = torch.nn.Sequential(
+            build_feedforward_network(dict(type='FFN', embed_dims=32, feedforward_channels=64,
+                                           ffn_drop=0.0)),
+            torch.nn.LayerNorm(32))
+        idx = dp.shard_samples(7, rr, world)
+        (net2(data[idx]).square().sum() / len(idx)).backward()
+        ref += torch.cat([p.grad.flatten() for p in net2.parameters()]) / world
+    ok = torch.allclose(grads, ref, rtol=1e-5, atol=1e-6)
+    tmax = dp.max_over_ranks(1.0 + rank)
+    dp.barrier()
+    ret[rank] = (ok, mine, tmax)
+    dist.destroy_process_group()
+
+
+def test_sample_sharding_contract():
+    from unibev_amd.dp import shard_samples
+    for n in (0, 1, 7, 8, 16, 17):
+        for w in (1, 2, 3, 8):
+            parts = [shard_samples(n, r, w) for r in range(w)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            sizes = [len(p) for p in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_gradient_allreduce_gloo():
+    ctx = mp.get_context('spawn')
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret[0][0] and ret[1][0]
+    assert ret[0][1] == [0, 1, 2, 3] and ret[1][1] == [4, 5, 6]
+    assert ret[0][2] == ret[1][2] == 2.0

@@ -15,7 +15,6 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unibev_amd import functional as UF      # noqa: E402
 from unibev_amd import synthetic as syn      # noqa: E402
-from bench import lift_bytes                  # noqa: E402
 
 
 def instance(name, B, dtype, dev, init_like=True, img_hw=(256, 704)):
@@ -73,22 +72,25 @@ def main():
         B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh = geom
         value.requires_grad_()
         offlog.requires_grad_()
-        UF.enable_profile(True)
         for it in range(a.iters + 3):
             if it == 3:
-                UF.enable_profile(True)
+                UF.kernel_profile(True)
             out = UF.bev_lift(value, offlog, ref, Nc, (fh, fw), H, P, vis0=vis0, count=count,
                               query_grid=(qh, qw), ref_is_grid=is_grid,
                               slot_center=None if a.no_center else center)
             out.backward(gout)
             value.grad = offlog.grad = None
-        res = UF.profile_results()
-        UF.enable_profile(False)
-        for kind in ('fwd', 'bwd'):
-            ms = np.median([m for m, _ in res['lift_' + kind]])
-            nb = lift_bytes(kind, geom, value.element_size())
-            print(f'{name:5s} {kind} B={B} {a.dtype}: {ms * 1e3:9.1f} us  alg {nb / 1e6:7.1f} MB  '
-                  f'{nb / ms / 1e6:8.1f} GB/s  ({100 * nb / ms / 1e6 / 8000:5.2f}% of 8 TB/s)')
+        res = UF.kernel_profile()
+        UF.kernel_profile(False)
+        tot = {'fwd': [0.0, 0.0], 'bwd': [0.0, 0.0]}
+        for kname, r in sorted(res.items()):
+            kind = 'fwd' if 'fwd' in kname else 'bwd'
+            tot[kind][0] += r['avg_us']
+            tot[kind][1] = max(tot[kind][1], r['bytes_per_launch'])
+            gbs = r['bytes_per_launch'] / r['avg_us'] / 1e3
+            print(f'  {kname:86s} {r["avg_us"]:9.1f} us  alg {r["bytes_per_launch"] / 1e6:7.1f} MB '
+                  f'{gbs:8.1f} GB/s ({100 * gbs / 8000:5.2f}% of 8 TB/s)')
+        print(f'{name:5s} B={B} {a.dtype}: fwd {tot["fwd"][0]:8.1f} us   bwd (all kernels) {tot["bwd"][0]:8.1f} us')
 
 
 if __name__ == '__main__':

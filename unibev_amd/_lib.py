@@ -20,6 +20,8 @@ SIGNATURES = {
     'ubv_version': (c_int, []),
     'ubv_last_error': (c_char_p, []),
     'ubv_arch': (c_char_p, []),
+    'ubv_profile_enable': (c_int, [c_int]),
+    'ubv_profile_read': (c_int64, [c_char_p, c_int64]),
     'ubv_ms_deform_attn_forward': (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 9 + [_P]),
     'ubv_ms_deform_attn_backward': (c_int, [_P] * 9 + [c_int] * 9 + [_P]),
     'ubv_bev_lift_forward': (c_int, [_P, _P, c_int64, _P, c_int64, _P, _P, _P, _P]

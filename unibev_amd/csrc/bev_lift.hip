@@ -671,23 +671,56 @@ __global__ __launch_bounds__(256) void lift_bwd_value_kernel(const LiftArgs a, c
 }
 
 // ---- dispatch ----------------------------------------------------------------------------------------
+// Algorithmic (compulsory) bytes of each kernel: every operand read once, every result written
+// once, gathers not counted.
+struct LiftBytes {
+  double value, value_f32, offlog, ref, vis, out, rec;
+};
+static LiftBytes lift_bytes(const LiftArgs& a, int Dh, int P, int esize) {
+  LiftBytes b;
+  const double C = (double)a.H * Dh, S = (double)a.fh * a.fw;
+  b.value = a.B * a.Nc * S * C * esize;
+  b.value_f32 = a.B * a.Nc * S * C * 4.0;
+  b.offlog = (double)a.B * a.Nq * a.H * P * 3 * 4;
+  b.ref = (double)a.Nc * a.B * a.Nq * a.Z * 2 * 4;
+  b.vis = a.Nc > 1 ? (double)a.Nc * a.Nq + (double)a.B * a.Nq * 4 : 0.0;
+  b.out = (double)a.B * a.Nq * C * esize;
+  b.rec = (double)a.B * a.Nq * a.H * P * 16;
+  return b;
+}
+
 template <typename T, int DH, int P>
 static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, hipStream_t st) {
   constexpr int VEC = 16 / elem<T>::kBytes;
   const int blocks = 8 * a.chunk;
+  const LiftBytes nb = lift_bytes(a, DH, P, elem<T>::kBytes);
+  char tag[96];
+  auto name = [&](const char* k) {
+    snprintf(tag, sizeof(tag), "%s<P=%d,Dh=%d,%dB> Nc=%d map=%dx%d Nq=%d B=%d", k, P, DH,
+             elem<T>::kBytes, a.Nc, a.fh, a.fw, a.Nq, a.B);
+    return tag;
+  };
   if (bwd_mode < 0) {
+    ProfScope ps(name("bev_lift_fwd"), st, nb.value + nb.offlog + nb.ref + nb.vis + nb.out);
     hipLaunchKernelGGL((lift_fwd_kernel<T, DH, VEC, P>), dim3(blocks), dim3(256), 0, st, a);
     return;
   }
+  // query kernel: value, offsets/logits, refs, grad_out in; d(offsets/logits) out (+ records)
+  const double q_bytes = nb.value + 2 * nb.offlog + nb.ref + nb.vis + nb.out;
   if (bwd_mode == kAtomAll) {
+    ProfScope ps(name("bev_lift_bwd_query+atomics"), st, q_bytes + nb.value_f32);
     hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomAll>), dim3(blocks), dim3(256), 0, st, a);
   } else if (bwd_mode == kAtomFar) {
     // the query kernel leaves one record per sampling point for the owner tiles and scatters the
     // (rare) far corners atomically into the zeroed grad_value; the owner tiles then add their
     // exclusive pixels on top with a plain read-add-store.
-    hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomFar>), dim3(blocks), dim3(256), 0, st, a);
+    {
+      ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes + nb.rec);
+      hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomFar>), dim3(blocks), dim3(256), 0, st, a);
+    }
     constexpr int RB = 2;
     const size_t lds = (size_t)t.waves * TileLds<T, DH, RB>::kWords * sizeof(uint16_t);
+    ProfScope ps(name("bev_lift_bwd_value_grid"), st, nb.rec + nb.ref + nb.out + nb.value_f32);
     hipLaunchKernelGGL((lift_bwd_value_kernel<T, DH, P, RB, 1>), dim3(8 * t.chunk), dim3(64 * t.waves),
                        lds, st, a, t);
   } else {
@@ -695,8 +728,13 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, hipS
                        a.cam_list, a.cam_n);
     constexpr int RB = 6;
     const size_t lds = (size_t)t.waves * TileLds<T, DH, RB>::kWords * sizeof(uint16_t);
-    hipLaunchKernelGGL((lift_bwd_value_kernel<T, DH, P, RB, 2>), dim3(8 * t.chunk), dim3(64 * t.waves),
-                       lds, st, a, t);
+    {
+      ProfScope ps(name("bev_lift_bwd_value_camera"), st,
+                   nb.offlog + nb.ref + nb.vis + nb.out + nb.value_f32);
+      hipLaunchKernelGGL((lift_bwd_value_kernel<T, DH, P, RB, 2>), dim3(8 * t.chunk),
+                         dim3(64 * t.waves), lds, st, a, t);
+    }
+    ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes);
     hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomNone>), dim3(blocks), dim3(256), 0, st, a);
   }
 }

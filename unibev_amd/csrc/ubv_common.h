@@ -189,4 +189,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int chunk) { return (bid & 7) 
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// RAII pair of HIP events around one kernel launch (a no-op unless ubv_profile_enable(1)).
+class ProfScope {
+ public:
+  ProfScope(const char* name, hipStream_t st, double algorithmic_bytes);
+  ~ProfScope();
+ private:
+  long idx_;
+  hipStream_t st_;
+};
+
 }  // namespace ubv

@@ -1,0 +1,62 @@
+"""Data-parallel harness: one process per GPU, samples sharded across ranks, gradients averaged with
+an all-reduce (RCCL over xGMI on MI355X: torch.distributed backend "nccl"; "gloo" on CPU for tests).
+
+The reference's only parallelism is mmcv's MMDistributedDataParallel (= torch DDP) over NCCL with
+``broadcast_buffers=False`` and a DistributedGroupSampler (tools/test_UniBEV.py:219-222,
+configs/unibev/unibev_nus_LC_cnw_256_modality_dropout.py:180-181, 410).  The BEV-encoder path has
+no cross-sample exchange step, so the only collective is the gradient all-reduce, bucketed and
+overlapped with backward by DDP; an 8-GPU MI355X node is fully connected over xGMI, so the buckets
+are kept large (32 MB) to stay bandwidth- rather than latency-bound per link.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None, device=None):
+    """Initialise the default process group from the torchrun environment (RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT).  Returns (rank, world_size).  A single process needs no group."""
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        kw = {}
+        if backend == 'nccl' and device is not None:
+            kw['device_id'] = device
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
+def shard_samples(num_samples, rank, world_size):
+    """Indices of the samples rank ``rank`` owns: contiguous, disjoint, covering, sizes differing
+    by at most one (the DistributedSampler contract without padding)."""
+    base, rem = divmod(num_samples, world_size)
+    start = rank * base + min(rank, rem)
+    return list(range(start, start + base + (1 if rank < rem else 0)))
+
+
+def wrap_ddp(module, device_ids=None, bucket_cap_mb=32):
+    """DistributedDataParallel with the reference's settings (no buffer broadcast); identity when
+    there is a single process."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return module
+    return torch.nn.parallel.DistributedDataParallel(
+        module, device_ids=device_ids, broadcast_buffers=False, gradient_as_bucket_view=True,
+        bucket_cap_mb=bucket_cap_mb)
+
+
+def max_over_ranks(value, device='cpu'):
+    """MAX of a python float over all ranks (bench.py times the slowest rank)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -54,6 +54,26 @@ class _timed:
             _PROFILE.setdefault(self.name, []).append((self.s, self.e, self.meta))
 
 
+def kernel_profile(enable=None):
+    """Per-kernel HIP-event timing inside the library (``ubv_profile_enable`` /
+    ``ubv_profile_read``).  ``kernel_profile(True)`` starts, ``kernel_profile(False)`` stops;
+    ``kernel_profile()`` returns {kernel name: dict(launches, total_ms, avg_us, bytes_per_launch)}
+    (synchronises on the recorded events)."""
+    if enable is not None:
+        check(lib().ubv_profile_enable(1 if enable else 0), 'profile_enable')
+        return None
+    n = lib().ubv_profile_read(None, 0)
+    buf = ctypes.create_string_buffer(int(n) + 16)
+    lib().ubv_profile_read(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms, nb = line.split('\t')
+        cnt, ms, nb = int(cnt), float(ms), float(nb)
+        out[name] = dict(launches=cnt, total_ms=ms, avg_us=1e3 * ms / max(cnt, 1),
+                         bytes_per_launch=nb)
+    return out
+
+
 def _dt(t):
     try:
         return _DT[t.dtype]
