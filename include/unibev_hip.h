@@ -198,6 +198,29 @@ int ubv_bev_fuse_backward(const void* grad_out, const void* img, const void* pts
                           float* grad_sw, int B, int Nq, int C, int cat, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused residual + dropout + LayerNorm:  y = LN(identity + dropout(x)) * gamma + beta.
+ * Replaces the tail `self.dropout(out) + identity` of every attention / FFN of an encoder layer
+ * (models/modules/decoder.py:338, spatial_cross_attention_img.py:215, spatial_cross_attention_pts.py:206,
+ * [ext] mmcv FFN) together with the following 'norm' of BaseTransformerLayer's operation_order
+ * (encoder_unibev_detr_img.py:434-436).
+ *   x        [R, C] dtype           identity, y, grad_y, grad_identity [R, C] f32
+ *   gamma, beta [C] f32             mean, rstd [R] f32 (saved for backward)
+ *   p        dropout probability (0 = eval); the keep mask is a stateless hash of (seed, element),
+ *            so backward regenerates it from the same seed and nothing is stored
+ *   grad_gamma, grad_beta [C] f32 ACCUMULATED (caller zeroes);  grad_x [R, C] dtype
+ *   C % 4 == 0, C <= 1024.
+ */
+int ubv_add_dropout_layernorm_forward(const void* x, const float* identity, const float* gamma,
+                                      const float* beta, float* y, float* mean, float* rstd,
+                                      int64_t R, int C, float eps, float p, uint64_t seed, int dtype,
+                                      void* stream);
+int ubv_add_dropout_layernorm_backward(const float* grad_y, const void* x, const float* identity,
+                                       const float* gamma, const float* mean, const float* rstd,
+                                       void* grad_x, float* grad_identity, float* grad_gamma,
+                                       float* grad_beta, int64_t R, int C, float p, uint64_t seed,
+                                       int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * LiDAR front end.
  * Replaces [ext] mmdet3d ops built from `pts_voxel_layer` and called at
  * models/detectors/unibev_detector.py:163-167 (Voxelization -> hard_voxelize, deterministic),

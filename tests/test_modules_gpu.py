@@ -210,3 +210,37 @@ def test_missing_extension_or_cpu_tensor_fails_loudly():
     from unibev_amd.functional import bev_fuse
     with pytest.raises(RuntimeError):
         bev_fuse(torch.zeros(1, 4, 8), None, torch.ones(8), torch.ones(8))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_add_dropout_layernorm_vs_torch(dtype):
+    """Fused residual + dropout + LayerNorm: eval mode equals F.layer_norm(x + identity) forward and
+    backward; train mode drops ~p of the elements, scales the rest, and its backward is consistent
+    with the regenerated mask."""
+    from unibev_amd.functional import add_dropout_layernorm
+    torch.manual_seed(0)
+    R, C = 1000, 256
+    x = torch.randn(R, C, device=DEV).to(dtype)
+    idn = torch.randn(R, C, device=DEV)
+    g = torch.randn(C, device=DEV) * 0.2 + 1
+    b = torch.randn(C, device=DEV) * 0.1
+    cot = torch.randn(R, C, device=DEV)
+    xa, ia, ga, ba = (v.clone().requires_grad_() for v in (x, idn, g, b))
+    y = add_dropout_layernorm(xa, ia, ga, ba, 0.1, training=False)
+    (y * cot).sum().backward()
+    xr, ir, gr, br = (v.clone().float().requires_grad_() for v in (x, idn, g, b))
+    yr = torch.nn.functional.layer_norm(xr + ir, (C,), gr, br, 1e-5)
+    (yr * cot).sum().backward()
+    tol = dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(y, yr, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(ia.grad, ir.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(xa.grad.float(), xr.grad, **tol)
+    torch.testing.assert_close(ga.grad, gr.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(ba.grad, br.grad, rtol=1e-3, atol=1e-3)
+    # train mode: x-gradient is zero exactly where the element was dropped; identity untouched
+    xa2 = x.clone().float().requires_grad_()
+    y2 = add_dropout_layernorm(xa2, torch.zeros_like(idn), torch.ones_like(g), torch.zeros_like(b),
+                               0.25, training=True)
+    y2.square().sum().backward()
+    dropped = (xa2.grad == 0).float().mean().item()
+    assert 0.22 < dropped < 0.28, dropped

@@ -32,7 +32,7 @@ struct LiftArgs {
   const void* gout; float* gvalue; float* goff; long goff_stride; float* glog; long glog_stride;
   int B, Nc, fh, fw, H, Nq, Z, qw, qh, tiles_x, tiles_per_sample, total_tiles, chunk;
   int R;                                         // near radius (pixels) of the owner-tile backward
-  float4* rec;                                   // [B,Nq,H,P] (x_pix, y_pix, w/count, -) or null
+  float4* rec;                                   // [B,H,P,Nq] (x_pix, y_pix, w/count, -) or null
   int* cam_list; int* cam_n;                     // per-camera compacted visible queries or null
   const float* center;                           // [H,P,2] slot centres in pixels or null
 };
@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) void lift_bwd_query_kernel(const LiftArgs a) {
           hx = home_pixel(r.x, a.fw) + slot_shift(a.center, h, P, p, 0);
           hy = home_pixel(r.y, a.fh) + slot_shift(a.center, h, P, p, 1);
           if (valid && cg == 0 && a.rec != nullptr)      // hand the point to the owner-tile kernel
-            a.rec[(bq * a.H + h) * P + p] = make_float4(xp, yp, w[p] / cnt, 0.0f);
+            // slot-major [b][h][p][q]: the owner tiles read runs of consecutive queries per slot
+            a.rec[(((long)b * a.H + h) * P + p) * a.Nq + q] = make_float4(xp, yp, w[p] / cnt, 0.0f);
         }
         float dot[4];
 #pragma unroll
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(256) void lift_bwd_value_kernel(const LiftArgs a, c
         cy += ((cy + 1) * cw <= cc) ? 1 : 0;
         q = (qy_lo + cy) * a.qw + qx_lo + (cc - cy * cw);
         const long bq = (long)g.b * a.Nq + q;
-        rec = a.rec[(bq * a.H + g.h) * P + p];
+        rec = a.rec[(((long)g.b * a.H + g.h) * P + p) * a.Nq + q];
         ref = *reinterpret_cast<const float2*>(a.ref + (bq * a.Z + zi) * 2);
         return valid;
       };

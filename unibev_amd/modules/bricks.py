@@ -98,6 +98,27 @@ class FFN(BaseModule):
                 x = layer(x)
         return x
 
+    def forward_parts(self, x, identity=None):
+        """(pre-dropout output, identity, p) for a caller that fuses the tail with the next norm;
+        None when this FFN's tail is not ``identity + Dropout(out)``."""
+        last = self.layers[-1]
+        if not (self.add_identity and isinstance(last, nn.Dropout) and
+                isinstance(self.dropout_layer, nn.Identity)):
+            return None
+        h = x
+        for layer in list(self.layers)[:-1]:
+            if isinstance(layer, nn.Linear):
+                h = ubv_linear(h, layer.weight, layer.bias)
+            else:
+                for sub in layer:
+                    if isinstance(sub, nn.Linear):
+                        h = ubv_linear(h, sub.weight, sub.bias)
+                    elif isinstance(sub, nn.ReLU):
+                        h = torch.relu(h)
+                    else:
+                        h = sub(h)
+        return h, (x if identity is None else identity), last.p
+
     def forward(self, x, identity=None):
         out = self._mlp(x)
         if not self.add_identity:

@@ -182,6 +182,8 @@ class MultiScaleDeformableAttention(_DeformAttnBase):
         output = ubv_linear(output, self.output_proj.weight, self.output_proj.bias)
         if not self.batch_first:
             output = output.permute(1, 0, 2)
+        if kwargs.get('return_parts'):            # the caller fuses dropout + residual + LayerNorm
+            return output, identity, self.dropout.p
         return self.dropout(output) + identity
 
 

@@ -238,18 +238,35 @@ class _BevLayer(BaseTransformerLayer):
             assert len(attn_masks) == self.num_attn, \
                 f'The length of attn_masks {len(attn_masks)} must be equal to the number of ' \
                 f'attention in operation_order {self.num_attn}'
-        for layer in self.operation_order:
+        order = self.operation_order
+        fuse_next = False                 # the previous op handed (out, identity, p) to this norm
+        for op_i, layer in enumerate(order):
+            # post-norm layers: `dropout(out) + identity` of an attention / FFN and the LayerNorm
+            # that follows run as ONE kernel (functional.add_dropout_layernorm)
+            parts = (not self.pre_norm and op_i + 1 < len(order) and order[op_i + 1] == 'norm'
+                     and query.is_cuda)
             if layer == 'self_attn':
                 ss, lsi = self._bev_shapes(bev_h, bev_w, query.device)
                 query = self.attentions[attn_index](
                     query, query, query, identity if self.pre_norm else None, query_pos=bev_pos,
                     key_pos=bev_pos, attn_mask=attn_masks[attn_index],
                     key_padding_mask=query_key_padding_mask, reference_points=ref_2d,
-                    spatial_shapes=ss, level_start_index=lsi, bev_h=bev_h, bev_w=bev_w, **kwargs)
+                    spatial_shapes=ss, level_start_index=lsi, bev_h=bev_h, bev_w=bev_w,
+                    return_parts=parts, **kwargs)
                 attn_index += 1
-                identity = query
+                fuse_next = parts and isinstance(query, tuple)
+                if not fuse_next:
+                    identity = query
             elif layer == 'norm':
-                query = self.norms[norm_index](query)
+                norm = self.norms[norm_index]
+                if fuse_next:
+                    out, res, p = query
+                    query = UF.add_dropout_layernorm(out, res, norm.weight, norm.bias, p,
+                                                     self.training, norm.eps)
+                    identity = query
+                    fuse_next = False
+                else:
+                    query = norm(query)
                 norm_index += 1
             elif layer == 'cross_attn':
                 pos = (bev_pos, bev_pos) if attn_index == 0 else (query_pos, key_pos)
@@ -257,11 +274,18 @@ class _BevLayer(BaseTransformerLayer):
                     query, key, value, identity if self.pre_norm else None, query_pos=pos[0],
                     key_pos=pos[1], reference_points=ref_3d, mask=mask,
                     attn_mask=attn_masks[attn_index], key_padding_mask=key_padding_mask,
-                    spatial_shapes=spatial_shapes, level_start_index=level_start_index, **kwargs)
+                    spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                    return_parts=parts, **kwargs)
                 attn_index += 1
-                identity = query
+                fuse_next = parts and isinstance(query, tuple)
+                if not fuse_next:
+                    identity = query
             elif layer == 'ffn':
-                query = self.ffns[ffn_index](query, identity if self.pre_norm else None)
+                fp = self.ffns[ffn_index].forward_parts(query) if parts else None
+                if fp is not None:
+                    query, fuse_next = fp, True
+                else:
+                    query = self.ffns[ffn_index](query, identity if self.pre_norm else None)
                 ffn_index += 1
         return query
 

@@ -78,6 +78,8 @@ class SpatialCrossAttentionImg(BaseModule):
             slots = self._rebatch_path(query, value, reference_points_cam, bev_mask,
                                        spatial_shapes, level_start_index)
         slots = ubv_linear(slots, self.output_proj.weight, self.output_proj.bias)
+        if kwargs.get('return_parts'):            # the caller fuses dropout + residual + LayerNorm
+            return slots, inp_residual, self.dropout.p
         return self.dropout(slots) + inp_residual
 
     def _rebatch_path(self, query, value, reference_points_cam, bev_mask, spatial_shapes,
@@ -144,4 +146,6 @@ class SpatialCrossAttentionPts(BaseModule):
             query_grid=kwargs.get('query_grid'), ref_is_grid=kwargs.get('ref_is_grid', False))
         queries = queries.view(bs, -1, self.embed_dims)
         out = ubv_linear(queries, self.output_proj.weight, self.output_proj.bias)
+        if kwargs.get('return_parts'):
+            return out, inp_residual, self.dropout.p
         return self.dropout(out) + inp_residual
