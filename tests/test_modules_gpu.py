@@ -244,3 +244,39 @@ def test_add_dropout_layernorm_vs_torch(dtype):
     y2.square().sum().backward()
     dropped = (xa2.grad == 0).float().mean().item()
     assert 0.22 < dropped < 0.28, dropped
+
+
+def test_lowp_weight_shadows_follow_optimizer_steps():
+    """The low-precision weight shadows (unibev_amd/linear.py) are refreshed on entry of every
+    ``lowp_step_cache`` context: after an optimizer step the next forward sees the new weights
+    (the fused AdamW kernel does not bump parameter versions, so nothing may be cached across
+    steps), and gradients reach the f32 master parameters."""
+    from unibev_amd.linear import linear, linear_cat, lowp_step_cache
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(64, 32).to(DEV)
+    lin2 = torch.nn.Linear(64, 16).to(DEV)
+    opt = torch.optim.AdamW(list(lin.parameters()) + list(lin2.parameters()), lr=0.1, fused=True)
+    x = torch.randn(4096, 64, device=DEV)
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.bfloat16), lowp_step_cache():
+            y = linear(x, lin.weight, lin.bias)
+            z = linear_cat(x, (lin.weight, lin2.weight), (lin.bias, lin2.bias))
+        ref = torch.nn.functional.linear(x.bfloat16(), lin.weight.bfloat16(), lin.bias.bfloat16())
+        torch.testing.assert_close(y, ref, rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(z[:, :32], ref, rtol=2e-2, atol=2e-2)
+        assert y.dtype == torch.bfloat16
+        (y.float().square().mean() + z.float().square().mean()).backward()
+        assert lin.weight.grad.dtype == torch.float32 and lin2.bias.grad is not None
+        opt.step()
+    # f32 path: gradients equal torch's
+    a = torch.randn(8192, 64, device=DEV, requires_grad=True)
+    w = torch.randn(32, 64, device=DEV, requires_grad=True)
+    b = torch.randn(32, device=DEV, requires_grad=True)
+    linear(a, w, b).square().sum().backward()
+    ga, gw, gb = a.grad.clone(), w.grad.clone(), b.grad.clone()
+    a.grad = w.grad = b.grad = None
+    torch.nn.functional.linear(a, w, b).square().sum().backward()
+    torch.testing.assert_close(ga, a.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gw, w.grad, rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(gb, b.grad, rtol=1e-4, atol=1e-2)

@@ -1,14 +1,27 @@
-"""Linear layers of the BEV encoder with a split-K weight gradient.
+"""Linear layers of the BEV encoder: library GEMMs with a split-K weight gradient and per-step cached
+low-precision weights.
 
-Forward and the input gradient are plain library GEMMs (M = bs*40 000 rows, hipBLASLt through
-torch).  The weight gradient dW = dY^T X reduces over those M rows into a 256x256 .. 512x256
-output: as one GEMM it occupies (N/64)*(K/64) = 16..32 workgroups of the 256 CUs (measured 198 us
-per call, 5.9 ms per training step, profiles/r01_v0_*).  Here the rows are split into S slices, the
-slices run as one strided-batched GEMM that fills the chip, and the S partial products are summed.
+* Forward and the input gradient are plain library GEMMs (M = bs*40 000 rows, hipBLASLt via torch).
+* The weight gradient dW = dY^T X reduces over those M rows into a 256x256 .. 512x256 output: as one
+  GEMM it occupies (N/64)*(K/64) = 16..32 workgroups of the 256 CUs (measured 198 us per call,
+  5.9 ms per training step, profiles/r01_v0_*).  Here the rows are split into S slices that run as
+  one strided-batched GEMM filling the chip, and the S partial products are summed in f32.
+* Under autocast the f32 master weights are cast to the autocast dtype by ONE multi-tensor copy
+  per forward pass (``lowp_step_cache``), not by one cast kernel per use, and the gradients come
+  back in f32 directly: per step this removes ~300 tiny cast kernels and their autograd nodes
+  (the eager step is host-bound below ~3.5 us per kernel, MI355X_MICROARCH.md).
+* ``linear_cat`` runs several Linear layers that share their input as ONE GEMM (the
+  ``sampling_offsets`` and ``attention_weights`` layers of every deformable attention).
 """
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
+
+import contextlib
+
+# (param ids, dtype) -> (concatenated low-precision buffer, per-parameter views, parameters)
+_SHADOWS = {}
+_ACTIVE = False
 
 
 def _splits(rows):
@@ -18,40 +31,117 @@ def _splits(rows):
     return 1
 
 
-class _LinearSplitK(Function):
+@contextlib.contextmanager
+def lowp_step_cache():
+    """Within this context (one forward pass of the encoder) the low-precision copies of the
+    weights are taken from persistent shadow buffers that are refreshed ON ENTRY with a single
+    multi-tensor copy (``torch._foreach_copy_``) instead of one cast kernel per use.  The shadows
+    are never trusted across optimizer steps: every entry re-copies from the f32 masters."""
+    global _ACTIVE
+    if _ACTIVE:                       # nested: the outer context already refreshed
+        yield
+        return
+    if _SHADOWS:
+        groups = {}                   # one multi-tensor copy per (dtypes, device) group
+        for buf, views, params in _SHADOWS.values():
+            g = groups.setdefault((buf.dtype, params[0].dtype, buf.device), ([], []))
+            g[0].extend(views)
+            g[1].extend(params)
+        with torch.no_grad():
+            for dst, src in groups.values():
+                torch._foreach_copy_(dst, src)
+    _ACTIVE = True
+    try:
+        yield
+    finally:
+        _ACTIVE = False
+
+
+def clear_lowp_cache():
+    _SHADOWS.clear()
+
+
+def _cached_lowp(params, dtype):
+    """Concatenation (dim 0) of ``params`` in ``dtype``."""
+    if all(p.dtype == dtype for p in params) and len(params) == 1:
+        return params[0]
+    key = tuple(id(p) for p in params) + (dtype,)
+    if _ACTIVE:
+        hit = _SHADOWS.get(key)
+        if hit is not None and hit[0].device == params[0].device:
+            return hit[0]
+    with torch.no_grad():
+        buf = torch.cat([p.detach() for p in params], 0).to(dtype) if len(params) > 1 \
+            else params[0].detach().to(dtype)
+    if _ACTIVE and all(isinstance(p, torch.nn.Parameter) for p in params):
+        if len(_SHADOWS) > 4096:
+            _SHADOWS.clear()
+        views = list(torch.split(buf, [p.shape[0] for p in params], 0))
+        _SHADOWS[key] = (buf, views, list(params))
+    return buf
+
+
+class _Linear(Function):
+    """y = x @ cat(weights)^T + cat(biases).  ``n`` weights followed by ``n`` biases (or none)."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+    def forward(ctx, x, dtype, n, has_bias, *params):
+        weights, biases = params[:n], params[n:]
+        w = _cached_lowp(weights, dtype)
+        b = _cached_lowp(biases, dtype) if has_bias else None
+        xc = x.to(dtype)
+        ctx.save_for_backward(xc, w)
+        ctx.meta = (x.dtype, n, has_bias, [p.shape[0] for p in weights], [p.dtype for p in params])
+        return F.linear(xc, w, b)
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, weight = ctx.saved_tensors
-        gx = gw = gb = None
+        xc, w = ctx.saved_tensors
+        x_dtype, n, has_bias, outs, pdt = ctx.meta
         go2 = grad_out.reshape(-1, grad_out.shape[-1])
+        gx = None
         if ctx.needs_input_grad[0]:
-            gx = (go2 @ weight).view(x.shape)
-        if ctx.needs_input_grad[1]:
-            x2 = x.reshape(-1, x.shape[-1])
-            rows = x2.shape[0]
+            gx = (go2 @ w).view(xc.shape).to(x_dtype)
+        x2 = xc.reshape(-1, xc.shape[-1])
+        rows = x2.shape[0]
+        gw = gb = None
+        if any(ctx.needs_input_grad[4:4 + n]):
             s = _splits(rows)
             if s > 1:
                 part = torch.bmm(go2.view(s, rows // s, -1).transpose(1, 2), x2.view(s, rows // s, -1))
-                gw = part.sum(0, dtype=torch.float32).to(weight.dtype)
+                gw = part.sum(0, dtype=torch.float32)
             else:
-                gw = go2.t() @ x2
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = go2.sum(0, dtype=torch.float32).to(grad_out.dtype)
-        return gx, gw, gb
+                gw = (go2.t() @ x2).float()
+        if has_bias and any(ctx.needs_input_grad[4 + n:]):
+            gb = go2.sum(0, dtype=torch.float32)
+        grads = []
+        off = 0
+        for i in range(n):
+            grads.append(None if gw is None else gw[off:off + outs[i]].to(pdt[i]))
+            off += outs[i]
+        off = 0
+        for i in range(n if has_bias else 0):
+            grads.append(None if gb is None else gb[off:off + outs[i]].to(pdt[n + i]))
+            off += outs[i]
+        return (gx, None, None, None, *grads)
+
+
+def _run(x, weights, biases):
+    has_bias = biases[0] is not None
+    params = list(weights) + (list(biases) if has_bias else [])
+    if x.is_cuda and torch.is_autocast_enabled('cuda'):
+        dt = torch.get_autocast_dtype('cuda')
+        with torch.autocast('cuda', enabled=False):
+            return _Linear.apply(x, dt, len(weights), has_bias, *params)
+    return _Linear.apply(x, x.dtype if x.dtype == weights[0].dtype else weights[0].dtype,
+                         len(weights), has_bias, *params)
 
 
 def linear(x, weight, bias=None):
-    """``F.linear`` with the split-K weight gradient; follows the ambient autocast dtype."""
-    if x.is_cuda and torch.is_autocast_enabled('cuda'):
-        dt = torch.get_autocast_dtype('cuda')
-        x, weight = x.to(dt), weight.to(dt)
-        bias = None if bias is None else bias.to(dt)
-        with torch.autocast('cuda', enabled=False):
-            return _LinearSplitK.apply(x, weight, bias)
-    return _LinearSplitK.apply(x, weight, bias)
+    """``F.linear(x, weight, bias)``; follows the ambient autocast dtype."""
+    return _run(x, [weight], [bias])
+
+
+def linear_cat(x, weights, biases):
+    """``F.linear(x, cat(weights), cat(biases))`` — several Linear layers on one input as one GEMM."""
+    return _run(x, list(weights), list(biases))

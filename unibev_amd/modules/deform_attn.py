@@ -23,6 +23,7 @@ import torch.nn.functional as F
 
 from .. import functional as UF
 from ..linear import linear as ubv_linear
+from ..linear import linear_cat
 from ..registry import ATTENTION
 from .bricks import BaseModule, constant_init, xavier_init
 
@@ -101,9 +102,8 @@ class _DeformAttnBase(BaseModule):
     # -- pieces --------------------------------------------------------------------------------
     def offsets_and_logits(self, query):
         """One GEMM for both query Linears: rows [H*L*P*2 offsets | H*L*P logits]."""
-        w = torch.cat((self.sampling_offsets.weight, self.attention_weights.weight), 0)
-        b = torch.cat((self.sampling_offsets.bias, self.attention_weights.bias), 0)
-        return ubv_linear(query, w, b)
+        return linear_cat(query, (self.sampling_offsets.weight, self.attention_weights.weight),
+                          (self.sampling_offsets.bias, self.attention_weights.bias))
 
     def can_lift(self, value):
         return (self.num_levels == 1 and

@@ -21,6 +21,7 @@ import torch.nn as nn
 from torch.nn.init import constant_, normal_
 
 from .. import functional as UF
+from ..linear import lowp_step_cache
 from ..registry import (TRANSFORMER, TRANSFORMER_LAYER_SEQUENCE,
                         build_transformer_layer_sequence)
 from .bricks import BaseModule, xavier_init
@@ -230,6 +231,12 @@ class UniBEVTransformer(BaseModule):
     def encode(self, img_mlvl_feats, pts_mlvl_feats, bev_queries, bev_h, bev_w, bev_pos=None,
                return_parts=False, **kwargs):
         """The hot path: everything of ``forward`` up to ``fused_bev_embed`` (Nq, bs, C*s)."""
+        with lowp_step_cache():
+            return self._encode(img_mlvl_feats, pts_mlvl_feats, bev_queries, bev_h, bev_w, bev_pos,
+                                return_parts, **kwargs)
+
+    def _encode(self, img_mlvl_feats, pts_mlvl_feats, bev_queries, bev_h, bev_w, bev_pos,
+                return_parts, **kwargs):
         bs = self._draw_modality_flags(img_mlvl_feats, pts_mlvl_feats)
         if bev_pos is not None:
             bev_pos = bev_pos.flatten(2).permute(2, 0, 1)
