@@ -250,7 +250,7 @@ static void fuse_launch(bool bwd, const void* gout, const void* img, const void*
     hipLaunchKernelGGL((fuse_fwd_kernel<T, VEC>), dim3(blocks), dim3(256), 0, st, (const T*)img,
                        (const T*)pts, cwi, cwp, swi, swp, (T*)o0, B, Nq, C, cat);
   } else {
-    const int rpw = 16;
+    const int rpw = 64;
     const long waves = (rows + rpw - 1) / rpw;
     const int blocks = (int)((waves + 3) / 4);
     hipLaunchKernelGGL((fuse_bwd_kernel<T, VEC>), dim3(blocks), dim3(256), 0, st, (const T*)gout,

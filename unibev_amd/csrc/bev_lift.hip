@@ -79,7 +79,7 @@ __device__ __forceinline__ void softmax_row(const float (&l)[P], float (&w)[P]) 
 }
 
 template <typename T, int DH, int VEC, int P>
-__global__ __launch_bounds__(256) void lift_fwd_kernel(const LiftArgs a) {
+__global__ __launch_bounds__(256, 2) void lift_fwd_kernel(const LiftArgs a) {
   constexpr int LP = DH / VEC;
   const int item = xcd_remap(blockIdx.x, a.chunk);
   if (item >= a.total_tiles) return;
