@@ -1,0 +1,124 @@
+"""Direct parity tests of the memory-bound glue kernels (flatten+embed, fusion epilogue) against the
+oracle's restatement of transformer_fusion.py, forward and backward, including ragged sizes."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import unibev_ref as R
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.mark.parametrize('N,groups,C,HW', [(12, 6, 256, 176), (2, 1, 128, 33 * 31), (6, 3, 64, 5),
+                                           (1, 1, 256, 180 * 180)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_flatten_embed_vs_oracle(N, groups, C, HW, dtype):
+    """_pre_process_img_feats / _pre_process_pts_feats: (N,C,HW) -> (N,HW,C) + cams_embeds + level."""
+    from unibev_amd.functional import flatten_embed
+    torch.manual_seed(0)
+    feat = torch.randn(N, C, HW, device=DEV).to(dtype)
+    ea = torch.randn(groups, C, device=DEV)
+    eb = torch.randn(C, device=DEV)
+    cot = torch.randn(N, HW, C, device=DEV)
+    f1, a1, b1 = feat.clone().requires_grad_(), ea.clone().requires_grad_(), eb.clone().requires_grad_()
+    out = flatten_embed(f1, a1 if groups > 1 else None, b1)
+    (out.float() * cot).sum().backward()
+    # oracle: transformer_fusion.py:241-245 (bs = N/groups samples, `groups` cameras)
+    f2, a2, b2 = (v.detach().float().cpu().requires_grad_() for v in (feat, ea, eb))
+    P = {'cams_embeds': a2, 'img_level_embeds': b2[None], 'pts_level_embeds': b2[None]}
+    if groups > 1:
+        flat, _ = R.pre_process_img_feats(P, [f2.view(N // groups, groups, C, HW, 1)])
+        ref = flat.permute(2, 0, 1, 3).reshape(N, HW, C)        # (Nc,hw,bs,C) -> (bs*Nc,hw,C)
+    else:
+        flat, _ = R.pre_process_pts_feats(P, [f2.view(N, C, HW, 1)])
+        ref = flat.permute(1, 0, 2)
+    (ref * cot.cpu()).sum().backward()
+    tol = 1e-6 if dtype == torch.float32 else 2e-2
+    torch.testing.assert_close(out.float().cpu(), ref.detach(), rtol=tol, atol=tol)
+    torch.testing.assert_close(f1.grad.float().cpu(), f2.grad, rtol=tol, atol=tol)
+    # embedding gradients are sums over N*HW rows of grad_out, which is rounded to `dtype`
+    eps = 1e-6 if dtype == torch.float32 else 2 ** -8
+    gtol = dict(rtol=1e-4, atol=10 * eps * (N * HW) ** 0.5 + 1e-4)
+    torch.testing.assert_close(b1.grad.cpu(), b2.grad, **gtol)
+    if groups > 1:
+        torch.testing.assert_close(a1.grad.cpu(), a2.grad, **gtol)
+
+
+@pytest.mark.parametrize('method,norm,flags', [('linear', 'ChannelNormWeights', (1, 1)),
+                                               ('linear', 'ChannelNormWeights', (1, 0)),
+                                               ('avg', None, (1, 1)), ('cat', None, (0, 1)),
+                                               ('cat', None, (1, 1))])
+@pytest.mark.parametrize('spatial', [False, True])
+def test_bev_fuse_vs_oracle(method, norm, flags, spatial):
+    """channel_feature_norm + spatial_feature_norm + multi_modal_fusion + permute, with modality
+    flags, forward and backward to features and to the CNW / spatial parameters."""
+    from unibev_amd.functional import bev_fuse
+    torch.manual_seed(1)
+    B, Nq, C = 2, 333, 128
+    c_flag, l_flag = flags
+    img = torch.randn(B, Nq, C, device=DEV)
+    pts = torch.randn(B, Nq, C, device=DEV)
+    cwp = {k: torch.randn(C) for k in ('img_channel_weights', 'pts_channel_weights')}
+    swp = {k: torch.randn(Nq) for k in ('img_spatial_weights', 'pts_spatial_weights')}
+    s = 2 if method == 'cat' else 1
+    cot = torch.randn(Nq, B, C * s)
+
+    def factors(P):
+        """host-side composition exactly as UniBEVTransformer._channel_factors / _spatial_factors"""
+        c, l = float(c_flag), float(l_flag)
+        if method == 'avg':
+            c, l = c / (c_flag + l_flag), l / (c_flag + l_flag)
+        if norm == 'ChannelNormWeights':
+            fw = torch.stack((P['img_channel_weights'], P['pts_channel_weights']), 0)
+            if c_flag == 1 and l_flag == 1:
+                n = fw.softmax(0)
+                iw, pw = n[0], n[1]
+            else:
+                iw, pw = fw[0:1].softmax(0)[0], fw[1:2].softmax(0)[0]
+            cw = (iw * c, pw * l)
+        else:
+            one = torch.ones(C, device=P['img_channel_weights'].device)
+            cw = (one * c, one * l)
+        sw = (None, None)
+        if spatial:
+            w = torch.stack((P['img_spatial_weights'], P['pts_spatial_weights']), 0)
+            n = w.softmax(0) if (c_flag == 1 and l_flag == 1) else None
+            sw = (n[0], n[1]) if n is not None else (w[:1].softmax(0)[0], w[1:].softmax(0)[0])
+        return cw, sw
+
+    Pg = {k: v.to(DEV).requires_grad_() for k, v in {**cwp, **swp}.items()}
+    i1, p1 = img.clone().requires_grad_(), pts.clone().requires_grad_()
+    cw, sw = factors(Pg)
+    out = bev_fuse(i1, p1, cw[0], cw[1], sw[0], sw[1], cat=(method == 'cat'))
+    (out * cot.to(DEV)).sum().backward()
+
+    Pc = {k: v.clone().requires_grad_() for k, v in {**cwp, **swp}.items()}
+    i2, p2 = img.cpu().clone().requires_grad_(), pts.cpu().clone().requires_grad_()
+    a, b = R.channel_feature_norm(Pc, i2, p2, norm, c_flag, l_flag)
+    a, b = R.spatial_feature_norm(Pc, a, b, 'SpatialNormWeights' if spatial else None, c_flag, l_flag)
+    ref = R.multi_modal_fusion(a, b, method, c_flag, l_flag).permute(1, 0, 2)
+    (ref * cot).sum().backward()
+    torch.testing.assert_close(out.cpu(), ref.detach(), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(i1.grad.cpu(), i2.grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(p1.grad.cpu(), p2.grad, rtol=1e-5, atol=1e-6)
+    if norm:
+        for k in cwp:
+            torch.testing.assert_close(Pg[k].grad.cpu(), Pc[k].grad, rtol=1e-3, atol=1e-3)
+    if spatial:
+        for k in swp:
+            torch.testing.assert_close(Pg[k].grad.cpu(), Pc[k].grad, rtol=1e-3, atol=1e-3)
+
+
+def test_bev_fuse_missing_modality_and_bad_shapes():
+    from unibev_amd.functional import bev_fuse
+    from unibev_amd._lib import UniBEVHipError
+    x = torch.randn(1, 50, 64, device=DEV)
+    one = torch.ones(64, device=DEV)
+    out = bev_fuse(x, None, one, one, cat=True)
+    assert out.shape == (50, 1, 128)
+    torch.testing.assert_close(out[:, 0, :64], x[0])
+    assert torch.all(out[:, 0, 64:] == 0)
+    with pytest.raises(UniBEVHipError):
+        bev_fuse(torch.randn(1, 5, 6, device=DEV), None, torch.ones(6, device=DEV),
+                 torch.ones(6, device=DEV))
