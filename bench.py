@@ -192,7 +192,9 @@ def main():
             traffic = None
             tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.exists(tfile):
-                traffic = json.load(open(tfile)).get(dom['kernel'].split('<')[0])
+                rec = json.load(open(tfile)).get(dom['kernel'].split('<')[0])
+                if rec:          # HBM-side bytes per launch from the PMC passes (see the file's note)
+                    traffic = rec['fetch_corrected'] + rec['write']
             out['roofline'] = {'bound': 'hbm', 'achieved': dom['achieved_GBps'], 'peak': HBM_PEAK_GBS,
                                'unit': 'GB/s', 'frac': dom['achieved_GBps'] / HBM_PEAK_GBS,
                                'traffic': traffic, 'kernel': dom['kernel'],

@@ -35,6 +35,7 @@ struct LiftArgs {
   float4* rec;                                   // [B,H,P,Nq] (x_pix, y_pix, w/count, -) or null
   int* cam_list; int* cam_n;                     // per-camera compacted visible queries or null
   const float* center;                           // [H,P,2] slot centres in pixels or null
+  float* slab;                                   // CAMERA: per-chunk partial maps or null
 };
 
 // Decode (b, q, valid) of the query this lane works on in iteration `it`.
@@ -663,12 +664,40 @@ __global__ __launch_bounds__(256) void lift_bwd_value_kernel(const LiftArgs a, c
         if (px < g.npx && lx < g.tw && ly < g.th) {
           const long o = ((long)(g.y0 + ly) * a.fw + (g.x0 + lx)) * row + col;
           const float v = ta.acc[rb][r];
-          if (MODE == 1) gv[o] += v;      // single owner; on top of the query kernel's far corners
-          else if (v != 0.0f) atomic_add_f32(gv + o, v);   // chunks of one camera share the map
+          if (MODE == 1) {
+            gv[o] += v;                   // single owner; on top of the query kernel's far corners
+          } else {
+            // the chunks of one camera share the map: each writes its partial map to its own slab
+            // ([b][cam][h][chunk][S][Dh], plain stores); slab_reduce_kernel sums the active chunks
+            const long so = ((((long)g.b * a.Nc + g.cam) * a.H + g.h) * t.chunks + g.ck) *
+                                ((long)a.fh * a.fw * DH) +
+                            ((long)(g.y0 + ly) * a.fw + (g.x0 + lx)) * DH + col;
+            a.slab[so] = v;
+          }
         }
       }
     }
   }
+}
+
+// Sums the partial maps of a camera's active list chunks into grad_value (plain stores: every
+// element of grad_value is written exactly once, so no zeroing and no atomics).
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const LiftArgs a, int chunks, int chunk_q,
+                                                          int Dh, int bands_cover) {
+  const long per_map = (long)a.fh * a.fw * Dh;                 // one (b, cam, h) map
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)a.B * a.Nc * a.H * per_map;
+  if (t >= total) return;
+  const long m = t / per_map, e = t - m * per_map;             // m = (b*Nc + cam)*H + h
+  const int h = (int)(m % a.H);
+  const int cam = (int)((m / a.H) % a.Nc);
+  const int b = (int)(m / ((long)a.H * a.Nc));
+  const int nact = min(chunks, (a.cam_n[cam] + chunk_q - 1) / chunk_q);
+  float s = 0.0f;
+  for (int c = 0; c < nact; ++c) s += a.slab[(m * chunks + c) * per_map + e];
+  const long px = e / Dh, col = e - px * Dh;
+  a.gvalue[(((long)b * a.Nc + cam) * a.fh * a.fw + px) * ((long)a.H * Dh) + h * Dh + col] = s;
+  (void)bands_cover;
 }
 
 // ---- dispatch ----------------------------------------------------------------------------------------
@@ -735,6 +764,11 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, hipS
       hipLaunchKernelGGL((lift_bwd_value_kernel<T, DH, P, RB, 2>), dim3(8 * t.chunk),
                          dim3(64 * t.waves), lds, st, a, t);
     }
+    {
+      const long n = (long)a.B * a.Nc * a.H * a.fh * a.fw * DH;
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a,
+                         t.chunks, t.chunk_q, DH, 1);
+    }
     ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes);
     hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomNone>), dim3(blocks), dim3(256), 0, st, a);
   }
@@ -783,9 +817,9 @@ static int plan_backward(const LiftArgs& a, int Dh, int P, int dtype, int ref_is
     t.tile_h = band;
     t.tiles_x = 1;
     t.tiles_y = bands;
-    // a chunk = 1024 entries of the camera's compacted visible-query list (device-side length:
+    // a chunk = 256 entries of the camera's compacted visible-query list (device-side length:
     // chunks past the end exit at once)
-    static const int cq = getenv("UBV_CAM_CHUNK") ? atoi(getenv("UBV_CAM_CHUNK")) : 1024;
+    static const int cq = getenv("UBV_CAM_CHUNK") ? atoi(getenv("UBV_CAM_CHUNK")) : 256;
     t.chunk_q = cq;
     t.chunks = (a.Nq + cq - 1) / cq;
     t.waves = (dtype == UBV_F32) ? 2 : 4;    // f32 data carries hi + lo operand tiles: 2x the LDS
@@ -795,9 +829,14 @@ static int plan_backward(const LiftArgs& a, int Dh, int P, int dtype, int ref_is
   return t.mode == 1 ? kAtomFar : kAtomNone;
 }
 
-static size_t lift_ws_bytes(int mode, const LiftArgs& a, int P) {
+static size_t lift_list_bytes(const LiftArgs& a) {
+  return (((size_t)a.Nc * a.Nq + a.Nc + 4) * sizeof(int) + 255) & ~(size_t)255;
+}
+static size_t lift_ws_bytes(int mode, const LiftArgs& a, const TileArgs& t, int Dh, int P) {
   if (mode == kAtomFar) return (size_t)a.B * a.Nq * a.H * P * sizeof(float4);
-  if (mode == kAtomNone) return ((size_t)a.Nc * a.Nq + a.Nc + 4) * sizeof(int);
+  if (mode == kAtomNone)     // visible-query lists + one partial map per (b, cam, head, chunk)
+    return lift_list_bytes(a) +
+           (size_t)a.B * a.Nc * a.H * t.chunks * a.fh * a.fw * Dh * sizeof(float);
   return 0;
 }
 
@@ -837,16 +876,22 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_g
   int mode = -1;
   if (bwd) {
     mode = plan_backward(a, Dh, P, dtype, ref_is_grid, t);
-    const size_t need = lift_ws_bytes(mode, a, P);
+    const size_t need = lift_ws_bytes(mode, a, t, Dh, P);
     UBV_CHECK_ARG(need == 0 || (ws != nullptr && ws_bytes >= (int64_t)need),
                   "bev_lift_backward: workspace of %lld bytes needed, got %lld", (long long)need,
                   (long long)ws_bytes);
     if (mode == kAtomFar) a.rec = (float4*)ws;
-    if (mode == kAtomNone) { a.cam_list = (int*)ws; a.cam_n = (int*)ws + (size_t)a.Nc * a.Nq; }
-    const size_t bytes = (size_t)a.B * a.Nc * a.fh * a.fw * a.H * Dh * sizeof(float);
-    if (hipMemsetAsync(a.gvalue, 0, bytes, st) != hipSuccess) {
-      set_error("bev_lift_backward: memset failed");
-      return UBV_ERR_LAUNCH;
+    if (mode == kAtomNone) {
+      a.cam_list = (int*)ws;
+      a.cam_n = (int*)ws + (size_t)a.Nc * a.Nq;
+      a.slab = (float*)((char*)ws + lift_list_bytes(a));
+    }
+    if (mode != kAtomNone) {   // CAMERA mode writes every element of grad_value exactly once
+      const size_t bytes = (size_t)a.B * a.Nc * a.fh * a.fw * a.H * Dh * sizeof(float);
+      if (hipMemsetAsync(a.gvalue, 0, bytes, st) != hipSuccess) {
+        set_error("bev_lift_backward: memset failed");
+        return UBV_ERR_LAUNCH;
+      }
     }
   }
   bool ok = false;
@@ -871,7 +916,7 @@ extern "C" int64_t ubv_bev_lift_backward_workspace(int B, int Nc, int fh, int fw
   a.qh = a.qw ? qgrid_h : 0;
   ubv::TileArgs t{};
   const int mode = ubv::plan_backward(a, Dh, P, UBV_BF16, ref_is_grid, t);
-  return (int64_t)ubv::lift_ws_bytes(mode, a, P);
+  return (int64_t)ubv::lift_ws_bytes(mode, a, t, Dh, P);
 }
 
 extern "C" int ubv_bev_lift_supported(int H, int Dh, int P, int dtype) {
