@@ -143,9 +143,10 @@ __global__ __launch_bounds__(256, 2) void lift_fwd_kernel(const LiftArgs a) {
 // scatters grad_value:
 //   kAtomAll : this kernel, one hardware f32 atomic per (corner, channel) — the mmcv scheme; kept for
 //              arbitrary reference points on large maps.
-//   kAtomFar : only corners farther than R pixels (Chebyshev) from the point's home pixel; the
-//              owner-tile kernel below takes every near corner without atomics.
-//   kAtomNone: never (the owner-tile kernel covers the whole map).
+//   kAtomNone: never — the owner-tile kernel below takes the corners without atomics (GRID: every
+//              corner within R pixels of the point's expected pixel, the rare rest is scattered by
+//              lift_record_kernel; CAMERA: the whole map).
+// kAtomFar names the GRID plan (records + far corners + owner tiles) in the launcher.
 enum { kAtomAll = 0, kAtomFar = 1, kAtomNone = 2 };
 
 __device__ __forceinline__ int home_pixel(float r, int n) {
@@ -207,14 +208,6 @@ __global__ __launch_bounds__(256) void lift_bwd_query_kernel(const LiftArgs a) {
         const float ly = r.y + off[2 * p + 1] / fhf;
         const float xp = lx * fwf - 0.5f, yp = ly * fhf - 0.5f;
         const Footprint f = footprint_px(xp, yp, a.fh, a.fw);
-        int hx = 0, hy = 0;
-        if (ATOMICS == kAtomFar) {
-          hx = home_pixel(r.x, a.fw) + slot_shift(a.center, h, P, p, 0);
-          hy = home_pixel(r.y, a.fh) + slot_shift(a.center, h, P, p, 1);
-          if (valid && cg == 0 && a.rec != nullptr)      // hand the point to the owner-tile kernel
-            // slot-major [b][h][p][q]: the owner tiles read runs of consecutive queries per slot
-            a.rec[(((long)b * a.H + h) * P + p) * a.Nq + q] = make_float4(xp, yp, w[p] / cnt, 0.0f);
-        }
         float dot[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -225,12 +218,9 @@ __global__ __launch_bounds__(256) void lift_bwd_query_kernel(const LiftArgs a) {
 #pragma unroll
           for (int i = 0; i < VEC; ++i) d = fmaf(go[i], v[i], d);
           dot[k] = d * f.m[k];
-          if (ATOMICS != kAtomNone) {
+          if (ATOMICS == kAtomAll) {
             const float c = w[p] * f.w[k];
-            bool scatter = valid && c != 0.0f;
-            if (ATOMICS == kAtomFar)
-              scatter = scatter && (abs(f.xc[k & 1] - hx) > a.R || abs(f.yc[k >> 1] - hy) > a.R);
-            if (scatter) {
+            if (valid && c != 0.0f) {
 #pragma unroll
               for (int i = 0; i < VEC; ++i) atomic_add_f32(a.gvalue + o + i, c * go[i]);
             }
@@ -266,6 +256,63 @@ __global__ __launch_bounds__(256) void lift_bwd_query_kernel(const LiftArgs a) {
       }
       store_row<P>(a.glog + bq * a.glog_stride + h * P, gl);
       store_row<2 * P>(a.goff + bq * a.goff_stride + h * 2 * P, gofs);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GRID plan, step 0 — one record (x_pix, y_pix, w/count) per sampling point for the owner tiles, and
+// the atomic scatter of the rare "far" corners (outside the owner kernel's radius R around the
+// slot's expected pixel).  A wave takes 64/H consecutive queries x H heads with the query index
+// fastest across lanes: the offset / logit rows of those queries are read as whole contiguous
+// runs, and each slot-major record row [b][h][p][q..] is written as one contiguous run.  (Writing
+// the records from lift_bwd_query_kernel cost 2.7x its run time: 16-B scattered stores from one
+// lane in four, and the atomics' registers pushed it to one wave per SIMD.)
+template <typename T, int DH, int P>
+__global__ __launch_bounds__(256) void lift_record_kernel(const LiftArgs a) {
+  const int QPW = kWave / a.H;
+  const int lane = threadIdx.x & 63;
+  const int h = lane / QPW, qs = lane - h * QPW;
+  const int waves_per_sample = (a.Nq + QPW - 1) / QPW;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= (long)a.B * waves_per_sample) return;
+  const int b = (int)(wave / waves_per_sample);
+  const int q = (int)(wave - (long)b * waves_per_sample) * QPW + qs;
+  if (q >= a.Nq) return;
+  const long bq = (long)b * a.Nq + q;
+  const float fwf = (float)a.fw, fhf = (float)a.fh;
+  const long row = (long)a.H * DH;
+  float lg[P], w[P], off[2 * P];
+  load_row<P>(a.logits + bq * a.log_stride + h * P, lg);
+  load_row<2 * P>(a.offsets + bq * a.off_stride + h * 2 * P, off);
+  softmax_row<P>(lg, w);
+  const float cnt = (a.count != nullptr) ? a.count[bq] : 1.0f;
+  const float* rp = a.ref + bq * a.Z * 2;                      // one map per sample (Nc == 1)
+  const T* __restrict__ gout = (const T*)a.gout + bq * row + h * DH;
+  float* __restrict__ gv = a.gvalue + (long)b * a.fh * a.fw * row + h * DH;
+  int zi = 0;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const float2 r = *reinterpret_cast<const float2*>(rp + zi * 2);
+    zi = (zi + 1 == a.Z) ? 0 : zi + 1;
+    const float lx = r.x + off[2 * p] / fwf;
+    const float ly = r.y + off[2 * p + 1] / fhf;
+    const float xp = lx * fwf - 0.5f, yp = ly * fhf - 0.5f;
+    a.rec[(((long)b * a.H + h) * P + p) * a.Nq + q] = make_float4(xp, yp, w[p] / cnt, 0.0f);
+    const Footprint f = footprint_px(xp, yp, a.fh, a.fw);
+    const int hx = home_pixel(r.x, a.fw) + slot_shift(a.center, h, P, p, 0);
+    const int hy = home_pixel(r.y, a.fh) + slot_shift(a.center, h, P, p, 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float c = w[p] * f.w[k];
+      if (c != 0.0f && (abs(f.xc[k & 1] - hx) > a.R || abs(f.yc[k >> 1] - hy) > a.R)) {
+        float* dst = gv + (long)f.idx[k] * row;
+#pragma unroll 1
+        for (int i = 0; i < DH; ++i) {
+          const float g = elem<T>::to_float(gout[i]);
+          atomic_add_f32(dst + i, c * (a.count != nullptr ? g / cnt : g));
+        }
+      }
     }
   }
 }
@@ -745,8 +792,15 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, hipS
     // (rare) far corners atomically into the zeroed grad_value; the owner tiles then add their
     // exclusive pixels on top with a plain read-add-store.
     {
-      ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes + nb.rec);
-      hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomFar>), dim3(blocks), dim3(256), 0, st, a);
+      const int qpw = kWave / a.H;
+      const long waves = (long)a.B * ((a.Nq + qpw - 1) / qpw);
+      ProfScope ps(name("bev_lift_bwd_records"), st, nb.offlog + nb.ref + nb.rec);
+      hipLaunchKernelGGL((lift_record_kernel<T, DH, P>), dim3((unsigned)((waves + 3) / 4)), dim3(256),
+                         0, st, a);
+    }
+    {
+      ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes);
+      hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomNone>), dim3(blocks), dim3(256), 0, st, a);
     }
     constexpr int RB = 2;
     const size_t lds = (size_t)t.waves * TileLds<T, DH, RB>::kWords * sizeof(uint16_t);
