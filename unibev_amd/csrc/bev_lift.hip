@@ -587,7 +587,7 @@ struct TileAcc {
 
 // MODE 1 = GRID, 2 = CAMERA.  One wave per tile, blockDim.x / 64 independent waves per block.
 template <typename T, int DH, int P, int RB, int MODE>
-__global__ __launch_bounds__(256) void lift_bwd_value_kernel(const LiftArgs a, const TileArgs t) {
+__global__ __launch_bounds__(256, (MODE == 1 ? 3 : 1)) void lift_bwd_value_kernel(const LiftArgs a, const TileArgs t) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds_all[];
   using L = TileLds<T, DH, RB>;
   TileGeom g;
