@@ -92,8 +92,11 @@ int ubv_ms_deform_attn_backward(const void* value, const int64_t* spatial_shapes
  *   SpatialCrossAttentionImg.forward     models/modules/spatial_cross_attention_img.py:141-212.
  *
  *   value     [B*Nc, S = fh*fw, H, Dh]  dtype   (batch-major, camera-minor)
- *   offsets   row (b,q) at offsets + (b*Nq+q)*off_stride : [H, P, 2] f32 raw Linear output
- *   logits    row (b,q) at logits  + (b*Nq+q)*log_stride : [H, P]    f32 raw Linear output
+ *   offsets   row (b,q) at element (b*Nq+q)*off_stride : [H, P, 2] raw Linear output
+ *   logits    row (b,q) at element (b*Nq+q)*log_stride : [H, P]    raw Linear output
+ *   offlog_dtype  element type of offsets / logits (and of their gradients in backward): UBV_F32,
+ *             or `dtype` itself — under autocast the Linear emits 16-bit values and the kernels
+ *             read them directly (bit-identical to up-casting first).  Rows 16-byte aligned.
  *   ref       [Nc, B, Nq, Z, 2] f32 reference points; flat point p uses anchor p % Z
  *             (quirk q3, spatial_cross_attention_img.py:407-419)
  *   vis0      [Nc, Nq] uint8 or NULL: camera i contributes to query q iff vis0[i,q] != 0
@@ -105,17 +108,20 @@ int ubv_ms_deform_attn_backward(const void* value, const int64_t* spatial_shapes
  * (L2 locality); pass 0 for raster order.
  * Supported shapes: see ubv_bev_lift_supported() (Dh in {16, 32}, P in {4, 8}).
  */
-int ubv_bev_lift_forward(const void* value, const float* offsets, int64_t off_stride,
-                         const float* logits, int64_t log_stride, const float* ref,
-                         const uint8_t* vis0, const float* count, void* out, int B, int Nc, int fh,
+int ubv_bev_lift_forward(const void* value, const void* offsets, int64_t off_stride,
+                         const void* logits, int64_t log_stride, int offlog_dtype,
+                         const float* ref, const uint8_t* vis0, const float* count, void* out, int B, int Nc, int fh,
                          int fw, int H, int Dh, int Nq, int P, int Z, int qgrid_w, int qgrid_h,
                          int dtype, void* stream);
 
 /*   grad_out     [B, Nq, H*Dh]       dtype
  *   grad_value   [B*Nc, S, H, Dh]    f32, WRITTEN (previous content ignored; zeroed internally
  *                                    only on the paths that accumulate)
- *   grad_offsets row (b,q) at grad_offsets + (b*Nq+q)*goff_stride : [H, P, 2] f32, written
- *   grad_logits  row (b,q) at grad_logits  + (b*Nq+q)*glog_stride : [H, P]    f32, written
+ *   grad_value_lowp  [B*Nc, S, H, Dh] dtype or NULL (16-bit dtypes only): when given, the final
+ *                grad_value is written HERE, rounded once from the f32 accumulation, and
+ *                grad_value is only the f32 accumulation scratch (content unspecified on return).
+ *   grad_offsets row (b,q) at element (b*Nq+q)*goff_stride : [H, P, 2] offlog_dtype, written
+ *   grad_logits  row (b,q) at element (b*Nq+q)*glog_stride : [H, P]    offlog_dtype, written
  *   ref_is_grid  1 iff Nc == 1 and ref[0,b,q,z] == ((qx+.5)/qgrid_w, (qy+.5)/qgrid_h) for every z
  *                (BEV self-attention and SCA-pts: the references are the BEV grid itself).  Selects
  *                the owner-tile grad_value kernel (LDS accumulation, no global atomics except for
@@ -130,12 +136,12 @@ int ubv_bev_lift_forward(const void* value, const float* offsets, int64_t off_st
 int64_t ubv_bev_lift_backward_workspace(int B, int Nc, int fh, int fw, int H, int Dh, int Nq, int P,
                                         int qgrid_w, int qgrid_h, int ref_is_grid);
 
-int ubv_bev_lift_backward(const void* value, const float* offsets, int64_t off_stride,
-                          const float* logits, int64_t log_stride, const float* ref,
-                          const uint8_t* vis0, const float* count, const float* slot_center,
-                          const void* grad_out, float* grad_value, float* grad_offsets,
-                          int64_t goff_stride,
-                          float* grad_logits, int64_t glog_stride, int B, int Nc, int fh, int fw,
+int ubv_bev_lift_backward(const void* value, const void* offsets, int64_t off_stride,
+                          const void* logits, int64_t log_stride, int offlog_dtype,
+                          const float* ref, const uint8_t* vis0, const float* count,
+                          const float* slot_center, const void* grad_out, float* grad_value,
+                          void* grad_value_lowp, void* grad_offsets, int64_t goff_stride,
+                          void* grad_logits, int64_t glog_stride, int B, int Nc, int fh, int fw,
                           int H, int Dh, int Nq, int P, int Z, int qgrid_w, int qgrid_h,
                           int ref_is_grid, int dtype, void* workspace, int64_t workspace_bytes,
                           void* stream);

@@ -203,3 +203,45 @@ def test_lift_backward_camera_mode_bands_and_chunks():
         np.testing.assert_allclose(v.grad.cpu().numpy(), v64.grad.numpy(), rtol=2e-4, atol=2e-4 * scale)
         bad = ~np.isclose(ol.grad.cpu().numpy(), ol64.grad.numpy(), rtol=2e-4, atol=1e-3)
         assert bad.sum() <= 1e-5 * bad.size + 1, int(bad.sum())       # pixel-boundary discontinuities
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('mode', ['grid', 'centred', 'atomics', 'camera'])
+def test_lift_16bit_offsets_logits_read_directly(mode, dtype):
+    """Under autocast the sampling_offsets / attention_weights Linear emits 16-bit rows; the
+    kernels read them (and write their gradients) in that type.  Must be BIT-identical to
+    up-casting the rows to f32 first and rounding the f32 gradients afterwards."""
+    from unibev_amd.functional import bev_lift
+    if mode == 'camera':
+        case = (2, 6, 8, 22, 8, 32, 30, 33, 8, 4)
+        B, Nc, fh, fw, H, Dh, qh, qw, P, Z = case
+        value, offlog, ref, vis0, count, gout = make_case(case, 21, True)
+        kw = dict(vis0=t(vis0, device=DEV), count=t(count, device=DEV), query_grid=(qh, qw))
+    else:
+        B, Nc, fh, fw, H, Dh, qh, qw, P, Z = 2, 1, 37, 41, 8, 32, 40, 45, 8, 4
+        rs = np.random.RandomState(5)
+        Nq = qh * qw
+        value = rs.standard_normal((B, fh * fw, H * Dh))
+        center = (rs.standard_normal(H * P * 2) * 4.0).astype(np.float32)
+        offlog = np.concatenate([center[None, None] + rs.standard_normal((B, Nq, H * P * 2)) * 4.0,
+                                 rs.standard_normal((B, Nq, H * P))], -1)
+        ref = grid_ref(B, qh, qw, Z)
+        gout = rs.standard_normal((B, Nq, H * Dh))
+        kw = dict(query_grid=(qh, qw), ref_is_grid=mode != 'atomics',
+                  slot_center=t(center, device=DEV) if mode == 'centred' else None)
+    res = []
+    for lowp in (True, False):
+        v = t(value, dtype, DEV).requires_grad_()
+        ol16 = t(offlog, dtype, DEV)
+        ol = (ol16 if lowp else ol16.float()).requires_grad_()
+        out = bev_lift(v, ol, t(ref, torch.float32, DEV), Nc, (fh, fw), H, P, **kw)
+        out.backward(t(gout, dtype, DEV))
+        assert ol.grad.dtype == ol.dtype
+        res.append((out.detach(), v.grad, ol.grad.to(dtype)))
+    names = ('out', 'grad_value', 'grad_offlog')
+    for name, a, b in zip(names, *res):
+        if name == 'grad_value' and mode != 'camera':
+            # far corners / the all-atomics plan add f32 atomically: the order varies run to run
+            torch.testing.assert_close(a.float(), b.float(), rtol=2e-2, atol=2e-2)
+        else:
+            assert torch.equal(a, b), name

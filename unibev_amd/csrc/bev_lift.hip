@@ -26,10 +26,13 @@
 namespace ubv {
 
 struct LiftArgs {
-  const void* value; const float* offsets; long off_stride; const float* logits; long log_stride;
+  const void* value; const void* offsets; long off_stride; const void* logits; long log_stride;
+  int ol16;                                      // offsets / logits (and their gradients) are f32 (0)
+                                                 // or the value's own 16-bit type (1)
   const float* ref; const uint8_t* vis0; const float* count;
   void* out;                                     // fwd
-  const void* gout; float* gvalue; float* goff; long goff_stride; float* glog; long glog_stride;
+  const void* gout; float* gvalue; void* goff; long goff_stride; void* glog; long glog_stride;
+  void* gvalue_lp;                               // final grad_value in the value's 16-bit type or null
   int B, Nc, fh, fw, H, Nq, Z, qw, qh, tiles_x, tiles_per_sample, total_tiles, chunk;
   int R;                                         // near radius (pixels) of the owner-tile backward
   float4* rec;                                   // [B,H,P,Nq] (x_pix, y_pix, w/count, -) or null
@@ -79,6 +82,71 @@ __device__ __forceinline__ void softmax_row(const float (&l)[P], float (&w)[P]) 
   for (int i = 0; i < P; ++i) w[i] = w[i] / s;
 }
 
+// Rows of offsets / logits / their gradients: f32, or (lowp) the value's 16-bit type.  Under
+// autocast the producing Linear already emits 16-bit values, so reading them here directly is
+// bit-identical to the f32 up-cast it replaces and saves a cast kernel + a 2x larger read.
+template <typename T, int N>
+__device__ __forceinline__ void load_ol(const void* base, long idx, bool lowp, float (&v)[N]) {
+  if constexpr (sizeof(T) == 2) {
+    if (lowp) {
+      const T* p = (const T*)base + idx;
+      if constexpr (N % 8 == 0) {
+#pragma unroll
+        for (int i = 0; i < N; i += 8) {
+          float t[8];
+          vec_io<T, 8>::load(p + i, t);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[i + k] = t[k];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < N; i += 4) {
+          float t[4];
+          vec_io<T, 4>::load(p + i, t);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[i + k] = t[k];
+        }
+      }
+      return;
+    }
+  }
+  load_row<N>((const float*)base + idx, v);
+}
+template <typename T, int N>
+__device__ __forceinline__ void store_ol(void* base, long idx, bool lowp, const float (&v)[N]) {
+  if constexpr (sizeof(T) == 2) {
+    if (lowp) {
+      T* p = (T*)base + idx;
+      if constexpr (N % 8 == 0) {
+#pragma unroll
+        for (int i = 0; i < N; i += 8) {
+          float t[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) t[k] = v[i + k];
+          vec_io<T, 8>::store(p + i, t);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < N; i += 4) {
+          float t[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) t[k] = v[i + k];
+          vec_io<T, 4>::store(p + i, t);
+        }
+      }
+      return;
+    }
+  }
+  store_row<N>((float*)base + idx, v);
+}
+template <typename T>
+__device__ __forceinline__ float ld_ol(const void* base, long idx, bool lowp) {
+  if constexpr (sizeof(T) == 2) {
+    if (lowp) return elem<T>::to_float(((const T*)base)[idx]);
+  }
+  return ((const float*)base)[idx];
+}
+
 template <typename T, int DH, int VEC, int P>
 __global__ __launch_bounds__(256, 2) void lift_fwd_kernel(const LiftArgs a) {
   constexpr int LP = DH / VEC;
@@ -98,8 +166,8 @@ __global__ __launch_bounds__(256, 2) void lift_fwd_kernel(const LiftArgs a) {
     if (!lift_query(a, item, li0 + wv * QW + sub, b, q)) continue;
     const long bq = (long)b * a.Nq + q;
     float lg[P], w[P], off[2 * P];
-    load_row<P>(a.logits + bq * a.log_stride + h * P, lg);
-    load_row<2 * P>(a.offsets + bq * a.off_stride + h * 2 * P, off);
+    load_ol<T, P>(a.logits, bq * a.log_stride + h * P, a.ol16, lg);
+    load_ol<T, 2 * P>(a.offsets, bq * a.off_stride + h * 2 * P, a.ol16, off);
     softmax_row<P>(lg, w);
 
     float acc[VEC];
@@ -180,8 +248,8 @@ __global__ __launch_bounds__(256) void lift_bwd_query_kernel(const LiftArgs a) {
     if (!valid) { b = 0; q = 0; }             // keep every lane in the shuffles below
     const long bq = (long)b * a.Nq + q;
     float lg[P], w[P], off[2 * P];
-    load_row<P>(a.logits + bq * a.log_stride + h * P, lg);
-    load_row<2 * P>(a.offsets + bq * a.off_stride + h * 2 * P, off);
+    load_ol<T, P>(a.logits, bq * a.log_stride + h * P, a.ol16, lg);
+    load_ol<T, 2 * P>(a.offsets, bq * a.off_stride + h * 2 * P, a.ol16, off);
     softmax_row<P>(lg, w);
 
     float go[VEC];
@@ -254,8 +322,8 @@ __global__ __launch_bounds__(256) void lift_bwd_query_kernel(const LiftArgs a) {
         gofs[2 * p] = (w[p] * gx[p] * fwf) / fwf;      // d loc = w*g*W ; d off = d loc / W
         gofs[2 * p + 1] = (w[p] * gy[p] * fhf) / fhf;
       }
-      store_row<P>(a.glog + bq * a.glog_stride + h * P, gl);
-      store_row<2 * P>(a.goff + bq * a.goff_stride + h * 2 * P, gofs);
+      store_ol<T, P>(a.glog, bq * a.glog_stride + h * P, a.ol16, gl);
+      store_ol<T, 2 * P>(a.goff, bq * a.goff_stride + h * 2 * P, a.ol16, gofs);
     }
   }
 }
@@ -283,8 +351,8 @@ __global__ __launch_bounds__(256) void lift_record_kernel(const LiftArgs a) {
   const float fwf = (float)a.fw, fhf = (float)a.fh;
   const long row = (long)a.H * DH;
   float lg[P], w[P], off[2 * P];
-  load_row<P>(a.logits + bq * a.log_stride + h * P, lg);
-  load_row<2 * P>(a.offsets + bq * a.off_stride + h * 2 * P, off);
+  load_ol<T, P>(a.logits, bq * a.log_stride + h * P, a.ol16, lg);
+  load_ol<T, 2 * P>(a.offsets, bq * a.off_stride + h * 2 * P, a.ol16, off);
   softmax_row<P>(lg, w);
   const float cnt = (a.count != nullptr) ? a.count[bq] : 1.0f;
   const float* rp = a.ref + bq * a.Z * 2;                      // one map per sample (Nc == 1)
@@ -667,8 +735,9 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 3 : 1)) void lift_bwd_value_kerne
       const long bq = (long)g.b * a.Nq + q;
       rw.ref = *reinterpret_cast<const float2*>(
           a.ref + ((((long)g.cam * a.B + g.b) * a.Nq + q) * a.Z + zi) * 2);
-      rw.lg = a.logits[bq * a.log_stride + g.h * P + p];
-      rw.off = *reinterpret_cast<const float2*>(a.offsets + bq * a.off_stride + g.h * 2 * P + 2 * p);
+      rw.lg = ld_ol<T>(a.logits, bq * a.log_stride + g.h * P + p, a.ol16);
+      const long oi = bq * a.off_stride + g.h * 2 * P + 2 * p;
+      rw.off = make_float2(ld_ol<T>(a.offsets, oi, a.ol16), ld_ol<T>(a.offsets, oi + 1, a.ol16));
       rw.cnt = (a.count != nullptr) ? a.count[bq] : 1.0f;
       return rw;
     };
@@ -712,7 +781,13 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 3 : 1)) void lift_bwd_value_kerne
           const long o = ((long)(g.y0 + ly) * a.fw + (g.x0 + lx)) * row + col;
           const float v = ta.acc[rb][r];
           if (MODE == 1) {
-            gv[o] += v;                   // single owner; on top of the query kernel's far corners
+            // single owner; on top of the record kernel's far corners
+            const float s = gv[o] + v;
+            if (sizeof(T) == 2 && a.gvalue_lp != nullptr)
+              ((T*)a.gvalue_lp)[(((long)g.b * a.Nc + g.cam) * a.fh * a.fw * row + g.h * DH) + o] =
+                  elem<T>::from_float(s);
+            else
+              gv[o] = s;
           } else {
             // the chunks of one camera share the map: each writes its partial map to its own slab
             // ([b][cam][h][chunk][S][Dh], plain stores); slab_reduce_kernel sums the active chunks
@@ -729,8 +804,9 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 3 : 1)) void lift_bwd_value_kerne
 
 // Sums the partial maps of a camera's active list chunks into grad_value (plain stores: every
 // element of grad_value is written exactly once, so no zeroing and no atomics).
+template <typename T>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const LiftArgs a, int chunks, int chunk_q,
-                                                          int Dh, int bands_cover) {
+                                                          int Dh) {
   const long per_map = (long)a.fh * a.fw * Dh;                 // one (b, cam, h) map
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)a.B * a.Nc * a.H * per_map;
@@ -743,8 +819,19 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const LiftArgs a, int 
   float s = 0.0f;
   for (int c = 0; c < nact; ++c) s += a.slab[(m * chunks + c) * per_map + e];
   const long px = e / Dh, col = e - px * Dh;
-  a.gvalue[(((long)b * a.Nc + cam) * a.fh * a.fw + px) * ((long)a.H * Dh) + h * Dh + col] = s;
-  (void)bands_cover;
+  const long o = (((long)b * a.Nc + cam) * a.fh * a.fw + px) * ((long)a.H * Dh) + h * Dh + col;
+  if (sizeof(T) == 2 && a.gvalue_lp != nullptr)
+    ((T*)a.gvalue_lp)[o] = elem<T>::from_float(s);
+  else
+    a.gvalue[o] = s;
+}
+
+// grad_value f32 -> the value's 16-bit type (only the all-atomics plan needs this separate pass)
+template <typename T>
+__global__ __launch_bounds__(256) void narrow_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                     long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = elem<T>::from_float(src[i]);
 }
 
 // ---- dispatch ----------------------------------------------------------------------------------------
@@ -787,6 +874,11 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, hipS
   if (bwd_mode == kAtomAll) {
     ProfScope ps(name("bev_lift_bwd_query+atomics"), st, q_bytes + nb.value_f32);
     hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomAll>), dim3(blocks), dim3(256), 0, st, a);
+    if (sizeof(T) == 2 && a.gvalue_lp != nullptr) {
+      const long n = (long)a.B * a.Nc * a.fh * a.fw * a.H * DH;
+      hipLaunchKernelGGL(narrow_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                         a.gvalue, (T*)a.gvalue_lp, n);
+    }
   } else if (bwd_mode == kAtomFar) {
     // the query kernel leaves one record per sampling point for the owner tiles and scatters the
     // (rare) far corners atomically into the zeroed grad_value; the owner tiles then add their
@@ -820,8 +912,8 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, hipS
     }
     {
       const long n = (long)a.B * a.Nc * a.H * a.fh * a.fw * DH;
-      hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a,
-                         t.chunks, t.chunk_q, DH, 1);
+      hipLaunchKernelGGL(slab_reduce_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a,
+                         t.chunks, t.chunk_q, DH);
     }
     ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes);
     hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomNone>), dim3(blocks), dim3(256), 0, st, a);
@@ -903,12 +995,16 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_g
     set_error("bev_lift: no kernel for H=%d Dh=%d P=%d dtype=%d", a.H, Dh, P, dtype);
     return UBV_ERR_UNSUPPORTED;
   }
-  UBV_CHECK_ARG((a.off_stride % 4) == 0 && (a.log_stride % 4) == 0 &&
+  UBV_CHECK_ARG(!a.ol16 || dtype != UBV_F32, "bev_lift: offlog_dtype must be f32 or equal dtype");
+  const int ol_align = a.ol16 ? 8 : 4;            // elements per 16 bytes
+  UBV_CHECK_ARG((a.off_stride % ol_align) == 0 && (a.log_stride % ol_align) == 0 &&
                     ((uintptr_t)a.offsets % 16) == 0 && ((uintptr_t)a.logits % 16) == 0,
                 "bev_lift: offsets/logits rows must be 16-byte aligned");
+  UBV_CHECK_ARG(a.gvalue_lp == nullptr || dtype != UBV_F32,
+                "bev_lift_backward: grad_value_lowp needs a 16-bit dtype");
   UBV_CHECK_ARG(((uintptr_t)a.ref % 8) == 0, "bev_lift: ref must be 8-byte aligned");
   if (bwd)
-    UBV_CHECK_ARG((a.goff_stride % 4) == 0 && (a.glog_stride % 4) == 0 &&
+    UBV_CHECK_ARG((a.goff_stride % ol_align) == 0 && (a.glog_stride % ol_align) == 0 &&
                       ((uintptr_t)a.goff % 16) == 0 && ((uintptr_t)a.glog % 16) == 0,
                   "bev_lift: grad rows must be 16-byte aligned");
   if (a.qw > 0 && (long)a.qw * a.qh == a.Nq) {
@@ -977,13 +1073,17 @@ extern "C" int ubv_bev_lift_supported(int H, int Dh, int P, int dtype) {
   return ubv::lift_shape_ok(H, Dh, P, dtype) ? 1 : 0;
 }
 
-extern "C" int ubv_bev_lift_forward(const void* value, const float* offsets, int64_t off_stride,
-                                    const float* logits, int64_t log_stride, const float* ref,
+extern "C" int ubv_bev_lift_forward(const void* value, const void* offsets, int64_t off_stride,
+                                    const void* logits, int64_t log_stride, int offlog_dtype,
+                                    const float* ref,
                                     const uint8_t* vis0, const float* count, void* out, int B,
                                     int Nc, int fh, int fw, int H, int Dh, int Nq, int P, int Z,
                                     int qgrid_w, int qgrid_h, int dtype, void* stream) {
   UBV_CHECK_ARG(value && offsets && logits && ref && out, "bev_lift_forward: null pointer");
+  UBV_CHECK_ARG(offlog_dtype == UBV_F32 || offlog_dtype == dtype,
+                "bev_lift: offlog_dtype %d must be f32 or equal dtype %d", offlog_dtype, dtype);
   ubv::LiftArgs a{};
+  a.ol16 = (offlog_dtype != UBV_F32) ? 1 : 0;
   a.value = value; a.offsets = offsets; a.off_stride = off_stride; a.logits = logits;
   a.log_stride = log_stride; a.ref = ref; a.vis0 = vis0; a.count = count; a.out = out;
   a.B = B; a.Nc = Nc; a.fh = fh; a.fw = fw; a.H = H; a.Nq = Nq; a.Z = Z; a.qw = qgrid_w;
@@ -991,22 +1091,26 @@ extern "C" int ubv_bev_lift_forward(const void* value, const float* offsets, int
   return ubv::lift_run(a, Dh, P, dtype, false, 0, nullptr, 0, stream);
 }
 
-extern "C" int ubv_bev_lift_backward(const void* value, const float* offsets, int64_t off_stride,
-                                     const float* logits, int64_t log_stride, const float* ref,
-                                     const uint8_t* vis0, const float* count,
+extern "C" int ubv_bev_lift_backward(const void* value, const void* offsets, int64_t off_stride,
+                                     const void* logits, int64_t log_stride, int offlog_dtype,
+                                     const float* ref, const uint8_t* vis0, const float* count,
                                      const float* slot_center, const void* grad_out,
-                                     float* grad_value, float* grad_offsets, int64_t goff_stride,
-                                     float* grad_logits, int64_t glog_stride, int B, int Nc, int fh,
+                                     float* grad_value, void* grad_value_lowp, void* grad_offsets,
+                                     int64_t goff_stride, void* grad_logits, int64_t glog_stride,
+                                     int B, int Nc, int fh,
                                      int fw, int H, int Dh, int Nq, int P, int Z, int qgrid_w,
                                      int qgrid_h, int ref_is_grid, int dtype, void* workspace,
                                      int64_t workspace_bytes, void* stream) {
   UBV_CHECK_ARG(value && offsets && logits && ref && grad_out && grad_value && grad_offsets &&
                     grad_logits, "bev_lift_backward: null pointer");
+  UBV_CHECK_ARG(offlog_dtype == UBV_F32 || offlog_dtype == dtype,
+                "bev_lift: offlog_dtype %d must be f32 or equal dtype %d", offlog_dtype, dtype);
   ubv::LiftArgs a{};
+  a.ol16 = (offlog_dtype != UBV_F32) ? 1 : 0;
   a.value = value; a.offsets = offsets; a.off_stride = off_stride; a.logits = logits;
   a.log_stride = log_stride; a.ref = ref; a.vis0 = vis0; a.count = count; a.gout = grad_out;
   a.center = slot_center;
-  a.gvalue = grad_value; a.goff = grad_offsets; a.goff_stride = goff_stride; a.glog = grad_logits;
+  a.gvalue = grad_value; a.gvalue_lp = grad_value_lowp; a.goff = grad_offsets; a.goff_stride = goff_stride; a.glog = grad_logits;
   a.glog_stride = glog_stride;
   a.B = B; a.Nc = Nc; a.fh = fh; a.fw = fw; a.H = H; a.Nq = Nq; a.Z = Z; a.qw = qgrid_w;
   a.qh = qgrid_h;

@@ -169,7 +169,9 @@ class _BevLift(Function):
         B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh, grid = geom
         _need_cuda(value, offlog, ref, vis0, count, center)
         value = value.contiguous()
-        ol = offlog.float().contiguous()
+        # the kernels read offsets / logits as f32 or in the value's own 16-bit type (autocast)
+        lowp = value.dtype != torch.float32 and offlog.dtype == value.dtype
+        ol = (offlog if lowp else offlog.float()).contiguous()
         ref = ref.float().contiguous()
         row = H * P * 3
         assert ol.shape[-1] == row and ol.numel() == B * Nq * row
@@ -179,7 +181,8 @@ class _BevLift(Function):
         base = ol.data_ptr()
         with _timed('lift_fwd', (geom, value.element_size())):
             check(lib().ubv_bev_lift_forward(
-                _p(value), ctypes.c_void_p(base), row, ctypes.c_void_p(base + H * P * 2 * 4), row,
+                _p(value), ctypes.c_void_p(base), row,
+                ctypes.c_void_p(base + H * P * 2 * ol.element_size()), row, _dt(ol),
                 _p(ref), _p(vis0), _p(count), _p(out), B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh,
                 _dt(value), _stream()), 'bev_lift_forward')
         if center is not None:
@@ -197,19 +200,23 @@ class _BevLift(Function):
         B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh, grid = ctx.geom
         row = H * P * 3
         go = grad_output.to(value.dtype).contiguous()
+        # f32 accumulation map; with 16-bit data the kernels round it once into gv_lp themselves
         gv = torch.empty(value.shape, dtype=torch.float32, device=value.device)
+        gv_lp = torch.empty_like(value) if value.dtype != torch.float32 else None
         gol = torch.empty_like(ol)
         base, gbase = ol.data_ptr(), gol.data_ptr()
-        off2 = H * P * 2 * 4
+        off2 = H * P * 2 * ol.element_size()
         nws = lib().ubv_bev_lift_backward_workspace(B, Nc, fh, fw, H, Dh, Nq, P, qw, qh, int(grid))
         ws = _workspace(nws, value.device) if nws > 0 else None
         with _timed('lift_bwd', (ctx.geom, value.element_size())):
             check(lib().ubv_bev_lift_backward(
-                _p(value), ctypes.c_void_p(base), row, ctypes.c_void_p(base + off2), row, _p(ref),
-                _p(vis0), _p(count), _p(center), _p(go), _p(gv), ctypes.c_void_p(gbase), row,
-                ctypes.c_void_p(gbase + off2), row, B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh,
+                _p(value), ctypes.c_void_p(base), row, ctypes.c_void_p(base + off2), row, _dt(ol),
+                _p(ref), _p(vis0), _p(count), _p(center), _p(go), _p(gv), _p(gv_lp),
+                ctypes.c_void_p(gbase), row, ctypes.c_void_p(gbase + off2), row,
+                B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh,
                 int(grid), _dt(value), _p(ws), int(nws), _stream()), 'bev_lift_backward')
-        return gv.to(value.dtype), gol.to(ctx.ol_dtype), None, None, None, None, None
+        gvalue = gv_lp if gv_lp is not None else gv
+        return gvalue, gol.to(ctx.ol_dtype), None, None, None, None, None
 
 
 def bev_lift(value, offlog, ref, num_cams, feat_hw, num_heads, num_points, vis0=None, count=None,
