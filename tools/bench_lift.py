@@ -63,6 +63,7 @@ def main():
     ap.add_argument('--random-offsets', action='store_true')
     ap.add_argument('--only', default='self,pts,img')
     ap.add_argument('--no-center', action='store_true')
+    ap.add_argument('--f32-offlog', action='store_true')
     a = ap.parse_args()
     dev = 'cuda'
     dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[a.dtype]
@@ -70,6 +71,8 @@ def main():
         value, offlog, ref, vis0, count, gout, geom, is_grid, center = instance(
             name, a.bs, dtype, dev, not a.random_offsets)
         B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh = geom
+        if dtype != torch.float32 and not a.f32_offlog:
+            offlog = offlog.to(dtype)        # what the sampling_offsets Linear emits under autocast
         value.requires_grad_()
         offlog.requires_grad_()
         for it in range(a.iters + 3):

@@ -147,7 +147,7 @@ __device__ __forceinline__ float ld_ol(const void* base, long idx, bool lowp) {
   return ((const float*)base)[idx];
 }
 
-template <typename T, int DH, int VEC, int P>
+template <typename T, int DH, int VEC, int P, bool OL16>
 __global__ __launch_bounds__(256, 2) void lift_fwd_kernel(const LiftArgs a) {
   constexpr int LP = DH / VEC;
   const int item = xcd_remap(blockIdx.x, a.chunk);
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256, 2) void lift_fwd_kernel(const LiftArgs a) {
     if (!lift_query(a, item, li0 + wv * QW + sub, b, q)) continue;
     const long bq = (long)b * a.Nq + q;
     float lg[P], w[P], off[2 * P];
-    load_ol<T, P>(a.logits, bq * a.log_stride + h * P, a.ol16, lg);
-    load_ol<T, 2 * P>(a.offsets, bq * a.off_stride + h * 2 * P, a.ol16, off);
+    load_ol<T, P>(a.logits, bq * a.log_stride + h * P, OL16, lg);
+    load_ol<T, 2 * P>(a.offsets, bq * a.off_stride + h * 2 * P, OL16, off);
     softmax_row<P>(lg, w);
 
     float acc[VEC];
@@ -228,7 +228,7 @@ __device__ __forceinline__ int slot_shift(const float* __restrict__ center, int 
   return center ? (int)rintf(center[(h * P + p) * 2 + axis]) : 0;
 }
 
-template <typename T, int DH, int VEC, int P, int ATOMICS>
+template <typename T, int DH, int VEC, int P, int ATOMICS, bool OL16>
 __global__ __launch_bounds__(256) void lift_bwd_query_kernel(const LiftArgs a) {
   constexpr int LP = DH / VEC;
   const int item = xcd_remap(blockIdx.x, a.chunk);
@@ -248,8 +248,8 @@ __global__ __launch_bounds__(256) void lift_bwd_query_kernel(const LiftArgs a) {
     if (!valid) { b = 0; q = 0; }             // keep every lane in the shuffles below
     const long bq = (long)b * a.Nq + q;
     float lg[P], w[P], off[2 * P];
-    load_ol<T, P>(a.logits, bq * a.log_stride + h * P, a.ol16, lg);
-    load_ol<T, 2 * P>(a.offsets, bq * a.off_stride + h * 2 * P, a.ol16, off);
+    load_ol<T, P>(a.logits, bq * a.log_stride + h * P, OL16, lg);
+    load_ol<T, 2 * P>(a.offsets, bq * a.off_stride + h * 2 * P, OL16, off);
     softmax_row<P>(lg, w);
 
     float go[VEC];
@@ -322,8 +322,8 @@ __global__ __launch_bounds__(256) void lift_bwd_query_kernel(const LiftArgs a) {
         gofs[2 * p] = (w[p] * gx[p] * fwf) / fwf;      // d loc = w*g*W ; d off = d loc / W
         gofs[2 * p + 1] = (w[p] * gy[p] * fhf) / fhf;
       }
-      store_ol<T, P>(a.glog, bq * a.glog_stride + h * P, a.ol16, gl);
-      store_ol<T, 2 * P>(a.goff, bq * a.goff_stride + h * 2 * P, a.ol16, gofs);
+      store_ol<T, P>(a.glog, bq * a.glog_stride + h * P, OL16, gl);
+      store_ol<T, 2 * P>(a.goff, bq * a.goff_stride + h * 2 * P, OL16, gofs);
     }
   }
 }
@@ -515,9 +515,11 @@ __device__ __forceinline__ bool tile_own(const Footprint& f, float w, bool valid
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int cx = f.xc[k & 1], cy = f.yc[k >> 1];
-    bool own = valid && f.w[k] != 0.0f && cx >= g.x0 && cx < g.x0 + g.tw && cy >= g.y0 &&
-               cy < g.y0 + g.th;
-    if (NEAR) own = own && abs(cx - ex) <= R && abs(cy - ey) <= R;
+    // bitwise, not short-circuit: keeps the four corners straight-line code
+    int o = (int)valid & (int)(f.w[k] != 0.0f) & (int)((unsigned)(cx - g.x0) < (unsigned)g.tw) &
+            (int)((unsigned)(cy - g.y0) < (unsigned)g.th);
+    if (NEAR) o = o & (int)(abs(cx - ex) <= R) & (int)(abs(cy - ey) <= R);
+    const bool own = o != 0;
     lp[k] = own ? (cy - g.y0) * tile_w + (cx - g.x0) : -1;
     cwt[k] = own ? w * f.w[k] : 0.0f;
     any = any || own;
@@ -653,21 +655,16 @@ struct TileAcc {
   }
 };
 
-// MODE 1 = GRID, 2 = CAMERA.  One wave per tile, blockDim.x / 64 independent waves per block.
-template <typename T, int DH, int P, int RB, int MODE>
-__global__ __launch_bounds__(256, (MODE == 1 ? 3 : 1)) void lift_bwd_value_kernel(const LiftArgs a, const TileArgs t) {
+// GRID owner tiles.  One wave per tile, blockDim.x / 64 independent waves per block; registers
+// capped for 3 waves per SIMD (the kernel is bound by its dependent loads: 470 -> 345 us).
+template <typename T, int DH, int P, int RB>
+__global__ __launch_bounds__(256, 3) void lift_bwd_value_kernel(const LiftArgs a, const TileArgs t) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds_all[];
   using L = TileLds<T, DH, RB>;
   TileGeom g;
   if (!tile_decode(a, t, g)) return;
   const int lane = threadIdx.x & 63;
   uint16_t* __restrict__ lds = lds_all + (threadIdx.x >> 6) * L::kWords;
-  int ncand_cam = 0, l0 = 0;
-  if (MODE == 2) {
-    l0 = g.ck * t.chunk_q;                                // offset into this camera's list
-    ncand_cam = min(t.chunk_q, a.cam_n[g.cam] - l0);
-    if (ncand_cam <= 0) return;                           // nothing visible in this chunk
-  }
   TileAcc<T, DH, RB> ta;
   ta.init(lds, lane);
   const long row = (long)a.H * DH;
@@ -677,8 +674,8 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 3 : 1)) void lift_bwd_value_kerne
     ta.add(lp, cwt, any, gout + ((long)g.b * a.Nq + q) * row + g.h * DH, lane);
   };
 
-  if (MODE == 1) {
-    // ---- GRID: per sampling slot p, lane = candidate query, records from lift_bwd_query_kernel
+  {
+    // ---- per sampling slot p, lane = candidate query, records from lift_record_kernel
     const float sx = (float)a.qw / (float)a.fw, sy = (float)a.qh / (float)a.fh;
     for (int p = 0; p < P; ++p) {
       const int dx = slot_shift(a.center, g.h, P, p, 0), dy = slot_shift(a.center, g.h, P, p, 1);
@@ -718,53 +715,6 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 3 : 1)) void lift_bwd_value_kerne
         rounds(lp, cwt, any, q);
       }
     }
-  } else {
-    // ---- CAMERA: lane = (query slot, point); three-stage pipeline list entry -> inputs -> use
-    constexpr int QB = kWave / P;
-    const float fwf = (float)a.fw, fhf = (float)a.fh;
-    const int qi = lane / P, p = lane % P, zi = p % a.Z;
-    struct Raw { float2 off, ref; float lg, cnt; int q; bool valid; };
-    auto stage0 = [&](int c0, bool& valid) -> int {
-      const int c = c0 + qi;
-      valid = c < ncand_cam;
-      return a.cam_list[(long)g.cam * a.Nq + l0 + (valid ? c : 0)];
-    };
-    auto stage1 = [&](int q, bool valid) -> Raw {
-      Raw rw;
-      rw.q = q; rw.valid = valid;
-      const long bq = (long)g.b * a.Nq + q;
-      rw.ref = *reinterpret_cast<const float2*>(
-          a.ref + ((((long)g.cam * a.B + g.b) * a.Nq + q) * a.Z + zi) * 2);
-      rw.lg = ld_ol<T>(a.logits, bq * a.log_stride + g.h * P + p, a.ol16);
-      const long oi = bq * a.off_stride + g.h * 2 * P + 2 * p;
-      rw.off = make_float2(ld_ol<T>(a.offsets, oi, a.ol16), ld_ol<T>(a.offsets, oi + 1, a.ol16));
-      rw.cnt = (a.count != nullptr) ? a.count[bq] : 1.0f;
-      return rw;
-    };
-    bool v1, v2;
-    const int q1 = stage0(0, v1);
-    Raw nxt = stage1(q1, v1);
-    int q2 = stage0(QB, v2);
-    for (int c0 = 0; c0 < ncand_cam; c0 += QB) {
-      const Raw cur = nxt;
-      nxt = stage1(q2, v2);
-      q2 = stage0(c0 + 2 * QB, v2);
-      // softmax weight of this lane's point: max / sum over the P lanes of its query
-      float m = cur.lg;
-#pragma unroll
-      for (int d = 1; d < P; d <<= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-      const float e = expf(cur.lg - m);
-      float ssum = e;
-#pragma unroll
-      for (int d = 1; d < P; d <<= 1) ssum += __shfl_xor(ssum, d, 64);
-      const float w = (e / ssum) / cur.cnt;               // (g / count) * w * bilinear
-      int lp[4];
-      float cwt[4];
-      const Footprint f = make_footprint(cur.ref.x + cur.off.x / fwf, cur.ref.y + cur.off.y / fhf,
-                                         a.fh, a.fw);
-      const bool any = tile_own<false>(f, w, cur.valid, g, t.tile_w, 0, 0, 0, lp, cwt);
-      rounds(lp, cwt, any, cur.q);
-    }
   }
   if (ta.fill > 0) ta.flush(lane);
   // ---- flush the accumulators: D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -780,23 +730,193 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 3 : 1)) void lift_bwd_value_kerne
         if (px < g.npx && lx < g.tw && ly < g.th) {
           const long o = ((long)(g.y0 + ly) * a.fw + (g.x0 + lx)) * row + col;
           const float v = ta.acc[rb][r];
-          if (MODE == 1) {
-            // single owner; on top of the record kernel's far corners
-            const float s = gv[o] + v;
-            if (sizeof(T) == 2 && a.gvalue_lp != nullptr)
-              ((T*)a.gvalue_lp)[(((long)g.b * a.Nc + g.cam) * a.fh * a.fw * row + g.h * DH) + o] =
-                  elem<T>::from_float(s);
-            else
-              gv[o] = s;
-          } else {
-            // the chunks of one camera share the map: each writes its partial map to its own slab
-            // ([b][cam][h][chunk][S][Dh], plain stores); slab_reduce_kernel sums the active chunks
-            const long so = ((((long)g.b * a.Nc + g.cam) * a.H + g.h) * t.chunks + g.ck) *
-                                ((long)a.fh * a.fw * DH) +
-                            ((long)(g.y0 + ly) * a.fw + (g.x0 + lx)) * DH + col;
-            a.slab[so] = v;
+          // single owner; on top of the record kernel's far corners
+          const float s = gv[o] + v;
+          if (sizeof(T) == 2 && a.gvalue_lp != nullptr)
+            ((T*)a.gvalue_lp)[(((long)g.b * a.Nc + g.cam) * a.fh * a.fw * row + g.h * DH) + o] =
+                elem<T>::from_float(s);
+          else
+            gv[o] = s;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CAMERA owner tiles, one lane per QUERY: a round trip to memory fetches everything 64 queries need
+// (list entry -> offsets, logits, anchors, count, grad_out row), double-buffered in registers, and
+// buys 64*P sampling points of work, so the fetch latency hides under the MFMA phase instead of
+// being paid once per 64 points.  Per batch the 64 grad_out rows are staged in LDS once and their
+// B fragments stay in registers for all P slots; per slot p the 64 points (one per lane) scatter
+// their <= 4 coefficients into column `lane` of A[pixels][64], the touched 32-pixel row blocks run
+// 4 MFMAs (K = 64) each, and the lanes clear exactly what they wrote.
+// A camera's visible-query list is dealt evenly, in whole batches of 64, to `chunks` waves.
+__device__ __forceinline__ int cam_chunk_len(int n, int chunks) {
+  return ((n + chunks * 64 - 1) / (chunks * 64)) * 64;
+}
+
+constexpr int kCStride = 72;      // u16 per A row: 64 query columns + 8 pad (144 B: conflict-free b128)
+
+template <typename T, int DH, int RB>
+struct CamLds {
+  static constexpr bool kSplit = mma_traits<T>::kSplit;
+  static constexpr int kA = 32 * RB * kCStride;
+  static constexpr int kG = 64 * DH;
+  static constexpr int kWords = (kA + kG) * (kSplit ? 2 : 1);      // u16 per wave
+};
+
+template <typename T, int DH, int P, int RB>
+__global__ __launch_bounds__(256) void lift_bwd_value_camera_kernel(const LiftArgs a, const TileArgs t) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds_all[];
+  using M = mma_traits<T>;
+  using L = CamLds<T, DH, RB>;
+  constexpr int NV = DH * elem<T>::kBytes / 16;
+  TileGeom g;
+  if (!tile_decode(a, t, g)) return;
+  const int lane = threadIdx.x & 63;
+  const int cq = cam_chunk_len(a.cam_n[g.cam], t.chunks);
+  const int l0 = g.ck * cq;                               // offset into this camera's list
+  const int ncand = min(cq, a.cam_n[g.cam] - l0);
+  if (ncand <= 0) return;                                 // nothing visible in this chunk
+  uint16_t* __restrict__ lds = lds_all + (threadIdx.x >> 6) * L::kWords;
+  uint16_t* __restrict__ a_hi = lds;
+  uint16_t* __restrict__ a_lo = lds + L::kA;
+  uint16_t* __restrict__ g_hi = lds + (M::kSplit ? 2 : 1) * L::kA;
+  uint16_t* __restrict__ g_lo = g_hi + L::kG;
+  for (int i = lane; i < L::kWords / 8; i += 64) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+  f32x16_t acc[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
+
+  const long row = (long)a.H * DH;
+  const T* __restrict__ gout = (const T*)a.gout;
+  const float fwf = (float)a.fw, fhf = (float)a.fh;
+  const int n = lane & 31, kg = lane >> 5;
+  const int nn = (DH >= 32) ? n : (n % DH);               // Dh = 16: columns 16..31 are don't-care
+  const float inv_fw = 1.0f / fwf, inv_fh = 1.0f / fhf;
+
+  struct Raw {
+    float off[2 * P], lg[P];
+    float2 ref[P];
+    float cnt;
+    uint4 grow[NV];
+    bool valid;
+  };
+  auto fetch_q = [&](int c0, bool& valid) -> int {
+    const int c = c0 + lane;
+    valid = c < ncand;
+    return a.cam_list[(long)g.cam * a.Nq + l0 + (valid ? c : 0)];
+  };
+  auto fetch_raw = [&](int q, bool valid, Raw& rw) {
+    rw.valid = valid;
+    const long bq = (long)g.b * a.Nq + q;
+    load_ol<T, P>(a.logits, bq * a.log_stride + g.h * P, a.ol16, rw.lg);
+    load_ol<T, 2 * P>(a.offsets, bq * a.off_stride + g.h * 2 * P, a.ol16, rw.off);
+    const float* rp = a.ref + (((long)g.cam * a.B + g.b) * a.Nq + q) * a.Z * 2;
+    int zi = 0;                                           // anchor of flat point p is p % Z
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      rw.ref[p] = *reinterpret_cast<const float2*>(rp + zi * 2);
+      zi = (zi + 1 == a.Z) ? 0 : zi + 1;
+    }
+    rw.cnt = (a.count != nullptr) ? a.count[bq] : 1.0f;
+    const uint4* gp = reinterpret_cast<const uint4*>(gout + bq * row + g.h * DH);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) rw.grow[i] = gp[i];
+  };
+
+  bool v1, v2;
+  Raw cur, nxt;
+  const int q1 = fetch_q(0, v1);
+  fetch_raw(q1, v1, nxt);
+  int q2 = fetch_q(64, v2);
+  for (int c0 = 0; c0 < ncand; c0 += 64) {
+    cur = nxt;
+    if (c0 + 64 < ncand) {
+      fetch_raw(q2, v2, nxt);
+      q2 = fetch_q(c0 + 128, v2);
+    }
+    // grad_out rows of the 64 queries -> LDS, then this lane's B fragments for the 4 K-blocks
+    stage_row<T, DH, NV>(g_hi, g_lo, lane, cur.grow);
+    uint4 b_hi[4], b_lo[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      uint16_t bh[8], bl[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        bh[j] = g_hi[(kb * 16 + kg * 8 + j) * DH + nn];
+        if (M::kSplit) bl[j] = g_lo[(kb * 16 + kg * 8 + j) * DH + nn];
+      }
+      b_hi[kb] = make_uint4(bh[0] | ((uint32_t)bh[1] << 16), bh[2] | ((uint32_t)bh[3] << 16),
+                            bh[4] | ((uint32_t)bh[5] << 16), bh[6] | ((uint32_t)bh[7] << 16));
+      if (M::kSplit)
+        b_lo[kb] = make_uint4(bl[0] | ((uint32_t)bl[1] << 16), bl[2] | ((uint32_t)bl[3] << 16),
+                              bl[4] | ((uint32_t)bl[5] << 16), bl[6] | ((uint32_t)bl[7] << 16));
+    }
+    float w[P];
+    softmax_row<P>(cur.lg, w);
+    const float inv_cnt = 1.0f / cur.cnt;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      int lp[4];
+      float cwt[4];
+      // reciprocal multiplies: the location may differ from the forward's by an ulp, to which the
+      // scattered gradient is continuous
+      const Footprint f = make_footprint(cur.ref[p].x + cur.off[2 * p] * inv_fw,
+                                         cur.ref[p].y + cur.off[2 * p + 1] * inv_fh, a.fh, a.fw);
+      const bool any = tile_own<false>(f, w[p] * inv_cnt, cur.valid, g, t.tile_w, 0, 0, 0, lp, cwt);
+      if (__ballot(any) == 0ull) continue;
+      unsigned touched = 0;                               // 32-pixel row blocks this lane writes
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (lp[k] >= 0) {
+          const uint16_t hi = M::enc(cwt[k]);
+          a_hi[lp[k] * kCStride + lane] = hi;
+          if (M::kSplit) a_lo[lp[k] * kCStride + lane] = M::enc(cwt[k] - M::dec(hi));
+          touched |= 1u << (lp[k] >> 5);
+        }
+      }
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        if (__ballot((touched >> rb) & 1u) == 0ull) continue;       // wave-uniform skip
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          const int ao = (rb * 32 + n) * kCStride + kb * 16 + kg * 8;
+          const uint4 f_hi = *reinterpret_cast<const uint4*>(a_hi + ao);
+          acc[rb] = M::mma(f_hi, b_hi[kb], acc[rb]);
+          if (M::kSplit) {
+            const uint4 f_lo = *reinterpret_cast<const uint4*>(a_lo + ao);
+            acc[rb] = M::mma(f_lo, b_hi[kb], acc[rb]);
+            acc[rb] = M::mma(f_hi, b_lo[kb], acc[rb]);
           }
         }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (lp[k] >= 0) {
+          a_hi[lp[k] * kCStride + lane] = 0;
+          if (M::kSplit) a_lo[lp[k] * kCStride + lane] = 0;
+        }
+      }
+    }
+  }
+  // ---- this chunk's partial map -> its slab ([b][cam][h][chunk][S][Dh], plain stores);
+  // slab_reduce_kernel sums the active chunks.  D layout: col = lane & 31,
+  // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  const int col = lane & 31;
+  if (col < DH) {
+    float* __restrict__ slab = a.slab + ((((long)g.b * a.Nc + g.cam) * a.H + g.h) * t.chunks + g.ck) *
+                                            ((long)a.fh * a.fw * DH);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        // bands are whole rows (tile_w == fw, x0 == 0): the band-local pixel index is linear
+        const int px = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (px < g.th * a.fw) slab[((long)g.y0 * a.fw + px) * DH + col] = acc[rb][r];
       }
     }
   }
@@ -805,8 +925,7 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 3 : 1)) void lift_bwd_value_kerne
 // Sums the partial maps of a camera's active list chunks into grad_value (plain stores: every
 // element of grad_value is written exactly once, so no zeroing and no atomics).
 template <typename T>
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const LiftArgs a, int chunks, int chunk_q,
-                                                          int Dh) {
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const LiftArgs a, int chunks, int Dh) {
   const long per_map = (long)a.fh * a.fw * Dh;                 // one (b, cam, h) map
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)a.B * a.Nc * a.H * per_map;
@@ -815,7 +934,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const LiftArgs a, int 
   const int h = (int)(m % a.H);
   const int cam = (int)((m / a.H) % a.Nc);
   const int b = (int)(m / ((long)a.H * a.Nc));
-  const int nact = min(chunks, (a.cam_n[cam] + chunk_q - 1) / chunk_q);
+  const int cq = cam_chunk_len(a.cam_n[cam], chunks);
+  const int nact = cq > 0 ? min(chunks, (a.cam_n[cam] + cq - 1) / cq) : 0;
   float s = 0.0f;
   for (int c = 0; c < nact; ++c) s += a.slab[(m * chunks + c) * per_map + e];
   const long px = e / Dh, col = e - px * Dh;
@@ -845,7 +965,7 @@ static LiftBytes lift_bytes(const LiftArgs& a, int Dh, int P, int esize) {
   const double C = (double)a.H * Dh, S = (double)a.fh * a.fw;
   b.value = a.B * a.Nc * S * C * esize;
   b.value_f32 = a.B * a.Nc * S * C * 4.0;
-  b.offlog = (double)a.B * a.Nq * a.H * P * 3 * 4;
+  b.offlog = (double)a.B * a.Nq * a.H * P * 3 * (a.ol16 ? 2 : 4);
   b.ref = (double)a.Nc * a.B * a.Nq * a.Z * 2 * 4;
   b.vis = a.Nc > 1 ? (double)a.Nc * a.Nq + (double)a.B * a.Nq * 4 : 0.0;
   b.out = (double)a.B * a.Nq * C * esize;
@@ -866,14 +986,20 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, hipS
   };
   if (bwd_mode < 0) {
     ProfScope ps(name("bev_lift_fwd"), st, nb.value + nb.offlog + nb.ref + nb.vis + nb.out);
-    hipLaunchKernelGGL((lift_fwd_kernel<T, DH, VEC, P>), dim3(blocks), dim3(256), 0, st, a);
+    if (sizeof(T) == 2 && a.ol16)
+      hipLaunchKernelGGL((lift_fwd_kernel<T, DH, VEC, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((lift_fwd_kernel<T, DH, VEC, P, false>), dim3(blocks), dim3(256), 0, st, a);
     return;
   }
   // query kernel: value, offsets/logits, refs, grad_out in; d(offsets/logits) out (+ records)
   const double q_bytes = nb.value + 2 * nb.offlog + nb.ref + nb.vis + nb.out;
   if (bwd_mode == kAtomAll) {
     ProfScope ps(name("bev_lift_bwd_query+atomics"), st, q_bytes + nb.value_f32);
-    hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomAll>), dim3(blocks), dim3(256), 0, st, a);
+    if (sizeof(T) == 2 && a.ol16)
+      hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomAll, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomAll, false>), dim3(blocks), dim3(256), 0, st, a);
     if (sizeof(T) == 2 && a.gvalue_lp != nullptr) {
       const long n = (long)a.B * a.Nc * a.fh * a.fw * a.H * DH;
       hipLaunchKernelGGL(narrow_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
@@ -892,31 +1018,37 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, hipS
     }
     {
       ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes);
-      hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomNone>), dim3(blocks), dim3(256), 0, st, a);
+      if (sizeof(T) == 2 && a.ol16)
+        hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomNone, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomNone, false>), dim3(blocks), dim3(256), 0, st, a);
     }
     constexpr int RB = 2;
     const size_t lds = (size_t)t.waves * TileLds<T, DH, RB>::kWords * sizeof(uint16_t);
     ProfScope ps(name("bev_lift_bwd_value_grid"), st, nb.rec + nb.ref + nb.out + nb.value_f32);
-    hipLaunchKernelGGL((lift_bwd_value_kernel<T, DH, P, RB, 1>), dim3(8 * t.chunk), dim3(64 * t.waves),
+    hipLaunchKernelGGL((lift_bwd_value_kernel<T, DH, P, RB>), dim3(8 * t.chunk), dim3(64 * t.waves),
                        lds, st, a, t);
   } else {
     hipLaunchKernelGGL(compact_visible_kernel, dim3(a.Nc), dim3(1024), 0, st, a.vis0, a.Nq,
                        a.cam_list, a.cam_n);
     constexpr int RB = 6;
-    const size_t lds = (size_t)t.waves * TileLds<T, DH, RB>::kWords * sizeof(uint16_t);
+    const size_t lds = (size_t)t.waves * CamLds<T, DH, RB>::kWords * sizeof(uint16_t);
     {
       ProfScope ps(name("bev_lift_bwd_value_camera"), st,
                    nb.offlog + nb.ref + nb.vis + nb.out + nb.value_f32);
-      hipLaunchKernelGGL((lift_bwd_value_kernel<T, DH, P, RB, 2>), dim3(8 * t.chunk),
+      hipLaunchKernelGGL((lift_bwd_value_camera_kernel<T, DH, P, RB>), dim3(8 * t.chunk),
                          dim3(64 * t.waves), lds, st, a, t);
     }
     {
       const long n = (long)a.B * a.Nc * a.H * a.fh * a.fw * DH;
       hipLaunchKernelGGL(slab_reduce_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a,
-                         t.chunks, t.chunk_q, DH);
+                         t.chunks, DH);
     }
     ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes);
-    hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomNone>), dim3(blocks), dim3(256), 0, st, a);
+    if (sizeof(T) == 2 && a.ol16)
+      hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomNone, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomNone, false>), dim3(blocks), dim3(256), 0, st, a);
   }
 }
 
@@ -963,12 +1095,18 @@ static int plan_backward(const LiftArgs& a, int Dh, int P, int dtype, int ref_is
     t.tile_h = band;
     t.tiles_x = 1;
     t.tiles_y = bands;
-    // a chunk = 256 entries of the camera's compacted visible-query list (device-side length:
-    // chunks past the end exit at once)
-    static const int cq = getenv("UBV_CAM_CHUNK") ? atoi(getenv("UBV_CAM_CHUNK")) : 256;
-    t.chunk_q = cq;
-    t.chunks = (a.Nq + cq - 1) / cq;
-    t.waves = (dtype == UBV_F32) ? 2 : 4;    // f32 data carries hi + lo operand tiles: 2x the LDS
+    // each (sample, camera, band, head) list is dealt evenly (device side, cam_chunk_len) to
+    // `chunks` waves, enough of them to give every SIMD of the chip one wave: a wave keeps its
+    // partial map in registers across all of its batches and writes ONE slab
+    static const int split_env = getenv("UBV_CAM_SPLIT") ? atoi(getenv("UBV_CAM_SPLIT")) : 0;
+    // (one block per CU: its LDS holds 4 waves' operand tiles, or 2 with f32 data's hi + lo tiles;
+    // one block too many would cost a whole second round, so round down)
+    t.waves = (dtype == UBV_F32) ? 2 : 4;
+    const int combos = a.B * a.Nc * bands * a.H;
+    int split = split_env > 0 ? split_env : (256 * t.waves) / combos;
+    split = max(1, min(split, (a.Nq + 63) / 64));
+    t.chunk_q = 0;
+    t.chunks = split;
   }
   t.total = a.B * a.Nc * t.tiles_y * t.tiles_x * t.chunks * a.H;
   t.chunk = ((t.total + t.waves - 1) / t.waves + 7) / 8;       // blocks per XCD
