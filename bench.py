@@ -192,8 +192,8 @@ def main():
             traffic = None
             tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.exists(tfile):
-                rec = json.load(open(tfile)).get(dom['kernel'].split('<')[0])
-                if rec:          # HBM-side bytes per launch from the PMC passes (see the file's note)
+                rec = json.load(open(tfile)).get(dom['kernel'].split(',')[0])   # name<P=..
+                if rec and 'write' in rec and 'fetch_corrected' in rec:          # HBM-side bytes per launch from the PMC passes (see the file's note)
                     traffic = rec['fetch_corrected'] + rec['write']
             out['roofline'] = {'bound': 'hbm', 'achieved': dom['achieved_GBps'], 'peak': HBM_PEAK_GBS,
                                'unit': 'GB/s', 'frac': dom['achieved_GBps'] / HBM_PEAK_GBS,
