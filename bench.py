@@ -48,6 +48,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--eval-mode', action='store_true', help='dropout / modality dropout off')
+    ap.add_argument('--fp32-stream', action='store_true',
+                    help='keep the encoder residual stream in f32 under autocast (default: the '
+                         'autocast dtype, as the reference\'s fp16 mode runs it)')
     return ap.parse_args()
 
 
@@ -127,6 +130,7 @@ def main():
     np.random.seed(rank)          # modality dropout is per process, as in the reference
     head, tcfg = build_head(args.workload, device)
     head.train(not args.eval_mode)
+    head.transformer.lowp_stream = not args.fp32_stream
     dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.dtype]
     img, pts, metas = synth_inputs(args.workload, args.bs, dtype, device, rank)
 
@@ -177,6 +181,7 @@ def main():
             'config': {'workload': WORKLOADS[args.workload][3], 'per_gpu_batch': args.bs,
                        'global_batch': world * args.bs, 'encoder_layers': 3,
                        'mode': 'eval' if args.eval_mode else 'train (dropout 0.1, modality dropout)',
+                       'residual_stream': 'f32' if (args.fp32_stream or args.dtype == 'fp32') else args.dtype,
                        'step': 'fwd + bwd + grad all-reduce + clip + AdamW',
                        'parallelism': f'dp{world}'},
         }

@@ -209,22 +209,25 @@ int ubv_bev_fuse_backward(const void* grad_out, const void* img, const void* pts
  * (models/modules/decoder.py:338, spatial_cross_attention_img.py:215, spatial_cross_attention_pts.py:206,
  * [ext] mmcv FFN) together with the following 'norm' of BaseTransformerLayer's operation_order
  * (encoder_unibev_detr_img.py:434-436).
- *   x        [R, C] dtype           identity, y, grad_y, grad_identity [R, C] f32
+ *   x        [R, C] dtype           identity, y, grad_y, grad_identity [R, C] stream_dtype
+ *   stream_dtype  element type of the residual stream: UBV_F32, or `dtype` itself (the reference's
+ *            fp16 mode keeps the stream in half, mmcv wrap_fp16_model); mean / variance / the
+ *            normalisation are computed in f32 either way and y is rounded once
  *   gamma, beta [C] f32             mean, rstd [R] f32 (saved for backward)
  *   p        dropout probability (0 = eval); the keep mask is a stateless hash of (seed, element),
  *            so backward regenerates it from the same seed and nothing is stored
  *   grad_gamma, grad_beta [C] f32 ACCUMULATED (caller zeroes);  grad_x [R, C] dtype
  *   C % 4 == 0, C <= 1024.
  */
-int ubv_add_dropout_layernorm_forward(const void* x, const float* identity, const float* gamma,
-                                      const float* beta, float* y, float* mean, float* rstd,
+int ubv_add_dropout_layernorm_forward(const void* x, const void* identity, const float* gamma,
+                                      const float* beta, void* y, float* mean, float* rstd,
                                       int64_t R, int C, float eps, float p, uint64_t seed, int dtype,
-                                      void* stream);
-int ubv_add_dropout_layernorm_backward(const float* grad_y, const void* x, const float* identity,
+                                      int stream_dtype, void* stream);
+int ubv_add_dropout_layernorm_backward(const void* grad_y, const void* x, const void* identity,
                                        const float* gamma, const float* mean, const float* rstd,
-                                       void* grad_x, float* grad_identity, float* grad_gamma,
+                                       void* grad_x, void* grad_identity, float* grad_gamma,
                                        float* grad_beta, int64_t R, int C, float p, uint64_t seed,
-                                       int dtype, void* stream);
+                                       int dtype, int stream_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LiDAR front end.

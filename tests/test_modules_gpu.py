@@ -192,15 +192,19 @@ def test_encoder_fullsize_vs_reference_statistics():
     np.testing.assert_allclose(checksum(pts_bev.cpu().numpy())[1], g['pts_bev_ck'][1], rtol=1e-4)
 
 
+@pytest.mark.parametrize('lowp_stream', [True, False])
 @pytest.mark.parametrize('dtype,tol', [(torch.float16, 1e-2), (torch.bfloat16, 5e-2)])
-def test_encoder_autocast_close_to_fp32(dtype, tol):
-    """Mixed precision (autocast: GEMMs and sampled values in 16-bit, LayerNorm/softmax/locations
-    fp32) stays within a stated normwise distance of the fp32 reference output."""
+def test_encoder_autocast_close_to_fp32(dtype, tol, lowp_stream):
+    """Mixed precision (autocast: GEMMs and sampled values in 16-bit, LayerNorm statistics /
+    softmax / locations in f32; residual stream in 16-bit like the reference's fp16 mode, or f32)
+    stays within a stated normwise distance of the fp32 reference output."""
     cfg, sd, inp, g = encoder_case('cnw')
     model = _build(cfg).to(DEV).eval()
+    model.lowp_stream = lowp_stream
     _load(model, sd)
     with torch.no_grad(), torch.autocast('cuda', dtype=dtype):
-        fused, _, _ = _run(model, inp)
+        fused, img_bev, _ = _run(model, inp)
+    assert img_bev.dtype == (dtype if lowp_stream else torch.float32)
     ref = g['fused']
     err = np.linalg.norm(fused.float().cpu().numpy() - ref) / np.linalg.norm(ref)
     assert err < tol, err
@@ -210,6 +214,37 @@ def test_missing_extension_or_cpu_tensor_fails_loudly():
     from unibev_amd.functional import bev_fuse
     with pytest.raises(RuntimeError):
         bev_fuse(torch.zeros(1, 4, 8), None, torch.ones(8), torch.ones(8))
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_add_dropout_layernorm_16bit_stream(dtype):
+    """identity / y / their gradients in the branch's own 16-bit type (stream_dtype == dtype):
+    equals the f32-stream kernel fed the same 16-bit values, rounded once at the end."""
+    from unibev_amd.functional import add_dropout_layernorm
+    torch.manual_seed(1)
+    R, C = 777, 256
+    x = torch.randn(R, C, device=DEV).to(dtype)
+    idn = torch.randn(R, C, device=DEV).to(dtype)
+    g = torch.randn(C, device=DEV) * 0.2 + 1
+    b = torch.randn(C, device=DEV) * 0.1
+    cot = torch.randn(R, C, device=DEV).to(dtype)
+    outs = []
+    for stream16 in (True, False):
+        xa, ga, ba = (v.clone().requires_grad_() for v in (x, g, b))
+        ia = (idn if stream16 else idn.float()).clone().requires_grad_()
+        y = add_dropout_layernorm(xa, ia, ga, ba, 0.0, training=False)
+        assert y.dtype == (dtype if stream16 else torch.float32)
+        y.backward(cot if stream16 else cot.float())
+        assert ia.grad.dtype == ia.dtype
+        outs.append((y, xa.grad, ia.grad, ga.grad, ba.grad))
+    (y16, gx16, gi16, gg16, gb16), (y32, gx32, gi32, gg32, gb32) = outs
+    # same arithmetic in both instantiations up to fused-multiply-add placement: equal to one
+    # unit in the last place of the 16-bit type, and bit-equal almost everywhere
+    for a, b in ((y16, y32.to(dtype)), (gx16, gx32), (gi16, gi32.to(dtype))):
+        torch.testing.assert_close(a.float(), b.float(), rtol=2.0 ** -7, atol=1e-5)
+        assert (a != b).float().mean().item() < 1e-2
+    torch.testing.assert_close(gg16, gg32, rtol=1e-5, atol=1e-4)   # atomics: order varies
+    torch.testing.assert_close(gb16, gb32, rtol=1e-5, atol=1e-4)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])

@@ -34,10 +34,13 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-template <typename T>
+// T: element type of the branch output x (and grad_x); S: element type of the residual stream
+// (identity, y and their gradients) — f32, or T itself (the reference's fp16 mode keeps the
+// stream in half: mmcv wrap_fp16_model; statistics and the normalisation stay in f32 either way).
+template <typename T, typename S>
 __global__ __launch_bounds__(256) void add_norm_fwd_kernel(
-    const T* __restrict__ x, const float* __restrict__ identity, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ mean,
+    const T* __restrict__ x, const S* __restrict__ identity, const float* __restrict__ gamma,
+    const float* __restrict__ beta, S* __restrict__ y, float* __restrict__ mean,
     float* __restrict__ rstd, long R, int C, float eps, uint32_t thresh, float scale, uint64_t seed) {
   const int lane = threadIdx.x & 63;
   const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void add_norm_fwd_kernel(
       if (c < C) {
         float xv[4], iv[4];
         load4<T>(x + r * C + c, xv);
-        load4<float>(identity + r * C + c, iv);
+        load4<S>(identity + r * C + c, iv);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float d = xv[i];
@@ -81,18 +84,18 @@ __global__ __launch_bounds__(256) void add_norm_fwd_kernel(
         load4<float>(beta + c, b);
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = (s[k][i] - mu) * rs * g[i] + b[i];
-        store4<float>(y + r * C + c, o);
+        store4<S>(y + r * C + c, o);
       }
     }
     if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
   }
 }
 
-template <typename T>
+template <typename T, typename S>
 __global__ __launch_bounds__(256) void add_norm_bwd_kernel(
-    const float* __restrict__ gy, const T* __restrict__ x, const float* __restrict__ identity,
+    const S* __restrict__ gy, const T* __restrict__ x, const S* __restrict__ identity,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
-    T* __restrict__ gx, float* __restrict__ gid, float* __restrict__ dgamma,
+    T* __restrict__ gx, S* __restrict__ gid, float* __restrict__ dgamma,
     float* __restrict__ dbeta, long R, int C, uint32_t thresh, float scale, uint64_t seed) {
   __shared__ float red[2][4][kNormChunks * 256];       // [gamma|beta][wave][column]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -115,9 +118,9 @@ __global__ __launch_bounds__(256) void add_norm_bwd_kernel(
       if (c < C) {
         float xv[4], iv[4], g[4], go[4];
         load4<T>(x + r * C + c, xv);
-        load4<float>(identity + r * C + c, iv);
+        load4<S>(identity + r * C + c, iv);
         load4<float>(gamma + c, g);
-        load4<float>(gy + r * C + c, go);
+        load4<S>(gy + r * C + c, go);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           keep[k][i] = 1.0f;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void add_norm_bwd_kernel(
           ds[i] = rs * (dxh[k][i] - s1 - xh[k][i] * s2);
           dx[i] = ds[i] * keep[k][i];
         }
-        store4<float>(gid + r * C + c, ds);
+        store4<S>(gid + r * C + c, ds);
         store4<T>(gx + r * C + c, dx);
       }
     }
@@ -168,10 +171,12 @@ __global__ __launch_bounds__(256) void add_norm_bwd_kernel(
   }
 }
 
-static int norm_check(long R, int C, int dtype, const char* who) {
+static int norm_check(long R, int C, int dtype, int stream_dtype, const char* who) {
   UBV_CHECK_ARG(R >= 0 && C > 0 && C % 4 == 0 && C <= 64 * 4 * kNormChunks,
                 "%s: C=%d must be a multiple of 4 and <= %d", who, C, 64 * 4 * kNormChunks);
   UBV_CHECK_ARG(dtype >= 0 && dtype <= 2, "%s: unknown dtype %d", who, dtype);
+  UBV_CHECK_ARG(stream_dtype == UBV_F32 || stream_dtype == dtype,
+                "%s: stream_dtype %d must be f32 or equal dtype %d", who, stream_dtype, dtype);
   return UBV_OK;
 }
 
@@ -184,14 +189,14 @@ static void drop_params(float p, uint32_t& thresh, float& scale) {
 
 }  // namespace ubv
 
-extern "C" int ubv_add_dropout_layernorm_forward(const void* x, const float* identity,
-                                                 const float* gamma, const float* beta, float* y,
+extern "C" int ubv_add_dropout_layernorm_forward(const void* x, const void* identity,
+                                                 const float* gamma, const float* beta, void* y,
                                                  float* mean, float* rstd, int64_t R, int C,
                                                  float eps, float p, uint64_t seed, int dtype,
-                                                 void* stream) {
+                                                 int stream_dtype, void* stream) {
   using namespace ubv;
   UBV_CHECK_ARG(x && identity && gamma && beta && y && mean && rstd, "add_norm_forward: null pointer");
-  int rc = norm_check(R, C, dtype, "add_norm_forward");
+  int rc = norm_check(R, C, dtype, stream_dtype, "add_norm_forward");
   if (rc) return rc;
   if (R == 0) return UBV_OK;
   uint32_t th; float sc;
@@ -199,25 +204,31 @@ extern "C" int ubv_add_dropout_layernorm_forward(const void* x, const float* ide
   const long waves = R < 8192 ? R : 8192;
   const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   hipStream_t st = as_stream(stream);
+#define UBV_NORM_FWD(T, S)                                                                        \
+  hipLaunchKernelGGL((add_norm_fwd_kernel<T, S>), grid, block, 0, st, (const T*)x,                \
+                     (const S*)identity, gamma, beta, (S*)y, mean, rstd, (long)R, C, eps, th, sc, seed)
+  const bool lowp = stream_dtype != UBV_F32;
   switch (dtype) {
-    case UBV_F32: hipLaunchKernelGGL((add_norm_fwd_kernel<float>), grid, block, 0, st, (const float*)x, identity, gamma, beta, y, mean, rstd, (long)R, C, eps, th, sc, seed); break;
-    case UBV_F16: hipLaunchKernelGGL((add_norm_fwd_kernel<f16_t>), grid, block, 0, st, (const f16_t*)x, identity, gamma, beta, y, mean, rstd, (long)R, C, eps, th, sc, seed); break;
-    default: hipLaunchKernelGGL((add_norm_fwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, identity, gamma, beta, y, mean, rstd, (long)R, C, eps, th, sc, seed); break;
+    case UBV_F32: UBV_NORM_FWD(float, float); break;
+    case UBV_F16: if (lowp) UBV_NORM_FWD(f16_t, f16_t); else UBV_NORM_FWD(f16_t, float); break;
+    default: if (lowp) UBV_NORM_FWD(bf16_t, bf16_t); else UBV_NORM_FWD(bf16_t, float); break;
   }
+#undef UBV_NORM_FWD
   UBV_CHECK_LAUNCH("add_norm_forward");
   return UBV_OK;
 }
 
-extern "C" int ubv_add_dropout_layernorm_backward(const float* grad_y, const void* x,
-                                                  const float* identity, const float* gamma,
+extern "C" int ubv_add_dropout_layernorm_backward(const void* grad_y, const void* x,
+                                                  const void* identity, const float* gamma,
                                                   const float* mean, const float* rstd, void* grad_x,
-                                                  float* grad_identity, float* grad_gamma,
+                                                  void* grad_identity, float* grad_gamma,
                                                   float* grad_beta, int64_t R, int C, float p,
-                                                  uint64_t seed, int dtype, void* stream) {
+                                                  uint64_t seed, int dtype, int stream_dtype,
+                                                  void* stream) {
   using namespace ubv;
   UBV_CHECK_ARG(grad_y && x && identity && gamma && mean && rstd && grad_x && grad_identity &&
                     grad_gamma && grad_beta, "add_norm_backward: null pointer");
-  int rc = norm_check(R, C, dtype, "add_norm_backward");
+  int rc = norm_check(R, C, dtype, stream_dtype, "add_norm_backward");
   if (rc) return rc;
   if (R == 0) return UBV_OK;
   uint32_t th; float sc;
@@ -225,11 +236,17 @@ extern "C" int ubv_add_dropout_layernorm_backward(const float* grad_y, const voi
   const long waves = R < 2048 ? R : 2048;
   const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   hipStream_t st = as_stream(stream);
+#define UBV_NORM_BWD(T, S)                                                                        \
+  hipLaunchKernelGGL((add_norm_bwd_kernel<T, S>), grid, block, 0, st, (const S*)grad_y,           \
+                     (const T*)x, (const S*)identity, gamma, mean, rstd, (T*)grad_x,              \
+                     (S*)grad_identity, grad_gamma, grad_beta, (long)R, C, th, sc, seed)
+  const bool lowp = stream_dtype != UBV_F32;
   switch (dtype) {
-    case UBV_F32: hipLaunchKernelGGL((add_norm_bwd_kernel<float>), grid, block, 0, st, grad_y, (const float*)x, identity, gamma, mean, rstd, (float*)grad_x, grad_identity, grad_gamma, grad_beta, (long)R, C, th, sc, seed); break;
-    case UBV_F16: hipLaunchKernelGGL((add_norm_bwd_kernel<f16_t>), grid, block, 0, st, grad_y, (const f16_t*)x, identity, gamma, mean, rstd, (f16_t*)grad_x, grad_identity, grad_gamma, grad_beta, (long)R, C, th, sc, seed); break;
-    default: hipLaunchKernelGGL((add_norm_bwd_kernel<bf16_t>), grid, block, 0, st, grad_y, (const bf16_t*)x, identity, gamma, mean, rstd, (bf16_t*)grad_x, grad_identity, grad_gamma, grad_beta, (long)R, C, th, sc, seed); break;
+    case UBV_F32: UBV_NORM_BWD(float, float); break;
+    case UBV_F16: if (lowp) UBV_NORM_BWD(f16_t, f16_t); else UBV_NORM_BWD(f16_t, float); break;
+    default: if (lowp) UBV_NORM_BWD(bf16_t, bf16_t); else UBV_NORM_BWD(bf16_t, float); break;
   }
+#undef UBV_NORM_BWD
   UBV_CHECK_LAUNCH("add_norm_backward");
   return UBV_OK;
 }

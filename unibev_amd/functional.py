@@ -377,17 +377,21 @@ class _AddDropoutNorm(Function):
         _need_cuda(x, identity, gamma, beta)
         C = x.shape[-1]
         x2 = x.reshape(-1, C).contiguous()
-        id2 = identity.reshape(-1, C).float().contiguous()
+        # residual stream: f32, or the branch's own 16-bit type when the caller keeps it there
+        lowp = x2.dtype != torch.float32 and identity.dtype == x2.dtype
+        sdt = x2.dtype if lowp else torch.float32
+        id2 = identity.reshape(-1, C).to(sdt).contiguous()
         R = x2.shape[0]
         g, b = gamma.float().contiguous(), beta.float().contiguous()
-        y = torch.empty(R, C, dtype=torch.float32, device=x.device)
+        y = torch.empty(R, C, dtype=sdt, device=x.device)
         mean = torch.empty(R, dtype=torch.float32, device=x.device)
         rstd = torch.empty(R, dtype=torch.float32, device=x.device)
         # seed from torch's CPU generator: reproducible under torch.manual_seed, no device sync
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
         check(lib().ubv_add_dropout_layernorm_forward(_p(x2), _p(id2), _p(g), _p(b), _p(y), _p(mean),
                                                       _p(rstd), R, C, float(eps), float(p), seed,
-                                                      _dt(x2), _stream()), 'add_dropout_layernorm_forward')
+                                                      _dt(x2), _DT[sdt], _stream()),
+              'add_dropout_layernorm_forward')
         ctx.save_for_backward(x2, id2, g, mean, rstd)
         ctx.p, ctx.seed, ctx.shape = float(p), seed, x.shape
         ctx.dts = (identity.dtype, gamma.dtype, beta.dtype)
@@ -398,14 +402,14 @@ class _AddDropoutNorm(Function):
     def backward(ctx, grad_y):
         x2, id2, g, mean, rstd = ctx.saved_tensors
         R, C = x2.shape
-        gy = grad_y.reshape(R, C).float().contiguous()
+        gy = grad_y.reshape(R, C).to(id2.dtype).contiguous()
         gx = torch.empty_like(x2)
-        gid = torch.empty(R, C, dtype=torch.float32, device=x2.device)
+        gid = torch.empty_like(id2)
         dg = torch.zeros(C, dtype=torch.float32, device=x2.device)
         db = torch.zeros(C, dtype=torch.float32, device=x2.device)
         check(lib().ubv_add_dropout_layernorm_backward(_p(gy), _p(x2), _p(id2), _p(g), _p(mean),
                                                        _p(rstd), _p(gx), _p(gid), _p(dg), _p(db), R, C,
-                                                       ctx.p, ctx.seed, _dt(x2), _stream()),
+                                                       ctx.p, ctx.seed, _dt(x2), _dt(id2), _stream()),
               'add_dropout_layernorm_backward')
         return (gx.view(ctx.shape), gid.view(ctx.shape).to(ctx.dts[0]), dg.to(ctx.dts[1]),
                 db.to(ctx.dts[2]), None, None)

@@ -136,7 +136,10 @@ class ImgEncoder(_EncoderBase):
     def forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,
                 spatial_shapes=None, level_start_index=None, valid_ratios=None, **kwargs):
         """bev_query (Nq, bs, C); key/value (num_cam, sum hw, bs, C) -> (bs, Nq, C)."""
-        bs, dev, dt = bev_query.size(1), bev_query.device, bev_query.dtype
+        bs, dev = bev_query.size(1), bev_query.device
+        # reference points stay f32 even when the query stream is 16-bit: a bf16 (x+.5)/200
+        # would move the sampling grid by up to a pixel
+        dt = bev_query.dtype if bev_query.dtype in (torch.float32, torch.float64) else torch.float32
         Z = self.pc_range[5] - self.pc_range[2]
         D = self.num_points_in_pillar
         axes = self._cached(('axes', bev_h, bev_w, Z, D, dev),
@@ -177,7 +180,10 @@ class PtsEncoder(_EncoderBase):
     def forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,
                 spatial_shapes=None, level_start_index=None, valid_ratios=None, prev_bev=None,
                 shift=0., **kwargs):
-        bs, dev, dt = bev_query.size(1), bev_query.device, bev_query.dtype
+        bs, dev = bev_query.size(1), bev_query.device
+        # reference points stay f32 even when the query stream is 16-bit: a bf16 (x+.5)/200
+        # would move the sampling grid by up to a pixel
+        dt = bev_query.dtype if bev_query.dtype in (torch.float32, torch.float64) else torch.float32
         Z = self.pc_range[5] - self.pc_range[2]
         D = self.num_points_in_pillar_lidar
         ref_3d = self._cached(('3d', bev_h, bev_w, Z, D, bs, dev, dt),

@@ -15,6 +15,7 @@ MI355X form of the glue:
   * modality dropout draws from ``np.random`` exactly like the reference (:227-228, 463-477), so a
     seeded run drops the same modalities.
 """
+import os
 import numpy as np
 import torch
 import torch.nn as nn
@@ -50,6 +51,8 @@ class UniBEVTransformer(BaseModule):
         if decoder is not None and decoder.get('type') in TRANSFORMER_LAYER_SEQUENCE:
             self.decoder = build_transformer_layer_sequence(decoder)
         self.dual_queries = dual_queries
+        # residual stream of the encoders under autocast: 16-bit (the reference's fp16 convention) or f32
+        self.lowp_stream = os.environ.get('UBV_STREAM', 'lowp') != 'fp32'
         self.embed_dims = embed_dims
         self.num_feature_levels = num_feature_levels
         self.num_cams = num_cams
@@ -240,6 +243,17 @@ class UniBEVTransformer(BaseModule):
         bs = self._draw_modality_flags(img_mlvl_feats, pts_mlvl_feats)
         if bev_pos is not None:
             bev_pos = bev_pos.flatten(2).permute(2, 0, 1)
+        if torch.is_autocast_enabled('cuda') and \
+                (bev_queries[0] if isinstance(bev_queries, list) else bev_queries).is_cuda:
+            # Residual stream under autocast.  lowp_stream (default): 16-bit, as the reference's own
+            # mixed-precision mode runs it (mmcv wrap_fp16_model: activations in half, norm
+            # statistics in f32) — the queries enter in the autocast dtype, every fused
+            # add+dropout+LayerNorm returns it, and no per-Linear cast / f32 gradient accumulation
+            # pass remains.  Otherwise f32 (torch.autocast's LayerNorm convention).
+            adt = torch.get_autocast_dtype('cuda') if self.lowp_stream else torch.float32
+            bev_queries = [q.to(adt) for q in bev_queries] if isinstance(bev_queries, list) \
+                else bev_queries.to(adt)
+            bev_pos = None if bev_pos is None else bev_pos.to(adt)
         if self.dual_queries:
             assert isinstance(bev_queries, list)
             q_img = bev_queries[0].unsqueeze(1).expand(-1, bs, -1)
