@@ -230,6 +230,20 @@ int ubv_add_dropout_layernorm_backward(const void* grad_y, const void* x, const 
                                        int dtype, int stream_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Reductions behind the gradients of the encoder's Linear layers (value_proj, sampling_offsets,
+ * attention_weights, output_proj, FFN; [ext] torch.nn.Linear backward in the reference), one launch
+ * per Linear:
+ *   grad_bias[n] += sum_m grad_out[m, n]     grad_out [rows, N] dtype (NULL to skip),
+ *                                            grad_bias [N] f32 ACCUMULATED (caller zeroes)
+ *   grad_weight[i] = sum_s partials[s, i]    partials [S, NK] dtype: the split-K slices of the
+ *                                            weight-gradient GEMM (NULL to skip), grad_weight [NK] f32
+ * N and NK multiples of 16 bytes' worth of elements, N <= 256 * that.
+ */
+int ubv_linear_grad_reduce(const void* grad_out, int64_t rows, int N, float* grad_bias,
+                           const void* partials, int S, int64_t NK, float* grad_weight, int dtype,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * LiDAR front end.
  * Replaces [ext] mmdet3d ops built from `pts_voxel_layer` and called at
  * models/detectors/unibev_detector.py:163-167 (Voxelization -> hard_voxelize, deterministic),

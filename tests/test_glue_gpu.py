@@ -122,3 +122,52 @@ def test_bev_fuse_missing_modality_and_bad_shapes():
     with pytest.raises(UniBEVHipError):
         bev_fuse(torch.randn(1, 5, 6, device=DEV), None, torch.ones(6, device=DEV),
                  torch.ones(6, device=DEV))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('rows,N,K', [(80000, 256, 256), (4099, 96, 256), (12345, 192, 64), (7, 512, 256)])
+def test_linear_grad_reduce_vs_torch(dtype, rows, N, K):
+    """Bias column sums and the split-K slice sum of a Linear's backward in one launch
+    (ubv_linear_grad_reduce) against torch reductions in f64."""
+    from unibev_amd.functional import linear_grad_reduce
+    torch.manual_seed(rows)
+    go = torch.randn(rows, N, device=DEV).to(dtype)
+    part = torch.randn(5, N, K, device=DEV).to(dtype)
+    gb, gw = linear_grad_reduce(go, part)
+    assert gb.dtype == torch.float32 and gw.dtype == torch.float32 and gw.shape == (N, K)
+    scale = max(1.0, rows ** 0.5)
+    torch.testing.assert_close(gb.double(), go.double().sum(0), rtol=1e-5, atol=2e-5 * scale)
+    torch.testing.assert_close(gw.double(), part.double().sum(0), rtol=1e-6, atol=1e-5)
+    gb2, none = linear_grad_reduce(go, None)
+    assert none is None
+    torch.testing.assert_close(gb2, gb, rtol=1e-5, atol=1e-4 * scale)      # atomics: order varies
+    none, gw2 = linear_grad_reduce(None, part)
+    assert none is None and torch.equal(gw2, gw)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_linear_function_gradients_vs_torch(dtype):
+    """unibev_amd.linear.linear / linear_cat (library GEMMs + split-K weight gradient + fused
+    reductions) against F.linear, forward and all gradients."""
+    from unibev_amd.linear import linear, linear_cat
+    torch.manual_seed(3)
+    rows, K = 8192, 256
+    x = torch.randn(2, rows // 2, K, device=DEV)
+    l1, l2 = torch.nn.Linear(K, 128).to(DEV), torch.nn.Linear(K, 64).to(DEV)
+    cot = torch.randn(2, rows // 2, 192, device=DEV)
+    xa = x.clone().requires_grad_()
+    with torch.autocast('cuda', dtype=dtype, enabled=dtype != torch.float32):
+        y = linear_cat(xa, (l1.weight, l2.weight), (l1.bias, l2.bias))
+    y.backward(cot.to(y.dtype))
+    got = (y.detach().float(), xa.grad, l1.weight.grad, l2.weight.grad, l1.bias.grad, l2.bias.grad)
+    for l in (l1, l2):
+        l.weight.grad = l.bias.grad = None
+    xr = x.clone().requires_grad_()
+    yr = torch.cat((torch.nn.functional.linear(xr, l1.weight, l1.bias),
+                    torch.nn.functional.linear(xr, l2.weight, l2.bias)), -1)
+    yr.backward(cot)
+    ref = (yr.detach(), xr.grad, l1.weight.grad, l2.weight.grad, l1.bias.grad, l2.bias.grad)
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    for a, b in zip(got, ref):
+        assert a.dtype == b.dtype
+        torch.testing.assert_close(a, b, rtol=tol, atol=tol * float(b.abs().max()))

@@ -1,0 +1,117 @@
+// Reductions behind the Linear layers' weight / bias gradients (unibev_amd/linear.py):
+//   * grad_bias[n]  = sum over the M = bs*Nq rows of grad_out[M, N]          (column sum)
+//   * grad_weight   = sum over the S split-K slices of the strided-batched GEMM partials [S, N*K]
+// As framework reductions these were 96 launches and 1.7 ms per training step (9 % of the kernel
+// time, profiles/r01_v7_*): a generic reduce kernel per tensor at 17.7 us average.  Here one launch
+// serves both outputs of one Linear; the column sum streams grad_out once with 16-byte loads.
+#include "ubv_common.h"
+
+namespace ubv {
+
+template <typename T> struct red_vec { static constexpr int kVec = 16 / elem<T>::kBytes; };
+
+// blocks [0, col_blocks): column sums of go[rows, N] into gb (f32, zeroed by the caller, one atomic
+// per column per block); blocks [col_blocks, ...): out[i] = sum_s part[s][i], 16 bytes per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void linear_grad_reduce_kernel(
+    const T* __restrict__ go, long rows, int N, float* __restrict__ gb, int col_blocks,
+    int rows_per_block, const T* __restrict__ part, int S, long NK, float* __restrict__ gw) {
+  constexpr int VEC = red_vec<T>::kVec;
+  __shared__ float red[256][VEC];
+  if ((int)blockIdx.x < col_blocks) {
+    const int lpr = N / VEC;                       // threads per row
+    const int G = 256 / lpr;                       // rows per block step
+    const int sub = threadIdx.x / lpr, c = (threadIdx.x - sub * lpr) * VEC;
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
+    if (sub < G) {
+      const long r0 = (long)blockIdx.x * rows_per_block;
+      const long r1 = min(rows, r0 + rows_per_block);
+      long r = r0 + sub;
+      for (; r + G < r1; r += 2 * G) {              // two independent rows in flight
+        float a[VEC], b[VEC];
+        vec_io<T, VEC>::load(go + r * N + c, a);
+        vec_io<T, VEC>::load(go + (r + G) * N + c, b);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += a[i] + b[i];
+      }
+      if (r < r1) {
+        float a[VEC];
+        vec_io<T, VEC>::load(go + r * N + c, a);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += a[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) red[threadIdx.x][i] = acc[i];
+    __syncthreads();
+    for (int col = threadIdx.x; col < N; col += 256) {
+      const int cl = col / VEC, e = col - cl * VEC;
+      float s = 0.0f;
+      for (int g = 0; g < G; ++g) s += red[g * lpr + cl][e];
+      atomic_add_f32(gb + col, s);
+    }
+    return;
+  }
+  const long i0 = ((long)(blockIdx.x - col_blocks) * 256 + threadIdx.x) * VEC;
+  if (i0 >= NK) return;
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
+  for (int s = 0; s < S; ++s) {
+    float a[VEC];
+    vec_io<T, VEC>::load(part + (long)s * NK + i0, a);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] += a[i];
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; i += 4)
+    *reinterpret_cast<float4*>(gw + i0 + i) = make_float4(acc[i], acc[i + 1], acc[i + 2], acc[i + 3]);
+}
+
+template <typename T>
+static void linear_grad_launch(const void* go, long rows, int N, float* gb, const void* part, int S,
+                               long NK, float* gw, hipStream_t st) {
+  constexpr int VEC = red_vec<T>::kVec;
+  int col_blocks = 0, rpb = 0;
+  if (go != nullptr && rows > 0) {
+    // enough blocks to fill the chip, few enough that the per-block atomics stay negligible
+    rpb = (int)max(64L, (rows + 511) / 512);
+    col_blocks = (int)((rows + rpb - 1) / rpb);
+  }
+  const int sum_blocks = (part != nullptr) ? (int)((NK / VEC + 255) / 256) : 0;
+  if (col_blocks + sum_blocks == 0) return;
+  hipLaunchKernelGGL((linear_grad_reduce_kernel<T>), dim3(col_blocks + sum_blocks), dim3(256), 0, st,
+                     (const T*)go, rows, N, gb, col_blocks, rpb, (const T*)part, S, NK, gw);
+}
+
+}  // namespace ubv
+
+extern "C" int ubv_linear_grad_reduce(const void* grad_out, int64_t rows, int N, float* grad_bias,
+                                      const void* partials, int S, int64_t NK, float* grad_weight,
+                                      int dtype, void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(dtype >= 0 && dtype <= 2, "linear_grad_reduce: unknown dtype %d", dtype);
+  const int vec = dtype == UBV_F32 ? 4 : 8;
+  if (grad_out != nullptr) {
+    UBV_CHECK_ARG(grad_bias != nullptr && rows >= 0 && N > 0, "linear_grad_reduce: bad bias arguments");
+    UBV_CHECK_ARG(N % vec == 0 && N / vec <= 256, "linear_grad_reduce: N=%d must be a multiple of %d and <= %d",
+                  N, vec, 256 * vec);
+    UBV_CHECK_ARG(((uintptr_t)grad_out % 16) == 0, "linear_grad_reduce: grad_out must be 16-byte aligned");
+  }
+  if (partials != nullptr) {
+    UBV_CHECK_ARG(grad_weight != nullptr && S > 0 && NK > 0 && NK % vec == 0,
+                  "linear_grad_reduce: bad split-K arguments");
+    UBV_CHECK_ARG(((uintptr_t)partials % 16) == 0 && ((uintptr_t)grad_weight % 16) == 0,
+                  "linear_grad_reduce: partials / grad_weight must be 16-byte aligned");
+  }
+  hipStream_t st = as_stream(stream);
+  switch (dtype) {
+    case UBV_F32: linear_grad_launch<float>(grad_out, rows, N, grad_bias, partials, S, NK, grad_weight, st); break;
+    case UBV_F16: linear_grad_launch<f16_t>(grad_out, rows, N, grad_bias, partials, S, NK, grad_weight, st); break;
+    default: linear_grad_launch<bf16_t>(grad_out, rows, N, grad_bias, partials, S, NK, grad_weight, st); break;
+  }
+  UBV_CHECK_LAUNCH("linear_grad_reduce");
+  return UBV_OK;
+}

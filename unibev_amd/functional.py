@@ -420,6 +420,33 @@ def add_dropout_layernorm(x, identity, gamma, beta, p=0.0, training=False, eps=1
     return _AddDropoutNorm.apply(x, identity, gamma, beta, float(p) if training else 0.0, eps)
 
 
+# ----------------------------------------------------------------------------------------------- linear grads
+@torch.no_grad()
+def linear_grad_reduce(grad_out=None, partials=None):
+    """(grad_bias f32 [N] or None, grad_weight f32 [N, K] or None) in one launch
+    (``ubv_linear_grad_reduce``): column sums of ``grad_out`` [rows, N] and the sum over the
+    split-K slices ``partials`` [S, N, K].  Both inputs must share one dtype."""
+    gb = gw = None
+    go_p = part_p = None
+    rows = N = S = NK = 0
+    ref = grad_out if grad_out is not None else partials
+    _need_cuda(ref)
+    if grad_out is not None:
+        grad_out = grad_out.contiguous()
+        rows, N = grad_out.shape
+        gb = torch.zeros(N, dtype=torch.float32, device=ref.device)
+        go_p = _p(grad_out)
+    if partials is not None:
+        assert grad_out is None or partials.dtype == grad_out.dtype
+        partials = partials.contiguous()
+        S, NK = partials.shape[0], partials[0].numel()
+        gw = torch.empty(partials.shape[1:], dtype=torch.float32, device=ref.device)
+        part_p = _p(partials)
+    check(lib().ubv_linear_grad_reduce(go_p, rows, N, _p(gb), part_p, S, NK, _p(gw), _dt(ref),
+                                       _stream()), 'linear_grad_reduce')
+    return gb, gw
+
+
 # ----------------------------------------------------------------------------------------------- voxels
 _WS = {}
 

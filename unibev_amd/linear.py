@@ -105,15 +105,28 @@ class _Linear(Function):
         x2 = xc.reshape(-1, xc.shape[-1])
         rows = x2.shape[0]
         gw = gb = None
-        if any(ctx.needs_input_grad[4:4 + n]):
+        need_w = any(ctx.needs_input_grad[4:4 + n])
+        need_b = has_bias and any(ctx.needs_input_grad[4 + n:])
+        part = None
+        if need_w:
             s = _splits(rows)
             if s > 1:
                 part = torch.bmm(go2.view(s, rows // s, -1).transpose(1, 2), x2.view(s, rows // s, -1))
-                gw = part.sum(0, dtype=torch.float32)
             else:
                 gw = (go2.t() @ x2).float()
-        if has_bias and any(ctx.needs_input_grad[4 + n:]):
-            gb = go2.sum(0, dtype=torch.float32)
+        vec = 16 // go2.element_size()
+        if go2.is_cuda and (need_b or part is not None) and go2.shape[1] % vec == 0 and \
+                go2.shape[1] // vec <= 256 and \
+                (part is None or (part.dtype == go2.dtype and part[0].numel() % vec == 0)):
+            # one launch: bias column sums + the sum over the split-K slices (library reductions)
+            from . import functional as UF
+            gb, gw_p = UF.linear_grad_reduce(go2 if need_b else None, part)
+            gw = gw_p if part is not None else gw
+        else:
+            if part is not None:
+                gw = part.sum(0, dtype=torch.float32)
+            if need_b:
+                gb = go2.sum(0, dtype=torch.float32)
         grads = []
         off = 0
         for i in range(n):
