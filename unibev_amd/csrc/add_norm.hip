@@ -171,6 +171,158 @@ __global__ __launch_bounds__(256) void add_norm_bwd_kernel(
   }
 }
 
+// ---- packed rows: C / VEC lanes per row (VEC = 16 bytes of T), 64 / LPR rows per wave step --------
+// For C = 256 in 16-bit data a row is 32 lanes of 16-byte vectors: two rows per wave step, no idle
+// lanes, half the dependent iterations of the one-row-per-wave kernels above (which remain for the
+// widths this layout does not cover).  Same arithmetic, same hash, same reductions.
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+  for (int m = LPR >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+template <typename T, typename S, int LPR>
+__global__ __launch_bounds__(256) void add_norm_fwd_rows_kernel(
+    const T* __restrict__ x, const S* __restrict__ identity, const float* __restrict__ gamma,
+    const float* __restrict__ beta, S* __restrict__ y, float* __restrict__ mean,
+    float* __restrict__ rstd, long R, int C, float eps, uint32_t thresh, float scale, uint64_t seed) {
+  constexpr int VEC = 16 / elem<T>::kBytes, G = 64 / LPR;
+  const int lane = threadIdx.x & 63, sub = lane / LPR, c = (lane % LPR) * VEC;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  float g[VEC], b[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; i += 4) {
+    float t4[4];
+    load4<float>(gamma + c + i, t4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g[i + k] = t4[k];
+    load4<float>(beta + c + i, t4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[i + k] = t4[k];
+  }
+  for (long r0 = wave * G; r0 < R; r0 += nwaves * G) {
+    const long r = r0 + sub;
+    const bool ok = r < R;
+    const long rr = ok ? r : 0;
+    float xv[VEC], iv[VEC], s[VEC];
+    vec_io<T, VEC>::load(x + rr * C + c, xv);
+#pragma unroll
+    for (int i = 0; i < VEC; i += 4) {
+      float t4[4];
+      load4<S>(identity + rr * C + c + i, t4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) iv[i + k] = t4[k];
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float d = xv[i];
+      if (thresh != 0u) d = (drop_hash(seed, (uint64_t)(rr * C + c + i)) >= thresh) ? d * scale : 0.0f;
+      s[i] = iv[i] + d;
+      sum += s[i];
+    }
+    const float mu = row_sum<LPR>(sum) / (float)C;
+    float var = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { const float d = s[i] - mu; var = fmaf(d, d, var); }
+    const float rs = rsqrtf(row_sum<LPR>(var) / (float)C + eps);
+    if (ok) {
+#pragma unroll
+      for (int i = 0; i < VEC; i += 4) {
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (s[i + k] - mu) * rs * g[i + k] + b[i + k];
+        store4<S>(y + r * C + c + i, o);
+      }
+      if (c == 0) { mean[r] = mu; rstd[r] = rs; }
+    }
+  }
+}
+
+template <typename T, typename S, int LPR>
+__global__ __launch_bounds__(256) void add_norm_bwd_rows_kernel(
+    const S* __restrict__ gy, const T* __restrict__ x, const S* __restrict__ identity,
+    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+    T* __restrict__ gx, S* __restrict__ gid, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, long R, int C, uint32_t thresh, float scale, uint64_t seed) {
+  constexpr int VEC = 16 / elem<T>::kBytes, G = 64 / LPR;
+  __shared__ float red[2][4][64][VEC];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int sub = lane / LPR, c = (lane % LPR) * VEC;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  float g[VEC], ag[VEC], ab[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; i += 4) {
+    float t4[4];
+    load4<float>(gamma + c + i, t4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { g[i + k] = t4[k]; ag[i + k] = 0.0f; ab[i + k] = 0.0f; }
+  }
+  for (long r0 = wave * G; r0 < R; r0 += nwaves * G) {
+    const long r = r0 + sub;
+    const bool ok = r < R;
+    const long rr = ok ? r : 0;
+    const float mu = mean[rr], rs = rstd[rr];
+    float xv[VEC], iv[VEC], go[VEC], xh[VEC], dxh[VEC], keep[VEC];
+    vec_io<T, VEC>::load(x + rr * C + c, xv);
+#pragma unroll
+    for (int i = 0; i < VEC; i += 4) {
+      float t4[4];
+      load4<S>(identity + rr * C + c + i, t4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) iv[i + k] = t4[k];
+      load4<S>(gy + rr * C + c + i, t4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) go[i + k] = ok ? t4[k] : 0.0f;
+    }
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      keep[i] = 1.0f;
+      if (thresh != 0u) keep[i] = (drop_hash(seed, (uint64_t)(rr * C + c + i)) >= thresh) ? scale : 0.0f;
+      const float s = iv[i] + xv[i] * keep[i];
+      xh[i] = (s - mu) * rs;
+      dxh[i] = go[i] * g[i];
+      s1 += dxh[i];
+      s2 = fmaf(dxh[i], xh[i], s2);
+      ag[i] = fmaf(go[i], xh[i], ag[i]);
+      ab[i] += go[i];
+    }
+    s1 = row_sum<LPR>(s1) / (float)C;
+    s2 = row_sum<LPR>(s2) / (float)C;
+    if (ok) {
+      float dx[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; i += 4) {
+        float ds[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          ds[k] = rs * (dxh[i + k] - s1 - xh[i + k] * s2);
+          dx[i + k] = ds[k] * keep[i + k];
+        }
+        store4<S>(gid + r * C + c + i, ds);
+      }
+      vec_io<T, VEC>::store(gx + r * C + c, dx);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { red[0][wv][lane][i] = ag[i]; red[1][wv][lane][i] = ab[i]; }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 2 * C; t += 256) {
+    const int which = t / C, col = t - which * C;
+    const int cl = col / VEC, e = col - cl * VEC;
+    float sum = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int gq = 0; gq < G; ++gq) sum += red[which][w][gq * LPR + cl][e];
+    atomic_add_f32((which ? dbeta : dgamma) + col, sum);
+  }
+}
+
 static int norm_check(long R, int C, int dtype, int stream_dtype, const char* who) {
   UBV_CHECK_ARG(R >= 0 && C > 0 && C % 4 == 0 && C <= 64 * 4 * kNormChunks,
                 "%s: C=%d must be a multiple of 4 and <= %d", who, C, 64 * 4 * kNormChunks);
@@ -185,6 +337,41 @@ static void drop_params(float p, uint32_t& thresh, float& scale) {
   const double t = (double)p * 4294967296.0;
   thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
   scale = 1.0f / (1.0f - p);
+}
+
+// Packed-rows kernels where a row is 16, 32 or 64 lanes of 16-byte vectors, else one row per wave.
+template <typename T, typename S>
+static void norm_fwd_launch(dim3 grid, hipStream_t st, const void* x, const void* identity,
+                            const float* gamma, const float* beta, void* y, float* mean,
+                            float* rstd, long R, int C, float eps, uint32_t th, float sc,
+                            uint64_t seed) {
+  constexpr int VEC = 16 / elem<T>::kBytes;
+  const int lpr = (C % VEC == 0) ? C / VEC : 0;
+  auto run = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, (const T*)x, (const S*)identity, gamma, beta,
+                       (S*)y, mean, rstd, R, C, eps, th, sc, seed);
+  };
+  if (lpr == 64) run(add_norm_fwd_rows_kernel<T, S, 64>);
+  else if (lpr == 32) run(add_norm_fwd_rows_kernel<T, S, 32>);
+  else if (lpr == 16) run(add_norm_fwd_rows_kernel<T, S, 16>);
+  else run(add_norm_fwd_kernel<T, S>);
+}
+
+template <typename T, typename S>
+static void norm_bwd_launch(dim3 grid, hipStream_t st, const void* gy, const void* x,
+                            const void* identity, const float* gamma, const float* mean,
+                            const float* rstd, void* gx, void* gid, float* dgamma, float* dbeta,
+                            long R, int C, uint32_t th, float sc, uint64_t seed) {
+  constexpr int VEC = 16 / elem<T>::kBytes;
+  const int lpr = (C % VEC == 0) ? C / VEC : 0;
+  auto run = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, (const S*)gy, (const T*)x, (const S*)identity,
+                       gamma, mean, rstd, (T*)gx, (S*)gid, dgamma, dbeta, R, C, th, sc, seed);
+  };
+  if (lpr == 64) run(add_norm_bwd_rows_kernel<T, S, 64>);
+  else if (lpr == 32) run(add_norm_bwd_rows_kernel<T, S, 32>);
+  else if (lpr == 16) run(add_norm_bwd_rows_kernel<T, S, 16>);
+  else run(add_norm_bwd_kernel<T, S>);
 }
 
 }  // namespace ubv
@@ -202,11 +389,9 @@ extern "C" int ubv_add_dropout_layernorm_forward(const void* x, const void* iden
   uint32_t th; float sc;
   drop_params(p, th, sc);
   const long waves = R < 8192 ? R : 8192;
-  const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  const dim3 grid((unsigned)((waves + 3) / 4));
   hipStream_t st = as_stream(stream);
-#define UBV_NORM_FWD(T, S)                                                                        \
-  hipLaunchKernelGGL((add_norm_fwd_kernel<T, S>), grid, block, 0, st, (const T*)x,                \
-                     (const S*)identity, gamma, beta, (S*)y, mean, rstd, (long)R, C, eps, th, sc, seed)
+#define UBV_NORM_FWD(T, S) norm_fwd_launch<T, S>(grid, st, x, identity, gamma, beta, y, mean, rstd, (long)R, C, eps, th, sc, seed)
   const bool lowp = stream_dtype != UBV_F32;
   switch (dtype) {
     case UBV_F32: UBV_NORM_FWD(float, float); break;
@@ -234,12 +419,9 @@ extern "C" int ubv_add_dropout_layernorm_backward(const void* grad_y, const void
   uint32_t th; float sc;
   drop_params(p, th, sc);
   const long waves = R < 2048 ? R : 2048;
-  const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  const dim3 grid((unsigned)((waves + 3) / 4));
   hipStream_t st = as_stream(stream);
-#define UBV_NORM_BWD(T, S)                                                                        \
-  hipLaunchKernelGGL((add_norm_bwd_kernel<T, S>), grid, block, 0, st, (const S*)grad_y,           \
-                     (const T*)x, (const S*)identity, gamma, mean, rstd, (T*)grad_x,              \
-                     (S*)grad_identity, grad_gamma, grad_beta, (long)R, C, th, sc, seed)
+#define UBV_NORM_BWD(T, S) norm_bwd_launch<T, S>(grid, st, grad_y, x, identity, gamma, mean, rstd, grad_x, grad_identity, grad_gamma, grad_beta, (long)R, C, th, sc, seed)
   const bool lowp = stream_dtype != UBV_F32;
   switch (dtype) {
     case UBV_F32: UBV_NORM_BWD(float, float); break;
