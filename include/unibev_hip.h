@@ -229,6 +229,15 @@ int ubv_add_dropout_layernorm_backward(const void* grad_y, const void* x, const 
                                        float* grad_beta, int64_t R, int C, float p, uint64_t seed,
                                        int dtype, int stream_dtype, void* stream);
 
+/* FFN activation of the encoder layers, y = dropout(relu(x)) in one pass ([ext] mmcv FFN:
+ * Sequential(Linear, ReLU, Dropout(ffn_drop)); configs/unibev: feedforward_channels=512,
+ * ffn_dropout=0.1).  Same stateless keep mask as above; backward needs only y
+ * (grad_x = grad_y / (1-p) where y != 0).  n elements of dtype, n a multiple of 16 bytes' worth. */
+int ubv_relu_dropout_forward(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype,
+                             void* stream);
+int ubv_relu_dropout_backward(const void* grad_y, const void* y, void* grad_x, int64_t n, float p,
+                              int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Reductions behind the gradients of the encoder's Linear layers (value_proj, sampling_offsets,
  * attention_weights, output_proj, FFN; [ext] torch.nn.Linear backward in the reference), one launch

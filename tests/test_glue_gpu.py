@@ -171,3 +171,46 @@ def test_linear_function_gradients_vs_torch(dtype):
     for a, b in zip(got, ref):
         assert a.dtype == b.dtype
         torch.testing.assert_close(a, b, rtol=tol, atol=tol * float(b.abs().max()))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+def test_relu_dropout_fused(dtype):
+    """dropout(relu(x)) in one pass: eval mode == relu forward and backward; train mode keeps
+    ~(1-p) of the positive elements scaled by 1/(1-p), and the gradient follows the same mask
+    (recovered from the output alone)."""
+    from unibev_amd.functional import relu_dropout
+    torch.manual_seed(0)
+    x = torch.randn(4096, 512, device=DEV).to(dtype)
+    cot = torch.randn_like(x)
+    xa = x.clone().requires_grad_()
+    y = relu_dropout(xa, 0.3, training=False)
+    y.backward(cot)
+    assert torch.equal(y.detach(), torch.relu(x))
+    assert torch.equal(xa.grad, torch.where(x > 0, cot, torch.zeros_like(cot)))
+    xb = x.clone().requires_grad_()
+    p = 0.25
+    y2 = relu_dropout(xb, p, training=True)
+    y2.backward(cot)
+    pos = x > 0
+    kept = (y2 != 0) & pos
+    frac = kept.float().sum() / pos.float().sum()
+    assert abs(float(frac) - (1 - p)) < 0.01, float(frac)
+    assert not bool((y2 != 0)[~pos].any())
+    scale = 1.0 / (1.0 - p)
+    torch.testing.assert_close(y2.detach()[kept].float(), (x[kept].float() * scale), rtol=1e-2, atol=1e-6)
+    torch.testing.assert_close(xb.grad[kept].float(), cot[kept].float() * scale, rtol=1e-2, atol=1e-6)
+    assert not bool(xb.grad[~kept].any())
+
+
+def test_zero_arena_hands_out_disjoint_zeroed_slices():
+    from unibev_amd import functional as UF
+    UF.new_step()
+    a = UF.zeros_f32(256, torch.device(DEV, 0))
+    b = UF.zeros_f32(100, torch.device(DEV, 0))
+    a += 1
+    assert float(b.abs().sum()) == 0 and a.data_ptr() % 256 == 0 and b.data_ptr() % 256 == 0
+    UF.new_step()
+    c = UF.zeros_f32(256, torch.device(DEV, 0))
+    assert float(c.abs().sum()) == 0 and float(a.sum()) == 256     # the old step's slices survive
+    big = UF.zeros_f32(1 << 20, torch.device(DEV, 0))                # larger than the arena: regrows
+    assert float(big.abs().sum()) == 0

@@ -323,6 +323,47 @@ __global__ __launch_bounds__(256) void add_norm_bwd_rows_kernel(
   }
 }
 
+// ---- FFN activation: y = dropout(relu(x)) in one pass --------------------------------------------
+// ([ext] mmcv FFN: Sequential(Linear, ReLU, Dropout(ffn_drop)), 80 000 x 512 hidden rows here.)
+// Same stateless keep mask as above.  Backward needs only y: y != 0 <=> (x > 0 and kept), so
+// grad_x = grad_y * scale where y != 0 — no mask, no pre-activation saved.
+template <typename T>
+__global__ __launch_bounds__(256) void relu_dropout_fwd_kernel(const T* __restrict__ x,
+                                                               T* __restrict__ y, long n,
+                                                               uint32_t thresh, float scale,
+                                                               uint64_t seed) {
+  constexpr int VEC = 16 / elem<T>::kBytes;
+  const long stride = (long)gridDim.x * blockDim.x * VEC;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC; i < n; i += stride) {
+    float v[VEC];
+    vec_io<T, VEC>::load(x + i, v);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      float r = fmaxf(v[k], 0.0f);
+      if (thresh != 0u) r = (drop_hash(seed, (uint64_t)(i + k)) >= thresh) ? r * scale : 0.0f;
+      v[k] = r;
+    }
+    vec_io<T, VEC>::store(y + i, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const T* __restrict__ gy,
+                                                               const T* __restrict__ y,
+                                                               T* __restrict__ gx, long n,
+                                                               float scale) {
+  constexpr int VEC = 16 / elem<T>::kBytes;
+  const long stride = (long)gridDim.x * blockDim.x * VEC;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC; i < n; i += stride) {
+    float g[VEC], o[VEC];
+    vec_io<T, VEC>::load(gy + i, g);
+    vec_io<T, VEC>::load(y + i, o);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) g[k] = (o[k] != 0.0f) ? g[k] * scale : 0.0f;
+    vec_io<T, VEC>::store(gx + i, g);
+  }
+}
+
 static int norm_check(long R, int C, int dtype, int stream_dtype, const char* who) {
   UBV_CHECK_ARG(R >= 0 && C > 0 && C % 4 == 0 && C <= 64 * 4 * kNormChunks,
                 "%s: C=%d must be a multiple of 4 and <= %d", who, C, 64 * 4 * kNormChunks);
@@ -430,5 +471,52 @@ extern "C" int ubv_add_dropout_layernorm_backward(const void* grad_y, const void
   }
 #undef UBV_NORM_BWD
   UBV_CHECK_LAUNCH("add_norm_backward");
+  return UBV_OK;
+}
+
+extern "C" int ubv_relu_dropout_forward(const void* x, void* y, int64_t n, float p, uint64_t seed,
+                                        int dtype, void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(x && y && n >= 0, "relu_dropout_forward: bad arguments");
+  UBV_CHECK_ARG(dtype >= 0 && dtype <= 2, "relu_dropout_forward: unknown dtype %d", dtype);
+  const int vec = dtype == UBV_F32 ? 4 : 8;
+  UBV_CHECK_ARG(n % vec == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0,
+                "relu_dropout_forward: n must be a multiple of %d and the buffers 16-byte aligned", vec);
+  if (n == 0) return UBV_OK;
+  uint32_t th; float sc;
+  drop_params(p, th, sc);
+  const long threads = n / vec;
+  const dim3 grid((unsigned)min((threads + 255) / 256, 8192L));
+  hipStream_t st = as_stream(stream);
+  switch (dtype) {
+    case UBV_F32: hipLaunchKernelGGL(relu_dropout_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)y, (long)n, th, sc, seed); break;
+    case UBV_F16: hipLaunchKernelGGL(relu_dropout_fwd_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, (long)n, th, sc, seed); break;
+    default: hipLaunchKernelGGL(relu_dropout_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, (long)n, th, sc, seed); break;
+  }
+  UBV_CHECK_LAUNCH("relu_dropout_forward");
+  return UBV_OK;
+}
+
+extern "C" int ubv_relu_dropout_backward(const void* grad_y, const void* y, void* grad_x, int64_t n,
+                                         float p, int dtype, void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(grad_y && y && grad_x && n >= 0, "relu_dropout_backward: bad arguments");
+  UBV_CHECK_ARG(dtype >= 0 && dtype <= 2, "relu_dropout_backward: unknown dtype %d", dtype);
+  const int vec = dtype == UBV_F32 ? 4 : 8;
+  UBV_CHECK_ARG(n % vec == 0 && ((uintptr_t)grad_y % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+                    ((uintptr_t)grad_x % 16) == 0,
+                "relu_dropout_backward: n must be a multiple of %d and the buffers 16-byte aligned", vec);
+  if (n == 0) return UBV_OK;
+  uint32_t th; float sc;
+  drop_params(p, th, sc);
+  const long threads = n / vec;
+  const dim3 grid((unsigned)min((threads + 255) / 256, 8192L));
+  hipStream_t st = as_stream(stream);
+  switch (dtype) {
+    case UBV_F32: hipLaunchKernelGGL(relu_dropout_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)grad_y, (const float*)y, (float*)grad_x, (long)n, sc); break;
+    case UBV_F16: hipLaunchKernelGGL(relu_dropout_bwd_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t*)grad_y, (const f16_t*)y, (f16_t*)grad_x, (long)n, sc); break;
+    default: hipLaunchKernelGGL(relu_dropout_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)grad_y, (const bf16_t*)y, (bf16_t*)grad_x, (long)n, sc); break;
+  }
+  UBV_CHECK_LAUNCH("relu_dropout_backward");
   return UBV_OK;
 }

@@ -41,6 +41,8 @@ def lowp_step_cache():
     if _ACTIVE:                       # nested: the outer context already refreshed
         yield
         return
+    from . import functional as UF
+    UF.new_step()                     # backward accumulators of this pass come from a fresh arena
     if _SHADOWS:
         groups = {}                   # one multi-tensor copy per (dtypes, device) group
         for buf, views, params in _SHADOWS.values():

@@ -13,6 +13,7 @@ import warnings
 import torch
 import torch.nn as nn
 
+from .. import functional as UF
 from ..linear import linear as ubv_linear
 from ..registry import (ATTENTION, FEEDFORWARD_NETWORK, POSITIONAL_ENCODING, TRANSFORMER_LAYER,
                         TRANSFORMER_LAYER_SEQUENCE, build_attention, build_feedforward_network,
@@ -84,18 +85,32 @@ class FFN(BaseModule):
     def _mlp(self, x):
         """``self.layers(x)`` with the Linear layers routed through the split-K-wgrad linear."""
         for layer in self.layers:
-            if isinstance(layer, nn.Linear):
-                x = ubv_linear(x, layer.weight, layer.bias)
-            elif isinstance(layer, nn.Sequential):
-                for sub in layer:
-                    if isinstance(sub, nn.Linear):
-                        x = ubv_linear(x, sub.weight, sub.bias)
-                    elif isinstance(sub, nn.ReLU):
-                        x = torch.relu(x)          # out-of-place: x is the output of a custom op
-                    else:
-                        x = sub(x)
+            x = self._block(x, layer)
+        return x
+
+    def _block(self, x, layer):
+        """One entry of ``self.layers``: a Linear, the closing Dropout, or a
+        Sequential(Linear, act, Dropout) whose ReLU + Dropout run as one kernel on the GPU."""
+        if isinstance(layer, nn.Linear):
+            return ubv_linear(x, layer.weight, layer.bias)
+        if not isinstance(layer, nn.Sequential):
+            return layer(x)
+        subs = list(layer)
+        i = 0
+        while i < len(subs):
+            sub = subs[i]
+            if isinstance(sub, nn.Linear):
+                x = ubv_linear(x, sub.weight, sub.bias)
+            elif isinstance(sub, nn.ReLU):
+                nxt = subs[i + 1] if i + 1 < len(subs) else None
+                if x.is_cuda and isinstance(nxt, nn.Dropout) and x.numel() % 8 == 0:
+                    x = UF.relu_dropout(x, nxt.p, self.training)
+                    i += 1
+                else:
+                    x = torch.relu(x)              # out-of-place: x is the output of a custom op
             else:
-                x = layer(x)
+                x = sub(x)
+            i += 1
         return x
 
     def forward_parts(self, x, identity=None):
@@ -107,16 +122,7 @@ class FFN(BaseModule):
             return None
         h = x
         for layer in list(self.layers)[:-1]:
-            if isinstance(layer, nn.Linear):
-                h = ubv_linear(h, layer.weight, layer.bias)
-            else:
-                for sub in layer:
-                    if isinstance(sub, nn.Linear):
-                        h = ubv_linear(h, sub.weight, sub.bias)
-                    elif isinstance(sub, nn.ReLU):
-                        h = torch.relu(h)
-                    else:
-                        h = sub(h)
+            h = self._block(h, layer)
         return h, (x if identity is None else identity), last.p
 
     def forward(self, x, identity=None):
@@ -334,6 +340,17 @@ class LearnedPositionalEncoding(BaseModule):
         return pos.permute(2, 0, 1).unsqueeze(0).expand(bs, -1, -1, -1)
 
 
+def cast_keep_expand(t, dtype):
+    """``t.to(dtype)`` that keeps a batch-expanded (stride-0 leading dim) tensor expanded: the cast
+    touches one sample's worth of data and every later broadcast add reads it once, instead of
+    materialising bs copies (and their transposed strides) as a plain ``.to`` would."""
+    if t is None or t.dtype == dtype:
+        return t
+    if t.dim() > 1 and t.stride(0) == 0 and t.shape[0] > 1:
+        return t[:1].to(dtype).expand(t.shape)
+    return t.to(dtype)
+
+
 __all__ = ['BaseModule', 'FFN', 'MultiheadAttention', 'BaseTransformerLayer',
            'DetrTransformerDecoderLayer', 'TransformerLayerSequence', 'LearnedPositionalEncoding',
-           'xavier_init', 'constant_init', 'TRANSFORMER_LAYER_SEQUENCE']
+           'xavier_init', 'constant_init', 'TRANSFORMER_LAYER_SEQUENCE', 'cast_keep_expand']

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from ..registry import HEADS, build_positional_encoding, build_transformer
-from .bricks import BaseModule
+from .bricks import BaseModule, cast_keep_expand
 from .decoder import inverse_sigmoid
 
 
@@ -90,7 +90,7 @@ class UniBEV_Head(BaseModule):
         else:
             bev_queries = self.bev_embedding.weight.to(dtype)
         bev_mask = torch.zeros((bs, self.bev_h, self.bev_w), device=device).to(dtype)
-        return bev_queries, self.positional_encoding(bev_mask).to(dtype)
+        return bev_queries, cast_keep_expand(self.positional_encoding(bev_mask), dtype)
 
     def forward_bev(self, mlvl_img_feats, pts_feats, img_metas):
         """The hot path only: BEV features ``bev_embed`` (Nq, bs, C*s)."""

@@ -25,7 +25,7 @@ from .. import functional as UF
 from ..linear import lowp_step_cache
 from ..registry import (TRANSFORMER, TRANSFORMER_LAYER_SEQUENCE,
                         build_transformer_layer_sequence)
-from .bricks import BaseModule, xavier_init
+from .bricks import BaseModule, cast_keep_expand, xavier_init
 from .deform_attn import _DeformAttnBase, shapes_tensor
 
 _UNSUPPORTED_NORMS = ('MLP_ChannelNormWeights', 'Leaky_ReLU_MLP_ChannelNormWeights',
@@ -253,7 +253,9 @@ class UniBEVTransformer(BaseModule):
             adt = torch.get_autocast_dtype('cuda') if self.lowp_stream else torch.float32
             bev_queries = [q.to(adt) for q in bev_queries] if isinstance(bev_queries, list) \
                 else bev_queries.to(adt)
-            bev_pos = None if bev_pos is None else bev_pos.to(adt)
+            # (hw, bs, C) view of a batch-expanded tensor: cast one sample, keep the expansion
+            bev_pos = None if bev_pos is None else \
+                cast_keep_expand(bev_pos.permute(1, 0, 2), adt).permute(1, 0, 2)
         if self.dual_queries:
             assert isinstance(bev_queries, list)
             q_img = bev_queries[0].unsqueeze(1).expand(-1, bs, -1)
