@@ -70,7 +70,9 @@ __device__ __forceinline__ void store_row(float* p, const float (&v)[P]) {
     *reinterpret_cast<float4*>(p + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
 }
 
-template <int P>
+// FAST (16-bit data paths): one reciprocal instead of P IEEE divisions — an ulp of f32 that the
+// 16-bit values downstream cannot see.  f32 data keeps the reference's exact divisions.
+template <int P, bool FAST = false>
 __device__ __forceinline__ void softmax_row(const float (&l)[P], float (&w)[P]) {
   float m = l[0];
 #pragma unroll
@@ -78,8 +80,15 @@ __device__ __forceinline__ void softmax_row(const float (&l)[P], float (&w)[P]) 
   float s = 0.0f;
 #pragma unroll
   for (int i = 0; i < P; ++i) { w[i] = expf(l[i] - m); s += w[i]; }
+  const float inv = 1.0f / s;
 #pragma unroll
-  for (int i = 0; i < P; ++i) w[i] = w[i] / s;
+  for (int i = 0; i < P; ++i) w[i] = FAST ? w[i] * inv : w[i] / s;
+}
+
+// a / b, or a * (1/b) with a precomputed reciprocal on the 16-bit data paths (see softmax_row)
+template <bool FAST>
+__device__ __forceinline__ float div_or_mul(float a, float b, float inv_b) {
+  return FAST ? a * inv_b : a / b;
 }
 
 // Rows of offsets / logits / their gradients: f32, or (lowp) the value's 16-bit type.  Under
@@ -160,6 +169,9 @@ __global__ __launch_bounds__(256, 2) void lift_fwd_kernel(const LiftArgs a) {
   const T* __restrict__ value = (const T*)a.value;
   T* __restrict__ out = (T*)a.out;
   const float fwf = (float)a.fw, fhf = (float)a.fh;
+  constexpr bool FAST = sizeof(T) == 2;
+  const float inv_fw = 1.0f / fwf, inv_fh = 1.0f / fhf;
+  const int rowi = (int)row;                          // element offsets of a map fit 32 bits (checked)
 
   for (int li0 = 0; li0 < 64; li0 += 4 * QW) {
     int b, q;
@@ -168,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void lift_fwd_kernel(const LiftArgs a) {
     float lg[P], w[P], off[2 * P];
     load_ol<T, P>(a.logits, bq * a.log_stride + h * P, OL16, lg);
     load_ol<T, 2 * P>(a.offsets, bq * a.off_stride + h * 2 * P, OL16, off);
-    softmax_row<P>(lg, w);
+    softmax_row<P, FAST>(lg, w);
 
     float acc[VEC];
 #pragma unroll
@@ -183,13 +195,13 @@ __global__ __launch_bounds__(256, 2) void lift_fwd_kernel(const LiftArgs a) {
       for (int p = 0; p < P; ++p) {
         const float2 r = *reinterpret_cast<const float2*>(rp + zi * 2);
         zi = (zi + 1 == a.Z) ? 0 : zi + 1;
-        const float lx = r.x + off[2 * p] / fwf;
-        const float ly = r.y + off[2 * p + 1] / fhf;
+        const float lx = r.x + div_or_mul<FAST>(off[2 * p], fwf, inv_fw);
+        const float ly = r.y + div_or_mul<FAST>(off[2 * p + 1], fhf, inv_fh);
         const Footprint f = make_footprint(lx, ly, a.fh, a.fw);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float v[VEC];
-          vec_io<T, VEC>::load(vb + (long)f.idx[k] * row, v);
+          vec_io<T, VEC>::load(vb + f.idx[k] * rowi, v);
           const float c = w[p] * f.w[k];
 #pragma unroll
           for (int i = 0; i < VEC; ++i) acc[i] = fmaf(c, v[i], acc[i]);
@@ -197,9 +209,9 @@ __global__ __launch_bounds__(256, 2) void lift_fwd_kernel(const LiftArgs a) {
       }
     }
     if (a.count != nullptr) {
-      const float cnt = a.count[bq];
+      const float cnt = a.count[bq], inv_cnt = 1.0f / cnt;
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] = acc[i] / cnt;
+      for (int i = 0; i < VEC; ++i) acc[i] = div_or_mul<FAST>(acc[i], cnt, inv_cnt);
     }
     vec_io<T, VEC>::store(out + bq * row + h * DH + cg * VEC, acc);
   }
@@ -229,7 +241,8 @@ __device__ __forceinline__ int slot_shift(const float* __restrict__ center, int 
 }
 
 template <typename T, int DH, int VEC, int P, int ATOMICS, bool OL16>
-__global__ __launch_bounds__(256) void lift_bwd_query_kernel(const LiftArgs a) {
+// P = 4 runs best at 3 waves per SIMD (127 -> 96 us); P = 8 loses to its own cache footprint there.
+__global__ __launch_bounds__(256, ((ATOMICS == kAtomNone && P == 4) ? 3 : 1)) void lift_bwd_query_kernel(const LiftArgs a) {
   constexpr int LP = DH / VEC;
   const int item = xcd_remap(blockIdx.x, a.chunk);
   if (item >= a.total_tiles) return;
@@ -241,6 +254,9 @@ __global__ __launch_bounds__(256) void lift_bwd_query_kernel(const LiftArgs a) {
   const T* __restrict__ value = (const T*)a.value;
   const T* __restrict__ gout = (const T*)a.gout;
   const float fwf = (float)a.fw, fhf = (float)a.fh;
+  constexpr bool FAST = sizeof(T) == 2;       // reciprocals instead of IEEE divisions (softmax_row)
+  const float inv_fw = 1.0f / fwf, inv_fh = 1.0f / fhf;
+  const int rowi = (int)row;
 
   for (int li0 = 0; li0 < 64; li0 += 4 * QW) {
     int b, q;
@@ -250,14 +266,16 @@ __global__ __launch_bounds__(256) void lift_bwd_query_kernel(const LiftArgs a) {
     float lg[P], w[P], off[2 * P];
     load_ol<T, P>(a.logits, bq * a.log_stride + h * P, OL16, lg);
     load_ol<T, 2 * P>(a.offsets, bq * a.off_stride + h * 2 * P, OL16, off);
-    softmax_row<P>(lg, w);
+    softmax_row<P, FAST>(lg, w);
 
     float go[VEC];
     vec_io<T, VEC>::load(gout + bq * row + h * DH + cg * VEC, go);
     const float inv = valid ? 1.0f : 0.0f;
     const float cnt = (a.count != nullptr) ? a.count[bq] : 1.0f;
+    const float inv_cnt = 1.0f / cnt;
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) go[i] = (a.count != nullptr ? go[i] / cnt : go[i]) * inv;
+    for (int i = 0; i < VEC; ++i)
+      go[i] = (a.count != nullptr ? div_or_mul<FAST>(go[i], cnt, inv_cnt) : go[i]) * inv;
 
     float gw[P], gx[P], gy[P];
 #pragma unroll
@@ -272,15 +290,15 @@ __global__ __launch_bounds__(256) void lift_bwd_query_kernel(const LiftArgs a) {
       for (int p = 0; p < P; ++p) {
         const float2 r = *reinterpret_cast<const float2*>(rp + zi * 2);
         zi = (zi + 1 == a.Z) ? 0 : zi + 1;
-        const float lx = r.x + off[2 * p] / fwf;
-        const float ly = r.y + off[2 * p + 1] / fhf;
+        const float lx = r.x + div_or_mul<FAST>(off[2 * p], fwf, inv_fw);
+        const float ly = r.y + div_or_mul<FAST>(off[2 * p + 1], fhf, inv_fh);
         const float xp = lx * fwf - 0.5f, yp = ly * fhf - 0.5f;
         const Footprint f = footprint_px(xp, yp, a.fh, a.fw);
         float dot[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float v[VEC];
-          const long o = vo + (long)f.idx[k] * row;
+          const long o = vo + f.idx[k] * rowi;
           vec_io<T, VEC>::load(value + o, v);
           float d = 0.0f;
 #pragma unroll
@@ -319,8 +337,9 @@ __global__ __launch_bounds__(256) void lift_bwd_query_kernel(const LiftArgs a) {
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         gl[p] = w[p] * (gw[p] - s);
-        gofs[2 * p] = (w[p] * gx[p] * fwf) / fwf;      // d loc = w*g*W ; d off = d loc / W
-        gofs[2 * p + 1] = (w[p] * gy[p] * fhf) / fhf;
+        // d loc = w*g*W ; d off = d loc / W (the reference's rounding; elided on 16-bit paths)
+        gofs[2 * p] = FAST ? w[p] * gx[p] : (w[p] * gx[p] * fwf) / fwf;
+        gofs[2 * p + 1] = FAST ? w[p] * gy[p] : (w[p] * gy[p] * fhf) / fhf;
       }
       store_ol<T, P>(a.glog, bq * a.glog_stride + h * P, OL16, gl);
       store_ol<T, 2 * P>(a.goff, bq * a.goff_stride + h * 2 * P, OL16, gofs);
@@ -1129,6 +1148,8 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_g
   UBV_CHECK_ARG(a.B > 0 && a.Nc > 0 && a.fh > 0 && a.fw > 0 && a.H > 0 && a.Nq > 0 && a.Z > 0,
                 "bev_lift: non-positive dimension");
   UBV_CHECK_ARG(P % a.Z == 0, "bev_lift: num_points %d not a multiple of Z %d", P, a.Z);
+  UBV_CHECK_ARG((long)a.fh * a.fw * a.H * Dh < (1L << 31),
+                "bev_lift: one value map must hold fewer than 2^31 elements");
   if (!lift_shape_ok(a.H, Dh, P, dtype)) {
     set_error("bev_lift: no kernel for H=%d Dh=%d P=%d dtype=%d", a.H, Dh, P, dtype);
     return UBV_ERR_UNSUPPORTED;
