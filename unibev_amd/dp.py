@@ -19,7 +19,8 @@ def init_distributed(backend=None, device=None):
     MASTER_ADDR / MASTER_PORT).  Returns (rank, world_size).  A single process needs no group."""
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_ddp()) and not dist.is_initialized():
+        os.environ.setdefault('MASTER_PORT', '29517')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
@@ -28,6 +29,13 @@ def init_distributed(backend=None, device=None):
             kw['device_id'] = device
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world
+
+
+def force_ddp():
+    """UBV_FORCE_DDP=1: build the process group and the DDP wrapper even for a single rank, so the
+    multi-GPU code path (bucketed all-reduce hooks, gradients as bucket views) can be exercised on
+    a one-GPU box."""
+    return os.environ.get('UBV_FORCE_DDP', '0') == '1'
 
 
 def shard_samples(num_samples, rank, world_size):
@@ -41,7 +49,7 @@ def shard_samples(num_samples, rank, world_size):
 def wrap_ddp(module, device_ids=None, bucket_cap_mb=32):
     """DistributedDataParallel with the reference's settings (no buffer broadcast); identity when
     there is a single process."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_ddp()):
         return module
     return torch.nn.parallel.DistributedDataParallel(
         module, device_ids=device_ids, broadcast_buffers=False, gradient_as_bucket_view=True,
