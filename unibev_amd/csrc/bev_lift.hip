@@ -385,10 +385,14 @@ __global__ __launch_bounds__(256) void lift_record_kernel(const LiftArgs a) {
     const float lx = r.x + off[2 * p] / fwf;
     const float ly = r.y + off[2 * p + 1] / fhf;
     const float xp = lx * fwf - 0.5f, yp = ly * fhf - 0.5f;
-    a.rec[(((long)b * a.H + h) * P + p) * a.Nq + q] = make_float4(xp, yp, w[p] / cnt, 0.0f);
     const Footprint f = footprint_px(xp, yp, a.fh, a.fw);
     const int hx = home_pixel(r.x, a.fw) + slot_shift(a.center, h, P, p, 0);
     const int hy = home_pixel(r.y, a.fh) + slot_shift(a.center, h, P, p, 1);
+    // the record carries the slot's expected pixel (two int16) so that the owner tiles need neither
+    // the reference point nor the slot centre again, and both kernels test the SAME integers
+    const uint32_t exy = ((uint32_t)hx & 0xffffu) | ((uint32_t)hy << 16);
+    a.rec[(((long)b * a.H + h) * P + p) * a.Nq + q] =
+        make_float4(xp, yp, w[p] / cnt, __uint_as_float(exy));
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float c = w[p] * f.w[k];
@@ -707,8 +711,7 @@ __global__ __launch_bounds__(256, 3) void lift_bwd_value_kernel(const LiftArgs a
       const int ncand = cw * (qy_hi - qy_lo + 1);
       if (cw <= 0 || ncand <= 0) continue;
       const float inv_cw = 1.0f / (float)cw;
-      const int zi = p % a.Z;
-      auto fetch = [&](int c0, float4& rec, float2& ref, int& q) -> bool {
+      auto fetch = [&](int c0, float4& rec, int& q) -> bool {
         const int c = c0 + lane;
         const bool valid = c < ncand;
         const int cc = valid ? c : 0;
@@ -716,21 +719,20 @@ __global__ __launch_bounds__(256, 3) void lift_bwd_value_kernel(const LiftArgs a
         cy -= (cy * cw > cc) ? 1 : 0;
         cy += ((cy + 1) * cw <= cc) ? 1 : 0;
         q = (qy_lo + cy) * a.qw + qx_lo + (cc - cy * cw);
-        const long bq = (long)g.b * a.Nq + q;
         rec = a.rec[(((long)g.b * a.H + g.h) * P + p) * a.Nq + q];
-        ref = *reinterpret_cast<const float2*>(a.ref + (bq * a.Z + zi) * 2);
         return valid;
       };
-      float4 nrec; float2 nref; int nq;
-      bool nvalid = fetch(0, nrec, nref, nq);
+      float4 nrec; int nq;
+      bool nvalid = fetch(0, nrec, nq);
       for (int c0 = 0; c0 < ncand; c0 += 64) {
-        const float4 rec = nrec; const float2 ref = nref; const int q = nq; const bool valid = nvalid;
-        if (c0 + 64 < ncand) nvalid = fetch(c0 + 64, nrec, nref, nq);
+        const float4 rec = nrec; const int q = nq; const bool valid = nvalid;
+        if (c0 + 64 < ncand) nvalid = fetch(c0 + 64, nrec, nq);
         int lp[4];
         float cwt[4];
         const Footprint f = footprint_px(rec.x, rec.y, a.fh, a.fw);
-        const bool any = tile_own<true>(f, rec.z, valid, g, t.tile_w, home_pixel(ref.x, a.fw) + dx,
-                                        home_pixel(ref.y, a.fh) + dy, a.R, lp, cwt);
+        const int exy = (int)__float_as_uint(rec.w);            // expected pixel, two int16
+        const bool any = tile_own<true>(f, rec.z, valid, g, t.tile_w, (exy << 16) >> 16, exy >> 16,
+                                        a.R, lp, cwt);
         rounds(lp, cwt, any, q);
       }
     }
