@@ -157,7 +157,10 @@ __device__ __forceinline__ float ld_ol(const void* base, long idx, bool lowp) {
 }
 
 template <typename T, int DH, int VEC, int P, bool OL16>
-__global__ __launch_bounds__(256, 2) void lift_fwd_kernel(const LiftArgs a) {
+// Register budget: the compiler's schedule depends on the occupancy it is allowed to aim for.  Measured
+// (bs = 2, bf16): P = 8 with at most 2 waves per SIMD 151 -> 126 us (SCA-pts), 183 -> 171 us (SCA-img);
+// P = 4 unconstrained (152 VGPRs, 3 waves) 87 -> 67 us.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (P == 8 ? 2 : 8)))) void lift_fwd_kernel(const LiftArgs a) {
   constexpr int LP = DH / VEC;
   const int item = xcd_remap(blockIdx.x, a.chunk);
   if (item >= a.total_tiles) return;
