@@ -19,6 +19,7 @@
 // wave64 holds 64/(H*LP) queries).  Work decomposition: a 256-thread block owns an 8x8 tile of
 // the BEV query grid (neighbouring queries sample neighbouring pixels: L1/L2 reuse), and tiles
 // are dealt to XCDs in contiguous bands so a band's value rows stay in one XCD's L2.
+#include <limits.h>
 #include <stdlib.h>
 
 #include "ubv_common.h"
@@ -34,10 +35,12 @@ struct LiftArgs {
   const void* gout; float* gvalue; void* goff; long goff_stride; void* glog; long glog_stride;
   void* gvalue_lp;                               // final grad_value in the value's 16-bit type or null
   int B, Nc, fh, fw, H, Nq, Z, qw, qh, tiles_x, tiles_per_sample, total_tiles, chunk;
-  int R;                                         // near radius (pixels) of the owner-tile backward
-  float4* rec;                                   // [B,H,P,Nq] (x_pix, y_pix, w/count, -) or null
+  // GRID backward: sampling points binned by owner tile
+  int* bin_cnt;                                  // [B,H,tiles] points appended per tile (may exceed cap)
+  float4* bins;                                  // [B,H,tiles,cap] (x_pix, y_pix, w/count, query index)
+  int cap;                                       // bucket capacity
+  int* ovf_n; float4* ovf_rec; int* ovf_tile; int ovf_cap;   // the appends that did not fit
   int* cam_list; int* cam_n;                     // per-camera compacted visible queries or null
-  const float* center;                           // [H,P,2] slot centres in pixels or null
   float* slab;                                   // CAMERA: per-chunk partial maps or null
 };
 
@@ -232,16 +235,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (P == 8 
 // kAtomFar names the GRID plan (records + far corners + owner tiles) in the launcher.
 enum { kAtomAll = 0, kAtomFar = 1, kAtomNone = 2 };
 
-__device__ __forceinline__ int home_pixel(float r, int n) {
-  return min(max((int)floorf(r * (float)n), 0), n - 1);
-}
-
-// Expected pixel of sampling slot (h, p) of a query: its home pixel shifted by the slot centre
-// (the sampling_offsets bias, i.e. where the slot samples when the learned offset is the bias).
-__device__ __forceinline__ int slot_shift(const float* __restrict__ center, int h, int P, int p,
-                                          int axis) {
-  return center ? (int)rintf(center[(h * P + p) * 2 + axis]) : 0;
-}
 
 template <typename T, int DH, int VEC, int P, int ATOMICS, bool OL16>
 // P = 4 runs best at 3 waves per SIMD (127 -> 96 us); P = 8 loses to its own cache footprint there.
@@ -351,35 +344,62 @@ __global__ __launch_bounds__(256, ((ATOMICS == kAtomNone && P == 4) ? 3 : 1)) vo
 }
 
 // ------------------------------------------------------------------------------------------------
-// GRID plan, step 0 — one record (x_pix, y_pix, w/count) per sampling point for the owner tiles, and
-// the atomic scatter of the rare "far" corners (outside the owner kernel's radius R around the
-// slot's expected pixel).  A wave takes 64/H consecutive queries x H heads with the query index
-// fastest across lanes: the offset / logit rows of those queries are read as whole contiguous
-// runs, and each slot-major record row [b][h][p][q..] is written as one contiguous run.  (Writing
-// the records from lift_bwd_query_kernel cost 2.7x its run time: 16-B scattered stores from one
-// lane in four, and the atomics' registers pushed it to one wave per SIMD.)
+// GRID plan, step 0 — bin the sampling points by OWNER TILE.  A point (query, head, slot) touches
+// up to 4 corners in up to 4 of the 8x8-pixel tiles of its (sample, head) map; its record
+// (x_pix, y_pix, w/count, query) is appended to the bucket of every tile that holds a corner with
+// non-zero weight (1.3 buckets per point on average), so the owner-tile kernel below reads exactly
+// the points it owns — the previous plan searched a 14x14 query window per slot and discarded 2/3
+// of what it evaluated.  A wave is one (8x8 query tile, head): its points fall into <= ~4 tiles, so
+// the appends are wave-aggregated — one atomic per distinct tile per corner slot, ranks by ballot /
+// popcount.  Buckets have a fixed capacity (2x the expected load); what does not fit goes to an
+// overflow list that lift_ovf_* scatter atomically, so the result is exact for ANY offsets.
+struct TileArgs;
+
 template <typename T, int DH, int P>
-__global__ __launch_bounds__(256) void lift_record_kernel(const LiftArgs a) {
-  const int QPW = kWave / a.H;
-  const int lane = threadIdx.x & 63;
-  const int h = lane / QPW, qs = lane - h * QPW;
-  const int waves_per_sample = (a.Nq + QPW - 1) / QPW;
+__global__ __launch_bounds__(256) void lift_bin_kernel(const LiftArgs a, int tiles_x, int tiles) {
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wave >= (long)a.B * waves_per_sample) return;
-  const int b = (int)(wave / waves_per_sample);
-  const int q = (int)(wave - (long)b * waves_per_sample) * QPW + qs;
-  if (q >= a.Nq) return;
+  if (wave >= (long)a.total_tiles * a.H) return;
+  const int item = (int)(wave / a.H), h = (int)(wave - (long)item * a.H);   // head fastest
+  const int lane = threadIdx.x & 63;
+  int b, q;
+  const bool valid = lift_query(a, item, lane, b, q);
+  if (!valid) q = 0;                                   // b is wave-uniform either way
   const long bq = (long)b * a.Nq + q;
   const float fwf = (float)a.fw, fhf = (float)a.fh;
-  const long row = (long)a.H * DH;
   float lg[P], w[P], off[2 * P];
   load_ol<T, P>(a.logits, bq * a.log_stride + h * P, a.ol16, lg);
   load_ol<T, 2 * P>(a.offsets, bq * a.off_stride + h * 2 * P, a.ol16, off);
   softmax_row<P>(lg, w);
   const float cnt = (a.count != nullptr) ? a.count[bq] : 1.0f;
-  const float* rp = a.ref + bq * a.Z * 2;                      // one map per sample (Nc == 1)
-  const T* __restrict__ gout = (const T*)a.gout + bq * row + h * DH;
-  float* __restrict__ gv = a.gvalue + (long)b * a.fh * a.fw * row + h * DH;
+  const float* rp = a.ref + bq * a.Z * 2;              // one map per sample (Nc == 1)
+  int* __restrict__ cntp = a.bin_cnt + ((long)b * a.H + h) * tiles;
+  float4* __restrict__ binp = a.bins + ((long)b * a.H + h) * tiles * a.cap;
+  const int tile_base = (b * a.H + h) * tiles;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+
+  auto append = [&](bool lead, int tile, const float4& rec) {
+    unsigned long long m = __ballot(lead);
+    while (m != 0ull) {
+      const int leader = __ffsll((long long)m) - 1;
+      const int tl = __shfl(tile, leader, 64);
+      const bool mine = lead && tile == tl;
+      const unsigned long long same = __ballot(mine);
+      int base = 0;
+      if (lane == leader) base = atomicAdd(cntp + tl, __popcll(same));
+      base = __shfl(base, leader, 64);
+      if (mine) {
+        const int idx = base + __popcll(same & lt);
+        if (idx < a.cap) {
+          binp[(long)tl * a.cap + idx] = rec;
+        } else {
+          const int o = atomicAdd(a.ovf_n, 1);
+          if (o < a.ovf_cap) { a.ovf_rec[o] = rec; a.ovf_tile[o] = tile_base + tl; }
+        }
+      }
+      m &= ~same;
+    }
+  };
+
   int zi = 0;
 #pragma unroll
   for (int p = 0; p < P; ++p) {
@@ -389,24 +409,71 @@ __global__ __launch_bounds__(256) void lift_record_kernel(const LiftArgs a) {
     const float ly = r.y + off[2 * p + 1] / fhf;
     const float xp = lx * fwf - 0.5f, yp = ly * fhf - 0.5f;
     const Footprint f = footprint_px(xp, yp, a.fh, a.fw);
-    const int hx = home_pixel(r.x, a.fw) + slot_shift(a.center, h, P, p, 0);
-    const int hy = home_pixel(r.y, a.fh) + slot_shift(a.center, h, P, p, 1);
-    // the record carries the slot's expected pixel (two int16) so that the owner tiles need neither
-    // the reference point nor the slot centre again, and both kernels test the SAME integers
-    const uint32_t exy = ((uint32_t)hx & 0xffffu) | ((uint32_t)hy << 16);
-    a.rec[(((long)b * a.H + h) * P + p) * a.Nq + q] =
-        make_float4(xp, yp, w[p] / cnt, __uint_as_float(exy));
+    const float wn = w[p] / cnt;
+    const float4 rec = make_float4(xp, yp, wn, __int_as_float(q));
+    int tk[4];
+    bool nz[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float c = w[p] * f.w[k];
-      if (c != 0.0f && (abs(f.xc[k & 1] - hx) > a.R || abs(f.yc[k >> 1] - hy) > a.R)) {
-        float* dst = gv + (long)f.idx[k] * row;
-#pragma unroll 1
-        for (int i = 0; i < DH; ++i) {
-          const float g = elem<T>::to_float(gout[i]);
-          atomic_add_f32(dst + i, c * (a.count != nullptr ? g / cnt : g));
-        }
-      }
+      nz[k] = valid && wn != 0.0f && f.w[k] != 0.0f;
+      tk[k] = (f.yc[k >> 1] >> 3) * tiles_x + (f.xc[k & 1] >> 3);
+    }
+    // a tile receives the record once: through its first corner with non-zero weight
+    const bool l0 = nz[0];
+    const bool l1 = nz[1] && !(nz[0] && tk[1] == tk[0]);
+    const bool l2 = nz[2] && !(nz[0] && tk[2] == tk[0]) && !(nz[1] && tk[2] == tk[1]);
+    const bool l3 = nz[3] && !(nz[0] && tk[3] == tk[0]) && !(nz[1] && tk[3] == tk[1]) &&
+                    !(nz[2] && tk[3] == tk[2]);
+    append(l0, tk[0], rec);
+    append(l1, tk[1], rec);
+    append(l2, tk[2], rec);
+    append(l3, tk[3], rec);
+  }
+}
+
+// Overflow handling (rare: a tile received more than `cap` points).  Step A zeroes the f32 map of
+// the overflowed tiles, step B scatters the overflow list atomically into it; the owner kernel adds
+// its bucket sums on top for exactly those tiles.  Both exit at once when nothing overflowed.
+__global__ __launch_bounds__(256) void lift_ovf_zero_kernel(const LiftArgs a, int tiles_x, int tiles,
+                                                            int Dh) {
+  if (*a.ovf_n == 0) return;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= (long)a.B * a.H * tiles) return;
+  if (a.bin_cnt[wave] <= a.cap) return;
+  const int lane = threadIdx.x & 63;
+  const int tl = (int)(wave % tiles), bh = (int)(wave / tiles);
+  const int h = bh % a.H, b = bh / a.H;
+  const int x0 = (tl % tiles_x) * 8, y0 = (tl / tiles_x) * 8;
+  const long row = (long)a.H * Dh;
+  float* gv = a.gvalue + (long)b * a.fh * a.fw * row + h * Dh;
+  const int py = lane >> 3, px = lane & 7;
+  if (y0 + py < a.fh && x0 + px < a.fw)
+    for (int c = 0; c < Dh; ++c) gv[((long)(y0 + py) * a.fw + (x0 + px)) * row + c] = 0.0f;
+}
+
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void lift_ovf_scatter_kernel(const LiftArgs a, int tiles_x, int tiles) {
+  const int n = min(*a.ovf_n, a.ovf_cap);
+  if (n == 0) return;
+  const long row = (long)a.H * DH;
+  const int c = threadIdx.x & 31;                      // channel; 32 threads per overflow entry
+  const long stride = (long)gridDim.x * 8;
+  for (long e = (long)blockIdx.x * 8 + (threadIdx.x >> 5); e < n; e += stride) {
+    const float4 rec = a.ovf_rec[e];
+    const int t = a.ovf_tile[e];
+    const int tl = t % tiles, bh = t / tiles;
+    const int h = bh % a.H, b = bh / a.H;
+    const int tx = tl % tiles_x, ty = tl / tiles_x;
+    const int q = __float_as_int(rec.w);
+    const Footprint f = footprint_px(rec.x, rec.y, a.fh, a.fw);
+    if (c >= DH) continue;
+    const float go = elem<T>::to_float(((const T*)a.gout)[((long)b * a.Nq + q) * row + h * DH + c]);
+    float* gv = a.gvalue + (long)b * a.fh * a.fw * row + h * DH + c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float cw = rec.z * f.w[k];
+      if (cw != 0.0f && (f.xc[k & 1] >> 3) == tx && (f.yc[k >> 1] >> 3) == ty)
+        atomic_add_f32(gv + (long)f.idx[k] * row, cw * go);
     }
   }
 }
@@ -451,6 +518,7 @@ struct TileArgs {
   int chunks, chunk_q; // CAMERA: query chunks per tile
   int total, chunk;    // tiles, blocks per XCD
   int waves;           // waves (= tiles) per block
+  int cap;             // GRID: bucket capacity (records per tile)
 };
 
 // Ordered compaction of each camera's visible queries (vis0[cam, q] != 0): list[cam, 0..n) holds the
@@ -681,8 +749,12 @@ struct TileAcc {
   }
 };
 
-// GRID owner tiles.  One wave per tile, blockDim.x / 64 independent waves per block; registers
-// capped for 3 waves per SIMD (the kernel is bound by its dependent loads: 470 -> 345 us).
+// GRID owner tiles.  One wave per (sample, head, 8x8-pixel tile), blockDim.x / 64 independent waves
+// per block; registers capped for 3 waves per SIMD.  The wave walks its bucket (lift_bin_kernel) 64
+// records at a time — record loads one batch ahead, contiguous — takes the corners that lie inside
+// its tile and accumulates them with TileAcc.  It is the single writer of its pixels: a plain store
+// of the finished tile (rounded once for 16-bit outputs), so grad_value needs no zeroing; only a
+// tile whose bucket overflowed adds its sums to what lift_ovf_* scattered there.
 template <typename T, int DH, int P, int RB>
 __global__ __launch_bounds__(256, 3) void lift_bwd_value_kernel(const LiftArgs a, const TileArgs t) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds_all[];
@@ -696,53 +768,30 @@ __global__ __launch_bounds__(256, 3) void lift_bwd_value_kernel(const LiftArgs a
   const long row = (long)a.H * DH;
   const T* __restrict__ gout = (const T*)a.gout;
 
-  auto rounds = [&](const int (&lp)[4], const float (&cwt)[4], bool any, int q) {
+  const int tiles = t.tiles_x * t.tiles_y;
+  const long bucket = ((long)g.b * a.H + g.h) * tiles + (g.y0 >> 3) * t.tiles_x + (g.x0 >> 3);
+  const int cnt_raw = a.bin_cnt[bucket];
+  const int n = min(cnt_raw, a.cap);
+  const float4* __restrict__ bp = a.bins + bucket * a.cap;
+  const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  float4 nrec = (lane < n) ? bp[lane] : zero4;
+  for (int e0 = 0; e0 < n; e0 += 64) {
+    const float4 rec = nrec;
+    const bool valid = e0 + lane < n;
+    if (e0 + 64 < n) nrec = (e0 + 64 + lane < n) ? bp[e0 + 64 + lane] : zero4;
+    const int q = valid ? __float_as_int(rec.w) : 0;
+    int lp[4];
+    float cwt[4];
+    const Footprint f = footprint_px(rec.x, rec.y, a.fh, a.fw);
+    const bool any = tile_own<false>(f, rec.z, valid, g, t.tile_w, 0, 0, 0, lp, cwt);
     ta.add(lp, cwt, any, gout + ((long)g.b * a.Nq + q) * row + g.h * DH, lane);
-  };
-
-  {
-    // ---- per sampling slot p, lane = candidate query, records from lift_record_kernel
-    const float sx = (float)a.qw / (float)a.fw, sy = (float)a.qh / (float)a.fh;
-    for (int p = 0; p < P; ++p) {
-      const int dx = slot_shift(a.center, g.h, P, p, 0), dy = slot_shift(a.center, g.h, P, p, 1);
-      // queries whose expected pixel can be within R of the tile (conservative superset)
-      const int qx_lo = max(0, (int)floorf((float)(g.x0 - a.R - dx) * sx) - 1);
-      const int qy_lo = max(0, (int)floorf((float)(g.y0 - a.R - dy) * sy) - 1);
-      const int qx_hi = min(a.qw - 1, (int)ceilf((float)(g.x0 + g.tw + a.R - dx) * sx) + 1);
-      const int qy_hi = min(a.qh - 1, (int)ceilf((float)(g.y0 + g.th + a.R - dy) * sy) + 1);
-      const int cw = qx_hi - qx_lo + 1;
-      const int ncand = cw * (qy_hi - qy_lo + 1);
-      if (cw <= 0 || ncand <= 0) continue;
-      const float inv_cw = 1.0f / (float)cw;
-      auto fetch = [&](int c0, float4& rec, int& q) -> bool {
-        const int c = c0 + lane;
-        const bool valid = c < ncand;
-        const int cc = valid ? c : 0;
-        int cy = (int)(((float)cc + 0.5f) * inv_cw);          // cc / cw for cc < 2^22
-        cy -= (cy * cw > cc) ? 1 : 0;
-        cy += ((cy + 1) * cw <= cc) ? 1 : 0;
-        q = (qy_lo + cy) * a.qw + qx_lo + (cc - cy * cw);
-        rec = a.rec[(((long)g.b * a.H + g.h) * P + p) * a.Nq + q];
-        return valid;
-      };
-      float4 nrec; int nq;
-      bool nvalid = fetch(0, nrec, nq);
-      for (int c0 = 0; c0 < ncand; c0 += 64) {
-        const float4 rec = nrec; const int q = nq; const bool valid = nvalid;
-        if (c0 + 64 < ncand) nvalid = fetch(c0 + 64, nrec, nq);
-        int lp[4];
-        float cwt[4];
-        const Footprint f = footprint_px(rec.x, rec.y, a.fh, a.fw);
-        const int exy = (int)__float_as_uint(rec.w);            // expected pixel, two int16
-        const bool any = tile_own<true>(f, rec.z, valid, g, t.tile_w, (exy << 16) >> 16, exy >> 16,
-                                        a.R, lp, cwt);
-        rounds(lp, cwt, any, q);
-      }
-    }
   }
   if (ta.fill > 0) ta.flush(lane);
-  // ---- flush the accumulators: D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-  float* __restrict__ gv = a.gvalue + ((long)g.b * a.Nc + g.cam) * a.fh * a.fw * row + g.h * DH;
+  // ---- store the tile: D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5);
+  // tiles are 8 pixels wide, so the tile-local pixel index splits with a shift
+  const bool rmw = cnt_raw > a.cap;                    // lift_ovf_* scattered part of this tile
+  const long mbase = (long)g.b * a.fh * a.fw * row + g.h * DH;
+  float* __restrict__ gv = a.gvalue + mbase;
   const int col = lane & 31;
   if (col < DH) {
 #pragma unroll
@@ -750,17 +799,13 @@ __global__ __launch_bounds__(256, 3) void lift_bwd_value_kernel(const LiftArgs a
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int px = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int lx = px % t.tile_w, ly = px / t.tile_w;
-        if (px < g.npx && lx < g.tw && ly < g.th) {
+        const int lx = px & 7, ly = px >> 3;
+        if (lx < g.tw && ly < g.th) {
           const long o = ((long)(g.y0 + ly) * a.fw + (g.x0 + lx)) * row + col;
-          const float v = ta.acc[rb][r];
-          // single owner; on top of the record kernel's far corners
-          const float s = gv[o] + v;
-          if (sizeof(T) == 2 && a.gvalue_lp != nullptr)
-            ((T*)a.gvalue_lp)[(((long)g.b * a.Nc + g.cam) * a.fh * a.fw * row + g.h * DH) + o] =
-                elem<T>::from_float(s);
-          else
-            gv[o] = s;
+          float v = ta.acc[rb][r];
+          if (rmw) v += gv[o];
+          if (sizeof(T) == 2 && a.gvalue_lp != nullptr) ((T*)a.gvalue_lp)[mbase + o] = elem<T>::from_float(v);
+          else gv[o] = v;
         }
       }
     }
@@ -1030,15 +1075,22 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, hipS
                          a.gvalue, (T*)a.gvalue_lp, n);
     }
   } else if (bwd_mode == kAtomFar) {
-    // the query kernel leaves one record per sampling point for the owner tiles and scatters the
-    // (rare) far corners atomically into the zeroed grad_value; the owner tiles then add their
-    // exclusive pixels on top with a plain read-add-store.
+    // bin the sampling points by owner tile (counters zeroed by the caller), scatter whatever
+    // overflowed a bucket (normally nothing: both kernels exit at once), then the query gradients
+    // and the owner tiles, each of which stores its finished pixels exactly once
+    const int tiles = t.tiles_x * t.tiles_y;
     {
-      const int qpw = kWave / a.H;
-      const long waves = (long)a.B * ((a.Nq + qpw - 1) / qpw);
-      ProfScope ps(name("bev_lift_bwd_records"), st, nb.offlog + nb.ref + nb.rec);
-      hipLaunchKernelGGL((lift_record_kernel<T, DH, P>), dim3((unsigned)((waves + 3) / 4)), dim3(256),
-                         0, st, a);
+      const long waves = (long)a.total_tiles * a.H;
+      ProfScope ps(name("bev_lift_bwd_bins"), st, nb.offlog + nb.ref + nb.rec);
+      hipLaunchKernelGGL((lift_bin_kernel<T, DH, P>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+                         st, a, t.tiles_x, tiles);
+    }
+    {
+      const long tw = (long)a.B * a.H * tiles;
+      hipLaunchKernelGGL(lift_ovf_zero_kernel, dim3((unsigned)((tw + 3) / 4)), dim3(256), 0, st, a,
+                         t.tiles_x, tiles, DH);
+      hipLaunchKernelGGL((lift_ovf_scatter_kernel<T, DH>), dim3(1024), dim3(256), 0, st, a, t.tiles_x,
+                         tiles);
     }
     {
       ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes);
@@ -1049,7 +1101,8 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, hipS
     }
     constexpr int RB = 2;
     const size_t lds = (size_t)t.waves * TileLds<T, DH, RB>::kWords * sizeof(uint16_t);
-    ProfScope ps(name("bev_lift_bwd_value_grid"), st, nb.rec + nb.ref + nb.out + nb.value_f32);
+    ProfScope ps(name("bev_lift_bwd_value_grid"), st,
+                 nb.rec + nb.out + (a.gvalue_lp != nullptr ? nb.value : nb.value_f32));
     hipLaunchKernelGGL((lift_bwd_value_kernel<T, DH, P, RB>), dim3(8 * t.chunk), dim3(64 * t.waves),
                        lds, st, a, t);
   } else {
@@ -1106,6 +1159,10 @@ static int plan_backward(const LiftArgs& a, int Dh, int P, int dtype, int ref_is
     t.chunks = 1;
     t.chunk_q = 0;
     t.waves = 4;
+    // bucket capacity: twice the expected records per tile (P points per query-head, Nq/S queries
+    // per pixel, 1.3 tiles per point); the overflow list takes whatever concentrates beyond that
+    const double expect = 1.3 * P * 64.0 * (double)a.Nq / ((double)a.fh * a.fw);
+    t.cap = (((int)(2.0 * expect) + 63) / 64) * 64 + 64;
   } else {
     // CAMERA: bands of full rows, at most 6 MFMA row blocks (192 pixels) per band, and few enough
     // bands that re-walking the visible queries once per band stays cheap
@@ -1140,8 +1197,22 @@ static int plan_backward(const LiftArgs& a, int Dh, int P, int dtype, int ref_is
 static size_t lift_list_bytes(const LiftArgs& a) {
   return (((size_t)a.Nc * a.Nq + a.Nc + 4) * sizeof(int) + 255) & ~(size_t)255;
 }
+// GRID workspace: [tile counters + overflow counter][buckets][overflow records][overflow tiles];
+// the overflow list is sized for the worst case (every point overflowing in all of its <= 4 tiles).
+struct GridWs { size_t cnt_bytes, bins_off, ovf_rec_off, ovf_tile_off, total; long ovf_cap; };
+static GridWs grid_ws(const LiftArgs& a, const TileArgs& t, int P) {
+  GridWs w;
+  const size_t tiles = (size_t)a.B * a.H * t.tiles_x * t.tiles_y;
+  w.cnt_bytes = ((tiles + 1) * sizeof(int) + 255) & ~(size_t)255;
+  w.bins_off = w.cnt_bytes;
+  w.ovf_cap = 4L * a.B * a.Nq * a.H * P;
+  w.ovf_rec_off = w.bins_off + tiles * t.cap * sizeof(float4);
+  w.ovf_tile_off = w.ovf_rec_off + (size_t)w.ovf_cap * sizeof(float4);
+  w.total = w.ovf_tile_off + (((size_t)w.ovf_cap * sizeof(int) + 255) & ~(size_t)255);
+  return w;
+}
 static size_t lift_ws_bytes(int mode, const LiftArgs& a, const TileArgs& t, int Dh, int P) {
-  if (mode == kAtomFar) return (size_t)a.B * a.Nq * a.H * P * sizeof(float4);
+  if (mode == kAtomFar) return grid_ws(a, t, P).total;
   if (mode == kAtomNone)     // visible-query lists + one partial map per (b, cam, head, chunk)
     return lift_list_bytes(a) +
            (size_t)a.B * a.Nc * a.H * t.chunks * a.fh * a.fw * Dh * sizeof(float);
@@ -1181,10 +1252,6 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_g
   }
   a.total_tiles = a.B * a.tiles_per_sample;
   a.chunk = (a.total_tiles + 7) / 8;
-  // near radius: around the slot centre when given (offset ~ bias), else around the home pixel
-  // (learned offsets start at <= P pixels, init_weights); anything farther is still exact
-  static const int r_env = getenv("UBV_NEAR_R") ? atoi(getenv("UBV_NEAR_R")) : -1;
-  a.R = r_env >= 0 ? r_env : (a.center ? 3 : P + 2);
   hipStream_t st = as_stream(stream);
   TileArgs t{};
   int mode = -1;
@@ -1194,13 +1261,26 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_g
     UBV_CHECK_ARG(need == 0 || (ws != nullptr && ws_bytes >= (int64_t)need),
                   "bev_lift_backward: workspace of %lld bytes needed, got %lld", (long long)need,
                   (long long)ws_bytes);
-    if (mode == kAtomFar) a.rec = (float4*)ws;
+    if (mode == kAtomFar) {
+      const GridWs w = grid_ws(a, t, P);
+      a.bin_cnt = (int*)ws;
+      a.ovf_n = a.bin_cnt + (size_t)a.B * a.H * t.tiles_x * t.tiles_y;
+      a.bins = (float4*)((char*)ws + w.bins_off);
+      a.ovf_rec = (float4*)((char*)ws + w.ovf_rec_off);
+      a.ovf_tile = (int*)((char*)ws + w.ovf_tile_off);
+      a.cap = t.cap;
+      a.ovf_cap = (int)min(w.ovf_cap, (long)INT_MAX);
+      if (hipMemsetAsync(ws, 0, w.cnt_bytes, st) != hipSuccess) {
+        set_error("bev_lift_backward: memset failed");
+        return UBV_ERR_LAUNCH;
+      }
+    }
     if (mode == kAtomNone) {
       a.cam_list = (int*)ws;
       a.cam_n = (int*)ws + (size_t)a.Nc * a.Nq;
       a.slab = (float*)((char*)ws + lift_list_bytes(a));
     }
-    if (mode != kAtomNone) {   // CAMERA mode writes every element of grad_value exactly once
+    if (mode == kAtomAll) {    // the owner-tile plans write every element of grad_value exactly once
       const size_t bytes = (size_t)a.B * a.Nc * a.fh * a.fw * a.H * Dh * sizeof(float);
       if (hipMemsetAsync(a.gvalue, 0, bytes, st) != hipSuccess) {
         set_error("bev_lift_backward: memset failed");
@@ -1273,7 +1353,7 @@ extern "C" int ubv_bev_lift_backward(const void* value, const void* offsets, int
   a.ol16 = (offlog_dtype != UBV_F32) ? 1 : 0;
   a.value = value; a.offsets = offsets; a.off_stride = off_stride; a.logits = logits;
   a.log_stride = log_stride; a.ref = ref; a.vis0 = vis0; a.count = count; a.gout = grad_out;
-  a.center = slot_center;
+  (void)slot_center;          // accepted for ABI stability; the bins plan does not need the hint
   a.gvalue = grad_value; a.gvalue_lp = grad_value_lowp; a.goff = grad_offsets; a.goff_stride = goff_stride; a.glog = grad_logits;
   a.glog_stride = glog_stride;
   a.B = B; a.Nc = Nc; a.fh = fh; a.fw = fw; a.H = H; a.Nq = Nq; a.Z = Z; a.qw = qgrid_w;
