@@ -350,17 +350,22 @@ __global__ __launch_bounds__(256, ((ATOMICS == kAtomNone && P == 4) ? 3 : 1)) vo
 // non-zero weight (1.3 buckets per point on average), so the owner-tile kernel below reads exactly
 // the points it owns — the previous plan searched a 14x14 query window per slot and discarded 2/3
 // of what it evaluated.  A wave is one (8x8 query tile, head): its points fall into <= ~4 tiles, so
-// the appends are wave-aggregated — one atomic per distinct tile per corner slot, ranks by ballot /
-// popcount.  Buckets have a fixed capacity (2x the expected load); what does not fit goes to an
+// the appends are wave-aggregated: ranks come from LDS counters on an 8x8 torus of tile slots and
+// each occupied slot costs ONE global atomic per sampling slot p, all of them in flight together
+// (a leader loop with one returning atomic per distinct tile ran at 93 us, bound by the round trips).  Buckets have a fixed capacity (2x the expected load); what does not fit goes to an
 // overflow list that lift_ovf_* scatter atomically, so the result is exact for ANY offsets.
 struct TileArgs;
 
 template <typename T, int DH, int P>
 __global__ __launch_bounds__(256) void lift_bin_kernel(const LiftArgs a, int tiles_x, int tiles) {
-  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // per wave: an 8x8 torus of tile slots — occupant tile, local count, global base
+  __shared__ int slot_tile[4][64], slot_cnt[4][64], slot_base[4][64];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  slot_tile[wv][lane] = -1;
+  slot_cnt[wv][lane] = 0;
+  const long wave = (long)blockIdx.x * 4 + wv;
   if (wave >= (long)a.total_tiles * a.H) return;
   const int item = (int)(wave / a.H), h = (int)(wave - (long)item * a.H);   // head fastest
-  const int lane = threadIdx.x & 63;
   int b, q;
   const bool valid = lift_query(a, item, lane, b, q);
   if (!valid) q = 0;                                   // b is wave-uniform either way
@@ -375,28 +380,13 @@ __global__ __launch_bounds__(256) void lift_bin_kernel(const LiftArgs a, int til
   int* __restrict__ cntp = a.bin_cnt + ((long)b * a.H + h) * tiles;
   float4* __restrict__ binp = a.bins + ((long)b * a.H + h) * tiles * a.cap;
   const int tile_base = (b * a.H + h) * tiles;
-  const unsigned long long lt = (1ull << lane) - 1ull;
 
-  auto append = [&](bool lead, int tile, const float4& rec) {
-    unsigned long long m = __ballot(lead);
-    while (m != 0ull) {
-      const int leader = __ffsll((long long)m) - 1;
-      const int tl = __shfl(tile, leader, 64);
-      const bool mine = lead && tile == tl;
-      const unsigned long long same = __ballot(mine);
-      int base = 0;
-      if (lane == leader) base = atomicAdd(cntp + tl, __popcll(same));
-      base = __shfl(base, leader, 64);
-      if (mine) {
-        const int idx = base + __popcll(same & lt);
-        if (idx < a.cap) {
-          binp[(long)tl * a.cap + idx] = rec;
-        } else {
-          const int o = atomicAdd(a.ovf_n, 1);
-          if (o < a.ovf_cap) { a.ovf_rec[o] = rec; a.ovf_tile[o] = tile_base + tl; }
-        }
-      }
-      m &= ~same;
+  auto put = [&](int tile, int idx, const float4& rec) {
+    if (idx < a.cap) {
+      binp[(long)tile * a.cap + idx] = rec;
+    } else {
+      const int o = atomicAdd(a.ovf_n, 1);
+      if (o < a.ovf_cap) { a.ovf_rec[o] = rec; a.ovf_tile[o] = tile_base + tile; }
     }
   };
 
@@ -411,23 +401,45 @@ __global__ __launch_bounds__(256) void lift_bin_kernel(const LiftArgs a, int til
     const Footprint f = footprint_px(xp, yp, a.fh, a.fw);
     const float wn = w[p] / cnt;
     const float4 rec = make_float4(xp, yp, wn, __int_as_float(q));
-    int tk[4];
-    bool nz[4];
+    int tk[4], hs[4], rank[4];
+    bool nz[4], lead[4], local[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       nz[k] = valid && wn != 0.0f && f.w[k] != 0.0f;
-      tk[k] = (f.yc[k >> 1] >> 3) * tiles_x + (f.xc[k & 1] >> 3);
+      const int tx = f.xc[k & 1] >> 3, ty = f.yc[k >> 1] >> 3;
+      tk[k] = ty * tiles_x + tx;
+      hs[k] = ((ty & 7) << 3) | (tx & 7);
     }
     // a tile receives the record once: through its first corner with non-zero weight
-    const bool l0 = nz[0];
-    const bool l1 = nz[1] && !(nz[0] && tk[1] == tk[0]);
-    const bool l2 = nz[2] && !(nz[0] && tk[2] == tk[0]) && !(nz[1] && tk[2] == tk[1]);
-    const bool l3 = nz[3] && !(nz[0] && tk[3] == tk[0]) && !(nz[1] && tk[3] == tk[1]) &&
-                    !(nz[2] && tk[3] == tk[2]);
-    append(l0, tk[0], rec);
-    append(l1, tk[1], rec);
-    append(l2, tk[2], rec);
-    append(l3, tk[3], rec);
+    lead[0] = nz[0];
+    lead[1] = nz[1] && !(nz[0] && tk[1] == tk[0]);
+    lead[2] = nz[2] && !(nz[0] && tk[2] == tk[0]) && !(nz[1] && tk[2] == tk[1]);
+    lead[3] = nz[3] && !(nz[0] && tk[3] == tk[0]) && !(nz[1] && tk[3] == tk[1]) &&
+              !(nz[2] && tk[3] == tk[2]);
+    // 1. rank within the wave through LDS counters (a wave's points span a few tiles; two tiles
+    //    that collide on the torus — never for coherent offsets — take the direct global path)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      local[k] = false;
+      rank[k] = 0;
+      if (lead[k]) {
+        const int prev = atomicCAS(&slot_tile[wv][hs[k]], -1, tk[k]);
+        local[k] = (prev == -1) || (prev == tk[k]);
+        if (local[k]) rank[k] = atomicAdd(&slot_cnt[wv][hs[k]], 1);
+        else put(tk[k], atomicAdd(cntp + tk[k], 1), rec);
+      }
+    }
+    // 2. ONE global atomic per occupied slot, all slots in parallel (lane = slot)
+    {
+      const int c = slot_cnt[wv][lane];
+      if (c > 0) slot_base[wv][lane] = atomicAdd(cntp + slot_tile[wv][lane], c);
+    }
+    // 3. write the records
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (lead[k] && local[k]) put(tk[k], slot_base[wv][hs[k]] + rank[k], rec);
+    slot_tile[wv][lane] = -1;
+    slot_cnt[wv][lane] = 0;
   }
 }
 
