@@ -122,16 +122,15 @@ int ubv_bev_lift_forward(const void* value, const void* offsets, int64_t off_str
  *                grad_value is only the f32 accumulation scratch (content unspecified on return).
  *   grad_offsets row (b,q) at element (b*Nq+q)*goff_stride : [H, P, 2] offlog_dtype, written
  *   grad_logits  row (b,q) at element (b*Nq+q)*glog_stride : [H, P]    offlog_dtype, written
- *   ref_is_grid  1 iff Nc == 1 and ref[0,b,q,z] == ((qx+.5)/qgrid_w, (qy+.5)/qgrid_h) for every z
- *                (BEV self-attention and SCA-pts: the references are the BEV grid itself).  Selects
- *                the owner-tile grad_value kernel (LDS accumulation, no global atomics except for
- *                sampling points farther than P+2 pixels from their reference).  0 is always safe.
- *   slot_center  [H, P, 2] f32 or NULL: where each sampling slot (h, p) lands relative to its
- *                reference when the learned offset equals the sampling_offsets bias, in pixels.
- *                A speed hint for the owner tiles (they search a 3-pixel window around it instead
- *                of P+2 around the reference); results do not depend on it.
+ *   ref_is_grid  1 iff Nc == 1 and the Nq queries form the qgrid_w x qgrid_h BEV grid with
+ *                reference points near their cell centres (BEV self-attention and SCA-pts).  Selects
+ *                the GRID plan: sampling points binned by 8x8-pixel owner tile, every tile summed
+ *                by one wave (MFMA) and stored once — no global atomics, no zeroing; exact for any
+ *                offsets (bucket overflow goes through an atomic side path).  0 is always safe.
+ *   slot_center  accepted for ABI stability, ignored (an earlier plan used it as a search hint).
  *   workspace    scratch of at least ubv_bev_lift_backward_workspace(...) bytes (may be NULL when
- *                that is 0): per-point records for the owner tiles / per-camera visible-query lists.
+ *                that is 0): per-tile buckets of point records / per-camera visible-query lists
+ *                and partial maps.
  */
 int64_t ubv_bev_lift_backward_workspace(int B, int Nc, int fh, int fw, int H, int Dh, int Nq, int P,
                                         int qgrid_w, int qgrid_h, int ref_is_grid);
