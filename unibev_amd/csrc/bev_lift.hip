@@ -236,6 +236,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (P == 8 
 enum { kAtomAll = 0, kAtomFar = 1, kAtomNone = 2 };
 
 
+// v + (v of the lane whose index differs in bit log2(M)): DPP quad permutes inside a quad (the
+// compiler folds them into the add), a wave shuffle beyond.
+template <int M>
+__device__ __forceinline__ float add_xor(float v) {
+  if constexpr (M == 1)
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+  else if constexpr (M == 2)
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+  else
+    return v + __shfl_xor(v, M, 64);
+}
+
 template <typename T, int DH, int VEC, int P, int ATOMICS, bool OL16>
 // P = 4 runs best at 3 waves per SIMD (127 -> 96 us); P = 8 loses to its own cache footprint there.
 __global__ __launch_bounds__(256, ((ATOMICS == kAtomNone && P == 4) ? 3 : 1)) void lift_bwd_query_kernel(const LiftArgs a) {
@@ -316,13 +328,10 @@ __global__ __launch_bounds__(256, ((ATOMICS == kAtomNone && P == 4) ? 3 : 1)) vo
     }
     // reduce the Dh partial dot products over the LP lanes of this (query, head)
 #pragma unroll
-    for (int m = 1; m < LP; m <<= 1) {
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        gw[p] += __shfl_xor(gw[p], m, 64);
-        gx[p] += __shfl_xor(gx[p], m, 64);
-        gy[p] += __shfl_xor(gy[p], m, 64);
-      }
+    for (int p = 0; p < P; ++p) {
+      if (LP > 1) { gw[p] = add_xor<1>(gw[p]); gx[p] = add_xor<1>(gx[p]); gy[p] = add_xor<1>(gy[p]); }
+      if (LP > 2) { gw[p] = add_xor<2>(gw[p]); gx[p] = add_xor<2>(gx[p]); gy[p] = add_xor<2>(gy[p]); }
+      if (LP > 4) { gw[p] = add_xor<4>(gw[p]); gx[p] = add_xor<4>(gx[p]); gy[p] = add_xor<4>(gy[p]); }
     }
     if (valid && cg == 0) {
       // softmax backward: dlogit_p = w_p * (gw_p - sum_k w_k gw_k)

@@ -230,7 +230,7 @@ def bev_lift(value, offlog, ref, num_cams, feat_hw, num_heads, num_points, vis0=
     count  (B, Nq) float32         camera count divisor, or None
     query_grid (qh, qw)            BEV grid the Nq queries form (tiling / owner-tile backward)
     ref_is_grid                    ref is exactly that grid's cell centres (and num_cams == 1)
-    slot_center (H*P*2,)           the sampling_offsets bias (pixels): speed hint for backward
+    slot_center (H*P*2,)           accepted for API stability; the bins plan ignores it
     """
     fh, fw = feat_hw
     BNc, S, C = value.shape[0], value.shape[1], value.shape[-1] if value.dim() == 3 else None
