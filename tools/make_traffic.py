@@ -16,7 +16,7 @@ import sys
 
 NAMES = [   # (kernel symbol regex, profile-name key with {P})
     (r'lift_fwd_kernel<[^,]+, \d+, \d+, (\d+)', 'bev_lift_fwd<P={P}'),
-    (r'lift_record_kernel<[^,]+, \d+, (\d+)', 'bev_lift_bwd_records<P={P}'),
+    (r'lift_bin_kernel<[^,]+, \d+, (\d+)', 'bev_lift_bwd_bins<P={P}'),
     (r'lift_bwd_query_kernel<[^,]+, \d+, \d+, (\d+)', 'bev_lift_bwd_query<P={P}'),
     (r'lift_bwd_value_kernel<[^,]+, \d+, (\d+)', 'bev_lift_bwd_value_grid<P={P}'),
     (r'lift_bwd_value_camera_kernel<[^,]+, \d+, (\d+)', 'bev_lift_bwd_value_camera<P={P}'),
