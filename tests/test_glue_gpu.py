@@ -214,3 +214,30 @@ def test_zero_arena_hands_out_disjoint_zeroed_slices():
     assert float(c.abs().sum()) == 0 and float(a.sum()) == 256     # the old step's slices survive
     big = UF.zeros_f32(1 << 20, torch.device(DEV, 0))                # larger than the arena: regrows
     assert float(big.abs().sum()) == 0
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_linear_pass_through_alias_gradients(dtype):
+    """linear_pass(x) returns (y, x'): using x' for the residual must give the same values and the
+    same gradients as using x itself (the two input gradients meet inside the input-gradient GEMM
+    instead of a separate add)."""
+    from unibev_amd.linear import linear, linear_pass
+    torch.manual_seed(5)
+    x = torch.randn(2, 4096, 256, device=DEV).to(dtype)
+    lin = torch.nn.Linear(256, 256).to(DEV)
+    c1, c2 = torch.randn_like(x), torch.randn_like(x)
+    res = []
+    for use_pass in (True, False):
+        xa = x.clone().requires_grad_()
+        lin.weight.grad = lin.bias.grad = None
+        with torch.autocast('cuda', dtype=dtype, enabled=dtype != torch.float32):
+            if use_pass:
+                y, xr = linear_pass(xa, lin.weight, lin.bias)
+            else:
+                y, xr = linear(xa, lin.weight, lin.bias), xa
+        assert torch.equal(xr.detach(), x)
+        ((y.to(dtype) * c1).sum() + (xr * c2).sum()).backward()
+        res.append((y.detach(), xa.grad, lin.weight.grad.clone(), lin.bias.grad.clone()))
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for a, b in zip(*res):
+        torch.testing.assert_close(a.float(), b.float(), rtol=tol, atol=tol * float(b.float().abs().max()))

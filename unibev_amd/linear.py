@@ -84,31 +84,42 @@ def _cached_lowp(params, dtype):
 
 
 class _Linear(Function):
-    """y = x @ cat(weights)^T + cat(biases).  ``n`` weights followed by ``n`` biases (or none)."""
+    """y = x @ cat(weights)^T + cat(biases).  ``n`` weights followed by ``n`` biases (or none).
+
+    ``passthru``: also return an alias of ``x`` for the caller's residual branch.  The two
+    gradients that autograd would otherwise add with a separate elementwise kernel then arrive
+    together, and the input-gradient GEMM takes the alias' gradient as its accumulator input
+    (``addmm``: D = grad_alias + grad_out @ W in the GEMM epilogue)."""
 
     @staticmethod
-    def forward(ctx, x, dtype, n, has_bias, *params):
+    def forward(ctx, x, dtype, n, has_bias, passthru, *params):
         weights, biases = params[:n], params[n:]
         w = _cached_lowp(weights, dtype)
         b = _cached_lowp(biases, dtype) if has_bias else None
         xc = x.to(dtype)
         ctx.save_for_backward(xc, w)
         ctx.meta = (x.dtype, n, has_bias, [p.shape[0] for p in weights], [p.dtype for p in params])
-        return F.linear(xc, w, b)
+        y = F.linear(xc, w, b)
+        return (y, x.view_as(x)) if passthru else y
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, grad_alias=None):
         xc, w = ctx.saved_tensors
         x_dtype, n, has_bias, outs, pdt = ctx.meta
         go2 = grad_out.reshape(-1, grad_out.shape[-1])
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = (go2 @ w).view(xc.shape).to(x_dtype)
+            if grad_alias is not None and grad_alias.dtype == go2.dtype == x_dtype:
+                gx = torch.addmm(grad_alias.reshape(-1, xc.shape[-1]), go2, w).view(xc.shape)
+            else:
+                gx = (go2 @ w).view(xc.shape).to(x_dtype)
+                if grad_alias is not None:
+                    gx = gx + grad_alias.to(x_dtype)
         x2 = xc.reshape(-1, xc.shape[-1])
         rows = x2.shape[0]
         gw = gb = None
-        need_w = any(ctx.needs_input_grad[4:4 + n])
-        need_b = has_bias and any(ctx.needs_input_grad[4 + n:])
+        need_w = any(ctx.needs_input_grad[5:5 + n])
+        need_b = has_bias and any(ctx.needs_input_grad[5 + n:])
         part = None
         if need_w:
             s = _splits(rows)
@@ -138,18 +149,18 @@ class _Linear(Function):
         for i in range(n if has_bias else 0):
             grads.append(None if gb is None else gb[off:off + outs[i]].to(pdt[n + i]))
             off += outs[i]
-        return (gx, None, None, None, *grads)
+        return (gx, None, None, None, None, *grads)
 
 
-def _run(x, weights, biases):
+def _run(x, weights, biases, passthru=False):
     has_bias = biases[0] is not None
     params = list(weights) + (list(biases) if has_bias else [])
     if x.is_cuda and torch.is_autocast_enabled('cuda'):
         dt = torch.get_autocast_dtype('cuda')
         with torch.autocast('cuda', enabled=False):
-            return _Linear.apply(x, dt, len(weights), has_bias, *params)
+            return _Linear.apply(x, dt, len(weights), has_bias, passthru, *params)
     return _Linear.apply(x, x.dtype if x.dtype == weights[0].dtype else weights[0].dtype,
-                         len(weights), has_bias, *params)
+                         len(weights), has_bias, passthru, *params)
 
 
 def linear(x, weight, bias=None):
@@ -160,3 +171,14 @@ def linear(x, weight, bias=None):
 def linear_cat(x, weights, biases):
     """``F.linear(x, cat(weights), cat(biases))`` — several Linear layers on one input as one GEMM."""
     return _run(x, list(weights), list(biases))
+
+
+def linear_pass(x, weight, bias=None):
+    """``(F.linear(x, weight, bias), x')`` with ``x'`` an alias of ``x`` for the residual branch
+    (see ``_Linear``): use ``x'`` wherever ``x`` would be used again."""
+    return _run(x, [weight], [bias], passthru=True)
+
+
+def linear_cat_pass(x, weights, biases):
+    """``linear_cat`` with the pass-through alias of ``linear_pass``."""
+    return _run(x, list(weights), list(biases), passthru=True)

@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from .. import functional as UF
 from ..linear import linear as ubv_linear
+from ..linear import linear_pass
 from ..registry import (ATTENTION, FEEDFORWARD_NETWORK, POSITIONAL_ENCODING, TRANSFORMER_LAYER,
                         TRANSFORMER_LAYER_SEQUENCE, build_attention, build_feedforward_network,
                         build_transformer_layer)
@@ -88,7 +89,7 @@ class FFN(BaseModule):
             x = self._block(x, layer)
         return x
 
-    def _block(self, x, layer):
+    def _block(self, x, layer, start=0):
         """One entry of ``self.layers``: a Linear, the closing Dropout, or a
         Sequential(Linear, act, Dropout) whose ReLU + Dropout run as one kernel on the GPU."""
         if isinstance(layer, nn.Linear):
@@ -96,7 +97,7 @@ class FFN(BaseModule):
         if not isinstance(layer, nn.Sequential):
             return layer(x)
         subs = list(layer)
-        i = 0
+        i = start
         while i < len(subs):
             sub = subs[i]
             if isinstance(sub, nn.Linear):
@@ -121,7 +122,15 @@ class FFN(BaseModule):
                 isinstance(self.dropout_layer, nn.Identity)):
             return None
         h = x
-        for layer in list(self.layers)[:-1]:
+        blocks = list(self.layers)[:-1]
+        first = blocks[0] if blocks else None
+        if identity is None and x.is_cuda and isinstance(first, nn.Sequential) and \
+                isinstance(first[0], nn.Linear):
+            # x feeds the first Linear AND the residual: pass-through (linear.linear_pass)
+            h, identity = linear_pass(x, first[0].weight, first[0].bias)
+            h = self._block(h, first, start=1)
+            blocks = blocks[1:]
+        for layer in blocks:
             h = self._block(h, layer)
         return h, (x if identity is None else identity), last.p
 

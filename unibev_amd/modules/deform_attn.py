@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from .. import functional as UF
 from ..linear import linear as ubv_linear
-from ..linear import linear_cat
+from ..linear import linear_cat, linear_cat_pass, linear_pass
 from ..registry import ATTENTION
 from .bricks import BaseModule, constant_init, xavier_init
 
@@ -100,17 +100,23 @@ class _DeformAttnBase(BaseModule):
     init_weight = init_weights
 
     # -- pieces --------------------------------------------------------------------------------
-    def offsets_and_logits(self, query):
-        """One GEMM for both query Linears: rows [H*L*P*2 offsets | H*L*P logits]."""
-        return linear_cat(query, (self.sampling_offsets.weight, self.attention_weights.weight),
-                          (self.sampling_offsets.bias, self.attention_weights.bias))
+    def offsets_and_logits(self, query, passthru=False):
+        """One GEMM for both query Linears: rows [H*L*P*2 offsets | H*L*P logits].
+        ``passthru``: also return the alias of ``query`` for the caller's residual branch
+        (``linear.linear_pass``)."""
+        fn = linear_cat_pass if passthru else linear_cat
+        return fn(query, (self.sampling_offsets.weight, self.attention_weights.weight),
+                  (self.sampling_offsets.bias, self.attention_weights.bias))
 
     def can_lift(self, value):
         return (self.num_levels == 1 and
                 UF.bev_lift_supported(self.num_heads, self.embed_dims // self.num_heads,
                                       self.num_points, value.dtype))
 
-    def project_value(self, value, key_padding_mask=None):
+    def project_value(self, value, key_padding_mask=None, passthru=False):
+        if passthru:
+            assert key_padding_mask is None
+            return linear_pass(value, self.value_proj.weight, self.value_proj.bias)
         value = ubv_linear(value, self.value_proj.weight, self.value_proj.bias)
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
@@ -152,7 +158,13 @@ class MultiScaleDeformableAttention(_DeformAttnBase):
         bs, num_value, _ = value.shape
         hw = static_hw(spatial_shapes)
         assert sum(h * w for h, w in hw) == num_value
-        value = self.project_value(value, key_padding_mask)
+        if kwargs.get('return_parts') and self.batch_first and identity is value and \
+                key_padding_mask is None and value.is_cuda:
+            # the layer input feeds value_proj AND the residual: route the residual through the
+            # Linear's pass-through so that its gradient joins the input-gradient GEMM
+            value, identity = self.project_value(value, passthru=True)
+        else:
+            value = self.project_value(value, key_padding_mask)
         H, L, P = self.num_heads, self.num_levels, self.num_points
         if reference_points.shape[-1] == 2 and self.can_lift(value) and \
                 reference_points.shape[2] == 1:
@@ -224,8 +236,14 @@ class _MSDeformableAttention3D(_DeformAttnBase):
                              f'{reference_points.shape[-1]} instead.')
         num_Z_anchors = reference_points.shape[2]
         assert P % num_Z_anchors == 0
+        alias = None
+        want_alias = bool(kwargs.get('want_query_alias')) and query_pos is None and \
+            self.batch_first and query.is_cuda
         if self.can_lift(value):
-            output = UF.bev_lift(value, self.offsets_and_logits(query),
+            offlog = self.offsets_and_logits(query, passthru=want_alias)
+            if want_alias:
+                offlog, alias = offlog
+            output = UF.bev_lift(value, offlog,
                                  reference_points.reshape(1, bs, num_query, num_Z_anchors, 2), 1,
                                  hw[0], H, P, query_grid=kwargs.get('query_grid'),
                                  ref_is_grid=bool(kwargs.get('ref_is_grid')),
@@ -244,6 +262,8 @@ class _MSDeformableAttention3D(_DeformAttnBase):
                              attention_weights)
         if not self.batch_first:
             output = output.permute(1, 0, 2)
+        if kwargs.get('want_query_alias'):        # (output, alias of query or None)
+            return output, alias
         return output
 
 

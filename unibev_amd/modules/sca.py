@@ -71,7 +71,12 @@ class SpatialCrossAttentionImg(BaseModule):
                 seen = bev_mask.any(-1)                                  # (Nc, B, Nq)
                 vis0 = seen[:, 0].to(torch.uint8).contiguous()
                 count = seen.sum(0).clamp(min=1).to(torch.float32).contiguous()
-            slots = UF.bev_lift(da.project_value(value), da.offsets_and_logits(query),
+            if kwargs.get('return_parts') and residual is None and query_pos is None and query.is_cuda:
+                # residual through the Linear's pass-through (linear.linear_pass)
+                offlog, inp_residual = da.offsets_and_logits(query, passthru=True)
+            else:
+                offlog = da.offsets_and_logits(query)
+            slots = UF.bev_lift(da.project_value(value), offlog,
                                 reference_points_cam, num_cams, hw[0], da.num_heads, da.num_points,
                                 vis0=vis0, count=count, query_grid=kwargs.get('query_grid'))
         else:
@@ -140,10 +145,16 @@ class SpatialCrossAttentionPts(BaseModule):
         bs = query.size(0)
         value = value.permute(1, 0, 2)                               # (hw, bs, C) -> (bs, hw, C)
         reference_points_lidar = reference_points_lidar.permute(1, 2, 0, 3)   # (bs, Nq, Z, 2)
+        want_alias = bool(kwargs.get('return_parts')) and residual is None and query_pos is None
         queries = self.deformable_attention(
             query=query, key=value, value=value, reference_points=reference_points_lidar,
             spatial_shapes=spatial_shapes, level_start_index=level_start_index,
-            query_grid=kwargs.get('query_grid'), ref_is_grid=kwargs.get('ref_is_grid', False))
+            query_grid=kwargs.get('query_grid'), ref_is_grid=kwargs.get('ref_is_grid', False),
+            want_query_alias=want_alias)
+        if want_alias:
+            queries, alias = queries
+            if alias is not None:
+                inp_residual = alias
         queries = queries.view(bs, -1, self.embed_dims)
         out = ubv_linear(queries, self.output_proj.weight, self.output_proj.bias)
         if kwargs.get('return_parts'):
