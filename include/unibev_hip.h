@@ -216,6 +216,8 @@ int ubv_bev_fuse_backward(const void* grad_out, const void* img, const void* pts
  *   p        dropout probability (0 = eval); the keep mask is a stateless hash of (seed, element),
  *            so backward regenerates it from the same seed and nothing is stored
  *   grad_gamma, grad_beta [C] f32 ACCUMULATED (caller zeroes);  grad_x [R, C] dtype
+ *   grad_x_colsum [C] f32 or NULL, ACCUMULATED: column sums of grad_x as stored — the bias
+ *            gradient of the Linear that produced x (its backward then need not re-read grad_x)
  *   C % 4 == 0, C <= 1024.
  */
 int ubv_add_dropout_layernorm_forward(const void* x, const void* identity, const float* gamma,
@@ -225,8 +227,9 @@ int ubv_add_dropout_layernorm_forward(const void* x, const void* identity, const
 int ubv_add_dropout_layernorm_backward(const void* grad_y, const void* x, const void* identity,
                                        const float* gamma, const float* mean, const float* rstd,
                                        void* grad_x, void* grad_identity, float* grad_gamma,
-                                       float* grad_beta, int64_t R, int C, float p, uint64_t seed,
-                                       int dtype, int stream_dtype, void* stream);
+                                       float* grad_beta, float* grad_x_colsum, int64_t R, int C,
+                                       float p, uint64_t seed, int dtype, int stream_dtype,
+                                       void* stream);
 
 /* FFN activation of the encoder layers, y = dropout(relu(x)) in one pass ([ext] mmcv FFN:
  * Sequential(Linear, ReLU, Dropout(ffn_drop)); configs/unibev: feedforward_channels=512,

@@ -241,3 +241,36 @@ def test_linear_pass_through_alias_gradients(dtype):
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     for a, b in zip(*res):
         torch.testing.assert_close(a.float(), b.float(), rtol=tol, atol=tol * float(b.float().abs().max()))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_bias_gradient_rides_on_layernorm_backward(dtype):
+    """Linear -> fused add+LayerNorm: the LayerNorm backward hands the column sums of grad_x to the
+    Linear's backward as its bias gradient (no second pass over grad_x).  All gradients equal the
+    torch composition."""
+    from unibev_amd.functional import add_dropout_layernorm
+    from unibev_amd.linear import linear
+    torch.manual_seed(7)
+    R, K, C = 6000, 128, 256
+    x = torch.randn(R, K, device=DEV)
+    idn = torch.randn(R, C, device=DEV)
+    lin = torch.nn.Linear(K, C).to(DEV)
+    ln = torch.nn.LayerNorm(C).to(DEV)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.uniform_(-0.2, 0.2)
+    cot = torch.randn(R, C, device=DEV)
+    with torch.autocast('cuda', dtype=dtype, enabled=dtype != torch.float32):
+        idt = idn.to(dtype) if dtype != torch.float32 else idn
+        y = add_dropout_layernorm(linear(x, lin.weight, lin.bias), idt, ln.weight, ln.bias, 0.0, False)
+    (y.float() * cot).sum().backward()
+    got = [p.grad.clone() for p in (lin.weight, lin.bias, ln.weight, ln.bias)]
+    for p in (lin.weight, lin.bias, ln.weight, ln.bias):
+        p.grad = None
+    yr = torch.nn.functional.layer_norm(torch.nn.functional.linear(x, lin.weight, lin.bias) + idn,
+                                        (C,), ln.weight, ln.bias)
+    (yr * cot).sum().backward()
+    ref = [p.grad for p in (lin.weight, lin.bias, ln.weight, ln.bias)]
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    for a, b in zip(got, ref):
+        torch.testing.assert_close(a, b, rtol=tol, atol=tol * float(b.abs().max()))

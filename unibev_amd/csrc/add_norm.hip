@@ -96,7 +96,8 @@ __global__ __launch_bounds__(256) void add_norm_bwd_kernel(
     const S* __restrict__ gy, const T* __restrict__ x, const S* __restrict__ identity,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
     T* __restrict__ gx, S* __restrict__ gid, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, long R, int C, uint32_t thresh, float scale, uint64_t seed) {
+    float* __restrict__ dbeta, float* __restrict__ dxsum, long R, int C, uint32_t thresh,
+    float scale, uint64_t seed) {
   __shared__ float red[2][4][kNormChunks * 256];       // [gamma|beta][wave][column]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -147,6 +148,8 @@ __global__ __launch_bounds__(256) void add_norm_bwd_kernel(
         for (int i = 0; i < 4; ++i) {
           ds[i] = rs * (dxh[k][i] - s1 - xh[k][i] * s2);
           dx[i] = ds[i] * keep[k][i];
+          if (dxsum != nullptr)        // rare widths: straight atomics
+            atomic_add_f32(dxsum + c + i, elem<T>::to_float(elem<T>::from_float(dx[i])));
         }
         store4<S>(gid + r * C + c, ds);
         store4<T>(gx + r * C + c, dx);
@@ -246,20 +249,21 @@ __global__ __launch_bounds__(256) void add_norm_bwd_rows_kernel(
     const S* __restrict__ gy, const T* __restrict__ x, const S* __restrict__ identity,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
     T* __restrict__ gx, S* __restrict__ gid, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, long R, int C, uint32_t thresh, float scale, uint64_t seed) {
+    float* __restrict__ dbeta, float* __restrict__ dxsum, long R, int C, uint32_t thresh,
+    float scale, uint64_t seed) {
   constexpr int VEC = 16 / elem<T>::kBytes, G = 64 / LPR;
-  __shared__ float red[2][4][64][VEC];
+  __shared__ float red[3][4][64][VEC];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int sub = lane / LPR, c = (lane % LPR) * VEC;
   const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
-  float g[VEC], ag[VEC], ab[VEC];
+  float g[VEC], ag[VEC], ab[VEC], ax[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; i += 4) {
     float t4[4];
     load4<float>(gamma + c + i, t4);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { g[i + k] = t4[k]; ag[i + k] = 0.0f; ab[i + k] = 0.0f; }
+    for (int k = 0; k < 4; ++k) { g[i + k] = t4[k]; ag[i + k] = 0.0f; ab[i + k] = 0.0f; ax[i + k] = 0.0f; }
   }
   for (long r0 = wave * G; r0 < R; r0 += nwaves * G) {
     const long r = r0 + sub;
@@ -302,6 +306,9 @@ __global__ __launch_bounds__(256) void add_norm_bwd_rows_kernel(
         for (int k = 0; k < 4; ++k) {
           ds[k] = rs * (dxh[i + k] - s1 - xh[i + k] * s2);
           dx[i + k] = ds[k] * keep[i + k];
+          // column sums of grad_x AS STORED (rounded to T): the bias gradient of the Linear that
+          // produced x, which would otherwise re-read grad_x
+          ax[i + k] += elem<T>::to_float(elem<T>::from_float(dx[i + k]));
         }
         store4<S>(gid + r * C + c + i, ds);
       }
@@ -309,9 +316,11 @@ __global__ __launch_bounds__(256) void add_norm_bwd_rows_kernel(
     }
   }
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) { red[0][wv][lane][i] = ag[i]; red[1][wv][lane][i] = ab[i]; }
+  for (int i = 0; i < VEC; ++i) {
+    red[0][wv][lane][i] = ag[i]; red[1][wv][lane][i] = ab[i]; red[2][wv][lane][i] = ax[i];
+  }
   __syncthreads();
-  for (int t = threadIdx.x; t < 2 * C; t += 256) {
+  for (int t = threadIdx.x; t < (dxsum != nullptr ? 3 : 2) * C; t += 256) {
     const int which = t / C, col = t - which * C;
     const int cl = col / VEC, e = col - cl * VEC;
     float sum = 0.0f;
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(256) void add_norm_bwd_rows_kernel(
     for (int w = 0; w < 4; ++w)
 #pragma unroll
       for (int gq = 0; gq < G; ++gq) sum += red[which][w][gq * LPR + cl][e];
-    atomic_add_f32((which ? dbeta : dgamma) + col, sum);
+    atomic_add_f32((which == 0 ? dgamma : which == 1 ? dbeta : dxsum) + col, sum);
   }
 }
 
@@ -402,12 +411,12 @@ template <typename T, typename S>
 static void norm_bwd_launch(dim3 grid, hipStream_t st, const void* gy, const void* x,
                             const void* identity, const float* gamma, const float* mean,
                             const float* rstd, void* gx, void* gid, float* dgamma, float* dbeta,
-                            long R, int C, uint32_t th, float sc, uint64_t seed) {
+                            float* dxsum, long R, int C, uint32_t th, float sc, uint64_t seed) {
   constexpr int VEC = 16 / elem<T>::kBytes;
   const int lpr = (C % VEC == 0) ? C / VEC : 0;
   auto run = [&](auto kernel) {
     hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, (const S*)gy, (const T*)x, (const S*)identity,
-                       gamma, mean, rstd, (T*)gx, (S*)gid, dgamma, dbeta, R, C, th, sc, seed);
+                       gamma, mean, rstd, (T*)gx, (S*)gid, dgamma, dbeta, dxsum, R, C, th, sc, seed);
   };
   if (lpr == 64) run(add_norm_bwd_rows_kernel<T, S, 64>);
   else if (lpr == 32) run(add_norm_bwd_rows_kernel<T, S, 32>);
@@ -448,7 +457,8 @@ extern "C" int ubv_add_dropout_layernorm_backward(const void* grad_y, const void
                                                   const void* identity, const float* gamma,
                                                   const float* mean, const float* rstd, void* grad_x,
                                                   void* grad_identity, float* grad_gamma,
-                                                  float* grad_beta, int64_t R, int C, float p,
+                                                  float* grad_beta, float* grad_x_colsum,
+                                                  int64_t R, int C, float p,
                                                   uint64_t seed, int dtype, int stream_dtype,
                                                   void* stream) {
   using namespace ubv;
@@ -462,7 +472,7 @@ extern "C" int ubv_add_dropout_layernorm_backward(const void* grad_y, const void
   const long waves = R < 2048 ? R : 2048;
   const dim3 grid((unsigned)((waves + 3) / 4));
   hipStream_t st = as_stream(stream);
-#define UBV_NORM_BWD(T, S) norm_bwd_launch<T, S>(grid, st, grad_y, x, identity, gamma, mean, rstd, grad_x, grad_identity, grad_gamma, grad_beta, (long)R, C, th, sc, seed)
+#define UBV_NORM_BWD(T, S) norm_bwd_launch<T, S>(grid, st, grad_y, x, identity, gamma, mean, rstd, grad_x, grad_identity, grad_gamma, grad_beta, grad_x_colsum, (long)R, C, th, sc, seed)
   const bool lowp = stream_dtype != UBV_F32;
   switch (dtype) {
     case UBV_F32: UBV_NORM_BWD(float, float); break;

@@ -406,12 +406,18 @@ class _AddDropoutNorm(Function):
         gx = torch.empty_like(x2)
         gid = torch.empty_like(id2)
         dg, db = zeros_f32(C, x2.device), zeros_f32(C, x2.device)
+        dxs = zeros_f32(C, x2.device)
         check(lib().ubv_add_dropout_layernorm_backward(_p(gy), _p(x2), _p(id2), _p(g), _p(mean),
-                                                       _p(rstd), _p(gx), _p(gid), _p(dg), _p(db), R, C,
-                                                       ctx.p, ctx.seed, _dt(x2), _dt(id2), _stream()),
+                                                       _p(rstd), _p(gx), _p(gid), _p(dg), _p(db),
+                                                       _p(dxs), R, C, ctx.p, ctx.seed, _dt(x2),
+                                                       _dt(id2), _stream()),
               'add_dropout_layernorm_backward')
-        return (gx.view(ctx.shape), gid.view(ctx.shape).to(ctx.dts[0]), dg.to(ctx.dts[1]),
-                db.to(ctx.dts[2]), None, None)
+        gx = gx.view(ctx.shape)
+        # column sums of grad_x ride along: if x came straight out of a Linear, its backward takes
+        # them as the bias gradient instead of reducing grad_x again (linear._Linear.backward)
+        gx._ubv_colsum = dxs
+        return (gx, gid.view(ctx.shape).to(ctx.dts[0]), dg.to(ctx.dts[1]), db.to(ctx.dts[2]), None,
+                None)
 
 
 def add_dropout_layernorm(x, identity, gamma, beta, p=0.0, training=False, eps=1e-5):

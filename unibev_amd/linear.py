@@ -128,12 +128,16 @@ class _Linear(Function):
             else:
                 gw = (go2.t() @ x2).float()
         vec = 16 // go2.element_size()
+        colsum = getattr(grad_out, '_ubv_colsum', None)
+        if need_b and colsum is not None and colsum.numel() == go2.shape[1]:
+            gb, need_b = colsum, False          # summed by the kernel that produced grad_out
         if go2.is_cuda and (need_b or part is not None) and go2.shape[1] % vec == 0 and \
                 go2.shape[1] // vec <= 256 and \
                 (part is None or (part.dtype == go2.dtype and part[0].numel() % vec == 0)):
             # one launch: bias column sums + the sum over the split-K slices (library reductions)
             from . import functional as UF
-            gb, gw_p = UF.linear_grad_reduce(go2 if need_b else None, part)
+            gb_k, gw_p = UF.linear_grad_reduce(go2 if need_b else None, part)
+            gb = gb_k if need_b else gb
             gw = gw_p if part is not None else gw
         else:
             if part is not None:
