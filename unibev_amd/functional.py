@@ -416,8 +416,9 @@ class _AddDropoutNorm(Function):
         # column sums of grad_x ride along: if x came straight out of a Linear, its backward takes
         # them as the bias gradient instead of reducing grad_x again (linear._Linear.backward)
         gx._ubv_colsum = dxs
-        return (gx, gid.view(ctx.shape).to(ctx.dts[0]), dg.to(ctx.dts[1]), db.to(ctx.dts[2]), None,
-                None)
+        gid = gid.view(ctx.shape).to(ctx.dts[0])
+        gid._ubv_owned = True         # fresh, single consumer: linear._Linear may accumulate into it
+        return (gx, gid, dg.to(ctx.dts[1]), db.to(ctx.dts[2]), None, None)
 
 
 def add_dropout_layernorm(x, identity, gamma, beta, p=0.0, training=False, eps=1e-5):

@@ -110,7 +110,15 @@ class _Linear(Function):
         gx = None
         if ctx.needs_input_grad[0]:
             if grad_alias is not None and grad_alias.dtype == go2.dtype == x_dtype:
-                gx = torch.addmm(grad_alias.reshape(-1, xc.shape[-1]), go2, w).view(xc.shape)
+                ga = grad_alias.reshape(-1, xc.shape[-1])
+                if getattr(grad_alias, '_ubv_owned', False) and ga.is_contiguous():
+                    # a fresh tensor produced for this edge alone (functional._AddDropoutNorm marks
+                    # its grad_identity): accumulate in place — out-of-place addmm would first copy
+                    # it into the result.  Untagged gradients may be shared (AddBackward hands ONE
+                    # tensor to both of its inputs) and are left untouched.
+                    gx = ga.addmm_(go2, w).view(xc.shape)
+                else:
+                    gx = torch.addmm(ga, go2, w).view(xc.shape)
             else:
                 gx = (go2 @ w).view(xc.shape).to(x_dtype)
                 if grad_alias is not None:
