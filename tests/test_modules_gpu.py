@@ -315,3 +315,34 @@ def test_lowp_weight_shadows_follow_optimizer_steps():
     torch.testing.assert_close(ga, a.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(gw, w.grad, rtol=1e-4, atol=1e-2)
     torch.testing.assert_close(gb, b.grad, rtol=1e-4, atol=1e-2)
+
+
+def test_two_forward_passes_before_backward():
+    """Gradient accumulation style: two forward passes, then both backward passes.  The weight
+    shadows must not be rewritten between them (the copies saved for backward would be invalidated),
+    and an optimizer step or an in-place parameter edit must still refresh them."""
+    from unibev_amd.linear import linear, lowp_step_cache
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(64, 32).to(DEV)
+    opt = torch.optim.SGD(lin.parameters(), lr=0.5)
+    x = torch.randn(512, 64, device=DEV)
+
+    def fwd():
+        with torch.autocast('cuda', dtype=torch.bfloat16), lowp_step_cache():
+            return linear(x, lin.weight, lin.bias).float().square().sum()
+
+    fwd()                                   # creates the shadows
+    a, b = fwd(), fwd()
+    (a + b).backward()                      # raised "modified by an inplace operation" before
+    g2 = lin.weight.grad.clone()
+    lin.weight.grad = lin.bias.grad = None
+    fwd().backward()
+    torch.testing.assert_close(g2, 2 * lin.weight.grad, rtol=1e-3, atol=1e-3)
+    before = fwd().item()
+    opt.step()                              # optimizer step -> refresh on the next pass
+    after = fwd().item()
+    assert abs(after - before) > 1e-3 * abs(before)
+    with torch.no_grad():
+        lin.weight.mul_(0.0)                # in-place edit bumps the version counter -> refresh
+        lin.bias.mul_(0.0)
+    assert fwd().item() == 0.0

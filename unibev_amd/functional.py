@@ -93,7 +93,9 @@ def _p(t):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw handle of torch's current stream (no Stream object per launch: the step is host-bound in
+    # its forward half, every microsecond per call shows)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 # ----------------------------------------------------------------------------------------------- k1
@@ -530,7 +532,7 @@ _WS = {}
 
 
 def _workspace(nbytes, device):
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    key = (device.index, torch._C._cuda_getCurrentRawStream(device.index))
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)

@@ -16,6 +16,7 @@ low-precision weights.
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
+from torch.optim.optimizer import register_optimizer_step_post_hook
 
 import contextlib
 
@@ -31,27 +32,60 @@ def _splits(rows):
     return 1
 
 
+# Shadows are refreshed when the masters may have changed: after any optimizer step (a global
+# post-step hook; the fused AdamW kernel does not bump parameter versions) or when a parameter's
+# version counter moved (load_state_dict, in-place edits).  Forward passes in between — gradient
+# accumulation, several forwards before one backward — reuse the shadows untouched, so the copies
+# saved for backward stay valid.
+_DIRTY = [True]
+_VERSIONS = {}
+
+
+def _mark_dirty(*_args, **_kwargs):
+    _DIRTY[0] = True
+
+
+register_optimizer_step_post_hook(_mark_dirty)
+
+
+def mark_weights_changed():
+    """Call after changing parameters in a way neither an optimizer step nor the version counters
+    reveal (e.g. through ``param.data``)."""
+    _DIRTY[0] = True
+
+
+def _masters_changed():
+    if _DIRTY[0]:
+        return True
+    for key, (_, _, params) in _SHADOWS.items():
+        if _VERSIONS.get(key) != tuple(p._version for p in params):
+            return True
+    return False
+
+
 @contextlib.contextmanager
 def lowp_step_cache():
     """Within this context (one forward pass of the encoder) the low-precision copies of the
-    weights are taken from persistent shadow buffers that are refreshed ON ENTRY with a single
-    multi-tensor copy (``torch._foreach_copy_``) instead of one cast kernel per use.  The shadows
-    are never trusted across optimizer steps: every entry re-copies from the f32 masters."""
+    weights are taken from persistent shadow buffers, refreshed ON ENTRY with a single multi-tensor
+    copy (``torch._foreach_copy_``) whenever the f32 masters may have changed since the last
+    refresh, instead of one cast kernel per use."""
     global _ACTIVE
     if _ACTIVE:                       # nested: the outer context already refreshed
         yield
         return
     from . import functional as UF
     UF.new_step()                     # backward accumulators of this pass come from a fresh arena
-    if _SHADOWS:
+    if _SHADOWS and _masters_changed():
         groups = {}                   # one multi-tensor copy per (dtypes, device) group
-        for buf, views, params in _SHADOWS.values():
+        for key, (buf, views, params) in _SHADOWS.items():
             g = groups.setdefault((buf.dtype, params[0].dtype, buf.device), ([], []))
             g[0].extend(views)
             g[1].extend(params)
+            _VERSIONS[key] = tuple(p._version for p in params)
         with torch.no_grad():
             for dst, src in groups.values():
                 torch._foreach_copy_(dst, src)
+        _DIRTY[0] = False
     _ACTIVE = True
     try:
         yield
@@ -61,6 +95,8 @@ def lowp_step_cache():
 
 def clear_lowp_cache():
     _SHADOWS.clear()
+    _VERSIONS.clear()
+    _DIRTY[0] = True
 
 
 def _cached_lowp(params, dtype):
@@ -80,6 +116,7 @@ def _cached_lowp(params, dtype):
             _SHADOWS.clear()
         views = list(torch.split(buf, [p.shape[0] for p in params], 0))
         _SHADOWS[key] = (buf, views, list(params))
+        _VERSIONS[key] = tuple(p._version for p in params)
     return buf
 
 
@@ -168,9 +205,11 @@ def _run(x, weights, biases, passthru=False):
     has_bias = biases[0] is not None
     params = list(weights) + (list(biases) if has_bias else [])
     if x.is_cuda and torch.is_autocast_enabled('cuda'):
-        dt = torch.get_autocast_dtype('cuda')
-        with torch.autocast('cuda', enabled=False):
-            return _Linear.apply(x, dt, len(weights), has_bias, passthru, *params)
+        # no autocast(enabled=False) scope here: every operand of the GEMM inside is already in the
+        # autocast dtype, so the ambient policy has nothing to cast (and the context manager costs
+        # ~1 us x 3 per call on a host-bound forward)
+        return _Linear.apply(x, torch.get_autocast_dtype('cuda'), len(weights), has_bias, passthru,
+                             *params)
     return _Linear.apply(x, x.dtype if x.dtype == weights[0].dtype else weights[0].dtype,
                          len(weights), has_bias, passthru, *params)
 
