@@ -6,12 +6,18 @@ low-precision weights.
   GEMM it occupies (N/64)*(K/64) = 16..32 workgroups of the 256 CUs (measured 198 us per call,
   5.9 ms per training step, profiles/r01_v0_*).  Here the rows are split into S slices that run as
   one strided-batched GEMM filling the chip, and the S partial products are summed in f32.
+* The partial products and the bias column sums are reduced by one library launch per Linear
+  (``ubv_linear_grad_reduce``); when the Linear's output went straight into the fused
+  add+dropout+LayerNorm, that kernel's backward supplies the bias gradient and grad_out is not read
+  again.
 * Under autocast the f32 master weights are cast to the autocast dtype by ONE multi-tensor copy
-  per forward pass (``lowp_step_cache``), not by one cast kernel per use, and the gradients come
-  back in f32 directly: per step this removes ~300 tiny cast kernels and their autograd nodes
-  (the eager step is host-bound below ~3.5 us per kernel, MI355X_MICROARCH.md).
+  (``lowp_step_cache``) after each optimizer step, not by one cast kernel per use, and the
+  gradients come back in f32 directly: per step this removes ~300 tiny cast kernels and their
+  autograd nodes (the eager step is host-bound below ~3.5 us per kernel, MI355X_MICROARCH.md).
 * ``linear_cat`` runs several Linear layers that share their input as ONE GEMM (the
   ``sampling_offsets`` and ``attention_weights`` layers of every deformable attention).
+* ``linear_pass`` / ``linear_cat_pass`` also return an alias of the input for the caller's residual
+  branch, so that the residual's gradient is accumulated by the input-gradient GEMM itself.
 """
 import torch
 import torch.nn.functional as F
