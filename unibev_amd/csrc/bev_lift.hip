@@ -229,11 +229,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (P == 8 
 // scatters grad_value:
 //   kAtomAll : this kernel, one hardware f32 atomic per (corner, channel) — the mmcv scheme; kept for
 //              arbitrary reference points on large maps.
-//   kAtomNone: never — the owner-tile kernel below takes the corners without atomics (GRID: every
-//              corner within R pixels of the point's expected pixel, the rare rest is scattered by
-//              lift_record_kernel; CAMERA: the whole map).
-// kAtomFar names the GRID plan (records + far corners + owner tiles) in the launcher.
-enum { kAtomAll = 0, kAtomFar = 1, kAtomNone = 2 };
+//   kAtomNone: never — the owner-tile kernels below take every corner without atomics.
+// The launcher names its three plans with the same enum: kAtomAll (this kernel scatters), kPlanGrid
+// (points binned by owner tile: lift_bin_kernel + lift_bwd_value_kernel) and kAtomNone for the
+// CAMERA plan (per-camera lists: lift_bwd_value_camera_kernel).
+enum { kAtomAll = 0, kPlanGrid = 1, kAtomNone = 2 };
 
 
 // v + (v of the lane whose index differs in bit log2(M)): DPP quad permutes inside a quad (the
@@ -521,17 +521,12 @@ __global__ __launch_bounds__(256) void lift_ovf_scatter_kernel(const LiftArgs a,
 // and three products are accumulated (hi*hi + lo*hi + hi*lo, relative error ~2^-16), f32
 // accumulation throughout.
 //
-//   GRID   (BEV-grid reference points, one map per sample: self-attention, SCA-pts): 8x8-pixel
-//          tiles.  For each sampling slot p the candidates are the queries whose expected pixel
-//          (home pixel + slot centre, i.e. where the slot lands when the learned offset equals
-//          the sampling_offsets bias) lies within R of the tile; a corner is taken iff it is
-//          inside the tile AND within R of that expected pixel.  The complement — "far" corners —
-//          is scattered atomically by lift_bwd_query_kernel<kAtomFar>, so the two kernels
-//          partition the corners exactly for ANY learned offset.
+//   GRID   (BEV-grid queries, one map per sample: self-attention, SCA-pts): 8x8-pixel tiles; the
+//          points of a tile come from its bucket, filled by lift_bin_kernel (above).
 //   CAMERA (small per-camera maps, arbitrary projected reference points: SCA-img): the tile is a
-//          band of full rows (the whole 8x22 map in one band), candidates = a chunk of the
-//          camera's compacted visible-query list; the chunks of one camera share the map, so the
-//          flush is one f32 atomic per tile element per chunk (~10^6 instead of ~10^9 atomics).
+//          band of full rows (the whole 8x22 map in one band), the points are a share of the
+//          camera's compacted visible-query list; the shares of one camera write partial maps
+//          ("slabs") that slab_reduce_kernel sums.
 struct TileArgs {
   int mode;            // 1 = GRID, 2 = CAMERA
   int tile_w, tile_h;  // pixels
@@ -620,12 +615,10 @@ __device__ __forceinline__ bool tile_decode(const LiftArgs& a, const TileArgs& t
   return true;
 }
 
-// Ownership of the 4 corners of a footprint by tile g (and, when NEAR, nearness to the slot's
-// expected pixel (ex, ey)): fills lp (tile-local pixel index or -1) and cwt (coefficient).
-template <bool NEAR>
+// Ownership of the 4 corners of a footprint by tile g: fills lp (tile-local pixel index or -1) and
+// cwt (coefficient).
 __device__ __forceinline__ bool tile_own(const Footprint& f, float w, bool valid, const TileGeom& g,
-                                         int tile_w, int ex, int ey, int R, int (&lp)[4],
-                                         float (&cwt)[4]) {
+                                         int tile_w, int (&lp)[4], float (&cwt)[4]) {
   bool any = false;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -633,7 +626,6 @@ __device__ __forceinline__ bool tile_own(const Footprint& f, float w, bool valid
     // bitwise, not short-circuit: keeps the four corners straight-line code
     int o = (int)valid & (int)(f.w[k] != 0.0f) & (int)((unsigned)(cx - g.x0) < (unsigned)g.tw) &
             (int)((unsigned)(cy - g.y0) < (unsigned)g.th);
-    if (NEAR) o = o & (int)(abs(cx - ex) <= R) & (int)(abs(cy - ey) <= R);
     const bool own = o != 0;
     lp[k] = own ? (cy - g.y0) * tile_w + (cx - g.x0) : -1;
     cwt[k] = own ? w * f.w[k] : 0.0f;
@@ -804,7 +796,7 @@ __global__ __launch_bounds__(256, 3) void lift_bwd_value_kernel(const LiftArgs a
     int lp[4];
     float cwt[4];
     const Footprint f = footprint_px(rec.x, rec.y, a.fh, a.fw);
-    const bool any = tile_own<false>(f, rec.z, valid, g, t.tile_w, 0, 0, 0, lp, cwt);
+    const bool any = tile_own(f, rec.z, valid, g, t.tile_w, lp, cwt);
     ta.add(lp, cwt, any, gout + ((long)g.b * a.Nq + q) * row + g.h * DH, lane);
   }
   if (ta.fill > 0) ta.flush(lane);
@@ -957,7 +949,7 @@ __global__ __launch_bounds__(256) void lift_bwd_value_camera_kernel(const LiftAr
       // scattered gradient is continuous
       const Footprint f = make_footprint(cur.ref[p].x + cur.off[2 * p] * inv_fw,
                                          cur.ref[p].y + cur.off[2 * p + 1] * inv_fh, a.fh, a.fw);
-      const bool any = tile_own<false>(f, w[p] * inv_cnt, cur.valid, g, t.tile_w, 0, 0, 0, lp, cwt);
+      const bool any = tile_own(f, w[p] * inv_cnt, cur.valid, g, t.tile_w, lp, cwt);
       if (__ballot(any) == 0ull) continue;
       unsigned touched = 0;                               // 32-pixel row blocks this lane writes
 #pragma unroll
@@ -1095,7 +1087,7 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, hipS
       hipLaunchKernelGGL(narrow_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                          a.gvalue, (T*)a.gvalue_lp, n);
     }
-  } else if (bwd_mode == kAtomFar) {
+  } else if (bwd_mode == kPlanGrid) {
     // bin the sampling points by owner tile (counters zeroed by the caller), scatter whatever
     // overflowed a bucket (normally nothing: both kernels exit at once), then the query gradients
     // and the owner tiles, each of which stores its finished pixels exactly once
@@ -1212,7 +1204,7 @@ static int plan_backward(const LiftArgs& a, int Dh, int P, int dtype, int ref_is
   }
   t.total = a.B * a.Nc * t.tiles_y * t.tiles_x * t.chunks * a.H;
   t.chunk = ((t.total + t.waves - 1) / t.waves + 7) / 8;       // blocks per XCD
-  return t.mode == 1 ? kAtomFar : kAtomNone;
+  return t.mode == 1 ? kPlanGrid : kAtomNone;
 }
 
 static size_t lift_list_bytes(const LiftArgs& a) {
@@ -1233,7 +1225,7 @@ static GridWs grid_ws(const LiftArgs& a, const TileArgs& t, int P) {
   return w;
 }
 static size_t lift_ws_bytes(int mode, const LiftArgs& a, const TileArgs& t, int Dh, int P) {
-  if (mode == kAtomFar) return grid_ws(a, t, P).total;
+  if (mode == kPlanGrid) return grid_ws(a, t, P).total;
   if (mode == kAtomNone)     // visible-query lists + one partial map per (b, cam, head, chunk)
     return lift_list_bytes(a) +
            (size_t)a.B * a.Nc * a.H * t.chunks * a.fh * a.fw * Dh * sizeof(float);
@@ -1282,7 +1274,7 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_g
     UBV_CHECK_ARG(need == 0 || (ws != nullptr && ws_bytes >= (int64_t)need),
                   "bev_lift_backward: workspace of %lld bytes needed, got %lld", (long long)need,
                   (long long)ws_bytes);
-    if (mode == kAtomFar) {
+    if (mode == kPlanGrid) {
       const GridWs w = grid_ws(a, t, P);
       a.bin_cnt = (int*)ws;
       a.ovf_n = a.bin_cnt + (size_t)a.B * a.H * t.tiles_x * t.tiles_y;
