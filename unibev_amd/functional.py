@@ -373,6 +373,24 @@ def bev_fuse(img, pts, cw_img, cw_pts, sw_img=None, sw_pts=None, cat=False):
 
 
 # ----------------------------------------------------------------------------------------------- add+norm
+# Dropout seeds: ONE draw from torch's CPU generator per forward pass (``new_step``) mixed with a
+# call counter — reproducible under torch.manual_seed, no device sync, and a few hundred nanoseconds
+# per call instead of the two tensor ops of torch.randint(...).item() (24 calls per forward pass on
+# a host-bound forward).
+_SEED_STATE = [None, 0]
+
+
+def _next_seed():
+    if _SEED_STATE[0] is None:
+        _SEED_STATE[0] = int(torch.randint(0, 2 ** 62, (1,)).item())
+        _SEED_STATE[1] = 0
+    _SEED_STATE[1] += 1
+    z = (_SEED_STATE[0] + _SEED_STATE[1] * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z ^= z >> 31
+    return z & 0x3FFFFFFFFFFFFFFF
+
+
 class _AddDropoutNorm(Function):
     @staticmethod
     def forward(ctx, x, identity, gamma, beta, p, eps):
@@ -389,7 +407,7 @@ class _AddDropoutNorm(Function):
         mean = torch.empty(R, dtype=torch.float32, device=x.device)
         rstd = torch.empty(R, dtype=torch.float32, device=x.device)
         # seed from torch's CPU generator: reproducible under torch.manual_seed, no device sync
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
+        seed = _next_seed() if p > 0 else 0
         check(lib().ubv_add_dropout_layernorm_forward(_p(x2), _p(id2), _p(g), _p(b), _p(y), _p(mean),
                                                       _p(rstd), R, C, float(eps), float(p), seed,
                                                       _dt(x2), _DT[sdt], _stream()),
@@ -467,6 +485,7 @@ def new_step():
     """Called once per forward pass (``linear.lowp_step_cache``): later backward accumulators come
     from a fresh zero buffer."""
     _ARENA.reset()
+    _SEED_STATE[0] = None             # dropout seeds of this pass: one fresh draw from torch's generator
 
 
 # ----------------------------------------------------------------------------------------------- relu + dropout
@@ -476,7 +495,7 @@ class _ReluDropout(Function):
         _need_cuda(x)
         xc = x.contiguous()
         y = torch.empty_like(xc)
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
+        seed = _next_seed() if p > 0 else 0
         check(lib().ubv_relu_dropout_forward(_p(xc), _p(y), xc.numel(), float(p), seed, _dt(xc),
                                              _stream()), 'relu_dropout_forward')
         ctx.save_for_backward(y)
