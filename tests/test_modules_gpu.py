@@ -346,3 +346,58 @@ def test_two_forward_passes_before_backward():
         lin.weight.mul_(0.0)                # in-place edit bumps the version counter -> refresh
         lin.bias.mul_(0.0)
     assert fwd().item() == 0.0
+
+
+@pytest.mark.parametrize('dtype,fwd_tol,cos_lo,norm_tol', [(torch.float16, 1.5e-2, 0.95, 0.1),
+                                                           (torch.bfloat16, 0.1, 0.75, 0.2)])
+def test_fullsize_training_gradients_16bit_vs_fp32(dtype, fwd_tol, cos_lo, norm_tol):
+    """cfg4 shapes (6 x 8x22 image feats, 180x180 LiDAR feats, 200x200 BEV, 3 layers), train-style
+    backward with dropout off: the whole 16-bit path (16-bit residual stream, 16-bit offsets /
+    logits, bins + MFMA owner tiles, fused norm / activation / Linear reductions) against the f32
+    path — output normwise, gradients by direction and norm, parameter group by parameter group.
+    The feature maps are box-filtered: on i.i.d. random pixels bilinear sampling turns the 2^-9
+    rounding of a 16-bit offset into an O(1) output change and nothing meaningful can be compared
+    (measured: 19 % output distance in bf16 on the raw maps, 5.9 % on the filtered ones; the f32 and
+    16-bit residual streams are within 15 % of each other on this measure either way)."""
+    import torch.nn.functional as F
+    cfg, sd, inp, g = encoder_case('fullsize')
+    model = _build(cfg).to(DEV).eval()                 # eval: dropout and modality dropout off
+    _load(model, sd)
+    torch.manual_seed(0)
+
+    def smooth(x, k=5):
+        y = F.avg_pool2d(x.reshape(-1, 1, *x.shape[-2:]), k, 1, k // 2, count_include_pad=False)
+        return (y * k).reshape(x.shape)
+
+    cot = None
+    grads, outs = {}, {}
+    for dt in (torch.float32, dtype):
+        model.zero_grad(set_to_none=True)
+        img = [smooth(t(x, torch.float32, DEV)).requires_grad_() for x in inp['img']]
+        pts = [smooth(t(x, torch.float32, DEV)).requires_grad_() for x in inp['pts']]
+        bev_q = t(inp['bev_q'], torch.float32, DEV).requires_grad_()
+        with torch.autocast('cuda', dtype=dt, enabled=dt != torch.float32):
+            fused = model.encode(img, pts, bev_q, inp['bev_h'], inp['bev_w'],
+                                 bev_pos=t(inp['bev_pos'], torch.float32, DEV), img_metas=inp['metas'])
+        if cot is None:
+            cot = torch.randn_like(fused.float()) / fused.shape[0] ** 0.5
+        (fused.float() * cot).sum().backward()
+        outs[dt] = fused.detach().float()
+        gd = {'bev_q': bev_q.grad, 'img': img[0].grad, 'pts': pts[0].grad}
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                parts = n.split('.')
+                gd.setdefault(parts[0] + ':' + '.'.join(parts[-2:]), []).append(p.grad.flatten().float())
+        grads[dt] = {k: (torch.cat(v) if isinstance(v, list) else v.flatten().float()) for k, v in gd.items()}
+    ferr = float((outs[dtype] - outs[torch.float32]).norm() / outs[torch.float32].norm())
+    assert ferr < fwd_tol, ferr
+    checked = 0
+    for k, a in grads[torch.float32].items():
+        b = grads[dtype][k]
+        if float(a.norm()) == 0.0:
+            continue
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+        ratio = float(b.norm() / a.norm())
+        assert cos > cos_lo and abs(ratio - 1.0) < norm_tol, (k, cos, ratio)
+        checked += 1
+    assert checked >= 10
