@@ -241,6 +241,19 @@ int ubv_relu_dropout_backward(const void* grad_y, const void* y, void* grad_x, i
                               int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * y[M, N] = x[M, K] . w[N, K]^T (+ bias[N]), row-major, all operands of `dtype`, f32 accumulation:
+ * the forward of the encoder's Linear layers ([ext] torch.nn.functional.linear behind value_proj,
+ * sampling_offsets / attention_weights, output_proj and the FFN of models/modules/*.py).  The GEMM
+ * is hipBLASLt's; this entry point keeps its descriptor, layouts and algorithm per (M, N, K, dtype,
+ * bias) so that a call costs one hipblasLtMatmul on the host (the framework path rebuilds them and
+ * re-queries the heuristic on every call).  bias may be NULL.  workspace: ubv_linear_workspace()
+ * bytes.  Returns UBV_ERR_UNSUPPORTED if hipBLASLt offers no algorithm for the shape.
+ */
+int64_t ubv_linear_workspace(void);
+int ubv_linear_forward(const void* x, const void* w, const void* bias, void* y, int64_t M, int N,
+                       int K, int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Reductions behind the gradients of the encoder's Linear layers (value_proj, sampling_offsets,
  * attention_weights, output_proj, FFN; [ext] torch.nn.Linear backward in the reference), one launch
  * per Linear:

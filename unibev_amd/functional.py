@@ -519,6 +519,32 @@ def relu_dropout(x, p=0.0, training=False):
     return _ReluDropout.apply(x, float(p) if training else 0.0)
 
 
+# ----------------------------------------------------------------------------------------------- linear forward
+_LINEAR_PLAN_OK = [True]
+
+
+@torch.no_grad()
+def linear_forward(x, weight, bias=None):
+    """``F.linear(x, weight, bias)`` through ``ubv_linear_forward`` (hipBLASLt with a cached plan),
+    or None when hipBLASLt has no algorithm for the shape (the caller then uses the framework GEMM).
+    x (..., K) contiguous, weight (N, K), bias (N,) or None, one dtype."""
+    if not _LINEAR_PLAN_OK[0]:
+        return None
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = weight.shape[0]
+    y = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+    nws = int(lib().ubv_linear_workspace())
+    ws = _workspace(nws, x.device)
+    rc = lib().ubv_linear_forward(_p(x), _p(weight), _p(bias), _p(y), M, N, K, _dt(x), _p(ws), nws,
+                                  _stream())
+    if rc == -3:                      # UBV_ERR_UNSUPPORTED: hipBLASLt has nothing for this shape
+        _LINEAR_PLAN_OK[0] = False
+        return None
+    check(rc, 'linear_forward')
+    return y
+
+
 # ----------------------------------------------------------------------------------------------- linear grads
 @torch.no_grad()
 def linear_grad_reduce(grad_out=None, partials=None):

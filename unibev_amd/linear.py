@@ -142,7 +142,14 @@ class _Linear(Function):
         xc = x.to(dtype)
         ctx.save_for_backward(xc, w)
         ctx.meta = (x.dtype, n, has_bias, [p.shape[0] for p in weights], [p.dtype for p in params])
-        y = F.linear(xc, w, b)
+        y = None
+        if xc.is_cuda and xc.dtype == w.dtype and (b is None or b.dtype == w.dtype) and \
+                xc.is_contiguous() and w.is_contiguous() and xc.numel() > 0:
+            # hipBLASLt with a cached plan (ubv_linear_forward): same GEMM, a third of the host time
+            from . import functional as UF
+            y = UF.linear_forward(xc, w, b)
+        if y is None:
+            y = F.linear(xc, w, b)
         return (y, x.view_as(x)) if passthru else y
 
     @staticmethod
