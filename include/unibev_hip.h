@@ -243,7 +243,7 @@ int ubv_relu_dropout_backward(const void* grad_y, const void* y, void* grad_x, i
 /* ------------------------------------------------------------------------------------------------
  * y[M, N] = x[M, K] . w[N, K]^T (+ bias[N]), row-major, all operands of `dtype`, f32 accumulation:
  * the forward of the encoder's Linear layers ([ext] torch.nn.functional.linear behind value_proj,
- * sampling_offsets / attention_weights, output_proj and the FFN of models/modules/*.py).  The GEMM
+ * sampling_offsets / attention_weights, output_proj and the FFN under models/modules).  The GEMM
  * is hipBLASLt's; this entry point keeps its descriptor, layouts and algorithm per (M, N, K, dtype,
  * bias) so that a call costs one hipblasLtMatmul on the host (the framework path rebuilds them and
  * re-queries the heuristic on every call).  bias may be NULL.  workspace: ubv_linear_workspace()
