@@ -44,7 +44,7 @@ def _splits(rows):
 # accumulation, several forwards before one backward — reuse the shadows untouched, so the copies
 # saved for backward stay valid.
 _DIRTY = [True]
-_VERSIONS = {}
+_PLAN = {'n': -1, 'groups': [], 'params': [], 'versions': None}   # cached refresh plan
 
 
 def _mark_dirty(*_args, **_kwargs):
@@ -60,13 +60,24 @@ def mark_weights_changed():
     _DIRTY[0] = True
 
 
+def _refresh_plan():
+    """(dst views, src parameters) per (dtypes, device) group; rebuilt only when shadows were added."""
+    if _PLAN['n'] != len(_SHADOWS):
+        groups, flat = {}, []
+        for buf, views, params in _SHADOWS.values():
+            g = groups.setdefault((buf.dtype, params[0].dtype, buf.device), ([], []))
+            g[0].extend(views)
+            g[1].extend(params)
+            flat.extend(params)
+        _PLAN.update(n=len(_SHADOWS), groups=list(groups.values()), params=flat, versions=None)
+    return _PLAN
+
+
 def _masters_changed():
     if _DIRTY[0]:
         return True
-    for key, (_, _, params) in _SHADOWS.items():
-        if _VERSIONS.get(key) != tuple(p._version for p in params):
-            return True
-    return False
+    plan = _refresh_plan()
+    return plan['versions'] != [p._version for p in plan['params']]
 
 
 @contextlib.contextmanager
@@ -82,15 +93,11 @@ def lowp_step_cache():
     from . import functional as UF
     UF.new_step()                     # backward accumulators of this pass come from a fresh arena
     if _SHADOWS and _masters_changed():
-        groups = {}                   # one multi-tensor copy per (dtypes, device) group
-        for key, (buf, views, params) in _SHADOWS.items():
-            g = groups.setdefault((buf.dtype, params[0].dtype, buf.device), ([], []))
-            g[0].extend(views)
-            g[1].extend(params)
-            _VERSIONS[key] = tuple(p._version for p in params)
+        plan = _refresh_plan()
         with torch.no_grad():
-            for dst, src in groups.values():
+            for dst, src in plan['groups']:
                 torch._foreach_copy_(dst, src)
+        plan['versions'] = [p._version for p in plan['params']]
         _DIRTY[0] = False
     _ACTIVE = True
     try:
@@ -101,7 +108,7 @@ def lowp_step_cache():
 
 def clear_lowp_cache():
     _SHADOWS.clear()
-    _VERSIONS.clear()
+    _PLAN.update(n=-1, groups=[], params=[], versions=None)
     _DIRTY[0] = True
 
 
@@ -122,7 +129,7 @@ def _cached_lowp(params, dtype):
             _SHADOWS.clear()
         views = list(torch.split(buf, [p.shape[0] for p in params], 0))
         _SHADOWS[key] = (buf, views, list(params))
-        _VERSIONS[key] = tuple(p._version for p in params)
+        _PLAN['versions'] = None      # a shadow created mid-pass: its versions are taken at the next refresh
     return buf
 
 
