@@ -107,12 +107,19 @@ int ubv_ms_deform_attn_backward(const void* value, const int64_t* spatial_shapes
  * qgrid_w/qgrid_h: if Nq == qgrid_w*qgrid_h the queries are walked in 8x8 tiles of that grid
  * (L2 locality); pass 0 for raster order.
  * Supported shapes: see ubv_bev_lift_supported() (Dh in {16, 32}, P in {4, 8}).
+ * workspace: optional scratch of ubv_bev_lift_forward_workspace(...) bytes.  When it is given and
+ * the shape qualifies (16-bit dtype, Dh = 32, P = 8, fh*fw <= 192: the 8x22 camera maps), the
+ * gather runs on the matrix cores as out^T = V^T . A^T with a per-wave coefficient matrix built in
+ * LDS, reading a fragment-ordered copy of `value` written into the scratch; otherwise (or with
+ * NULL) the gather kernel runs.  Both give the same result up to the rounding of the
+ * coefficients to `dtype`.
  */
+int64_t ubv_bev_lift_forward_workspace(int B, int Nc, int fh, int fw, int H, int Dh, int P, int dtype);
 int ubv_bev_lift_forward(const void* value, const void* offsets, int64_t off_stride,
                          const void* logits, int64_t log_stride, int offlog_dtype,
                          const float* ref, const uint8_t* vis0, const float* count, void* out, int B, int Nc, int fh,
                          int fw, int H, int Dh, int Nq, int P, int Z, int qgrid_w, int qgrid_h,
-                         int dtype, void* stream);
+                         int dtype, void* workspace, int64_t workspace_bytes, void* stream);
 
 /*   grad_out     [B, Nq, H*Dh]       dtype
  *   grad_value   [B*Nc, S, H, Dh]    f32, WRITTEN (previous content ignored; zeroed internally
@@ -131,9 +138,19 @@ int ubv_bev_lift_forward(const void* value, const void* offsets, int64_t off_str
  *   workspace    scratch of at least ubv_bev_lift_backward_workspace(...) bytes (may be NULL when
  *                that is 0): per-tile buckets of point records / per-camera visible-query lists
  *                and partial maps.
+ *   visible_lists  NULL, or the per-camera visible-query lists of ubv_compact_visible(vis0): the
+ *                CAMERA plan walks them; they depend on vis0 alone, so one compaction per forward
+ *                pass serves every layer's backward (NULL: compacted here, 37 us per call).
  */
 int64_t ubv_bev_lift_backward_workspace(int B, int Nc, int fh, int fw, int H, int Dh, int Nq, int P,
                                         int qgrid_w, int qgrid_h, int ref_is_grid);
+
+/* Ordered compaction of each camera's visible queries: lists[cam*Nq + i] = i-th query (ascending)
+ * with vis0[cam, q] != 0 (all queries when vis0 is NULL), lists[Nc*Nq + cam] = their number.
+ * `lists` holds ubv_visible_lists_elems(Nc, Nq) int32.  Replaces the per-camera
+ * `nonzero()` index lists of spatial_cross_attention_img.py:141-152 (six host syncs there). */
+int64_t ubv_visible_lists_elems(int Nc, int Nq);
+int ubv_compact_visible(const uint8_t* vis0, int Nc, int Nq, int32_t* lists, void* stream);
 
 int ubv_bev_lift_backward(const void* value, const void* offsets, int64_t off_stride,
                           const void* logits, int64_t log_stride, int offlog_dtype,
@@ -142,8 +159,8 @@ int ubv_bev_lift_backward(const void* value, const void* offsets, int64_t off_st
                           void* grad_value_lowp, void* grad_offsets, int64_t goff_stride,
                           void* grad_logits, int64_t glog_stride, int B, int Nc, int fh, int fw,
                           int H, int Dh, int Nq, int P, int Z, int qgrid_w, int qgrid_h,
-                          int ref_is_grid, int dtype, void* workspace, int64_t workspace_bytes,
-                          void* stream);
+                          int ref_is_grid, int dtype, const int32_t* visible_lists, void* workspace,
+                          int64_t workspace_bytes, void* stream);
 
 /* 1 if ubv_bev_lift_* has a kernel for this shape, else 0 (callers then compose k1). */
 int ubv_bev_lift_supported(int H, int Dh, int P, int dtype);

@@ -243,6 +243,13 @@ def test_lift_16bit_offsets_logits_read_directly(mode, dtype):
         if name == 'grad_value' and mode != 'camera':
             # far corners / the all-atomics plan add f32 atomically: the order varies run to run
             torch.testing.assert_close(a.float(), b.float(), rtol=2e-2, atol=2e-2)
+        elif name == 'grad_offlog' and mode == 'camera':
+            # the matrix-core plan's two instantiations (16-bit / f32 rows) are compiled separately:
+            # a differently contracted multiply-add may move a gradient by one f32 ulp, which now
+            # and then crosses a 16-bit rounding boundary
+            diff = (a != b)
+            assert diff.float().mean().item() < 1e-4, int(diff.sum())
+            torch.testing.assert_close(a.float(), b.float(), rtol=2.0 ** -7, atol=1e-6)
         else:
             assert torch.equal(a, b), name
 
@@ -280,3 +287,44 @@ def test_lift_backward_bins_overflow_is_exact(dtype):
     np.testing.assert_allclose(v.grad.float().cpu().numpy(), v64.grad.numpy(), rtol=tol, atol=tol * scale)
     bad = ~np.isclose(ol.grad.cpu().numpy(), ol64.grad.numpy(), rtol=2e-4, atol=2e-3)
     assert bad.sum() <= 1e-5 * bad.size + 1, int(bad.sum())
+
+
+@pytest.mark.parametrize('dtype,ftol', [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize('case', [
+    # B, Nc, fh, fw, H, Dh, qh, qw, P, Z
+    (2, 6, 8, 22, 8, 32, 30, 33, 8, 4),      # the BASELINE camera maps (176 pixels, 11 K-blocks)
+    (1, 3, 4, 6, 8, 32, 7, 9, 8, 4),         # 24 pixels: 2 K-blocks, one partial
+    (2, 2, 12, 16, 8, 32, 17, 20, 8, 2),     # 192 pixels: every K-block, both backward passes
+    (1, 1, 6, 9, 4, 32, 11, 13, 8, 8),       # one camera, 4 heads, Z = 8
+])
+@pytest.mark.parametrize('tiled', [True, False])
+def test_lift_camera_matrix_core_plan(case, dtype, ftol, tiled):
+    """Small per-camera maps with 16-bit data run the gather as an MFMA product against a
+    coefficient matrix built in LDS (bev_lift_cam.inl).  Inputs are made exactly representable, so
+    the forward differs from the fp64 oracle only by the rounding of the coefficients / the
+    output, and d(offsets), d(logits) — computed from f32 dot products — agree to f32 accuracy."""
+    from unibev_amd.functional import bev_lift
+    from unibev_amd._lib import lib, UBV_F16, UBV_BF16
+    B, Nc, fh, fw, H, Dh, qh, qw, P, Z = case
+    code = UBV_F16 if dtype == torch.float16 else UBV_BF16
+    assert lib().ubv_bev_lift_forward_workspace(B, Nc, fh, fw, H, Dh, P, code) > 0
+    value, offlog, ref, vis0, count, gout = make_case(case, 17, Nc > 1)
+    value = t(value).to(dtype).double().numpy()
+    gout = t(gout).to(dtype).double().numpy()
+    v64, ol64 = t(value).requires_grad_(), t(offlog).requires_grad_()
+    o_ref = oracle_lift(v64, ol64, t(ref), None if vis0 is None else t(vis0),
+                        None if count is None else t(count).double(), Nc, fh, fw, H, P)
+    o_ref.backward(t(gout))
+    v = t(value, dtype, DEV).requires_grad_()
+    ol = t(offlog, torch.float32, DEV).requires_grad_()
+    out = bev_lift(v, ol, t(ref, torch.float32, DEV), Nc, (fh, fw), H, P,
+                   vis0=None if vis0 is None else t(vis0, device=DEV),
+                   count=None if count is None else t(count, device=DEV),
+                   query_grid=(qh, qw) if tiled else None)
+    err = (out.float().cpu() - o_ref.detach().float()).abs().max() / o_ref.abs().max()
+    assert err < ftol, float(err)
+    out.backward(t(gout, dtype, DEV))
+    scale = np.abs(v64.grad.numpy()).max()
+    np.testing.assert_allclose(v.grad.float().cpu().numpy(), v64.grad.numpy(), rtol=2e-2, atol=2e-2 * scale)
+    bad = ~np.isclose(ol.grad.cpu().numpy(), ol64.grad.numpy(), rtol=2e-4, atol=1e-3)
+    assert bad.sum() <= 1e-5 * bad.size + 1, int(bad.sum())       # pixel-boundary discontinuities

@@ -75,12 +75,13 @@ def main():
             offlog = offlog.to(dtype)        # what the sampling_offsets Linear emits under autocast
         value.requires_grad_()
         offlog.requires_grad_()
+        lists = UF.compact_visible(vis0) if vis0 is not None else None
         for it in range(a.iters + 3):
             if it == 3:
                 UF.kernel_profile(True)
             out = UF.bev_lift(value, offlog, ref, Nc, (fh, fw), H, P, vis0=vis0, count=count,
                               query_grid=(qh, qw), ref_is_grid=is_grid,
-                              slot_center=None if a.no_center else center)
+                              slot_center=None if a.no_center else center, visible_lists=lists)
             out.backward(gout)
             value.grad = offlog.grad = None
         res = UF.kernel_profile()

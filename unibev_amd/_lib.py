@@ -24,10 +24,13 @@ SIGNATURES = {
     'ubv_profile_read': (c_int64, [c_char_p, c_int64]),
     'ubv_ms_deform_attn_forward': (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 9 + [_P]),
     'ubv_ms_deform_attn_backward': (c_int, [_P] * 9 + [c_int] * 9 + [_P]),
+    'ubv_bev_lift_forward_workspace': (c_int64, [c_int] * 8),
     'ubv_bev_lift_forward': (c_int, [_P, _P, c_int64, _P, c_int64, c_int, _P, _P, _P, _P]
-                             + [c_int] * 12 + [_P]),
+                             + [c_int] * 12 + [_P, c_int64, _P]),
     'ubv_bev_lift_backward': (c_int, [_P, _P, c_int64, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P,
-                                      _P, c_int64, _P, c_int64] + [c_int] * 13 + [_P, c_int64, _P]),
+                                      _P, c_int64, _P, c_int64] + [c_int] * 13 + [_P, _P, c_int64, _P]),
+    'ubv_visible_lists_elems': (c_int64, [c_int, c_int]),
+    'ubv_compact_visible': (c_int, [_P, c_int, c_int, _P, _P]),
     'ubv_bev_lift_backward_workspace': (c_int64, [c_int] * 11),
     'ubv_bev_lift_supported': (c_int, [c_int] * 4),
     'ubv_point_sampling': (c_int, [_P, _P, _P, _P, ctypes.POINTER(c_float), c_float, c_float,

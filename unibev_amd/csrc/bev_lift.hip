@@ -35,21 +35,29 @@ struct LiftArgs {
   const void* gout; float* gvalue; void* goff; long goff_stride; void* glog; long glog_stride;
   void* gvalue_lp;                               // final grad_value in the value's 16-bit type or null
   int B, Nc, fh, fw, H, Nq, Z, qw, qh, tiles_x, tiles_per_sample, total_tiles, chunk;
+  unsigned mg_tps, mg_tx;                        // multiply-high reciprocals of tiles_per_sample / tiles_x (0: divide)
   // GRID backward: sampling points binned by owner tile
   int* bin_cnt;                                  // [B,H,tiles] points appended per tile (may exceed cap)
   float4* bins;                                  // [B,H,tiles,cap] (x_pix, y_pix, w/count, query index)
   int cap;                                       // bucket capacity
   int* ovf_n; float4* ovf_rec; int* ovf_tile; int ovf_cap;   // the appends that did not fit
   int* cam_list; int* cam_n;                     // per-camera compacted visible queries or null
+  int ext_list;                                  // lists supplied by the caller (ubv_compact_visible)
   float* slab;                                   // CAMERA: per-chunk partial maps or null
 };
 
 // Decode (b, q, valid) of the query this lane works on in iteration `it`.
+// n / d through the host-made reciprocal mg = floor(2^32 / d) + 1 (exact while n * d < 2^32; the host
+// passes 0 otherwise): an integer division is ~40 instructions, this is one.
+__device__ __forceinline__ int div_mg(int n, int d, unsigned mg) {
+  return mg != 0u ? (int)__umulhi((unsigned)n, mg) : n / d;
+}
+
 __device__ __forceinline__ bool lift_query(const LiftArgs& a, int item, int li, int& b, int& q) {
-  b = item / a.tiles_per_sample;
+  b = div_mg(item, a.tiles_per_sample, a.mg_tps);
   const int tile = item - b * a.tiles_per_sample;
   if (a.qw > 0) {
-    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int ty = div_mg(tile, a.tiles_x, a.mg_tx), tx = tile - ty * a.tiles_x;
     const int qy = ty * 8 + (li >> 3), qx = tx * 8 + (li & 7);
     q = qy * a.qw + qx;
     return qy < a.qh && qx < a.qw;
@@ -81,9 +89,11 @@ __device__ __forceinline__ void softmax_row(const float (&l)[P], float (&w)[P]) 
 #pragma unroll
   for (int i = 1; i < P; ++i) m = fmaxf(m, l[i]);
   float s = 0.0f;
+  // FAST: v_exp_f32 on a pre-scaled argument and v_rcp_f32 (about 2 ulp of f32, invisible to 16-bit
+  // data) instead of expf's range reduction (~12 instructions each) and an IEEE division
 #pragma unroll
-  for (int i = 0; i < P; ++i) { w[i] = expf(l[i] - m); s += w[i]; }
-  const float inv = 1.0f / s;
+  for (int i = 0; i < P; ++i) { w[i] = FAST ? __expf(l[i] - m) : expf(l[i] - m); s += w[i]; }
+  const float inv = FAST ? __builtin_amdgcn_rcpf(s) : 1.0f / s;
 #pragma unroll
   for (int i = 0; i < P; ++i) w[i] = FAST ? w[i] * inv : w[i] / s;
 }
@@ -1036,6 +1046,8 @@ __global__ __launch_bounds__(256) void narrow_kernel(const float* __restrict__ s
   if (i < n) dst[i] = elem<T>::from_float(src[i]);
 }
 
+#include "bev_lift_cam.inl"
+
 // ---- dispatch ----------------------------------------------------------------------------------------
 // Algorithmic (compulsory) bytes of each kernel: every operand read once, every result written
 // once, gathers not counted.
@@ -1055,8 +1067,29 @@ static LiftBytes lift_bytes(const LiftArgs& a, int Dh, int P, int esize) {
   return b;
 }
 
+// CAMERA plan on the matrix cores (bev_lift_cam.inl): 16-bit data, Dh = 32, P = 8, maps of <= 192 pixels
+static bool cam_mfma_ok(const LiftArgs& a, int Dh, int P, int dtype) {
+  static const int env = getenv("UBV_CAM_MFMA") ? atoi(getenv("UBV_CAM_MFMA")) : 1;
+  return env != 0 && dtype != UBV_F32 && Dh == 32 && P == 8 && a.fh >= 1 && a.fw >= 1 && a.fh <= 13 &&
+         cam_kpad(a.fh, a.fw) <= 16 * kCamKbMax;
+}
+static size_t cam_vfrag_bytes(const LiftArgs& a) {
+  const size_t KB = cam_kpad(a.fh, a.fw) <= 14 * 16 ? 14 : 15;
+  return (size_t)a.B * a.Nc * a.H * KB * 64 * 16;
+}
+static CamArgs cam_args(const LiftArgs& a, const void* vfrag) {
+  CamArgs c{};
+  c.vfrag = vfrag;
+  c.KB = cam_kpad(a.fh, a.fw) <= 14 * 16 ? 14 : 15;       // 14 covers the 8x22 maps
+  c.witems = a.total_tiles * 2 * a.H;                      // a wave is half a tile for one head
+  c.chunk = (c.witems + 7) / 8;
+  c.fh1 = a.fh + 1;
+  return c;
+}
+
 template <typename T, int DH, int P>
-static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, hipStream_t st) {
+static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool cam_mfma, void* fwd_ws,
+                        hipStream_t st) {
   constexpr int VEC = 16 / elem<T>::kBytes;
   const int blocks = 8 * a.chunk;
   const LiftBytes nb = lift_bytes(a, DH, P, elem<T>::kBytes);
@@ -1068,6 +1101,24 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, hipS
   };
   if (bwd_mode < 0) {
     ProfScope ps(name("bev_lift_fwd"), st, nb.value + nb.offlog + nb.ref + nb.vis + nb.out);
+    if constexpr (DH == 32 && P == 8 && sizeof(T) == 2) {
+      if (cam_mfma) {
+        const CamArgs c = cam_args(a, fwd_ws);
+        const long nthreads = (long)a.B * a.Nc * a.H * c.KB * 64;
+        hipLaunchKernelGGL(value_frags_kernel<T>, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st,
+                           (const T*)a.value, (T*)fwd_ws, a.B * a.Nc, a.fh * a.fw, a.H, a.fh, a.fw, c.KB);
+        const size_t lds = (size_t)32 * (c.KB * 16 + 4) * sizeof(uint16_t);
+        const dim3 grid(8 * c.chunk), blk(64);
+        if (c.KB == 14) {
+          if (a.ol16) hipLaunchKernelGGL((lift_cam_fwd_kernel<T, 8, true, 14>), grid, blk, lds, st, a, c);
+          else hipLaunchKernelGGL((lift_cam_fwd_kernel<T, 8, false, 14>), grid, blk, lds, st, a, c);
+        } else {
+          if (a.ol16) hipLaunchKernelGGL((lift_cam_fwd_kernel<T, 8, true, 15>), grid, blk, lds, st, a, c);
+          else hipLaunchKernelGGL((lift_cam_fwd_kernel<T, 8, false, 15>), grid, blk, lds, st, a, c);
+        }
+        return;
+      }
+    }
     if (sizeof(T) == 2 && a.ol16)
       hipLaunchKernelGGL((lift_fwd_kernel<T, DH, VEC, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
     else
@@ -1119,8 +1170,9 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, hipS
     hipLaunchKernelGGL((lift_bwd_value_kernel<T, DH, P, RB>), dim3(8 * t.chunk), dim3(64 * t.waves),
                        lds, st, a, t);
   } else {
-    hipLaunchKernelGGL(compact_visible_kernel, dim3(a.Nc), dim3(1024), 0, st, a.vis0, a.Nq,
-                       a.cam_list, a.cam_n);
+    if (!a.ext_list)
+      hipLaunchKernelGGL(compact_visible_kernel, dim3(a.Nc), dim3(1024), 0, st, a.vis0, a.Nq,
+                         a.cam_list, a.cam_n);
     constexpr int RB = 6;
     const size_t lds = (size_t)t.waves * CamLds<T, DH, RB>::kWords * sizeof(uint16_t);
     {
@@ -1135,6 +1187,17 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, hipS
                          t.chunks, DH);
     }
     ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes);
+    if constexpr (DH == 32 && P == 8 && sizeof(T) == 2) {
+      if (cam_mfma) {
+        const CamArgs c = cam_args(a, nullptr);
+        const size_t lds = (size_t)32 * kCamDStr * sizeof(float);
+        if (a.ol16)
+          hipLaunchKernelGGL((lift_cam_bwd_query_kernel<T, 8, true>), dim3(8 * c.chunk), dim3(64), lds, st, a, c);
+        else
+          hipLaunchKernelGGL((lift_cam_bwd_query_kernel<T, 8, false>), dim3(8 * c.chunk), dim3(64), lds, st, a, c);
+        return;
+      }
+    }
     if (sizeof(T) == 2 && a.ol16)
       hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomNone, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
     else
@@ -1144,11 +1207,11 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, hipS
 
 template <typename T>
 static bool lift_dispatch_T(const LiftArgs& a, const TileArgs& t, int Dh, int P, int bwd_mode,
-                            hipStream_t st) {
-  if (Dh == 32 && P == 8) { lift_launch<T, 32, 8>(a, t, bwd_mode, st); return true; }
-  if (Dh == 32 && P == 4) { lift_launch<T, 32, 4>(a, t, bwd_mode, st); return true; }
-  if (Dh == 16 && P == 8) { lift_launch<T, 16, 8>(a, t, bwd_mode, st); return true; }
-  if (Dh == 16 && P == 4) { lift_launch<T, 16, 4>(a, t, bwd_mode, st); return true; }
+                            bool cam_mfma, void* fwd_ws, hipStream_t st) {
+  if (Dh == 32 && P == 8) { lift_launch<T, 32, 8>(a, t, bwd_mode, cam_mfma, fwd_ws, st); return true; }
+  if (Dh == 32 && P == 4) { lift_launch<T, 32, 4>(a, t, bwd_mode, cam_mfma, fwd_ws, st); return true; }
+  if (Dh == 16 && P == 8) { lift_launch<T, 16, 8>(a, t, bwd_mode, cam_mfma, fwd_ws, st); return true; }
+  if (Dh == 16 && P == 4) { lift_launch<T, 16, 4>(a, t, bwd_mode, cam_mfma, fwd_ws, st); return true; }
   return false;
 }
 
@@ -1265,6 +1328,12 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_g
   }
   a.total_tiles = a.B * a.tiles_per_sample;
   a.chunk = (a.total_tiles + 7) / 8;
+  auto magic = [](long nmax, int d) -> unsigned {
+    if (d <= 1 || nmax * (long)d >= (1L << 32)) return 0u;      // d == 1: plain division folds away
+    return (unsigned)((1UL << 32) / (unsigned long)d) + 1u;
+  };
+  a.mg_tps = magic(a.total_tiles, a.tiles_per_sample);
+  a.mg_tx = a.tiles_x > 0 ? magic(a.tiles_per_sample, a.tiles_x) : 0u;
   hipStream_t st = as_stream(stream);
   TileArgs t{};
   int mode = -1;
@@ -1289,8 +1358,10 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_g
       }
     }
     if (mode == kAtomNone) {
-      a.cam_list = (int*)ws;
-      a.cam_n = (int*)ws + (size_t)a.Nc * a.Nq;
+      if (!a.ext_list) {
+        a.cam_list = (int*)ws;
+        a.cam_n = (int*)ws + (size_t)a.Nc * a.Nq;
+      }
       a.slab = (float*)((char*)ws + lift_list_bytes(a));
     }
     if (mode == kAtomAll) {    // the owner-tile plans write every element of grad_value exactly once
@@ -1301,11 +1372,18 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_g
       }
     }
   }
+  // small per-camera maps: gather / dot products on the matrix cores (bev_lift_cam.inl)
+  bool cam_mfma = cam_mfma_ok(a, Dh, P, dtype) && (!bwd || mode == kAtomNone);
+  void* fwd_ws = nullptr;
+  if (cam_mfma && !bwd) {
+    if (ws != nullptr && ws_bytes >= (int64_t)cam_vfrag_bytes(a)) fwd_ws = ws;
+    else cam_mfma = false;                       // no scratch given: the gather kernel needs none
+  }
   bool ok = false;
   switch (dtype) {
-    case UBV_F32: ok = lift_dispatch_T<float>(a, t, Dh, P, mode, st); break;
-    case UBV_F16: ok = lift_dispatch_T<f16_t>(a, t, Dh, P, mode, st); break;
-    case UBV_BF16: ok = lift_dispatch_T<bf16_t>(a, t, Dh, P, mode, st); break;
+    case UBV_F32: ok = lift_dispatch_T<float>(a, t, Dh, P, mode, cam_mfma, fwd_ws, st); break;
+    case UBV_F16: ok = lift_dispatch_T<f16_t>(a, t, Dh, P, mode, cam_mfma, fwd_ws, st); break;
+    case UBV_BF16: ok = lift_dispatch_T<bf16_t>(a, t, Dh, P, mode, cam_mfma, fwd_ws, st); break;
   }
   if (!ok) { set_error("bev_lift: dispatch failed"); return UBV_ERR_UNSUPPORTED; }
   UBV_CHECK_LAUNCH(bwd ? "bev_lift_backward" : "bev_lift_forward");
@@ -1326,6 +1404,23 @@ extern "C" int64_t ubv_bev_lift_backward_workspace(int B, int Nc, int fh, int fw
   return (int64_t)ubv::lift_ws_bytes(mode, a, t, Dh, P);
 }
 
+extern "C" int64_t ubv_visible_lists_elems(int Nc, int Nq) { return (int64_t)Nc * Nq + Nc; }
+
+extern "C" int ubv_compact_visible(const uint8_t* vis0, int Nc, int Nq, int32_t* lists, void* stream) {
+  UBV_CHECK_ARG(lists != nullptr && Nc > 0 && Nq > 0, "compact_visible: bad arguments");
+  hipLaunchKernelGGL(ubv::compact_visible_kernel, dim3(Nc), dim3(1024), 0, ubv::as_stream(stream), vis0, Nq,
+                     lists, lists + (size_t)Nc * Nq);
+  UBV_CHECK_LAUNCH("compact_visible");
+  return UBV_OK;
+}
+
+extern "C" int64_t ubv_bev_lift_forward_workspace(int B, int Nc, int fh, int fw, int H, int Dh, int P,
+                                                  int dtype) {
+  ubv::LiftArgs a{};
+  a.B = B; a.Nc = Nc; a.fh = fh; a.fw = fw; a.H = H;
+  return ubv::cam_mfma_ok(a, Dh, P, dtype) ? (int64_t)ubv::cam_vfrag_bytes(a) : 0;
+}
+
 extern "C" int ubv_bev_lift_supported(int H, int Dh, int P, int dtype) {
   return ubv::lift_shape_ok(H, Dh, P, dtype) ? 1 : 0;
 }
@@ -1335,7 +1430,8 @@ extern "C" int ubv_bev_lift_forward(const void* value, const void* offsets, int6
                                     const float* ref,
                                     const uint8_t* vis0, const float* count, void* out, int B,
                                     int Nc, int fh, int fw, int H, int Dh, int Nq, int P, int Z,
-                                    int qgrid_w, int qgrid_h, int dtype, void* stream) {
+                                    int qgrid_w, int qgrid_h, int dtype, void* workspace,
+                                    int64_t workspace_bytes, void* stream) {
   UBV_CHECK_ARG(value && offsets && logits && ref && out, "bev_lift_forward: null pointer");
   UBV_CHECK_ARG(offlog_dtype == UBV_F32 || offlog_dtype == dtype,
                 "bev_lift: offlog_dtype %d must be f32 or equal dtype %d", offlog_dtype, dtype);
@@ -1345,7 +1441,7 @@ extern "C" int ubv_bev_lift_forward(const void* value, const void* offsets, int6
   a.log_stride = log_stride; a.ref = ref; a.vis0 = vis0; a.count = count; a.out = out;
   a.B = B; a.Nc = Nc; a.fh = fh; a.fw = fw; a.H = H; a.Nq = Nq; a.Z = Z; a.qw = qgrid_w;
   a.qh = qgrid_h;
-  return ubv::lift_run(a, Dh, P, dtype, false, 0, nullptr, 0, stream);
+  return ubv::lift_run(a, Dh, P, dtype, false, 0, workspace, workspace_bytes, stream);
 }
 
 extern "C" int ubv_bev_lift_backward(const void* value, const void* offsets, int64_t off_stride,
@@ -1356,7 +1452,8 @@ extern "C" int ubv_bev_lift_backward(const void* value, const void* offsets, int
                                      int64_t goff_stride, void* grad_logits, int64_t glog_stride,
                                      int B, int Nc, int fh,
                                      int fw, int H, int Dh, int Nq, int P, int Z, int qgrid_w,
-                                     int qgrid_h, int ref_is_grid, int dtype, void* workspace,
+                                     int qgrid_h, int ref_is_grid, int dtype,
+                                     const int32_t* visible_lists, void* workspace,
                                      int64_t workspace_bytes, void* stream) {
   UBV_CHECK_ARG(value && offsets && logits && ref && grad_out && grad_value && grad_offsets &&
                     grad_logits, "bev_lift_backward: null pointer");
@@ -1371,5 +1468,10 @@ extern "C" int ubv_bev_lift_backward(const void* value, const void* offsets, int
   a.glog_stride = glog_stride;
   a.B = B; a.Nc = Nc; a.fh = fh; a.fw = fw; a.H = H; a.Nq = Nq; a.Z = Z; a.qw = qgrid_w;
   a.qh = qgrid_h;
+  if (visible_lists != nullptr) {
+    a.ext_list = 1;
+    a.cam_list = const_cast<int*>(visible_lists);
+    a.cam_n = a.cam_list + (size_t)Nc * Nq;
+  }
   return ubv::lift_run(a, Dh, P, dtype, true, ref_is_grid, workspace, workspace_bytes, stream);
 }

@@ -28,7 +28,7 @@ struct GemmPlan {
 };
 
 static std::mutex g_gemm_mu;
-static hipblasLtHandle_t g_lt = nullptr;
+static std::map<int, hipblasLtHandle_t> g_lt;       // one handle per device (created under that device)
 static std::map<std::tuple<long, int, int, int, int, int>, GemmPlan> g_plans;
 constexpr size_t kGemmWorkspace = 32u << 20;
 
@@ -51,7 +51,11 @@ static GemmPlan* gemm_plan(long M, int N, int K, int dtype, int has_bias, int de
   auto it = g_plans.find(key);
   if (it != g_plans.end()) return it->second.ok ? &it->second : nullptr;
   GemmPlan& p = g_plans[key];
-  if (g_lt == nullptr) UBV_LT(hipblasLtCreate(&g_lt));
+  if (g_lt.find(device) == g_lt.end()) {
+    hipblasLtHandle_t hnd = nullptr;
+    UBV_LT(hipblasLtCreate(&hnd));
+    g_lt[device] = hnd;
+  }
   const hipDataType t = lt_type(dtype);
   UBV_LT(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
   const hipblasOperation_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
@@ -75,7 +79,7 @@ static GemmPlan* gemm_plan(long M, int N, int K, int dtype, int has_bias, int de
   hipblasLtMatmulHeuristicResult_t res[1];
   int found = 0;
   const hipblasStatus_t hs =
-      hipblasLtMatmulAlgoGetHeuristic(g_lt, p.desc, p.la, p.lb, p.lc, p.lc, pref, 1, res, &found);
+      hipblasLtMatmulAlgoGetHeuristic(g_lt[device], p.desc, p.la, p.lb, p.lc, p.lc, pref, 1, res, &found);
   hipblasLtMatmulPreferenceDestroy(pref);
   if (hs != HIPBLAS_STATUS_SUCCESS || found < 1) {
     set_error("linear_forward: no hipBLASLt algorithm for M=%ld N=%d K=%d dtype=%d (status %d)", M, N, K,
@@ -113,7 +117,7 @@ extern "C" int ubv_linear_forward(const void* x, const void* w, const void* bias
     if (s != HIPBLAS_STATUS_SUCCESS) { set_error("linear_forward: bias pointer (status %d)", (int)s); return UBV_ERR_LAUNCH; }
   }
   const float alpha = 1.0f, beta = 0.0f;
-  const hipblasStatus_t s = hipblasLtMatmul(g_lt, p->desc, &alpha, w, p->la, x, p->lb, &beta, y, p->lc, y,
+  const hipblasStatus_t s = hipblasLtMatmul(g_lt[device], p->desc, &alpha, w, p->la, x, p->lb, &beta, y, p->lc, y,
                                             p->lc, &p->algo, workspace, (size_t)workspace_bytes,
                                             as_stream(stream));
   if (s != HIPBLAS_STATUS_SUCCESS) {

@@ -35,12 +35,14 @@ struct bf16_t { uint16_t bits; };
 using f16_t = _Float16;
 
 __device__ __forceinline__ float bf16_bits_to_float(uint32_t b) { return __uint_as_float(b << 16); }
-__device__ __forceinline__ uint32_t float_to_bf16_bits(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);                                  // round to nearest even
-  return u >> 16;
+// f32 -> bf16, round to nearest even, NaN kept quiet: gfx950's v_cvt_pk_bf16_f32 (two values per
+// instruction; the software rounding is five VALU operations and a NaN branch per value).
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
 }
+__device__ __forceinline__ uint32_t float_to_bf16_bits(float f) { return cvt_pk_bf16(f, f) & 0xffffu; }
 
 template <typename T> struct elem;
 template <> struct elem<float> {
@@ -118,8 +120,7 @@ template <> struct vec_io<bf16_t, 8> {
   static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
     uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      w[i] = float_to_bf16_bits(v[2 * i]) | (float_to_bf16_bits(v[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = cvt_pk_bf16(v[2 * i], v[2 * i + 1]);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
   }
 };
@@ -131,8 +132,8 @@ template <> struct vec_io<bf16_t, 4> {
   }
   static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
     uint2 t;
-    t.x = float_to_bf16_bits(v[0]) | (float_to_bf16_bits(v[1]) << 16);
-    t.y = float_to_bf16_bits(v[2]) | (float_to_bf16_bits(v[3]) << 16);
+    t.x = cvt_pk_bf16(v[0], v[1]);
+    t.y = cvt_pk_bf16(v[2], v[3]);
     *reinterpret_cast<uint2*>(p) = t;
   }
 };

@@ -81,11 +81,37 @@ def _dt(t):
         raise TypeError(f'unsupported dtype {t.dtype}; expected float32, float16 or bfloat16')
 
 
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
 def _need_cuda(*tensors):
+    """Validates that every given tensor lives on ONE HIP device and returns a context manager that
+    makes it the current device for the duration of the launch (the kernels launch on the current
+    device and ``_stream()`` reads the current device's stream, like mmcv's CUDAGuard on
+    ``tensor.device()``).  A no-op object when that device already is current."""
+    idx = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError('unibev_amd ops run on the GPU only (got a CPU tensor); '
                                'there is no CPU fallback')
+        if idx is None:
+            idx = t.device.index
+        elif t.device.index != idx:
+            raise RuntimeError(f'unibev_amd op: operands on different devices (cuda:{idx} and '
+                               f'cuda:{t.device.index})')
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(idx)
 
 
 def _p(t):
@@ -93,8 +119,9 @@ def _p(t):
 
 
 def _stream():
-    # raw handle of torch's current stream (no Stream object per launch: the step is host-bound in
-    # its forward half, every microsecond per call shows)
+    # raw handle of torch's current stream on the CURRENT device — every op enters the guard
+    # returned by _need_cuda first, so that is the operands' device (no Stream object per launch:
+    # the step is host-bound in its forward half, every microsecond per call shows)
     return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
@@ -109,48 +136,49 @@ class MultiScaleDeformableAttnFunction(Function):
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
                 attention_weights, im2col_step=64):
-        _need_cuda(value, value_spatial_shapes, value_level_start_index, sampling_locations,
-                   attention_weights)
-        B, S, H, Dh = value.shape
-        _, Nq, H2, L, P, two = sampling_locations.shape
-        if H2 != H or two != 2 or attention_weights.shape != (B, Nq, H, L, P):
-            raise ValueError('ms_deform_attn: inconsistent shapes '
-                             f'{tuple(value.shape)} {tuple(sampling_locations.shape)} '
-                             f'{tuple(attention_weights.shape)}')
-        value = value.contiguous()
-        ss = value_spatial_shapes.to(torch.int64).contiguous()
-        ls = value_level_start_index.to(torch.int64).contiguous()
-        loc = sampling_locations.float().contiguous()
-        aw = attention_weights.float().contiguous()
-        out = torch.empty(B, Nq, H * Dh, dtype=value.dtype, device=value.device)
-        with _timed('k1_fwd'):
-            check(lib().ubv_ms_deform_attn_forward(_p(value), _p(ss), _p(ls), _p(loc), _p(aw),
-                                                   _p(out), B, S, H, Dh, L, Nq, P, _dt(value),
-                                                   int(im2col_step), _stream()),
-                  'ms_deform_attn_forward')
-        ctx.save_for_backward(value, ss, ls, loc, aw)
-        ctx.im2col_step = int(im2col_step)
-        ctx.in_dtypes = (sampling_locations.dtype, attention_weights.dtype)
-        return out
+        with _need_cuda(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                   attention_weights):
+            B, S, H, Dh = value.shape
+            _, Nq, H2, L, P, two = sampling_locations.shape
+            if H2 != H or two != 2 or attention_weights.shape != (B, Nq, H, L, P):
+                raise ValueError('ms_deform_attn: inconsistent shapes '
+                                 f'{tuple(value.shape)} {tuple(sampling_locations.shape)} '
+                                 f'{tuple(attention_weights.shape)}')
+            value = value.contiguous()
+            ss = value_spatial_shapes.to(torch.int64).contiguous()
+            ls = value_level_start_index.to(torch.int64).contiguous()
+            loc = sampling_locations.float().contiguous()
+            aw = attention_weights.float().contiguous()
+            out = torch.empty(B, Nq, H * Dh, dtype=value.dtype, device=value.device)
+            with _timed('k1_fwd'):
+                check(lib().ubv_ms_deform_attn_forward(_p(value), _p(ss), _p(ls), _p(loc), _p(aw),
+                                                       _p(out), B, S, H, Dh, L, Nq, P, _dt(value),
+                                                       int(im2col_step), _stream()),
+                      'ms_deform_attn_forward')
+            ctx.save_for_backward(value, ss, ls, loc, aw)
+            ctx.im2col_step = int(im2col_step)
+            ctx.in_dtypes = (sampling_locations.dtype, attention_weights.dtype)
+            return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
-        value, ss, ls, loc, aw = ctx.saved_tensors
-        B, S, H, Dh = value.shape
-        _, Nq, _, L, P, _ = loc.shape
-        go = grad_output.to(value.dtype).contiguous()
-        gv = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
-        gloc = torch.empty_like(loc)
-        gaw = torch.empty_like(aw)
-        with _timed('k1_bwd'):
-            check(lib().ubv_ms_deform_attn_backward(_p(value), _p(ss), _p(ls), _p(loc), _p(aw),
-                                                    _p(go), _p(gv), _p(gloc), _p(gaw), B, S, H, Dh,
-                                                    L, Nq, P, _dt(value), ctx.im2col_step,
-                                                    _stream()),
-                  'ms_deform_attn_backward')
-        return (gv.to(value.dtype), None, None, gloc.to(ctx.in_dtypes[0]),
-                gaw.to(ctx.in_dtypes[1]), None)
+        with _need_cuda(grad_output):
+            value, ss, ls, loc, aw = ctx.saved_tensors
+            B, S, H, Dh = value.shape
+            _, Nq, _, L, P, _ = loc.shape
+            go = grad_output.to(value.dtype).contiguous()
+            gv = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
+            gloc = torch.empty_like(loc)
+            gaw = torch.empty_like(aw)
+            with _timed('k1_bwd'):
+                check(lib().ubv_ms_deform_attn_backward(_p(value), _p(ss), _p(ls), _p(loc), _p(aw),
+                                                        _p(go), _p(gv), _p(gloc), _p(gaw), B, S, H, Dh,
+                                                        L, Nq, P, _dt(value), ctx.im2col_step,
+                                                        _stream()),
+                      'ms_deform_attn_backward')
+            return (gv.to(value.dtype), None, None, gloc.to(ctx.in_dtypes[0]),
+                    gaw.to(ctx.in_dtypes[1]), None)
 
 
 def ms_deform_attn(value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
@@ -167,62 +195,80 @@ def bev_lift_supported(num_heads, head_dim, num_points, dtype):
 
 class _BevLift(Function):
     @staticmethod
-    def forward(ctx, value, offlog, ref, vis0, count, center, geom):
+    def forward(ctx, value, offlog, ref, vis0, count, center, lists, geom):
         B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh, grid = geom
-        _need_cuda(value, offlog, ref, vis0, count, center)
-        value = value.contiguous()
-        # the kernels read offsets / logits as f32 or in the value's own 16-bit type (autocast)
-        lowp = value.dtype != torch.float32 and offlog.dtype == value.dtype
-        ol = (offlog if lowp else offlog.float()).contiguous()
-        ref = ref.float().contiguous()
-        row = H * P * 3
-        assert ol.shape[-1] == row and ol.numel() == B * Nq * row
-        assert value.numel() == B * Nc * fh * fw * H * Dh
-        assert ref.numel() == Nc * B * Nq * Z * 2
-        out = torch.empty(B, Nq, H * Dh, dtype=value.dtype, device=value.device)
-        base = ol.data_ptr()
-        with _timed('lift_fwd', (geom, value.element_size())):
-            check(lib().ubv_bev_lift_forward(
-                _p(value), ctypes.c_void_p(base), row,
-                ctypes.c_void_p(base + H * P * 2 * ol.element_size()), row, _dt(ol),
-                _p(ref), _p(vis0), _p(count), _p(out), B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh,
-                _dt(value), _stream()), 'bev_lift_forward')
-        if center is not None:
-            center = center.detach().float().contiguous()
-            assert center.numel() == H * P * 2
-        ctx.save_for_backward(value, ol, ref, vis0, count, center)
-        ctx.geom = geom
-        ctx.ol_dtype = offlog.dtype
-        return out
+        with _need_cuda(value, offlog, ref, vis0, count, center, lists):
+            value = value.contiguous()
+            # the kernels read offsets / logits as f32 or in the value's own 16-bit type (autocast)
+            lowp = value.dtype != torch.float32 and offlog.dtype == value.dtype
+            ol = (offlog if lowp else offlog.float()).contiguous()
+            ref = ref.float().contiguous()
+            row = H * P * 3
+            assert ol.shape[-1] == row and ol.numel() == B * Nq * row
+            assert value.numel() == B * Nc * fh * fw * H * Dh
+            assert ref.numel() == Nc * B * Nq * Z * 2
+            out = torch.empty(B, Nq, H * Dh, dtype=value.dtype, device=value.device)
+            base = ol.data_ptr()
+            nws = lib().ubv_bev_lift_forward_workspace(B, Nc, fh, fw, H, Dh, P, _dt(value))
+            ws = _workspace(nws, value.device) if nws > 0 else None
+            with _timed('lift_fwd', (geom, value.element_size())):
+                check(lib().ubv_bev_lift_forward(
+                    _p(value), ctypes.c_void_p(base), row,
+                    ctypes.c_void_p(base + H * P * 2 * ol.element_size()), row, _dt(ol),
+                    _p(ref), _p(vis0), _p(count), _p(out), B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh,
+                    _dt(value), _p(ws), int(nws), _stream()), 'bev_lift_forward')
+            if center is not None:
+                center = center.detach().float().contiguous()
+                assert center.numel() == H * P * 2
+            ctx.save_for_backward(value, ol, ref, vis0, count, center, lists)
+            ctx.geom = geom
+            ctx.ol_dtype = offlog.dtype
+            return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
-        value, ol, ref, vis0, count, center = ctx.saved_tensors
-        B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh, grid = ctx.geom
-        row = H * P * 3
-        go = grad_output.to(value.dtype).contiguous()
-        # f32 accumulation map; with 16-bit data the kernels round it once into gv_lp themselves
-        gv = torch.empty(value.shape, dtype=torch.float32, device=value.device)
-        gv_lp = torch.empty_like(value) if value.dtype != torch.float32 else None
-        gol = torch.empty_like(ol)
-        base, gbase = ol.data_ptr(), gol.data_ptr()
-        off2 = H * P * 2 * ol.element_size()
-        nws = lib().ubv_bev_lift_backward_workspace(B, Nc, fh, fw, H, Dh, Nq, P, qw, qh, int(grid))
-        ws = _workspace(nws, value.device) if nws > 0 else None
-        with _timed('lift_bwd', (ctx.geom, value.element_size())):
-            check(lib().ubv_bev_lift_backward(
-                _p(value), ctypes.c_void_p(base), row, ctypes.c_void_p(base + off2), row, _dt(ol),
-                _p(ref), _p(vis0), _p(count), _p(center), _p(go), _p(gv), _p(gv_lp),
-                ctypes.c_void_p(gbase), row, ctypes.c_void_p(gbase + off2), row,
-                B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh,
-                int(grid), _dt(value), _p(ws), int(nws), _stream()), 'bev_lift_backward')
-        gvalue = gv_lp if gv_lp is not None else gv
-        return gvalue, gol.to(ctx.ol_dtype), None, None, None, None, None
+        with _need_cuda(grad_output):
+            value, ol, ref, vis0, count, center, lists = ctx.saved_tensors
+            B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh, grid = ctx.geom
+            row = H * P * 3
+            go = grad_output.to(value.dtype).contiguous()
+            # f32 accumulation map; with 16-bit data the kernels round it once into gv_lp themselves
+            gv = torch.empty(value.shape, dtype=torch.float32, device=value.device)
+            gv_lp = torch.empty_like(value) if value.dtype != torch.float32 else None
+            gol = torch.empty_like(ol)
+            base, gbase = ol.data_ptr(), gol.data_ptr()
+            off2 = H * P * 2 * ol.element_size()
+            nws = lib().ubv_bev_lift_backward_workspace(B, Nc, fh, fw, H, Dh, Nq, P, qw, qh, int(grid))
+            ws = _workspace(nws, value.device) if nws > 0 else None
+            with _timed('lift_bwd', (ctx.geom, value.element_size())):
+                check(lib().ubv_bev_lift_backward(
+                    _p(value), ctypes.c_void_p(base), row, ctypes.c_void_p(base + off2), row, _dt(ol),
+                    _p(ref), _p(vis0), _p(count), _p(center), _p(go), _p(gv), _p(gv_lp),
+                    ctypes.c_void_p(gbase), row, ctypes.c_void_p(gbase + off2), row,
+                    B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh,
+                    int(grid), _dt(value), _p(lists), _p(ws), int(nws), _stream()),
+                      'bev_lift_backward')
+            gvalue = gv_lp if gv_lp is not None else gv
+            return gvalue, gol.to(ctx.ol_dtype), None, None, None, None, None, None
+
+
+@torch.no_grad()
+def compact_visible(vis0):
+    """Per-camera ordered lists of the visible queries (``ubv_compact_visible``): int32
+    [Nc*Nq + Nc], list of camera c at [c*Nq, c*Nq + n_c), the counts n_c at the end.  They depend on
+    the visibility alone: one compaction per forward pass serves every layer's backward."""
+    with _need_cuda(vis0):
+        Nc, Nq = vis0.shape
+        lists = torch.empty(int(lib().ubv_visible_lists_elems(Nc, Nq)), dtype=torch.int32,
+                            device=vis0.device)
+        check(lib().ubv_compact_visible(_p(vis0.contiguous()), Nc, Nq, _p(lists), _stream()),
+              'compact_visible')
+        return lists
 
 
 def bev_lift(value, offlog, ref, num_cams, feat_hw, num_heads, num_points, vis0=None, count=None,
-             query_grid=None, ref_is_grid=False, slot_center=None):
+             query_grid=None, ref_is_grid=False, slot_center=None, visible_lists=None):
     """Fused single-level BEV query lifting (``ubv_bev_lift_forward``).
 
     value  (B*num_cams, fh*fw, C)  projected features, batch-major / camera-minor
@@ -233,6 +279,7 @@ def bev_lift(value, offlog, ref, num_cams, feat_hw, num_heads, num_points, vis0=
     query_grid (qh, qw)            BEV grid the Nq queries form (tiling / owner-tile backward)
     ref_is_grid                    ref is exactly that grid's cell centres (and num_cams == 1)
     slot_center (H*P*2,)           accepted for API stability; the bins plan ignores it
+    visible_lists                  ``compact_visible(vis0)`` or None (compacted per backward then)
     """
     fh, fw = feat_hw
     BNc, S, C = value.shape[0], value.shape[1], value.shape[-1] if value.dim() == 3 else None
@@ -245,7 +292,7 @@ def bev_lift(value, offlog, ref, num_cams, feat_hw, num_heads, num_points, vis0=
     qw, qh = (query_grid[1], query_grid[0]) if query_grid is not None else (0, 0)
     grid = bool(ref_is_grid) and num_cams == 1 and qw > 0
     geom = (B, num_cams, fh, fw, num_heads, Dh, Nq, num_points, Z, qw, qh, grid)
-    return _BevLift.apply(value, offlog, ref, vis0, count, slot_center, geom)
+    return _BevLift.apply(value, offlog, ref, vis0, count, slot_center, visible_lists, geom)
 
 
 # ----------------------------------------------------------------------------------------------- geometry
@@ -257,57 +304,58 @@ def point_sampling(lidar2img, xs, ys, zs, pc_range, img_hw):
     Returns reference_points_cam (Nc,B,Nq,D,2) f32, bev_mask (Nc,B,Nq,D) bool, vis0 (Nc,Nq) uint8,
     count (B,Nq) f32.
     """
-    _need_cuda(lidar2img, xs, ys, zs)
-    B, Nc = lidar2img.shape[:2]
-    W, H, D = xs.numel(), ys.numel(), zs.numel()
-    Nq = H * W
-    dev = lidar2img.device
-    l2i = lidar2img.float().contiguous()
-    ref_cam = torch.empty(Nc, B, Nq, D, 2, dtype=torch.float32, device=dev)
-    mask = torch.empty(Nc, B, Nq, D, dtype=torch.uint8, device=dev)
-    vis0 = torch.empty(Nc, Nq, dtype=torch.uint8, device=dev)
-    count = torch.empty(B, Nq, dtype=torch.float32, device=dev)
-    check(lib().ubv_point_sampling(_p(l2i), _p(xs), _p(ys), _p(zs), _lib.float_array(pc_range),
-                                   float(img_hw[0]), float(img_hw[1]), _p(ref_cam), _p(mask),
-                                   _p(vis0), _p(count), B, Nc, H, W, D, _stream()),
-          'point_sampling')
-    return ref_cam, mask.view(torch.bool), vis0, count
+    with _need_cuda(lidar2img, xs, ys, zs):
+        B, Nc = lidar2img.shape[:2]
+        W, H, D = xs.numel(), ys.numel(), zs.numel()
+        Nq = H * W
+        dev = lidar2img.device
+        l2i = lidar2img.float().contiguous()
+        ref_cam = torch.empty(Nc, B, Nq, D, 2, dtype=torch.float32, device=dev)
+        mask = torch.empty(Nc, B, Nq, D, dtype=torch.uint8, device=dev)
+        vis0 = torch.empty(Nc, Nq, dtype=torch.uint8, device=dev)
+        count = torch.empty(B, Nq, dtype=torch.float32, device=dev)
+        check(lib().ubv_point_sampling(_p(l2i), _p(xs), _p(ys), _p(zs), _lib.float_array(pc_range),
+                                       float(img_hw[0]), float(img_hw[1]), _p(ref_cam), _p(mask),
+                                       _p(vis0), _p(count), B, Nc, H, W, D, _stream()),
+              'point_sampling')
+        return ref_cam, mask.view(torch.bool), vis0, count
 
 
 # ----------------------------------------------------------------------------------------------- flatten
 class _FlattenEmbed(Function):
     @staticmethod
     def forward(ctx, feat, embA, embB):
-        _need_cuda(feat, embA, embB)
-        N, C, HW = feat.shape
-        feat = feat.contiguous()
-        a = None if embA is None else embA.float().contiguous()
-        b = None if embB is None else embB.float().contiguous()
-        out = torch.empty(N, HW, C, dtype=feat.dtype, device=feat.device)
-        groups = 1 if a is None else a.shape[0]
-        check(lib().ubv_flatten_embed_forward(_p(feat), _p(a), groups, _p(b), _p(out), N, C, HW,
-                                              _dt(feat), _stream()), 'flatten_embed_forward')
-        ctx.groups = groups
-        ctx.has = (embA is not None, embB is not None)
-        ctx.emb_dtypes = (None if embA is None else embA.dtype, None if embB is None else embB.dtype)
-        return out
+        with _need_cuda(feat, embA, embB):
+            N, C, HW = feat.shape
+            feat = feat.contiguous()
+            a = None if embA is None else embA.float().contiguous()
+            b = None if embB is None else embB.float().contiguous()
+            out = torch.empty(N, HW, C, dtype=feat.dtype, device=feat.device)
+            groups = 1 if a is None else a.shape[0]
+            check(lib().ubv_flatten_embed_forward(_p(feat), _p(a), groups, _p(b), _p(out), N, C, HW,
+                                                  _dt(feat), _stream()), 'flatten_embed_forward')
+            ctx.groups = groups
+            ctx.has = (embA is not None, embB is not None)
+            ctx.emb_dtypes = (None if embA is None else embA.dtype, None if embB is None else embB.dtype)
+            return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out):
-        N, HW, C = grad_out.shape
-        go = grad_out.contiguous()
-        gin = torch.empty(N, C, HW, dtype=go.dtype, device=go.device)
-        need_emb = (ctx.has[0] and ctx.needs_input_grad[1]) or (ctx.has[1] and ctx.needs_input_grad[2])
-        gemb = torch.zeros(N, C, dtype=torch.float32, device=go.device) if need_emb else None
-        check(lib().ubv_flatten_embed_backward(_p(go), _p(gin), _p(gemb), N, C, HW, _dt(go),
-                                               _stream()), 'flatten_embed_backward')
-        ga = gb = None
-        if ctx.has[0] and ctx.needs_input_grad[1]:
-            ga = gemb.view(N // ctx.groups, ctx.groups, C).sum(0).to(ctx.emb_dtypes[0])
-        if ctx.has[1] and ctx.needs_input_grad[2]:
-            gb = gemb.sum(0).to(ctx.emb_dtypes[1])
-        return gin, ga, gb
+        with _need_cuda(grad_out):
+            N, HW, C = grad_out.shape
+            go = grad_out.contiguous()
+            gin = torch.empty(N, C, HW, dtype=go.dtype, device=go.device)
+            need_emb = (ctx.has[0] and ctx.needs_input_grad[1]) or (ctx.has[1] and ctx.needs_input_grad[2])
+            gemb = torch.zeros(N, C, dtype=torch.float32, device=go.device) if need_emb else None
+            check(lib().ubv_flatten_embed_backward(_p(go), _p(gin), _p(gemb), N, C, HW, _dt(go),
+                                                   _stream()), 'flatten_embed_backward')
+            ga = gb = None
+            if ctx.has[0] and ctx.needs_input_grad[1]:
+                ga = gemb.view(N // ctx.groups, ctx.groups, C).sum(0).to(ctx.emb_dtypes[0])
+            if ctx.has[1] and ctx.needs_input_grad[2]:
+                gb = gemb.sum(0).to(ctx.emb_dtypes[1])
+            return gin, ga, gb
 
 
 def flatten_embed(feat, embA=None, embB=None):
@@ -320,50 +368,51 @@ class _BevFuse(Function):
     @staticmethod
     def forward(ctx, img, pts, cw_img, cw_pts, sw_img, sw_pts, cat):
         ref = img if img is not None else pts
-        _need_cuda(ref, cw_img, cw_pts)
-        B, Nq, C = ref.shape
-        img_c = None if img is None else img.contiguous()
-        pts_c = None if pts is None else pts.to(ref.dtype).contiguous()
-        cwi, cwp = cw_img.float().contiguous(), cw_pts.float().contiguous()
-        swi = None if sw_img is None else sw_img.float().contiguous()
-        swp = None if sw_pts is None else sw_pts.float().contiguous()
-        out = torch.empty(Nq, B, C * (2 if cat else 1), dtype=ref.dtype, device=ref.device)
-        check(lib().ubv_bev_fuse_forward(_p(img_c), _p(pts_c), _p(cwi), _p(cwp), _p(swi), _p(swp),
-                                         _p(out), B, Nq, C, int(cat), _dt(ref), _stream()),
-              'bev_fuse_forward')
-        ctx.save_for_backward(img_c, pts_c, cwi, cwp, swi, swp)
-        ctx.cat = int(cat)
-        ctx.shape = (B, Nq, C)
-        ctx.dt = (cw_img.dtype, cw_pts.dtype, None if sw_img is None else sw_img.dtype,
-                  None if sw_pts is None else sw_pts.dtype)
-        return out
+        with _need_cuda(ref, cw_img, cw_pts):
+            B, Nq, C = ref.shape
+            img_c = None if img is None else img.contiguous()
+            pts_c = None if pts is None else pts.to(ref.dtype).contiguous()
+            cwi, cwp = cw_img.float().contiguous(), cw_pts.float().contiguous()
+            swi = None if sw_img is None else sw_img.float().contiguous()
+            swp = None if sw_pts is None else sw_pts.float().contiguous()
+            out = torch.empty(Nq, B, C * (2 if cat else 1), dtype=ref.dtype, device=ref.device)
+            check(lib().ubv_bev_fuse_forward(_p(img_c), _p(pts_c), _p(cwi), _p(cwp), _p(swi), _p(swp),
+                                             _p(out), B, Nq, C, int(cat), _dt(ref), _stream()),
+                  'bev_fuse_forward')
+            ctx.save_for_backward(img_c, pts_c, cwi, cwp, swi, swp)
+            ctx.cat = int(cat)
+            ctx.shape = (B, Nq, C)
+            ctx.dt = (cw_img.dtype, cw_pts.dtype, None if sw_img is None else sw_img.dtype,
+                      None if sw_pts is None else sw_pts.dtype)
+            return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out):
-        img, pts, cwi, cwp, swi, swp = ctx.saved_tensors
-        B, Nq, C = ctx.shape
-        ref = img if img is not None else pts
-        go = grad_out.to(ref.dtype).contiguous()
-        gimg = torch.empty_like(img) if (img is not None and ctx.needs_input_grad[0]) else None
-        gpts = torch.empty_like(pts) if (pts is not None and ctx.needs_input_grad[1]) else None
-        need_cw = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
-        need_sw = (swi is not None and ctx.needs_input_grad[4]) or \
-                  (swp is not None and ctx.needs_input_grad[5])
-        gcw = torch.zeros(2, C, dtype=torch.float32, device=go.device) if need_cw else None
-        gsw = torch.zeros(2, Nq, dtype=torch.float32, device=go.device) if need_sw else None
-        check(lib().ubv_bev_fuse_backward(_p(go), _p(img), _p(pts), _p(cwi), _p(cwp), _p(swi),
-                                          _p(swp), _p(gimg), _p(gpts), _p(gcw), _p(gsw), B, Nq, C,
-                                          ctx.cat, _dt(ref), _stream()), 'bev_fuse_backward')
-        g = [gimg, gpts, None, None, None, None, None]
-        if need_cw:
-            g[2], g[3] = gcw[0].to(ctx.dt[0]), gcw[1].to(ctx.dt[1])
-        if need_sw:
-            if swi is not None:
-                g[4] = gsw[0].to(ctx.dt[2])
-            if swp is not None:
-                g[5] = gsw[1].to(ctx.dt[3])
-        return tuple(g)
+        with _need_cuda(grad_out):
+            img, pts, cwi, cwp, swi, swp = ctx.saved_tensors
+            B, Nq, C = ctx.shape
+            ref = img if img is not None else pts
+            go = grad_out.to(ref.dtype).contiguous()
+            gimg = torch.empty_like(img) if (img is not None and ctx.needs_input_grad[0]) else None
+            gpts = torch.empty_like(pts) if (pts is not None and ctx.needs_input_grad[1]) else None
+            need_cw = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+            need_sw = (swi is not None and ctx.needs_input_grad[4]) or \
+                      (swp is not None and ctx.needs_input_grad[5])
+            gcw = torch.zeros(2, C, dtype=torch.float32, device=go.device) if need_cw else None
+            gsw = torch.zeros(2, Nq, dtype=torch.float32, device=go.device) if need_sw else None
+            check(lib().ubv_bev_fuse_backward(_p(go), _p(img), _p(pts), _p(cwi), _p(cwp), _p(swi),
+                                              _p(swp), _p(gimg), _p(gpts), _p(gcw), _p(gsw), B, Nq, C,
+                                              ctx.cat, _dt(ref), _stream()), 'bev_fuse_backward')
+            g = [gimg, gpts, None, None, None, None, None]
+            if need_cw:
+                g[2], g[3] = gcw[0].to(ctx.dt[0]), gcw[1].to(ctx.dt[1])
+            if need_sw:
+                if swi is not None:
+                    g[4] = gsw[0].to(ctx.dt[2])
+                if swp is not None:
+                    g[5] = gsw[1].to(ctx.dt[3])
+            return tuple(g)
 
 
 def bev_fuse(img, pts, cw_img, cw_pts, sw_img=None, sw_pts=None, cat=False):
@@ -394,51 +443,52 @@ def _next_seed():
 class _AddDropoutNorm(Function):
     @staticmethod
     def forward(ctx, x, identity, gamma, beta, p, eps):
-        _need_cuda(x, identity, gamma, beta)
-        C = x.shape[-1]
-        x2 = x.reshape(-1, C).contiguous()
-        # residual stream: f32, or the branch's own 16-bit type when the caller keeps it there
-        lowp = x2.dtype != torch.float32 and identity.dtype == x2.dtype
-        sdt = x2.dtype if lowp else torch.float32
-        id2 = identity.reshape(-1, C).to(sdt).contiguous()
-        R = x2.shape[0]
-        g, b = gamma.float().contiguous(), beta.float().contiguous()
-        y = torch.empty(R, C, dtype=sdt, device=x.device)
-        mean = torch.empty(R, dtype=torch.float32, device=x.device)
-        rstd = torch.empty(R, dtype=torch.float32, device=x.device)
-        # seed from torch's CPU generator: reproducible under torch.manual_seed, no device sync
-        seed = _next_seed() if p > 0 else 0
-        check(lib().ubv_add_dropout_layernorm_forward(_p(x2), _p(id2), _p(g), _p(b), _p(y), _p(mean),
-                                                      _p(rstd), R, C, float(eps), float(p), seed,
-                                                      _dt(x2), _DT[sdt], _stream()),
-              'add_dropout_layernorm_forward')
-        ctx.save_for_backward(x2, id2, g, mean, rstd)
-        ctx.p, ctx.seed, ctx.shape = float(p), seed, x.shape
-        ctx.dts = (identity.dtype, gamma.dtype, beta.dtype)
-        return y.view(x.shape)
+        with _need_cuda(x, identity, gamma, beta):
+            C = x.shape[-1]
+            x2 = x.reshape(-1, C).contiguous()
+            # residual stream: f32, or the branch's own 16-bit type when the caller keeps it there
+            lowp = x2.dtype != torch.float32 and identity.dtype == x2.dtype
+            sdt = x2.dtype if lowp else torch.float32
+            id2 = identity.reshape(-1, C).to(sdt).contiguous()
+            R = x2.shape[0]
+            g, b = gamma.float().contiguous(), beta.float().contiguous()
+            y = torch.empty(R, C, dtype=sdt, device=x.device)
+            mean = torch.empty(R, dtype=torch.float32, device=x.device)
+            rstd = torch.empty(R, dtype=torch.float32, device=x.device)
+            # seed from torch's CPU generator: reproducible under torch.manual_seed, no device sync
+            seed = _next_seed() if p > 0 else 0
+            check(lib().ubv_add_dropout_layernorm_forward(_p(x2), _p(id2), _p(g), _p(b), _p(y), _p(mean),
+                                                          _p(rstd), R, C, float(eps), float(p), seed,
+                                                          _dt(x2), _DT[sdt], _stream()),
+                  'add_dropout_layernorm_forward')
+            ctx.save_for_backward(x2, id2, g, mean, rstd)
+            ctx.p, ctx.seed, ctx.shape = float(p), seed, x.shape
+            ctx.dts = (identity.dtype, gamma.dtype, beta.dtype)
+            return y.view(x.shape)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_y):
-        x2, id2, g, mean, rstd = ctx.saved_tensors
-        R, C = x2.shape
-        gy = grad_y.reshape(R, C).to(id2.dtype).contiguous()
-        gx = torch.empty_like(x2)
-        gid = torch.empty_like(id2)
-        dg, db = zeros_f32(C, x2.device), zeros_f32(C, x2.device)
-        dxs = zeros_f32(C, x2.device)
-        check(lib().ubv_add_dropout_layernorm_backward(_p(gy), _p(x2), _p(id2), _p(g), _p(mean),
-                                                       _p(rstd), _p(gx), _p(gid), _p(dg), _p(db),
-                                                       _p(dxs), R, C, ctx.p, ctx.seed, _dt(x2),
-                                                       _dt(id2), _stream()),
-              'add_dropout_layernorm_backward')
-        gx = gx.view(ctx.shape)
-        # column sums of grad_x ride along: if x came straight out of a Linear, its backward takes
-        # them as the bias gradient instead of reducing grad_x again (linear._Linear.backward)
-        gx._ubv_colsum = dxs
-        gid = gid.view(ctx.shape).to(ctx.dts[0])
-        gid._ubv_owned = True         # fresh, single consumer: linear._Linear may accumulate into it
-        return (gx, gid, dg.to(ctx.dts[1]), db.to(ctx.dts[2]), None, None)
+        with _need_cuda(grad_y):
+            x2, id2, g, mean, rstd = ctx.saved_tensors
+            R, C = x2.shape
+            gy = grad_y.reshape(R, C).to(id2.dtype).contiguous()
+            gx = torch.empty_like(x2)
+            gid = torch.empty_like(id2)
+            dg, db = zeros_f32(C, x2.device), zeros_f32(C, x2.device)
+            dxs = zeros_f32(C, x2.device)
+            check(lib().ubv_add_dropout_layernorm_backward(_p(gy), _p(x2), _p(id2), _p(g), _p(mean),
+                                                           _p(rstd), _p(gx), _p(gid), _p(dg), _p(db),
+                                                           _p(dxs), R, C, ctx.p, ctx.seed, _dt(x2),
+                                                           _dt(id2), _stream()),
+                  'add_dropout_layernorm_backward')
+            gx = gx.view(ctx.shape)
+            # column sums of grad_x ride along: if x came straight out of a Linear, its backward takes
+            # them as the bias gradient instead of reducing grad_x again (linear._Linear.backward)
+            gx._ubv_colsum = dxs
+            gid = gid.view(ctx.shape).to(ctx.dts[0])
+            gid._ubv_owned = True         # fresh, single consumer: linear._Linear may accumulate into it
+            return (gx, gid, dg.to(ctx.dts[1]), db.to(ctx.dts[2]), None, None)
 
 
 def add_dropout_layernorm(x, identity, gamma, beta, p=0.0, training=False, eps=1e-5):
@@ -492,25 +542,26 @@ def new_step():
 class _ReluDropout(Function):
     @staticmethod
     def forward(ctx, x, p):
-        _need_cuda(x)
-        xc = x.contiguous()
-        y = torch.empty_like(xc)
-        seed = _next_seed() if p > 0 else 0
-        check(lib().ubv_relu_dropout_forward(_p(xc), _p(y), xc.numel(), float(p), seed, _dt(xc),
-                                             _stream()), 'relu_dropout_forward')
-        ctx.save_for_backward(y)
-        ctx.p = float(p)
-        return y
+        with _need_cuda(x):
+            xc = x.contiguous()
+            y = torch.empty_like(xc)
+            seed = _next_seed() if p > 0 else 0
+            check(lib().ubv_relu_dropout_forward(_p(xc), _p(y), xc.numel(), float(p), seed, _dt(xc),
+                                                 _stream()), 'relu_dropout_forward')
+            ctx.save_for_backward(y)
+            ctx.p = float(p)
+            return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_y):
-        y, = ctx.saved_tensors
-        gy = grad_y.to(y.dtype).contiguous()
-        gx = torch.empty_like(y)
-        check(lib().ubv_relu_dropout_backward(_p(gy), _p(y), _p(gx), y.numel(), ctx.p, _dt(y),
-                                              _stream()), 'relu_dropout_backward')
-        return gx, None
+        with _need_cuda(grad_y):
+            y, = ctx.saved_tensors
+            gy = grad_y.to(y.dtype).contiguous()
+            gx = torch.empty_like(y)
+            check(lib().ubv_relu_dropout_backward(_p(gy), _p(y), _p(gx), y.numel(), ctx.p, _dt(y),
+                                                  _stream()), 'relu_dropout_backward')
+            return gx, None
 
 
 def relu_dropout(x, p=0.0, training=False):
@@ -533,11 +584,12 @@ def linear_forward(x, weight, bias=None):
     K = x.shape[-1]
     M = x.numel() // K
     N = weight.shape[0]
-    y = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
-    nws = int(lib().ubv_linear_workspace())
-    ws = _workspace(nws, x.device)
-    rc = lib().ubv_linear_forward(_p(x), _p(weight), _p(bias), _p(y), M, N, K, _dt(x), _p(ws), nws,
-                                  _stream())
+    with _need_cuda(x, weight, bias):
+        y = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+        nws = int(lib().ubv_linear_workspace())
+        ws = _workspace(nws, x.device)
+        rc = lib().ubv_linear_forward(_p(x), _p(weight), _p(bias), _p(y), M, N, K, _dt(x), _p(ws),
+                                      nws, _stream())
     if rc == -3:                      # UBV_ERR_UNSUPPORTED: hipBLASLt has nothing for this shape
         _LINEAR_PLAN_OK[0] = False
         return None
@@ -555,21 +607,21 @@ def linear_grad_reduce(grad_out=None, partials=None):
     go_p = part_p = None
     rows = N = S = NK = 0
     ref = grad_out if grad_out is not None else partials
-    _need_cuda(ref)
-    if grad_out is not None:
-        grad_out = grad_out.contiguous()
-        rows, N = grad_out.shape
-        gb = zeros_f32(N, ref.device)
-        go_p = _p(grad_out)
-    if partials is not None:
-        assert grad_out is None or partials.dtype == grad_out.dtype
-        partials = partials.contiguous()
-        S, NK = partials.shape[0], partials[0].numel()
-        gw = torch.empty(partials.shape[1:], dtype=torch.float32, device=ref.device)
-        part_p = _p(partials)
-    check(lib().ubv_linear_grad_reduce(go_p, rows, N, _p(gb), part_p, S, NK, _p(gw), _dt(ref),
-                                       _stream()), 'linear_grad_reduce')
-    return gb, gw
+    with _need_cuda(ref):
+        if grad_out is not None:
+            grad_out = grad_out.contiguous()
+            rows, N = grad_out.shape
+            gb = zeros_f32(N, ref.device)
+            go_p = _p(grad_out)
+        if partials is not None:
+            assert grad_out is None or partials.dtype == grad_out.dtype
+            partials = partials.contiguous()
+            S, NK = partials.shape[0], partials[0].numel()
+            gw = torch.empty(partials.shape[1:], dtype=torch.float32, device=ref.device)
+            part_p = _p(partials)
+        check(lib().ubv_linear_grad_reduce(go_p, rows, N, _p(gb), part_p, S, NK, _p(gw), _dt(ref),
+                                           _stream()), 'linear_grad_reduce')
+        return gb, gw
 
 
 # ----------------------------------------------------------------------------------------------- voxels
@@ -593,54 +645,54 @@ def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels):
     num_points (max_voxels,) int32 and voxel_num (1,) int32 ON DEVICE; rows >= voxel_num are
     zero / undefined.  ``Voxelization.forward`` slices them to the reference's shapes.
     """
-    _need_cuda(points)
-    pts = points.float().contiguous()
-    N, F = pts.shape
-    dev = pts.device
-    voxels = torch.empty(max_voxels, max_points, F, dtype=torch.float32, device=dev)
-    coors = torch.zeros(max_voxels, 3, dtype=torch.int32, device=dev)
-    num = torch.empty(max_voxels, dtype=torch.int32, device=dev)
-    vnum = torch.empty(1, dtype=torch.int32, device=dev)
-    nbytes = lib().ubv_hard_voxelize_workspace(N, max_points, max_voxels)
-    ws = _workspace(nbytes, dev)
-    check(lib().ubv_hard_voxelize(_p(pts), _p(voxels), _p(coors), _p(num), _p(vnum), _p(ws),
-                                  ws.numel(), N, F, _lib.float_array(voxel_size),
-                                  _lib.float_array(coors_range), max_points, max_voxels, _stream()),
-          'hard_voxelize')
-    return voxels, coors, num, vnum
+    with _need_cuda(points):
+        pts = points.float().contiguous()
+        N, F = pts.shape
+        dev = pts.device
+        voxels = torch.empty(max_voxels, max_points, F, dtype=torch.float32, device=dev)
+        coors = torch.zeros(max_voxels, 3, dtype=torch.int32, device=dev)
+        num = torch.empty(max_voxels, dtype=torch.int32, device=dev)
+        vnum = torch.empty(1, dtype=torch.int32, device=dev)
+        nbytes = lib().ubv_hard_voxelize_workspace(N, max_points, max_voxels)
+        ws = _workspace(nbytes, dev)
+        check(lib().ubv_hard_voxelize(_p(pts), _p(voxels), _p(coors), _p(num), _p(vnum), _p(ws),
+                                      ws.numel(), N, F, _lib.float_array(voxel_size),
+                                      _lib.float_array(coors_range), max_points, max_voxels, _stream()),
+              'hard_voxelize')
+        return voxels, coors, num, vnum
 
 
 @torch.no_grad()
 def dynamic_voxelize(points, voxel_size, coors_range):
     """[ext] mmdet3d dynamic_voxelize: (N,3) int32 zyx coords, -1 outside."""
-    _need_cuda(points)
-    pts = points.float().contiguous()
-    N, F = pts.shape
-    coors = torch.empty(N, 3, dtype=torch.int32, device=pts.device)
-    check(lib().ubv_dynamic_voxelize(_p(pts), _p(coors), N, F, _lib.float_array(voxel_size),
-                                     _lib.float_array(coors_range), _stream()), 'dynamic_voxelize')
-    return coors
+    with _need_cuda(points):
+        pts = points.float().contiguous()
+        N, F = pts.shape
+        coors = torch.empty(N, 3, dtype=torch.int32, device=pts.device)
+        check(lib().ubv_dynamic_voxelize(_p(pts), _p(coors), N, F, _lib.float_array(voxel_size),
+                                         _lib.float_array(coors_range), _stream()), 'dynamic_voxelize')
+        return coors
 
 
 @torch.no_grad()
 def voxel_mean(voxels, num_points, voxel_num=None):
     """[ext] HardSimpleVFE: per-voxel mean of the stored points."""
-    _need_cuda(voxels, num_points)
-    M, T, F = voxels.shape
-    mean = torch.zeros(M, F, dtype=torch.float32, device=voxels.device)
-    check(lib().ubv_voxel_mean(_p(voxels.contiguous()), _p(num_points.contiguous()), _p(voxel_num),
-                               _p(mean), M, T, F, _stream()), 'voxel_mean')
-    return mean
+    with _need_cuda(voxels, num_points):
+        M, T, F = voxels.shape
+        mean = torch.zeros(M, F, dtype=torch.float32, device=voxels.device)
+        check(lib().ubv_voxel_mean(_p(voxels.contiguous()), _p(num_points.contiguous()), _p(voxel_num),
+                                   _p(mean), M, T, F, _stream()), 'voxel_mean')
+        return mean
 
 
 @torch.no_grad()
 def sparse_to_dense(feats, coors, batch_size, spatial_shape, m_dev=None):
     """SparseConvTensor.dense(): (M,C) feats at (M,4) int32 (b,z,y,x) -> (B,C,D,H,W)."""
-    _need_cuda(feats, coors)
-    M, C = feats.shape
-    D, Hs, Ws = spatial_shape
-    dense = torch.zeros(batch_size, C, D, Hs, Ws, dtype=torch.float32, device=feats.device)
-    check(lib().ubv_sparse_to_dense(_p(feats.float().contiguous()), _p(coors.contiguous()),
-                                    _p(m_dev), M, _p(dense), batch_size, C, D, Hs, Ws, _stream()),
-          'sparse_to_dense')
-    return dense
+    with _need_cuda(feats, coors):
+        M, C = feats.shape
+        D, Hs, Ws = spatial_shape
+        dense = torch.zeros(batch_size, C, D, Hs, Ws, dtype=torch.float32, device=feats.device)
+        check(lib().ubv_sparse_to_dense(_p(feats.float().contiguous()), _p(coors.contiguous()),
+                                        _p(m_dev), M, _p(dense), batch_size, C, D, Hs, Ws, _stream()),
+              'sparse_to_dense')
+        return dense

@@ -15,6 +15,7 @@ weights are never materialised.  Anything else composes the k1 operator exactly 
 reference does.
 """
 import math
+import os
 import warnings
 
 import torch
@@ -26,6 +27,10 @@ from ..linear import linear as ubv_linear
 from ..linear import linear_cat, linear_cat_pass, linear_pass
 from ..registry import ATTENTION
 from .bricks import BaseModule, constant_init, xavier_init
+
+
+def _OFFLOG_F32():
+    return os.environ.get('UBV_OFFLOG', '') == 'fp32'
 
 
 def static_hw(spatial_shapes):
@@ -104,6 +109,14 @@ class _DeformAttnBase(BaseModule):
         """One GEMM for both query Linears: rows [H*L*P*2 offsets | H*L*P logits].
         ``passthru``: also return the alias of ``query`` for the caller's residual branch
         (``linear.linear_pass``)."""
+        if _OFFLOG_F32() and query.is_cuda and torch.is_autocast_enabled('cuda'):
+            # offsets / logits computed and kept in f32 under autocast (precision knob: a 16-bit
+            # pixel offset of 8 px carries 4e-3 px of rounding)
+            with torch.autocast('cuda', enabled=False):
+                w = torch.cat((self.sampling_offsets.weight, self.attention_weights.weight), 0)
+                b = torch.cat((self.sampling_offsets.bias, self.attention_weights.bias), 0)
+                out = F.linear(query.float(), w.float(), b.float())
+            return (out, query) if passthru else out
         fn = linear_cat_pass if passthru else linear_cat
         return fn(query, (self.sampling_offsets.weight, self.attention_weights.weight),
                   (self.sampling_offsets.bias, self.attention_weights.bias))

@@ -149,13 +149,14 @@ class ImgEncoder(_EncoderBase):
         ref_2d = self._cached(('2d', bev_h, bev_w, bs, dev, dt),
                               lambda: reference_points_2d(bev_h, bev_w, bs, dev, dt))
         cam, mask, vis0, count = self._project(*axes, self.pc_range, kwargs['img_metas'], dev, True)
+        lists = UF.compact_visible(vis0)        # once per pass; every layer's backward walks them
         bev_query = bev_query.permute(1, 0, 2)
         if bev_pos is not None:
             bev_pos = bev_pos.permute(1, 0, 2)
         layer_kwargs = dict(kwargs, bev_pos=bev_pos, ref_2d=ref_2d, ref_3d=ref_3d, bev_h=bev_h,
                             bev_w=bev_w, spatial_shapes=spatial_shapes,
                             level_start_index=level_start_index, reference_points_cam=cam,
-                            bev_mask=mask, cam_vis0=vis0, cam_count=count,
+                            bev_mask=mask, cam_vis0=vis0, cam_count=count, cam_lists=lists,
                             query_grid=(bev_h, bev_w), ref_is_grid=True)
         return self._run_layers(bev_query, key, value, args, layer_kwargs)
 

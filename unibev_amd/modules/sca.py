@@ -78,7 +78,8 @@ class SpatialCrossAttentionImg(BaseModule):
                 offlog = da.offsets_and_logits(query)
             slots = UF.bev_lift(da.project_value(value), offlog,
                                 reference_points_cam, num_cams, hw[0], da.num_heads, da.num_points,
-                                vis0=vis0, count=count, query_grid=kwargs.get('query_grid'))
+                                vis0=vis0, count=count, query_grid=kwargs.get('query_grid'),
+                                visible_lists=kwargs.get('cam_lists') if kwargs.get('cam_vis0') is not None else None)
         else:
             slots = self._rebatch_path(query, value, reference_points_cam, bev_mask,
                                        spatial_shapes, level_start_index)
