@@ -313,6 +313,27 @@ int ubv_hard_voxelize(const float* points, float* voxels, int32_t* coors, int32_
 int ubv_dynamic_voxelize(const float* points, int32_t* coors, int N, int F,
                          const float* voxel_size_host, const float* range_host, void* stream);
 
+/* [ext] mmdet3d `dynamic_point_to_voxel_forward(feats, coors, reduce_type)` — DynamicScatter, the
+ * "dynamic_scatter" of BASELINE.json's north_star (the caller that would
+ * reach it is the dynamic branch of UniBEV.voxelize, models/detectors/unibev_detector.py:151-175;
+ * no shipped config selects it).
+ *   feats  [N, C] f32     coors [N, D] int32, D in 1..4 (z, y, x) or (batch, z, y, x);
+ *                         coordinates < 2^21 (D <= 3) / 2^15 (D = 4)
+ *   reduce_type  0 sum, 1 mean, 2 max
+ * A point with any negative coordinate is dropped (map -1).  Voxels are the unique coordinate rows
+ * in ascending lexicographic order (torch.unique_dim of the published op).  Outputs have capacity N:
+ *   voxel_feats [N, C] f32, voxel_coors [N, D] int32, voxel_points_count [N] int32 — rows
+ *   >= voxel_num[0] are unspecified;  point2voxel_map [N] int32;
+ *   voxel_num [2] int32 (device): [0] = number of voxels M, [1] = number of valid points.
+ * Deterministic: every voxel is reduced in input order (the published kernel adds atomically).
+ * Nothing is read back to the host.  workspace: ubv_dynamic_scatter_workspace(N) bytes. */
+int64_t ubv_dynamic_scatter_workspace(int N);
+int ubv_dynamic_point_to_voxel_forward(const float* feats, const int32_t* coors, int N, int C, int D,
+                                       int reduce_type, float* voxel_feats, int32_t* voxel_coors,
+                                       int32_t* point2voxel_map, int32_t* voxel_points_count,
+                                       int32_t* voxel_num, void* workspace, int64_t workspace_bytes,
+                                       void* stream);
+
 /* [ext] HardSimpleVFE: mean [M, F] = voxels[:, :, :F].sum(1) / num_points.  M is read from the
  * device counter `voxel_num` (rows >= *voxel_num are left untouched); max_voxels bounds the launch. */
 int ubv_voxel_mean(const float* voxels, const int32_t* num_points, const int32_t* voxel_num,

@@ -1,5 +1,6 @@
 """ORACLE — test infrastructure only.  ctypes wrapper of ``oracle/_build/liboracle.so`` (plain-C
-restatements in ``msda_ref.c`` and ``voxelize_ref.c``; build with ``make -C oracle``)."""
+restatements in ``msda_ref.c``, ``voxelize_ref.c`` and ``dynamic_scatter_ref.c``; build with
+``make -C oracle``)."""
 import ctypes
 import os
 import subprocess
@@ -49,6 +50,23 @@ def dynamic_voxelize(points, voxel_size, coors_range):
     lib().oracle_dynamic_voxelize(_f(pts), N, F, _f(np.asarray(voxel_size, np.float32)),
                                   _f(np.asarray(coors_range, np.float32)), _f(coors))
     return coors
+
+
+def dynamic_scatter(feats, coors, reduce_type):
+    """-> (voxel_feats [M,C], voxel_coors [M,D], point2voxel_map [N], voxel_points_count [M]);
+    reduce_type 'sum' | 'mean' | 'max'."""
+    f = np.ascontiguousarray(feats, np.float32)
+    c = np.ascontiguousarray(coors, np.int32)
+    N, C = f.shape
+    D = c.shape[1]
+    of = np.zeros((max(N, 1), C), np.float32)
+    oc = np.zeros((max(N, 1), D), np.int32)
+    mp = np.zeros((N,), np.int32)
+    cnt = np.zeros((max(N, 1),), np.int32)
+    lib().oracle_dynamic_scatter.restype = ctypes.c_int
+    m = lib().oracle_dynamic_scatter(_f(f), _f(c), N, C, D, {'sum': 0, 'mean': 1, 'max': 2}[reduce_type],
+                                     _f(of), _f(oc), _f(mp), _f(cnt))
+    return of[:m], oc[:m], mp, cnt[:m]
 
 
 def voxel_mean(voxels, num_points):

@@ -279,6 +279,156 @@ class BaseTransformerLayer(BaseModule):
             self.norms.append(nn.LayerNorm(self.embed_dims))
 
 
+def _base_layer_forward(self, query, key=None, value=None, query_pos=None, key_pos=None,
+                        attn_masks=None, query_key_padding_mask=None, key_padding_mask=None, **kwargs):
+    """mmcv 1.3.17 BaseTransformerLayer.forward: walk ``operation_order``; every attention / FFN
+    adds its own residual (``identity`` is only handed over in pre-norm layers)."""
+    norm_i = attn_i = ffn_i = 0
+    identity = query
+    masks = [None] * self.num_attn if attn_masks is None else (
+        [copy.deepcopy(attn_masks) for _ in range(self.num_attn)]
+        if isinstance(attn_masks, torch.Tensor) else attn_masks)
+    for op in self.operation_order:
+        if op == 'self_attn':
+            query = self.attentions[attn_i](
+                query, query, query, identity if self.pre_norm else None, query_pos=query_pos,
+                key_pos=query_pos, attn_mask=masks[attn_i], key_padding_mask=query_key_padding_mask,
+                **kwargs)
+            attn_i += 1
+            identity = query
+        elif op == 'cross_attn':
+            query = self.attentions[attn_i](
+                query, key, value, identity if self.pre_norm else None, query_pos=query_pos,
+                key_pos=key_pos, attn_mask=masks[attn_i], key_padding_mask=key_padding_mask, **kwargs)
+            attn_i += 1
+            identity = query
+        elif op == 'norm':
+            query = self.norms[norm_i](query)
+            norm_i += 1
+        elif op == 'ffn':
+            query = self.ffns[ffn_i](query, identity if self.pre_norm else None)
+            ffn_i += 1
+    return query
+
+
+BaseTransformerLayer.forward = _base_layer_forward
+
+
+class MultiheadAttention(BaseModule):
+    """mmcv 1.3.17 ``MultiheadAttention``: nn.MultiheadAttention with positional encodings added to
+    query / key, optional batch_first, and ``identity + dropout(proj_drop(out))``.  The deprecated
+    ``dropout`` kwarg sets both the attention dropout and the output dropout."""
+
+    def __init__(self, embed_dims, num_heads, attn_drop=0., proj_drop=0.,
+                 dropout_layer=dict(type='Dropout', drop_prob=0.), init_cfg=None, batch_first=False,
+                 **kwargs):
+        super().__init__(init_cfg)
+        dropout_layer = dict(dropout_layer) if dropout_layer else None
+        if 'dropout' in kwargs:
+            attn_drop = kwargs.pop('dropout')
+            dropout_layer = dict(type='Dropout', drop_prob=attn_drop)
+        self.embed_dims, self.num_heads, self.batch_first = embed_dims, num_heads, batch_first
+        self.attn = nn.MultiheadAttention(embed_dims, num_heads, attn_drop, **kwargs)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.dropout_layer = nn.Dropout(dropout_layer['drop_prob']) if dropout_layer else nn.Identity()
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None,
+                attn_mask=None, key_padding_mask=None, **kwargs):
+        key = query if key is None else key
+        value = key if value is None else value
+        identity = query if identity is None else identity
+        if key_pos is None and query_pos is not None and query_pos.shape == key.shape:
+            key_pos = query_pos
+        q = query if query_pos is None else query + query_pos
+        k = key if key_pos is None else key + key_pos
+        if self.batch_first:
+            q, k, value = q.transpose(0, 1), k.transpose(0, 1), value.transpose(0, 1)
+        out = self.attn(query=q, key=k, value=value, attn_mask=attn_mask,
+                        key_padding_mask=key_padding_mask)[0]
+        if self.batch_first:
+            out = out.transpose(0, 1)
+        return identity + self.dropout_layer(self.proj_drop(out))
+
+
+ATTENTION.register_module()(MultiheadAttention)
+
+
+class DetrTransformerDecoderLayer(BaseTransformerLayer):
+    """mmdet 2.19.0 ``DetrTransformerDecoderLayer``: a BaseTransformerLayer whose six operations
+    must be {self_attn, norm, cross_attn, ffn}."""
+
+    def __init__(self, attn_cfgs, feedforward_channels, ffn_dropout=0.0, operation_order=None,
+                 act_cfg=dict(type='ReLU', inplace=True), norm_cfg=dict(type='LN'), ffn_num_fcs=2,
+                 **kwargs):
+        super().__init__(attn_cfgs=attn_cfgs, feedforward_channels=feedforward_channels,
+                         ffn_dropout=ffn_dropout, operation_order=operation_order, act_cfg=act_cfg,
+                         norm_cfg=norm_cfg, ffn_num_fcs=ffn_num_fcs, **kwargs)
+        assert len(operation_order) == 6
+        assert set(operation_order) == set(['self_attn', 'norm', 'cross_attn', 'ffn'])
+
+
+TRANSFORMER_LAYER.register_module()(DetrTransformerDecoderLayer)
+
+
+# --------------------------------------------------------------------------- head-side [ext] pieces
+HEADS = Registry('head')
+POSITIONAL_ENCODING = Registry('position encoding')
+
+
+def inverse_sigmoid(x, eps=1e-5):
+    """mmdet.models.utils.transformer.inverse_sigmoid."""
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+def bias_init_with_prob(prior_prob):
+    import math
+    return float(-math.log((1 - prior_prob) / prior_prob))
+
+
+class LearnedPositionalEncoding(BaseModule):
+    """mmdet 2.19.0 ``LearnedPositionalEncoding``: x (column) half first."""
+
+    def __init__(self, num_feats, row_num_embed=50, col_num_embed=50, init_cfg=None):
+        super().__init__(init_cfg)
+        self.row_embed = nn.Embedding(row_num_embed, num_feats)
+        self.col_embed = nn.Embedding(col_num_embed, num_feats)
+
+    def forward(self, mask):
+        h, w = mask.shape[-2:]
+        x_embed = self.col_embed(torch.arange(w, device=mask.device))
+        y_embed = self.row_embed(torch.arange(h, device=mask.device))
+        pos = torch.cat((x_embed.unsqueeze(0).repeat(h, 1, 1), y_embed.unsqueeze(1).repeat(1, w, 1)),
+                        dim=-1).permute(2, 0, 1).unsqueeze(0).repeat(mask.shape[0], 1, 1, 1)
+        return pos
+
+
+POSITIONAL_ENCODING.register_module()(LearnedPositionalEncoding)
+
+
+class DETRHead(BaseModule):
+    """What mmdet 2.19.0 ``DETRHead.__init__`` leaves on ``self`` for a subclass that overrides
+    ``_init_layers`` / ``forward`` (losses, assigner and sampler are not built: the head's
+    forward never touches them)."""
+
+    def __init__(self, num_classes, in_channels, num_query=100, num_reg_fcs=2, transformer=None,
+                 sync_cls_avg_factor=False, positional_encoding=None, loss_cls=None, loss_bbox=None,
+                 loss_iou=None, train_cfg=None, test_cfg=None, init_cfg=None, **kwargs):
+        super().__init__(init_cfg)
+        self.num_query, self.num_classes, self.in_channels = num_query, num_classes, in_channels
+        self.num_reg_fcs = num_reg_fcs
+        self.sync_cls_avg_factor = sync_cls_avg_factor
+        use_sigmoid = (loss_cls or {}).get('use_sigmoid', False)
+        self.loss_cls = types.SimpleNamespace(use_sigmoid=use_sigmoid)
+        self.cls_out_channels = num_classes if use_sigmoid else num_classes + 1
+        self.act_cfg = (transformer or {}).get('act_cfg', dict(type='ReLU', inplace=True))
+        self.activate = nn.ReLU(inplace=True)
+        self.positional_encoding = build_from_cfg(positional_encoding, POSITIONAL_ENCODING)
+        self.transformer = build_from_cfg(transformer, TRANSFORMER)
+        self.embed_dims = self.transformer.embed_dims
+        self._init_layers()
+
+
 class TransformerLayerSequence(BaseModule):
     def __init__(self, transformerlayers=None, num_layers=None, init_cfg=None):
         super().__init__(init_cfg)
@@ -365,6 +515,22 @@ def install():
     for n in ('mmdet', 'mmdet.models', 'mmdet.models.utils'):
         _mod(n).__path__ = []
     _mod('mmdet.models.utils.builder', TRANSFORMER=TRANSFORMER)
+    # head-side imports of models/dense_heads/unibev_head.py:6-22
+    cnn.Linear = nn.Linear
+    cnn.bias_init_with_prob = bias_init_with_prob
+    mmcv.cnn = cnn
+    _mod('mmdet.core', multi_apply=lambda f, *a, **k: tuple(map(list, zip(*map(f, *a)))),
+         reduce_mean=lambda t: t)
+    _mod('mmdet.models.utils.transformer', inverse_sigmoid=inverse_sigmoid)
+    sys.modules['mmdet.models'].HEADS = HEADS
+    _mod('mmdet.models.dense_heads', DETRHead=DETRHead)
+    for n in ('mmdet3d', 'mmdet3d.core', 'mmdet3d.core.bbox', 'mmdet3d.unibev_plugin',
+              'mmdet3d.unibev_plugin.core', 'mmdet3d.unibev_plugin.core.bbox'):
+        _mod(n).__path__ = []
+    _mod('mmdet3d.core.bbox.coders',
+         build_bbox_coder=lambda cfg: types.SimpleNamespace(pc_range=cfg['pc_range']))
+    _mod('mmdet3d.unibev_plugin.core.bbox.util', normalize_bbox=lambda *a, **k: None)
+    _mod('numpy_unused')
     _mod('cv2')
     tv = _mod('torchvision')
     tv.__path__ = []

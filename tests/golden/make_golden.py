@@ -23,6 +23,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF_MODULES = '/root/reference/projects/UniBEV/unibev_plugin/models/modules'
+REF_HEADS = '/root/reference/projects/UniBEV/unibev_plugin/models/dense_heads'
 sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True
@@ -320,6 +321,66 @@ def gen_init(mods):
                               sd[pre + '0.attention_weights.bias'].abs().sum().item()]))
 
 
+# --------------------------------------------------------------------------- decoder + head (f1)
+HEAD_CASES = {
+    # name: (head kwargs, transformer kwargs, bs, img feat hw, pts feat hw, img_hw, seed)
+    'cnw': (dict(embed_dims=128, bev_h=10, bev_w=12, num_query=9, decoder_layers=2),
+            dict(num_layers=1, num_cams=2), 2, (4, 6), (9, 11), (64, 96), 41),
+    'cat': (dict(embed_dims=128, bev_h=10, bev_w=12, num_query=7, decoder_layers=2, with_box_refine=False),
+            dict(num_layers=1, num_cams=2, fusion_method='cat', feature_norm=None), 1, (4, 6), (9, 11),
+            (64, 96), 42),
+}
+
+
+def head_inputs(name, hkw, tkw, bs, img_hw_f, pts_hw_f, img_hw, seed):
+    C, nc = hkw['embed_dims'], tkw.get('num_cams', 6)
+    img = [syn.seeded_array(f'head:{name}:img', (bs, nc, C) + img_hw_f, seed)]
+    pts = [syn.seeded_array(f'head:{name}:pts', (bs, C) + pts_hw_f, seed)]
+    return img, pts, syn.img_metas(bs, nc, img_hw, jitter_seed=seed)
+
+
+def gen_head(mods):
+    """UniBEV_Head.forward (models/dense_heads/unibev_head.py:145-242) with the reference's
+    DetectionTransformerDecoder / CustomMSDeformableAttention (models/modules/decoder.py:51-338),
+    eval mode, seeded parameters: class scores, box predictions, decoder states and references."""
+    pkg = types.ModuleType('refheads')
+    pkg.__path__ = [REF_HEADS]
+    sys.modules['refheads'] = pkg
+    Head = importlib.import_module('refheads.unibev_head').UniBEV_Head
+    for name, case in HEAD_CASES.items():
+        hkw, tkw, bs, img_hw_f, pts_hw_f, img_hw, seed = case
+        cfg = cfgs.head_cfg(**hkw, **tkw)
+        args = json.loads(json.dumps(cfg))
+        args.pop('type')
+        head = Head(**args)
+        head.init_weights()
+        named = seeded_load(head, seed)
+        head.eval()
+        img, pts, metas = head_inputs(name, *case)
+        got = {}
+        head.transformer.register_forward_hook(lambda m, i, o: got.__setitem__('t', o))
+        with torch.no_grad():
+            outs = head([t(x) for x in img], [t(x) for x in pts], metas)
+        _, hs, init_ref, inter_ref = got['t']
+        save('head_' + name, cfg_json=np.array(json.dumps(cfg)),
+             param_names=np.array([n for n, _ in named]),
+             param_shapes=np.array([json.dumps(list(s)) for _, s in named]),
+             lidar2img=np.asarray([m['lidar2img'] for m in metas]),
+             img_ck=checksum(img[0]), pts_ck=checksum(pts[0]),
+             bev_embed=outs['bev_embed'].numpy(), all_cls_scores=outs['all_cls_scores'].numpy(),
+             all_bbox_preds=outs['all_bbox_preds'].numpy(), hs=hs.numpy(),
+             init_reference=init_ref.numpy(), inter_references=inter_ref.numpy())
+    # init_weights facts that do not depend on torch's RNG (unibev_head.py:137-143)
+    head = Head(**{k: v for k, v in json.loads(json.dumps(cfgs.head_cfg(**HEAD_CASES['cnw'][0],
+                                                                          **HEAD_CASES['cnw'][1]))).items()
+                   if k != 'type'})
+    torch.manual_seed(5)
+    before = head.positional_encoding.row_embed.weight.detach().clone()
+    head.init_weights()
+    save('head_init', cls_bias=head.cls_branches[0][-1].bias.detach().numpy(),
+         pos_untouched=np.array([float((head.positional_encoding.row_embed.weight == before).all())]))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -331,6 +392,7 @@ def main():
     gen_modality_dropout(mods)
     gen_init(mods)
     gen_fullsize(mods)
+    gen_head(mods)
 
 
 if __name__ == '__main__':

@@ -52,3 +52,47 @@ def test_defining_properties_on_the_synthetic_cloud():
     assert n.max() <= 10 and n.min() >= 1
     m = c_ref.voxel_mean(v, n)
     np.testing.assert_allclose(m, v.sum(1) / n[:, None], rtol=1e-6)
+
+
+def _np_scatter(feats, coors, reduce_type):
+    """numpy statement of the published op: np.unique(axis=0) is torch.unique_dim's sorted unique."""
+    ok = (coors >= 0).all(1)
+    uniq, inv = np.unique(coors[ok], axis=0, return_inverse=True)
+    inv = inv.reshape(-1)
+    mp = np.full(len(coors), -1, np.int32)
+    mp[ok] = inv
+    cnt = np.bincount(inv, minlength=len(uniq)).astype(np.int32)
+    out = np.zeros((len(uniq), feats.shape[1]), np.float64)
+    if reduce_type == 'max':
+        out[:] = -np.inf
+        np.maximum.at(out, inv, feats[ok].astype(np.float64))
+    else:
+        np.add.at(out, inv, feats[ok].astype(np.float64))
+        if reduce_type == 'mean':
+            out /= cnt[:, None]
+    return out, uniq.astype(np.int32), mp, cnt
+
+
+def test_dynamic_scatter_oracle_vs_numpy_unique():
+    """The C restatement of dynamic_point_to_voxel_forward against numpy's unique (what the
+    published op builds on): coordinates, map and counts identical, features to f32 round-off."""
+    rs = np.random.RandomState(4)
+    for D, N in ((3, 5000), (4, 3000), (3, 1), (2, 40)):
+        coors = rs.randint(0, 9, size=(N, D)).astype(np.int32)
+        coors[rs.random_sample(N) < 0.1, rs.randint(0, D)] = -1          # dropped points
+        feats = rs.standard_normal((N, 5)).astype(np.float32)
+        for red in ('sum', 'mean', 'max'):
+            vf, vc, mp, cnt = c_ref.dynamic_scatter(feats, coors, red)
+            ef, ec, emp, ecnt = _np_scatter(feats, coors, red)
+            np.testing.assert_array_equal(vc, ec)
+            np.testing.assert_array_equal(mp, emp)
+            np.testing.assert_array_equal(cnt, ecnt)
+            np.testing.assert_allclose(vf, ef, rtol=1e-5, atol=1e-5)
+    # known answer
+    coors = np.array([[1, 0, 2], [0, 5, 5], [1, 0, 2], [-1, 3, 3], [0, 5, 5], [0, 0, 9]], np.int32)
+    feats = np.arange(12, dtype=np.float32).reshape(6, 2)
+    vf, vc, mp, cnt = c_ref.dynamic_scatter(feats, coors, 'mean')
+    np.testing.assert_array_equal(vc, [[0, 0, 9], [0, 5, 5], [1, 0, 2]])
+    np.testing.assert_array_equal(mp, [2, 1, 2, -1, 1, 0])
+    np.testing.assert_array_equal(cnt, [1, 2, 2])
+    np.testing.assert_array_equal(vf, [[10, 11], [5, 6], [2, 3]])

@@ -119,3 +119,56 @@ def test_full_sweep_cloud_idempotent_property():
     owner = np.concatenate([np.repeat(c[i][None], n[i], 0) for i in range(0, len(v), 97)])
     np.testing.assert_array_equal(cc, owner)
     check_equal(pts, 10, 120000)
+
+
+@pytest.mark.parametrize('reduce_type', ['sum', 'mean', 'max'])
+@pytest.mark.parametrize('batched', [False, True])
+def test_dynamic_scatter_bit_exact_vs_oracle(reduce_type, batched):
+    """ubv_dynamic_point_to_voxel_forward on the dynamic voxelization of the synthetic cloud(s):
+    voxel coordinates, point->voxel map and counts bit-exact, features bit-exact too (both sides
+    reduce a voxel's points in input order)."""
+    from unibev_amd.functional import dynamic_scatter, dynamic_voxelize
+    clouds = [syn.lidar_points(30000, seed=s) for s in ((0, 1) if batched else (0,))]
+    coors, feats = [], []
+    for b, cloud in enumerate(clouds):
+        c = dynamic_voxelize(t(cloud, device=DEV), syn.VOXEL_SIZE, syn.PC_RANGE).cpu().numpy()
+        np.testing.assert_array_equal(c, c_ref.dynamic_voxelize(cloud, syn.VOXEL_SIZE, syn.PC_RANGE))
+        if batched:
+            c = np.concatenate([np.where((c < 0).any(1, keepdims=True), -1, b).astype(np.int32), c], 1)
+        coors.append(c)
+        feats.append(cloud)
+    coors, feats = np.concatenate(coors), np.concatenate(feats)
+    vf, vc, mp, cnt, vnum = dynamic_scatter(t(feats, device=DEV), t(coors, device=DEV), reduce_type)
+    m, nvalid = (int(v) for v in vnum.cpu())
+    ef, ec, emp, ecnt = c_ref.dynamic_scatter(feats, coors, reduce_type)
+    assert m == len(ec) and nvalid == int((emp >= 0).sum()) and m > 10000
+    np.testing.assert_array_equal(vc[:m].cpu().numpy(), ec)
+    np.testing.assert_array_equal(mp.cpu().numpy(), emp)
+    np.testing.assert_array_equal(cnt[:m].cpu().numpy(), ecnt)
+    np.testing.assert_array_equal(vf[:m].cpu().numpy(), ef)
+
+
+def test_dynamic_scatter_edge_cases_and_module():
+    from unibev_amd.functional import dynamic_scatter
+    from unibev_amd.modules.voxel import DynamicScatter
+    # nothing valid, a single voxel, an empty input
+    f = torch.arange(12, dtype=torch.float32, device=DEV).view(4, 3)
+    vf, vc, mp, cnt, vnum = dynamic_scatter(f, torch.full((4, 3), -1, dtype=torch.int32, device=DEV), 'max')
+    assert vnum.tolist() == [0, 0] and (mp == -1).all()
+    vf, vc, mp, cnt, vnum = dynamic_scatter(f, torch.tensor([[2, 3, 4]] * 4, dtype=torch.int32, device=DEV), 'max')
+    assert vnum.tolist() == [1, 4] and vc[0].tolist() == [2, 3, 4] and vf[0].tolist() == [9.0, 10.0, 11.0]
+    assert cnt[0].item() == 4 and (mp == 0).all()
+    vf, vc, mp, cnt, vnum = dynamic_scatter(f[:0], torch.zeros(0, 3, dtype=torch.int32, device=DEV), 'sum')
+    assert vnum.tolist() == [0, 0]
+    with pytest.raises(ValueError):
+        dynamic_scatter(f, torch.zeros(4, 3, dtype=torch.int32, device=DEV), 'median')
+    # module: exact shapes of the published op, gradient of the mean goes back divided by the count
+    coors = torch.tensor([[1, 0, 2], [0, 5, 5], [1, 0, 2], [-1, 3, 3], [0, 5, 5], [0, 0, 9]],
+                         dtype=torch.int32, device=DEV)
+    feats = torch.arange(12, dtype=torch.float32, device=DEV).view(6, 2).requires_grad_()
+    layer = DynamicScatter([0.1, 0.1, 0.1], [0, 0, 0, 1, 1, 1], True)
+    vfeat, vcoor = layer(feats, coors)
+    assert vcoor.tolist() == [[0, 0, 9], [0, 5, 5], [1, 0, 2]]
+    assert vfeat.tolist() == [[10.0, 11.0], [5.0, 6.0], [2.0, 3.0]]
+    vfeat.sum().backward()
+    assert feats.grad.tolist() == [[0.5, 0.5], [0.5, 0.5], [0.5, 0.5], [0.0, 0.0], [0.5, 0.5], [1.0, 1.0]]

@@ -54,6 +54,9 @@ SIGNATURES = {
                                   _P]),
     'ubv_dynamic_voxelize': (c_int, [_P, _P, c_int, c_int, ctypes.POINTER(c_float),
                                      ctypes.POINTER(c_float), _P]),
+    'ubv_dynamic_scatter_workspace': (c_int64, [c_int]),
+    'ubv_dynamic_point_to_voxel_forward': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P,
+                                                   _P, c_int64, _P]),
     'ubv_voxel_mean': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'ubv_sparse_to_dense': (c_int, [_P, _P, _P, c_int, _P] + [c_int] * 5 + [_P]),
 }

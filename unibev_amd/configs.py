@@ -54,3 +54,36 @@ def transformer_cfg(embed_dims=256, fusion_method='linear', feature_norm='Channe
         cfg['num_cams'] = num_cams
     cfg.update(extra)
     return cfg
+
+
+def decoder_cfg(embed_dims=256, num_layers=6, scale_factor=1):
+    """``transformer.decoder`` of the shipped configs
+    (configs/unibev/unibev_nus_LC_cnw_256_modality_dropout.py:325-349): ``scale_factor`` is 2 for
+    the cat fusion (``dec_scale_factor``)."""
+    dim = embed_dims * scale_factor
+    return dict(
+        type='DetectionTransformerDecoder', num_layers=num_layers, return_intermediate=True,
+        transformerlayers=dict(
+            type='DetrTransformerDecoderLayer',
+            attn_cfgs=[dict(type='MultiheadAttention', embed_dims=dim, num_heads=8, dropout=0.1),
+                       dict(type='CustomMSDeformableAttention', embed_dims=dim, num_levels=1)],
+            ffn_cfgs=dict(type='FFN', embed_dims=dim),
+            feedforward_channels=embed_dims * 2 * scale_factor, ffn_dropout=0.1,
+            operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))
+
+
+def head_cfg(embed_dims=256, bev_h=200, bev_w=200, num_query=900, num_classes=10,
+             decoder_layers=6, with_box_refine=True, **transformer_kw):
+    """``model.pts_bbox_head`` of the shipped configs (:245-378) without the loss / assigner
+    entries the forward never reads."""
+    s = 2 if transformer_kw.get('fusion_method') == 'cat' else 1
+    tcfg = transformer_cfg(embed_dims=embed_dims,
+                           decoder=decoder_cfg(embed_dims, decoder_layers, s), **transformer_kw)
+    return dict(type='UniBEV_Head', bev_h=bev_h, bev_w=bev_w, num_query=num_query,
+                num_classes=num_classes, in_channels=embed_dims, sync_cls_avg_factor=True,
+                with_box_refine=with_box_refine, as_two_stage=False, transformer=tcfg,
+                bbox_coder=dict(type='NMSFreeCoder', post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0],
+                                pc_range=PC_RANGE, max_num=300, num_classes=num_classes),
+                positional_encoding=dict(type='LearnedPositionalEncoding', num_feats=embed_dims // 2,
+                                         row_num_embed=bev_h, col_num_embed=bev_w),
+                loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=2.0))

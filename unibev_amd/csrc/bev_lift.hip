@@ -1227,7 +1227,13 @@ static bool lift_shape_ok(int H, int Dh, int P, int dtype) {
 // Chooses who scatters grad_value (see lift_bwd_value_kernel) and lays out the owner tiles.
 static int plan_backward(const LiftArgs& a, int Dh, int P, int dtype, int ref_is_grid, TileArgs& t) {
   t = TileArgs{};
-  if (ref_is_grid && a.Nc == 1 && a.qw > 0) {
+  // GRID: the BEV-grid instances (self-attention, SCA-pts), and any single-map instance whose map
+  // is too large for the CAMERA plan's row bands — the object-query decoder's cross-attention
+  // (900 queries anywhere on the 200x200 fused BEV map): binning does not care how the queries are
+  // laid out, clustered queries simply spill into the (exact) overflow list.
+  const int cband = a.fw <= 192 ? 192 / a.fw : 0;            // rows per CAMERA band
+  const bool cam_fits = cband >= 1 && (a.fh + cband - 1) / cband <= 8;
+  if (a.Nc == 1 && ((ref_is_grid && a.qw > 0) || !cam_fits)) {
     t.mode = 1;
     t.tile_w = t.tile_h = 8;                 // 64 pixels = 2 MFMA row blocks
     t.tiles_x = (a.fw + 7) / 8;

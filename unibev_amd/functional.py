@@ -674,6 +674,41 @@ def dynamic_voxelize(points, voxel_size, coors_range):
         return coors
 
 
+_REDUCE = {'sum': 0, 'mean': 1, 'max': 2}
+
+
+@torch.no_grad()
+def dynamic_scatter(feats, coors, reduce_type='max'):
+    """[ext] mmdet3d ``dynamic_point_to_voxel_forward`` (``ubv_dynamic_point_to_voxel_forward``),
+    sync-free full-capacity form.
+
+    feats (N, C) float, coors (N, D) int32 -> voxel_feats (N, C), voxel_coors (N, D) int32,
+    point2voxel_map (N,) int32, voxel_points_count (N,) int32, voxel_num (2,) int32 ON DEVICE
+    ([0] voxels M, [1] valid points); rows >= M are unspecified.  ``DynamicScatter`` slices them to
+    the published op's shapes."""
+    if reduce_type not in _REDUCE:
+        raise ValueError(f"reduce_type must be 'sum', 'mean' or 'max', got {reduce_type!r}")
+    with _need_cuda(feats, coors):
+        f = feats.float().contiguous()
+        c = coors.to(torch.int32).contiguous()
+        N, C = f.shape
+        D = c.shape[1]
+        dev = f.device
+        n = max(N, 1)
+        vf = torch.empty(n, C, dtype=torch.float32, device=dev)
+        vc = torch.empty(n, D, dtype=torch.int32, device=dev)
+        mp = torch.empty(N, dtype=torch.int32, device=dev)
+        cnt = torch.empty(n, dtype=torch.int32, device=dev)
+        vnum = torch.empty(2, dtype=torch.int32, device=dev)
+        nws = int(lib().ubv_dynamic_scatter_workspace(N))
+        ws = _workspace(nws, dev) if nws > 0 else None
+        check(lib().ubv_dynamic_point_to_voxel_forward(_p(f), _p(c), N, C, D, _REDUCE[reduce_type],
+                                                       _p(vf), _p(vc), _p(mp), _p(cnt), _p(vnum),
+                                                       _p(ws), nws, _stream()),
+              'dynamic_point_to_voxel_forward')
+        return vf, vc, mp, cnt, vnum
+
+
 @torch.no_grad()
 def voxel_mean(voxels, num_points, voxel_num=None):
     """[ext] HardSimpleVFE: per-voxel mean of the stored points."""

@@ -7,6 +7,7 @@ Hungarian loss / box decoding of the DETR3D head are out of scope (SURVEY.md sec
 classification / regression branches are built and applied when the transformer has a decoder.
 """
 import copy
+import math
 
 import torch
 import torch.nn as nn
@@ -27,7 +28,10 @@ class UniBEV_Head(BaseModule):
         self.bev_h, self.bev_w = bev_h, bev_w
         self.num_query = num_query
         self.num_classes = num_classes
-        self.cls_out_channels = num_classes          # sigmoid focal loss in every shipped config
+        # DETRHead: sigmoid classification (every shipped config: FocalLoss, use_sigmoid=True) has
+        # num_classes outputs, softmax one more for the background
+        self.use_sigmoid_cls = bool((loss_cls or {}).get('use_sigmoid', True))
+        self.cls_out_channels = num_classes if self.use_sigmoid_cls else num_classes + 1
         self.with_box_refine = with_box_refine
         self.as_two_stage = as_two_stage
         self.code_size = code_size
@@ -80,8 +84,15 @@ class UniBEV_Head(BaseModule):
             self.query_embedding = nn.Embedding(self.num_query, dims * 2)
 
     def init_weights(self):
+        """unibev_head.py:137-143: the transformer's own initialisation, then the focal-loss prior
+        (bias_init_with_prob(0.01)) on the last Linear of every classification branch.  Nothing
+        else is touched: ``positional_encoding`` keeps nn.Embedding's N(0, 1) (the reference head's
+        override never recurses into it)."""
         self.transformer.init_weights()
-        self.positional_encoding.init_weights()
+        if self.use_sigmoid_cls and hasattr(self, 'cls_branches'):
+            bias_init = float(-math.log((1 - 0.01) / 0.01))
+            for m in self.cls_branches:
+                nn.init.constant_(m[-1].bias, bias_init)
 
     def bev_inputs(self, bs, dtype, device):
         """(bev_queries, bev_pos) exactly as unibev_head.py:171-182 builds them."""

@@ -26,7 +26,9 @@ class Voxelization(nn.Module):
         self.voxel_size = [float(v) for v in voxel_size]
         self.point_cloud_range = [float(v) for v in point_cloud_range]
         self.max_num_points = max_num_points
-        self.max_voxels = max_voxels if isinstance(max_voxels, tuple) else (max_voxels, max_voxels)
+        # (train, test) pair, given as tuple or list (mmdet3d's _pair), or one number for both
+        self.max_voxels = tuple(max_voxels) if isinstance(max_voxels, (tuple, list)) \
+            else (max_voxels, max_voxels)
         self.deterministic = deterministic
         pcr = torch.tensor(self.point_cloud_range, dtype=torch.float32)
         vs = torch.tensor(self.voxel_size, dtype=torch.float32)
@@ -66,6 +68,82 @@ class HardSimpleVFE(nn.Module):
     def forward(self, features, num_points, coors=None):
         mean = UF.voxel_mean(features, num_points)
         return mean[:, :self.num_features].contiguous()
+
+    def forward_padded(self, features, num_points, voxel_num):
+        """Full-capacity buffers + the device-side voxel count (rows >= voxel_num stay zero)."""
+        return UF.voxel_mean(features, num_points, voxel_num)[:, :self.num_features]
+
+
+class _DynamicScatterFn(torch.autograd.Function):
+    """[ext] mmdet3d ``_dynamic_scatter``: forward through ``ubv_dynamic_point_to_voxel_forward``;
+    backward routes the voxel gradients back to the points (sum: copy, mean: / count, max: to the
+    points that hold the maximum)."""
+
+    @staticmethod
+    def forward(ctx, feats, coors, reduce_type):
+        vf, vc, mp, cnt, vnum = UF.dynamic_scatter(feats, coors, reduce_type)
+        m = int(vnum[0].item())          # the published op returns exact shapes: one read of M
+        vf, vc, cnt = vf[:m], vc[:m], cnt[:m]
+        ctx.reduce_type = reduce_type
+        ctx.save_for_backward(feats, vf, mp, cnt)
+        ctx.mark_non_differentiable(vc)
+        return vf.to(feats.dtype), vc
+
+    @staticmethod
+    def backward(ctx, grad_vf, grad_vc=None):
+        feats, vf, mp, cnt = ctx.saved_tensors
+        valid = mp >= 0
+        idx = mp.clamp(min=0).long()
+        g = grad_vf[idx]
+        if ctx.reduce_type == 'mean':
+            g = g / cnt[idx].to(g.dtype)[:, None]
+        elif ctx.reduce_type == 'max':
+            g = g * (feats.float() == vf[idx]).to(g.dtype)
+        return g * valid[:, None].to(g.dtype), None, None
+
+
+def dynamic_scatter(feats, coors, reduce_type='max'):
+    """(voxel_feats (M, C), voxel_coors (M, D)) as [ext] mmdet3d ``dynamic_scatter``."""
+    return _DynamicScatterFn.apply(feats, coors, reduce_type)
+
+
+class DynamicScatter(nn.Module):
+    """[ext] mmdet3d ``DynamicScatter(voxel_size, point_cloud_range, average_points)``: reduce the
+    features of the points of each voxel (mean if ``average_points`` else max).  ``coors`` is
+    (N, 3) zyx for one sample or (N, 4) with the batch index first.  The published module loops
+    over the batch with one host sync per sample; the batch index is simply the leading key here
+    (lexicographic order = per-sample results concatenated), so a batch is one launch.
+    ``forward_padded`` is the sync-free form: full-capacity outputs + device-side count."""
+
+    def __init__(self, voxel_size, point_cloud_range, average_points):
+        super().__init__()
+        self.voxel_size = voxel_size
+        self.point_cloud_range = point_cloud_range
+        self.average_points = average_points
+
+    @property
+    def reduce_type(self):
+        return 'mean' if self.average_points else 'max'
+
+    def forward_single(self, points, coors):
+        return dynamic_scatter(points.contiguous(), coors.contiguous(), self.reduce_type)
+
+    def forward_padded(self, points, coors):
+        return UF.dynamic_scatter(points, coors, self.reduce_type)
+
+    def forward(self, points, coors):
+        return self.forward_single(points, coors)
+
+    def __repr__(self):
+        return (f'{self.__class__.__name__}(voxel_size={self.voxel_size}, point_cloud_range='
+                f'{self.point_cloud_range}, average_points={self.average_points})')
+
+
+def voxelize_batch_padded(voxel_layer, points):
+    """Sync-free ``UniBEV.voxelize``: per-sample full-capacity buffers and device-side voxel counts;
+    nothing is sliced, so no voxel count is read back.  Returns lists of (voxels, coors, num, vnum)
+    per sample (``HardSimpleVFE.forward_padded`` / ``sparse_to_dense`` take the device counts)."""
+    return [voxel_layer.forward_padded(res) for res in points]
 
 
 def voxelize_batch(voxel_layer, points):
