@@ -11,13 +11,24 @@ tokens each, a 180x180x256 LiDAR BEV feature map as the voxelize/backbone front 
 200x200x256 BEV queries, L+C CNW fusion with modality dropout, bs = 2 per GPU = configs[3]):
 ``UniBEV_Head.forward_bev`` (BEV queries + learned positional encoding -> both 3-layer encoders ->
 CNW -> fusion), backward from a fixed random cotangent on ``fused_bev_embed`` to every encoder
-parameter and the input features, RCCL gradient all-reduce (DDP, one process per GPU) and an AdamW
-step.  Data parallel only: the per-GPU batch is fixed, so scaling is weak.
+parameter and the input features, one RCCL all-reduce of the flat gradient buffer (one process per
+GPU), gradient clipping and an AdamW step.  Data parallel only: the per-GPU batch is fixed, so
+scaling is weak.  Forward + backward replay as HIP graphs (unibev_amd/graph_step.py).
+
+Precision.  The reference computes in fp32 and BASELINE's bar is 1e-3 on BEV
+features.  The HEADLINE (`value`, `dtype`) is the fp32 path: it holds 6e-5 to the reference-recorded
+full-size vectors.  The 16-bit autocast paths run the same step ~2x faster but land at 2-3e-2 (fp16)
+/ 2e-1 (bf16) on that fixture and 1e-3 .. 1e-2 on realistic inputs (tests/test_modules_gpu.py,
+DESIGN.md section 4): they are reported as sub-records under `lowp`, each with the distance it was
+measured at, not as the headline.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      the dominant deformable-sampling kernel: algorithmic bytes per launch (DESIGN.md,
-                SURVEY.md section 8(d)) / its average launch duration, measured live with HIP
-                events on the launch stream inside the timed region;
+  roofline      the dominant deformable-sampling OP of the headline run: compulsory bytes per launch
+                (SURVEY.md section 8(d)) / the op's duration, HIP events on the launch stream;
+  roofline_ops  the same for every sampling op, forward and backward, with its kernels;
+  lowp          the 16-bit runs (value, ms_per_step, their own dominant-op roofline);
+  gemm          the projection GEMMs: time, TFLOP/s against the dense MFMA peak, GB/s;
+  voxel         the LiDAR front end (voxelize + VFE mean + dense scatter): points/s, bytes;
   cpu_baseline  the oracle (CPU port of the reference path) timed on this host (N = 1 only).
 """
 import argparse
@@ -35,6 +46,12 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured copy peak
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0, 'fp32': 157.3}   # dense (MI355X_MICROARCH.md)
+# full-size distance of each mode's BEV features to the reference-recorded vectors
+# (tests/golden/encoder_fullsize.npz; asserted in tests/test_modules_gpu.py)
+PARITY_NOTE = {'fp32': 'normwise 6e-5 vs reference vectors (i.i.d. maps, random offset weights); bar 1e-3: PASS',
+               'fp16': 'normwise 3e-2 on that fixture (6e-3 with f32 offsets + f32 stream); bar 1e-3: FAIL',
+               'bf16': 'normwise 2e-1 on that fixture; bar 1e-3: FAIL'}
 
 
 def parse():
@@ -43,10 +60,13 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--bs', type=int, default=2, help='samples per GPU (cfg4: 2)')
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
+    ap.add_argument('--dtype', default='all', choices=['all', 'bf16', 'fp16', 'fp32'],
+                    help="'all': fp32 headline + bf16 and fp16 sub-records")
     ap.add_argument('--workload', default='LC_cnw', choices=['LC_cnw', 'C', 'L', 'LC_cat128'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP graphs')
+    ap.add_argument('--no-extras', action='store_true', help='skip the gemm / voxel records')
     ap.add_argument('--eval-mode', action='store_true', help='dropout / modality dropout off')
     ap.add_argument('--fp32-stream', action='store_true',
                     help='keep the encoder residual stream in f32 under autocast (default: the '
@@ -69,6 +89,7 @@ WORKLOADS = {
                   'unibev_nus_LC_cat_128_modality_dropout: L+C cat, 6x(25x45) img tokens '
                   '[800x1440/32], 200x200x128 BEV'),
 }
+DTYPES = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}
 
 
 def build_head(workload, device):
@@ -111,6 +132,223 @@ def synth_inputs(workload, bs, dtype, device, rank):
     return img, pts, metas
 
 
+# ---- compulsory bytes of the sampling ops -------------------------------------
+def k1_bytes(B, S, Nq, C, H, P, esize, backward):
+    """k1 fwd: B S C e_v + B Nq H L P 3 4 + B Nq C e_o;  bwd: B S C (e_v + e_g) + 2 B Nq H L P 3 4 + B Nq C e_o."""
+    loc = B * Nq * H * P * 3 * 4
+    if backward:
+        return B * S * C * 2 * esize + 2 * loc + B * Nq * C * esize
+    return B * S * C * esize + loc + B * Nq * C * esize
+
+
+def sampling_ops(workload, bs, esize, visible_pairs):
+    """op name -> (map tag in the library's kernel names, fwd bytes, bwd bytes) per launch."""
+    kw, img_hw, pts_hw, _ = WORKLOADS[workload]
+    C, H, Nq = kw['embed_dims'], 8, 200 * 200
+    ops = {'self_attn': ('Nc=1 map=200x200', k1_bytes(bs, Nq, Nq, C, H, 4, esize, False),
+                         k1_bytes(bs, Nq, Nq, C, H, 4, esize, True))}
+    mods = kw.get('modalities', 'LC')
+    if 'L' in mods:
+        S = pts_hw[0] * pts_hw[1]
+        ops['sca_pts'] = (f'Nc=1 map={pts_hw[0]}x{pts_hw[1]}', k1_bytes(bs, S, Nq, C, H, 8, esize, False),
+                          k1_bytes(bs, S, Nq, C, H, 8, esize, True))
+    if 'C' in mods:
+        fh, fw = img_hw[0] // 32, img_hw[1] // 32
+        # the reference pads every camera to max_len; the contract is the UNPADDED count of visible
+        # (camera, query) pairs (SURVEY.md section 8(d)): value maps of all cameras + one row per pair
+        S6 = 6 * fh * fw
+        pairs = visible_pairs
+        fwd = bs * S6 * C * esize + pairs * H * 8 * 3 * 4 + pairs * C * esize
+        bwd = bs * S6 * C * 2 * esize + 2 * pairs * H * 8 * 3 * 4 + pairs * C * esize
+        ops['sca_img'] = (f'Nc=6 map={fh}x{fw}', fwd, bwd)
+    return ops
+
+
+def op_roofline(prof, ops):
+    """Per sampling op and direction: duration = the library's op-level HIP-event scope, achieved =
+    compulsory bytes / duration; plus the kernels the op consists of."""
+    out = []
+    for op, (tag, fb, bb) in ops.items():
+        for direction, scope, nbytes in (('fwd', 'bev_lift_fwd<', fb), ('bwd', 'bev_lift_bwd_op<', bb)):
+            hit = [(k, r) for k, r in prof.items() if k.startswith(scope) and tag in k]
+            if not hit:
+                continue
+            us = sum(r['avg_us'] for _, r in hit)
+            launches = hit[0][1]['launches']
+            kern = {k.split('<')[0]: round(r['avg_us'], 1) for k, r in prof.items()
+                    if tag in k and k.startswith('bev_lift_' + direction) and not k.startswith('bev_lift_bwd_op')}
+            gbs = nbytes / (us * 1e-6) / 1e9
+            out.append({'op': op, 'pass': direction, 'launches': launches, 'avg_us': us,
+                        'compulsory_bytes_per_launch': float(nbytes), 'achieved_GBps': gbs,
+                        'frac': gbs / HBM_PEAK_GBS, 'kernels_us': kern})
+    out.sort(key=lambda d: -d['avg_us'] * d['launches'])
+    return out
+
+
+def traffic_of(op_rec):
+    """HBM bytes per launch of an op from the committed PMC passes (profiles/traffic.json, made by
+    tools/make_traffic.py with the corrections of MI355X_MICROARCH.md section HBM), or None."""
+    tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if not os.path.exists(tfile):
+        return None
+    rec = json.load(open(tfile)).get('ops', {}).get(f"{op_rec['op']}:{op_rec['pass']}")
+    return None if rec is None else rec.get('hbm_bytes_per_launch')
+
+
+def run_mode(args, name, head, world, rank, device, want_ops):
+    """Warm up, capture, time K steps of one precision mode.  Returns the mode's record."""
+    from unibev_amd import functional as UF
+    from unibev_amd.graph_step import GraphedStep
+    dtype = DTYPES[name]
+    kw = WORKLOADS[args.workload][0]
+    mods = kw.get('modalities', 'LC')
+    img, pts, metas = synth_inputs(args.workload, args.bs, dtype, device, rank)
+    head.transformer.lowp_stream = not args.fp32_stream
+    params = [p for p in head.parameters() if p.requires_grad]
+    for p in params:
+        p.grad = None
+    opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.01, fused=True)
+    s = 2 if kw.get('fusion_method') == 'cat' else 1
+    C = kw['embed_dims']
+    cot = torch.randn(200 * 200, args.bs, C * s, device=device) / 200.0
+    gs = GraphedStep(head.transformer, lambda: head.forward_bev(img, pts, metas), cot, params,
+                     inputs=(img or []) + (pts or []), has_img='C' in mods, has_pts='L' in mods,
+                     autocast_dtype=None if dtype == torch.float32 else dtype)
+
+    def finish():
+        torch.nn.utils.clip_grad_norm_(params, 35.0)
+        opt.step()
+
+    graphed = not args.no_graph
+    for _ in range(args.warmup):
+        gs.eager_step()
+        finish()
+    if graphed:
+        try:
+            gs.capture()
+        except Exception as e:                     # never lose the number to a capture problem
+            print(f'[bench] HIP graph capture failed ({type(e).__name__}: {e}); eager launches', file=sys.stderr)
+            graphed = False
+            gs.close()
+    step = gs.step if graphed else gs.eager_step
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step()
+    finish()                                       # first replay outside the timed region
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        finish()
+    host_dt = time.perf_counter() - t0             # host-side enqueue time (before the final sync)
+    barrier()
+    dt = time.perf_counter() - t0
+    from unibev_amd import dp
+    dt = dp.max_over_ranks(dt, device)
+    rec = {'dtype': name, 'value': world * args.bs * args.steps / dt, 'ms_per_step': 1e3 * dt / args.steps,
+           'host_enqueue_ms_per_step': 1e3 * host_dt / args.steps, 'hip_graphs': graphed,
+           'residual_stream': 'f32' if (args.fp32_stream or name == 'fp32') else name,
+           'parity': PARITY_NOTE[name]}
+    # ---- per-op roofline: the same step, eager, HIP events on the launch stream around every
+    # sampling kernel / op (events cannot be read back from inside a captured graph)
+    if want_ops and not args.no_kernel_timing:
+        UF.set_seed_base(None)
+        UF.kernel_profile(True)
+        for _ in range(min(args.steps, 10)):
+            gs.eager_step()
+        torch.cuda.synchronize()
+        prof = UF.kernel_profile()
+        UF.kernel_profile(False)
+        pairs = args.bs * 40000
+        if 'C' in mods:
+            from unibev_amd.modules.encoders import pillar_axes, _lidar2img_tensor
+            axes = pillar_axes(200, 200, 8, 4, device)
+            _, _, vis0, _ = UF.point_sampling(_lidar2img_tensor(metas, device), *axes,
+                                              head.transformer.img_bev_encoder.pc_range,
+                                              WORKLOADS[args.workload][1])
+            pairs = args.bs * int(vis0.sum().item())         # rows of sample 0's visibility (quirk q1) per sample
+        ops = op_roofline(prof, sampling_ops(args.workload, args.bs, 4 if name == 'fp32' else 2, pairs))
+        for o in ops:
+            o['traffic'] = traffic_of(o) if name != 'fp32' else None
+        rec['roofline_ops'] = ops
+        if ops:
+            dom = ops[0]
+            rec['roofline'] = {'bound': 'hbm', 'achieved': dom['achieved_GBps'], 'peak': HBM_PEAK_GBS,
+                               'unit': 'GB/s', 'frac': dom['frac'], 'traffic': dom['traffic'],
+                               'kernel': f"{dom['op']} {dom['pass']}: " + ' + '.join(dom['kernels_us']),
+                               'avg_launch_us': dom['avg_us'],
+                               'algorithmic_bytes_per_launch': dom['compulsory_bytes_per_launch']}
+    gs.close()
+    del gs, opt
+    for p in params:
+        p.grad = None
+    torch.cuda.empty_cache()
+    return rec
+
+
+def gemm_record(device, bs):
+    """The projection GEMMs of one encoder layer (M = bs x 40 000 rows): time per call, TFLOP/s
+    against the dense MFMA peak, operand GB/s — through the same entry point the layers use."""
+    from unibev_amd import functional as UF
+    M, C = bs * 40000, 256
+    shapes = [('value_proj / output_proj', C, C), ('offsets+logits (P=8)', 192, C),
+              ('offsets+logits (P=4)', 96, C), ('ffn up', 2 * C, C), ('ffn down', C, 2 * C)]
+    out = []
+    for dname, dt in (('bf16', torch.bfloat16), ('fp32', torch.float32)):
+        for label, N, K in shapes:
+            x = torch.randn(M, K, device=device, dtype=dt)
+            w = torch.randn(N, K, device=device, dtype=dt) / K ** 0.5
+            b = torch.zeros(N, device=device, dtype=dt)
+            for _ in range(3):
+                y = UF.linear_forward(x, w, b)
+            if y is None:
+                continue
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                UF.linear_forward(x, w, b)
+            e1.record()
+            torch.cuda.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / 20
+            flops, nbytes = 2.0 * M * N * K, (M * K + N * K + M * N) * x.element_size()
+            out.append({'gemm': label, 'dtype': dname, 'M': M, 'N': N, 'K': K, 'us': us,
+                        'TFLOPs': flops / us / 1e6, 'mfma_frac': flops / us / 1e6 / MFMA_PEAK_TFLOPS[dname],
+                        'GBps': nbytes / us / 1e3, 'hbm_frac': nbytes / us / 1e3 / HBM_PEAK_GBS})
+    return out
+
+
+def voxel_record(device):
+    """LiDAR front end at cfg3's size: hard voxelization (T = 10, 90 000 voxel budget) of a 30 000
+    point cloud + VFE mean + the dense scatter of a SparseEncoder-sized output; nothing read back."""
+    from unibev_amd import functional as UF
+    from unibev_amd import synthetic as syn
+    pts = torch.from_numpy(syn.lidar_points(30000, seed=0)).to(device)
+    N, F = pts.shape
+
+    def front():
+        voxels, coors, num, vnum = UF.hard_voxelize(pts, syn.VOXEL_SIZE, syn.PC_RANGE, 10, 90000)
+        return UF.voxel_mean(voxels, num, vnum), coors, vnum
+
+    for _ in range(3):
+        mean, coors, vnum = front()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        mean, coors, vnum = front()
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / 20
+    m = int(vnum.item())
+    nbytes = N * F * 4 + N * 3 * 4 + m * (F + 3 + 1) * 4           # SURVEY.md section 8(d)
+    return {'points': N, 'voxels': m, 'us_per_cloud': us, 'points_per_s': N / us * 1e6,
+            'algorithmic_bytes': nbytes, 'GBps': nbytes / us / 1e3,
+            'note': 'hard voxelize + VFE mean, 7 launches: latency-bound, not bandwidth-bound'}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -122,94 +360,44 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
+    # everything runs on one non-default stream: HIP-graph capture needs the gradient accumulation of
+    # every parameter pinned to the capturing stream (graph_step.GraphedStep.capture)
+    torch.cuda.set_stream(torch.cuda.Stream(device))
     from unibev_amd import dp
     dp.init_distributed('nccl', device)                       # RCCL over xGMI (no-op for N = 1)
 
-    from unibev_amd import functional as UF
     torch.manual_seed(0)          # identical replicas
     np.random.seed(rank)          # modality dropout is per process, as in the reference
     head, tcfg = build_head(args.workload, device)
     head.train(not args.eval_mode)
-    head.transformer.lowp_stream = not args.fp32_stream
-    dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.dtype]
-    img, pts, metas = synth_inputs(args.workload, args.bs, dtype, device, rank)
-
-    head.forward = head.forward_bev           # DDP calls module.forward
-    model = dp.wrap_ddp(head, device_ids=[local])
-    fwd = lambda: model(img, pts, metas)       # noqa: E731
-    params = [p for p in head.parameters() if p.requires_grad]
-    opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.01, fused=True)
-    s = 2 if WORKLOADS[args.workload][0].get('fusion_method') == 'cat' else 1
-    C = WORKLOADS[args.workload][0]['embed_dims']
-    cot = torch.randn(200 * 200, args.bs, C * s, device=device) / 200.0
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        for x in (img or []) + (pts or []):
-            x.grad = None
-        with torch.autocast('cuda', dtype=dtype, enabled=dtype != torch.float32):
-            fused = fwd()
-        (fused.float() * cot).sum().backward()
-        torch.nn.utils.clip_grad_norm_(params, 35.0)
-        opt.step()
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    if not args.no_kernel_timing:
-        UF.kernel_profile(True)          # HIP events around every sampling kernel, on its stream
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    host_dt = time.perf_counter() - t0       # host-side enqueue time (before the final sync)
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = {} if args.no_kernel_timing else UF.kernel_profile()
-    UF.kernel_profile(False)
-    dt = dp.max_over_ranks(dt, device)
+    names = ['fp32', 'bf16', 'fp16'] if args.dtype == 'all' else [args.dtype]
+    recs = [run_mode(args, n, head, world, rank, device, want_ops=True) for n in names]
 
     if rank == 0:
+        main_rec = recs[0]
         out = {
-            'metric': 'nuScenes samples/sec BEV-encoder fwd+bwd', 'value': world * args.bs * args.steps / dt,
+            'metric': 'nuScenes samples/sec BEV-encoder fwd+bwd', 'value': main_rec['value'],
             'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * dt / args.steps, 'host_enqueue_ms_per_step': 1e3 * host_dt / args.steps,
+            'ms_per_step': main_rec['ms_per_step'],
+            'host_enqueue_ms_per_step': main_rec['host_enqueue_ms_per_step'],
             'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': main_rec['dtype'], 'data': 'synthetic',
             'config': {'workload': WORKLOADS[args.workload][3], 'per_gpu_batch': args.bs,
                        'global_batch': world * args.bs, 'encoder_layers': 3,
                        'mode': 'eval' if args.eval_mode else 'train (dropout 0.1, modality dropout)',
-                       'residual_stream': 'f32' if (args.fp32_stream or args.dtype == 'fp32') else args.dtype,
-                       'step': 'fwd + bwd + grad all-reduce + clip + AdamW',
-                       'parallelism': f'dp{world}'},
+                       'residual_stream': main_rec['residual_stream'],
+                       'step': 'fwd + bwd (HIP graphs) + flat-gradient all-reduce + clip + AdamW'
+                               if main_rec['hip_graphs'] else 'fwd + bwd + flat-gradient all-reduce + clip + AdamW',
+                       'parallelism': f'dp{world}', 'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
+                       'parity': main_rec['parity']},
+            'roofline': main_rec.get('roofline'),
+            'roofline_ops': main_rec.get('roofline_ops'),
         }
-        # ---- roofline of the dominant sampling kernel (HIP events inside the library) -------
-        detail = []
-        for name, r in prof.items():
-            detail.append({'kernel': name, 'launches': r['launches'], 'avg_us': r['avg_us'],
-                           'algorithmic_bytes_per_launch': r['bytes_per_launch'],
-                           'achieved_GBps': r['bytes_per_launch'] / (r['avg_us'] * 1e-6) / 1e9})
-        detail.sort(key=lambda d: -d['avg_us'] * d['launches'])
-        if detail:
-            dom = detail[0]
-            traffic = None
-            tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-            if os.path.exists(tfile):
-                rec = json.load(open(tfile)).get(dom['kernel'].split(',')[0])   # name<P=..
-                if rec and 'write' in rec and 'fetch_corrected' in rec:          # HBM-side bytes per launch from the PMC passes (see the file's note)
-                    traffic = rec['fetch_corrected'] + rec['write']
-            out['roofline'] = {'bound': 'hbm', 'achieved': dom['achieved_GBps'], 'peak': HBM_PEAK_GBS,
-                               'unit': 'GB/s', 'frac': dom['achieved_GBps'] / HBM_PEAK_GBS,
-                               'traffic': traffic, 'kernel': dom['kernel'],
-                               'avg_launch_us': dom['avg_us'],
-                               'algorithmic_bytes_per_launch': dom['algorithmic_bytes_per_launch']}
-            out['roofline_detail'] = detail
-        else:
-            out['roofline'] = None
+        if len(recs) > 1:
+            out['lowp'] = recs[1:]
+        if world == 1 and not args.no_extras:
+            out['gemm'] = gemm_record(device, args.bs)
+            out['voxel'] = voxel_record(device)
         # ---- CPU baseline: the oracle's forward on this host ------------------------------
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, tcfg, head)
@@ -220,17 +408,17 @@ def main():
 
 def cpu_baseline(args, tcfg, head):
     """The oracle (CPU restatement of the reference path, oracle/unibev_ref.py) timed on the host:
-    forward only, fp32, bs = 1, eval mode, 1 warm-up + 2 timed passes (~10-20 s)."""
+    forward only, fp32, bs = 1, eval mode; SURVEY.md section 8(d)'s protocol — 3 warm-up + 10 timed
+    passes, median — bounded to ~30 s of timed work (fewer passes on a slow host, stated)."""
     from oracle import unibev_ref as R
     # a 256-thread host oversubscribes torch's small CPU kernels (78.9 s/pass measured with all
-    # threads vs ~5 s with 16): the baseline uses at most 16 threads and says so
+    # threads vs ~3 s with 16): the baseline uses at most 16 threads and says so
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
     sd = {k[len('transformer.'):]: v.detach().float().cpu() for k, v in head.state_dict().items()
           if k.startswith('transformer.')}
     img, pts, metas = synth_inputs(args.workload, 1, torch.float32, 'cpu', 0)
     metas = [dict(lidar2img=[m.numpy() for m in metas[0]['lidar2img']], img_shape=metas[0]['img_shape'])]
     bev_q = head.state_dict()['bev_embedding.weight'].float().cpu()
-    C = bev_q.shape[1]
     pos = R.learned_positional_encoding(head.state_dict()['positional_encoding.row_embed.weight'].float().cpu(),
                                         head.state_dict()['positional_encoding.col_embed.weight'].float().cpu(),
                                         1, 200, 200)
@@ -241,15 +429,25 @@ def cpu_baseline(args, tcfg, head):
             return R.transformer_encode_fuse(sd, cfg, None if img is None else [x.detach() for x in img],
                                              None if pts is None else [x.detach() for x in pts],
                                              bev_q, 200, 200, pos, metas)
-    run()
-    n = 2
-    t0 = time.perf_counter()
-    for _ in range(n):
+    for _ in range(3):
         run()
-    dt = (time.perf_counter() - t0) / n
-    return {'value': 1.0 / dt, 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'forward only, fp32, bs=1, eval, {n} timed passes of the same workload '
-                      f'({dt:.2f} s each) through oracle/unibev_ref.py (torch CPU)'}
+    times, spent = [], 0.0
+    while len(times) < 10 and spent < 30.0:
+        t0 = time.perf_counter()
+        run()
+        times.append(time.perf_counter() - t0)
+        spent += times[-1]
+    med = float(np.median(times))
+    import platform
+    cpu = platform.processor() or ''
+    try:
+        cpu = [ln.split(':', 1)[1].strip() for ln in open('/proc/cpuinfo') if ln.startswith('model name')][0]
+    except Exception:
+        pass
+    return {'value': 1.0 / med, 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'cpu': cpu, 'host_cores': os.cpu_count(),
+            'sample': f'forward only, fp32, bs=1, eval: 3 warm-up + {len(times)} timed passes of the same '
+                      f'workload, median {med:.2f} s, through oracle/unibev_ref.py (torch CPU)'}
 
 
 if __name__ == '__main__':

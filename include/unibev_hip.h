@@ -232,6 +232,9 @@ int ubv_bev_fuse_backward(const void* grad_out, const void* img, const void* pts
  *   gamma, beta [C] f32             mean, rstd [R] f32 (saved for backward)
  *   p        dropout probability (0 = eval); the keep mask is a stateless hash of (seed, element),
  *            so backward regenerates it from the same seed and nothing is stored
+ *   seed_dev NULL, or a device pointer to a per-step base that is ADDED to `seed` by the kernel:
+ *            a captured HIP graph bakes `seed` in, the base is advanced on the device between
+ *            replays (forward and backward of one step must see the same value)
  *   grad_gamma, grad_beta [C] f32 ACCUMULATED (caller zeroes);  grad_x [R, C] dtype
  *   grad_x_colsum [C] f32 or NULL, ACCUMULATED: column sums of grad_x as stored — the bias
  *            gradient of the Linear that produced x (its backward then need not re-read grad_x)
@@ -239,21 +242,22 @@ int ubv_bev_fuse_backward(const void* grad_out, const void* img, const void* pts
  */
 int ubv_add_dropout_layernorm_forward(const void* x, const void* identity, const float* gamma,
                                       const float* beta, void* y, float* mean, float* rstd,
-                                      int64_t R, int C, float eps, float p, uint64_t seed, int dtype,
-                                      int stream_dtype, void* stream);
+                                      int64_t R, int C, float eps, float p, uint64_t seed,
+                                      const uint64_t* seed_dev, int dtype, int stream_dtype,
+                                      void* stream);
 int ubv_add_dropout_layernorm_backward(const void* grad_y, const void* x, const void* identity,
                                        const float* gamma, const float* mean, const float* rstd,
                                        void* grad_x, void* grad_identity, float* grad_gamma,
                                        float* grad_beta, float* grad_x_colsum, int64_t R, int C,
-                                       float p, uint64_t seed, int dtype, int stream_dtype,
-                                       void* stream);
+                                       float p, uint64_t seed, const uint64_t* seed_dev, int dtype,
+                                       int stream_dtype, void* stream);
 
 /* FFN activation of the encoder layers, y = dropout(relu(x)) in one pass ([ext] mmcv FFN:
  * Sequential(Linear, ReLU, Dropout(ffn_drop)); configs/unibev: feedforward_channels=512,
  * ffn_dropout=0.1).  Same stateless keep mask as above; backward needs only y
  * (grad_x = grad_y / (1-p) where y != 0).  n elements of dtype, n a multiple of 16 bytes' worth. */
-int ubv_relu_dropout_forward(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype,
-                             void* stream);
+int ubv_relu_dropout_forward(const void* x, void* y, int64_t n, float p, uint64_t seed,
+                             const uint64_t* seed_dev, int dtype, void* stream);
 int ubv_relu_dropout_backward(const void* grad_y, const void* y, void* grad_x, int64_t n, float p,
                               int dtype, void* stream);
 

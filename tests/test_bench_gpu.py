@@ -1,5 +1,5 @@
-"""bench.py end to end on one GPU: the JSON contract, and the multi-GPU code path (process group,
-DDP wrapper with gradients as bucket views, RCCL all-reduce hooks) forced on for a single rank."""
+"""bench.py end to end on one GPU: the JSON contract, HIP-graph replay of the step, and the multi-GPU
+code path (process group, RCCL all-reduce of the flat gradient buffer) forced on for a single rank."""
 import json
 import os
 import subprocess
@@ -33,3 +33,63 @@ def test_bench_json_contract(force_ddp):
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and 0 < r['frac'] < 1
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    # the headline is the parity-grade precision; the 16-bit runs ride along with their own numbers
+    assert d['dtype'] == 'fp32' and [x['dtype'] for x in d['lowp']] == ['bf16', 'fp16']
+    assert all(x['value'] > d['value'] for x in d['lowp'])
+    assert d['config']['rccl_ranks'] == 1
+    ops = {(o['op'], o['pass']) for o in d['roofline_ops']}
+    assert ops == {(o, p) for o in ('self_attn', 'sca_pts', 'sca_img') for p in ('fwd', 'bwd')}
+    if force_ddp == '0':
+        assert d['gemm'] and d['voxel']['voxels'] > 10000 and d['voxel']['points_per_s'] > 0
+
+
+def test_graph_replay_matches_eager_and_follows_the_modality_protocol():
+    """GraphedStep: with dropout off the replayed gradients equal the eager ones (up to the order of
+    f32 atomic adds); the per-step graph is chosen by the reference's
+    np.random protocol (flags recorded from the reference, tests/golden/modality_dropout.npz)."""
+    import numpy as np
+    import torch
+    from _util import encoder_case, golden, t
+    from unibev_amd import build_transformer
+    from unibev_amd.graph_step import GraphedStep
+    dev = 'cuda'
+    torch.cuda.set_stream(torch.cuda.Stream())       # capture and every earlier pass on one side stream
+    cfg, sd, inp, g = encoder_case('cnw')
+    cfg = json.loads(json.dumps(cfg))
+    cfg['drop_modality'] = 0.5
+    model = build_transformer(cfg).to(dev).train()
+    model.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    img = [t(x, device=dev).requires_grad_() for x in inp['img']]
+    pts = [t(x, device=dev).requires_grad_() for x in inp['pts']]
+    bev_q, bev_pos = t(inp['bev_q'], device=dev), t(inp['bev_pos'], device=dev)
+    fwd = lambda: model.encode(img, pts, bev_q, inp['bev_h'], inp['bev_w'], bev_pos=bev_pos,   # noqa: E731
+                               img_metas=inp['metas'])
+    params = [p for n, p in model.named_parameters() if not n.startswith('reference_points')]
+    cot = torch.randn(inp['bev_h'] * inp['bev_w'], inp['bs'], 128, device=dev)
+    for m in model.modules():                      # dropout off: replay must reproduce eager exactly
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if hasattr(m, 'ffn_drop'):
+            m.ffn_drop = 0.0
+    gs = GraphedStep(model, fwd, cot, params, inputs=img + pts).capture()
+    assert set(gs.graphs) == {(1, 1), (1, 0), (0, 1)}
+    flags = golden('modality_dropout')['float_flags']
+    np.random.seed(1234)
+    seen = []
+    for _ in range(len(flags)):
+        combo = gs.step()
+        seen.append(combo)
+        replayed = gs.grads.flat.clone()
+        model.forced_flags = combo
+        gs._clear_grads()
+        gs._fwd_bwd()
+        model.forced_flags = None
+        gs.grads.attach()
+        # same kernels, same data; only the f32 atomics behind the norm / bias gradients add in a
+        # different order from run to run
+        scale = float(replayed.abs().max())
+        assert scale > 0
+        torch.testing.assert_close(replayed, gs.grads.flat, rtol=1e-4, atol=1e-5 * scale)
+    np.testing.assert_array_equal(np.asarray(seen), flags)
+    gs.close()
+    torch.cuda.set_stream(torch.cuda.default_stream())

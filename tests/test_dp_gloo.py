@@ -1,5 +1,5 @@
 """The data-parallel harness on CPU: 2 processes, gloo.  Checks the sample sharding contract, that
-DDP-averaged gradients of encoder-side torch modules (FFN + LayerNorm built through the registry)
+DDP-averaged gradients (and the flat-buffer single all-reduce the bench uses) of encoder-side torch modules (FFN + LayerNorm built through the registry)
 equal the average of the per-rank gradients, and the max-over-ranks timing reduction."""
 import os
 import socket
@@ -49,6 +49,20 @@ def _worker(rank, world, port, ret):
         (net2(data[idx]).square().sum() / len(idx)).backward()
         ref += torch.cat([p.grad.flatten() for p in net2.parameters()]) / world
     ok = torch.allclose(grads, ref, rtol=1e-5, atol=1e-6)
+    # the flat-gradient exchange bench.py / graph_step.GraphedStep use: ONE all-reduce of one buffer
+    torch.manual_seed(0)
+    net3 = torch.nn.Sequential(
+        build_feedforward_network(dict(type='FFN', embed_dims=32, feedforward_channels=64,
+                                       ffn_drop=0.0)),
+        torch.nn.LayerNorm(32))
+    (net3(data[mine]).square().sum() / len(mine)).backward()
+    fg = dp.FlatGradients(list(net3.parameters()))
+    fg.collect()
+    fg.attach()
+    fg.all_reduce_mean()
+    flat = torch.cat([p.grad.flatten() for p in net3.parameters()])
+    ok = ok and torch.allclose(flat, ref, rtol=1e-5, atol=1e-6) and torch.equal(flat, fg.flat) \
+        and all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(net3.parameters(), fg.views))
     tmax = dp.max_over_ranks(1.0 + rank)
     dp.barrier()
     ret[rank] = (ok, mine, tmax)

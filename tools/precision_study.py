@@ -23,14 +23,15 @@ def main():
     model.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
     idx, sub = g['fused_idx'], g['fused_sub']
     scale = np.abs(sub).max()
-    modes = [('fp32', torch.float32, False, {})]
+    modes = [('fp32', torch.float32, False, {}), ('fp32/gemm-bf16x3', torch.float32, False, {'UBV_GEMM_EMU': 'bf16x3'}),
+             ('fp32/gemm-bf16x3 except offsets+logits', torch.float32, False, {'UBV_GEMM_EMU': 'bf16x3-keep-offlog'})]
     for dt, name in ((torch.float16, 'fp16'), (torch.bfloat16, 'bf16')):
         modes.append((name + '/stream16', dt, True, {}))
         modes.append((name + '/stream32', dt, False, {}))
         modes.append((name + '/stream32/offlog32', dt, False, {'UBV_OFFLOG': 'fp32'}))
         modes.append((name + '/stream16/offlog32', dt, True, {'UBV_OFFLOG': 'fp32'}))
     for name, dt, lowp, env in modes:
-        for k in ('UBV_OFFLOG',):
+        for k in ('UBV_OFFLOG', 'UBV_GEMM_EMU'):
             os.environ.pop(k, None)
         os.environ.update(env)
         model.lowp_stream = lowp

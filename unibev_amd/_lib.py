@@ -40,10 +40,10 @@ SIGNATURES = {
     'ubv_bev_fuse_forward': (c_int, [_P] * 7 + [c_int] * 5 + [_P]),
     'ubv_bev_fuse_backward': (c_int, [_P] * 11 + [c_int] * 5 + [_P]),
     'ubv_add_dropout_layernorm_forward': (c_int, [_P] * 7 + [c_int64, c_int, c_float, c_float, c_uint64,
-                                                          c_int, c_int, _P]),
+                                                          _P, c_int, c_int, _P]),
     'ubv_add_dropout_layernorm_backward': (c_int, [_P] * 11 + [c_int64, c_int, c_float, c_uint64,
-                                                            c_int, c_int, _P]),
-    'ubv_relu_dropout_forward': (c_int, [_P, _P, c_int64, c_float, c_uint64, c_int, _P]),
+                                                            _P, c_int, c_int, _P]),
+    'ubv_relu_dropout_forward': (c_int, [_P, _P, c_int64, c_float, c_uint64, _P, c_int, _P]),
     'ubv_relu_dropout_backward': (c_int, [_P, _P, _P, c_int64, c_float, c_int, _P]),
     'ubv_linear_workspace': (c_int64, []),
     'ubv_linear_forward': (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, c_int64, _P]),

@@ -41,7 +41,8 @@ template <typename T, typename S>
 __global__ __launch_bounds__(256) void add_norm_fwd_kernel(
     const T* __restrict__ x, const S* __restrict__ identity, const float* __restrict__ gamma,
     const float* __restrict__ beta, S* __restrict__ y, float* __restrict__ mean,
-    float* __restrict__ rstd, long R, int C, float eps, uint32_t thresh, float scale, uint64_t seed) {
+    float* __restrict__ rstd, long R, int C, float eps, uint32_t thresh, float scale, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev != nullptr) seed += *seed_dev;   // per-step base kept on the device (graph replays)
   const int lane = threadIdx.x & 63;
   const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(256) void add_norm_bwd_kernel(
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
     T* __restrict__ gx, S* __restrict__ gid, float* __restrict__ dgamma,
     float* __restrict__ dbeta, float* __restrict__ dxsum, long R, int C, uint32_t thresh,
-    float scale, uint64_t seed) {
+    float scale, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev != nullptr) seed += *seed_dev;   // per-step base kept on the device (graph replays)
   __shared__ float red[2][4][kNormChunks * 256];       // [gamma|beta][wave][column]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -189,7 +191,8 @@ template <typename T, typename S, int LPR>
 __global__ __launch_bounds__(256) void add_norm_fwd_rows_kernel(
     const T* __restrict__ x, const S* __restrict__ identity, const float* __restrict__ gamma,
     const float* __restrict__ beta, S* __restrict__ y, float* __restrict__ mean,
-    float* __restrict__ rstd, long R, int C, float eps, uint32_t thresh, float scale, uint64_t seed) {
+    float* __restrict__ rstd, long R, int C, float eps, uint32_t thresh, float scale, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev != nullptr) seed += *seed_dev;   // per-step base kept on the device (graph replays)
   constexpr int VEC = 16 / elem<T>::kBytes, G = 64 / LPR;
   const int lane = threadIdx.x & 63, sub = lane / LPR, c = (lane % LPR) * VEC;
   const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -250,7 +253,8 @@ __global__ __launch_bounds__(256) void add_norm_bwd_rows_kernel(
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
     T* __restrict__ gx, S* __restrict__ gid, float* __restrict__ dgamma,
     float* __restrict__ dbeta, float* __restrict__ dxsum, long R, int C, uint32_t thresh,
-    float scale, uint64_t seed) {
+    float scale, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev != nullptr) seed += *seed_dev;   // per-step base kept on the device (graph replays)
   constexpr int VEC = 16 / elem<T>::kBytes, G = 64 / LPR;
   __shared__ float red[3][4][64][VEC];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -340,7 +344,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void relu_dropout_fwd_kernel(const T* __restrict__ x,
                                                                T* __restrict__ y, long n,
                                                                uint32_t thresh, float scale,
-                                                               uint64_t seed) {
+                                                               uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev != nullptr) seed += *seed_dev;   // per-step base kept on the device (graph replays)
   constexpr int VEC = 16 / elem<T>::kBytes;
   const long stride = (long)gridDim.x * blockDim.x * VEC;
   for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC; i < n; i += stride) {
@@ -394,12 +399,12 @@ template <typename T, typename S>
 static void norm_fwd_launch(dim3 grid, hipStream_t st, const void* x, const void* identity,
                             const float* gamma, const float* beta, void* y, float* mean,
                             float* rstd, long R, int C, float eps, uint32_t th, float sc,
-                            uint64_t seed) {
+                            uint64_t seed, const uint64_t* seed_dev) {
   constexpr int VEC = 16 / elem<T>::kBytes;
   const int lpr = (C % VEC == 0) ? C / VEC : 0;
   auto run = [&](auto kernel) {
     hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, (const T*)x, (const S*)identity, gamma, beta,
-                       (S*)y, mean, rstd, R, C, eps, th, sc, seed);
+                       (S*)y, mean, rstd, R, C, eps, th, sc, seed, seed_dev);
   };
   if (lpr == 64) run(add_norm_fwd_rows_kernel<T, S, 64>);
   else if (lpr == 32) run(add_norm_fwd_rows_kernel<T, S, 32>);
@@ -411,12 +416,12 @@ template <typename T, typename S>
 static void norm_bwd_launch(dim3 grid, hipStream_t st, const void* gy, const void* x,
                             const void* identity, const float* gamma, const float* mean,
                             const float* rstd, void* gx, void* gid, float* dgamma, float* dbeta,
-                            float* dxsum, long R, int C, uint32_t th, float sc, uint64_t seed) {
+                            float* dxsum, long R, int C, uint32_t th, float sc, uint64_t seed, const uint64_t* seed_dev) {
   constexpr int VEC = 16 / elem<T>::kBytes;
   const int lpr = (C % VEC == 0) ? C / VEC : 0;
   auto run = [&](auto kernel) {
     hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, (const S*)gy, (const T*)x, (const S*)identity,
-                       gamma, mean, rstd, (T*)gx, (S*)gid, dgamma, dbeta, dxsum, R, C, th, sc, seed);
+                       gamma, mean, rstd, (T*)gx, (S*)gid, dgamma, dbeta, dxsum, R, C, th, sc, seed, seed_dev);
   };
   if (lpr == 64) run(add_norm_bwd_rows_kernel<T, S, 64>);
   else if (lpr == 32) run(add_norm_bwd_rows_kernel<T, S, 32>);
@@ -429,7 +434,8 @@ static void norm_bwd_launch(dim3 grid, hipStream_t st, const void* gy, const voi
 extern "C" int ubv_add_dropout_layernorm_forward(const void* x, const void* identity,
                                                  const float* gamma, const float* beta, void* y,
                                                  float* mean, float* rstd, int64_t R, int C,
-                                                 float eps, float p, uint64_t seed, int dtype,
+                                                 float eps, float p, uint64_t seed,
+                                                 const uint64_t* seed_dev, int dtype,
                                                  int stream_dtype, void* stream) {
   using namespace ubv;
   UBV_CHECK_ARG(x && identity && gamma && beta && y && mean && rstd, "add_norm_forward: null pointer");
@@ -441,7 +447,7 @@ extern "C" int ubv_add_dropout_layernorm_forward(const void* x, const void* iden
   const long waves = R < 8192 ? R : 8192;
   const dim3 grid((unsigned)((waves + 3) / 4));
   hipStream_t st = as_stream(stream);
-#define UBV_NORM_FWD(T, S) norm_fwd_launch<T, S>(grid, st, x, identity, gamma, beta, y, mean, rstd, (long)R, C, eps, th, sc, seed)
+#define UBV_NORM_FWD(T, S) norm_fwd_launch<T, S>(grid, st, x, identity, gamma, beta, y, mean, rstd, (long)R, C, eps, th, sc, seed, seed_dev)
   const bool lowp = stream_dtype != UBV_F32;
   switch (dtype) {
     case UBV_F32: UBV_NORM_FWD(float, float); break;
@@ -459,8 +465,8 @@ extern "C" int ubv_add_dropout_layernorm_backward(const void* grad_y, const void
                                                   void* grad_identity, float* grad_gamma,
                                                   float* grad_beta, float* grad_x_colsum,
                                                   int64_t R, int C, float p,
-                                                  uint64_t seed, int dtype, int stream_dtype,
-                                                  void* stream) {
+                                                  uint64_t seed, const uint64_t* seed_dev, int dtype,
+                                                  int stream_dtype, void* stream) {
   using namespace ubv;
   UBV_CHECK_ARG(grad_y && x && identity && gamma && mean && rstd && grad_x && grad_identity &&
                     grad_gamma && grad_beta, "add_norm_backward: null pointer");
@@ -472,7 +478,7 @@ extern "C" int ubv_add_dropout_layernorm_backward(const void* grad_y, const void
   const long waves = R < 2048 ? R : 2048;
   const dim3 grid((unsigned)((waves + 3) / 4));
   hipStream_t st = as_stream(stream);
-#define UBV_NORM_BWD(T, S) norm_bwd_launch<T, S>(grid, st, grad_y, x, identity, gamma, mean, rstd, grad_x, grad_identity, grad_gamma, grad_beta, grad_x_colsum, (long)R, C, th, sc, seed)
+#define UBV_NORM_BWD(T, S) norm_bwd_launch<T, S>(grid, st, grad_y, x, identity, gamma, mean, rstd, grad_x, grad_identity, grad_gamma, grad_beta, grad_x_colsum, (long)R, C, th, sc, seed, seed_dev)
   const bool lowp = stream_dtype != UBV_F32;
   switch (dtype) {
     case UBV_F32: UBV_NORM_BWD(float, float); break;
@@ -485,7 +491,7 @@ extern "C" int ubv_add_dropout_layernorm_backward(const void* grad_y, const void
 }
 
 extern "C" int ubv_relu_dropout_forward(const void* x, void* y, int64_t n, float p, uint64_t seed,
-                                        int dtype, void* stream) {
+                                        const uint64_t* seed_dev, int dtype, void* stream) {
   using namespace ubv;
   UBV_CHECK_ARG(x && y && n >= 0, "relu_dropout_forward: bad arguments");
   UBV_CHECK_ARG(dtype >= 0 && dtype <= 2, "relu_dropout_forward: unknown dtype %d", dtype);
@@ -499,9 +505,9 @@ extern "C" int ubv_relu_dropout_forward(const void* x, void* y, int64_t n, float
   const dim3 grid((unsigned)min((threads + 255) / 256, 8192L));
   hipStream_t st = as_stream(stream);
   switch (dtype) {
-    case UBV_F32: hipLaunchKernelGGL(relu_dropout_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)y, (long)n, th, sc, seed); break;
-    case UBV_F16: hipLaunchKernelGGL(relu_dropout_fwd_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, (long)n, th, sc, seed); break;
-    default: hipLaunchKernelGGL(relu_dropout_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, (long)n, th, sc, seed); break;
+    case UBV_F32: hipLaunchKernelGGL(relu_dropout_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)y, (long)n, th, sc, seed, seed_dev); break;
+    case UBV_F16: hipLaunchKernelGGL(relu_dropout_fwd_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, (long)n, th, sc, seed, seed_dev); break;
+    default: hipLaunchKernelGGL(relu_dropout_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, (long)n, th, sc, seed, seed_dev); break;
   }
   UBV_CHECK_LAUNCH("relu_dropout_forward");
   return UBV_OK;

@@ -1127,6 +1127,11 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
   }
   // query kernel: value, offsets/logits, refs, grad_out in; d(offsets/logits) out (+ records)
   const double q_bytes = nb.value + 2 * nb.offlog + nb.ref + nb.vis + nb.out;
+  // the whole backward op (every kernel launched below, scoped or not): op-level timing for the
+  // roofline, with the op's compulsory bytes (operands and results once; scratch is overhead)
+  ProfScope op_scope(name("bev_lift_bwd_op"), st,
+                     nb.value + (a.gvalue_lp != nullptr ? nb.value : nb.value_f32) + 2 * nb.offlog + nb.ref +
+                         nb.vis + nb.out);
   if (bwd_mode == kAtomAll) {
     ProfScope ps(name("bev_lift_bwd_query+atomics"), st, q_bytes + nb.value_f32);
     if (sizeof(T) == 2 && a.ol16)

@@ -68,3 +68,45 @@ def max_over_ranks(value, device='cpu'):
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+class FlatGradients:
+    """The gradients of ``params`` as views of ONE flat f32 buffer, exchanged with a single
+    all-reduce per step.
+
+    The BEV-encoder side has 13.9 M parameters (55.6 MB of f32 gradients).  xGMI is point-to-point
+    (7 links per GPU), so a collective is bound per link and wants few, large messages: one
+    55.6 MB all-reduce per step instead of DDP's bucket stream — it also keeps RCCL out of the
+    captured HIP graphs (``graph_step.GraphedStep`` copies the gradients here at the end of its
+    graph; the collective is issued eagerly behind the replay, on the same stream).
+    """
+
+    def __init__(self, params, dtype=torch.float32):
+        self.params = [p for p in params]
+        dev = self.params[0].device
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dtype, device=dev)
+        self.views, o = [], 0
+        for p in self.params:
+            self.views.append(self.flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+
+    def collect(self):
+        """Copy every parameter's current ``.grad`` into its view (one multi-tensor copy)."""
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+        torch._foreach_copy_(self.views, grads)
+
+    def attach(self):
+        """Make the views the parameters' ``.grad`` (what the optimizer then reads)."""
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def all_reduce_mean(self):
+        """Average over the ranks (no-op for a single process): RCCL's AVG, or SUM / world on
+        back-ends without it (gloo)."""
+        if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_ddp()):
+            return
+        if dist.get_backend() == 'nccl':
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(dist.get_world_size())

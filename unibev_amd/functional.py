@@ -427,6 +427,17 @@ def bev_fuse(img, pts, cw_img, cw_pts, sw_img=None, sw_pts=None, cat=False):
 # per call instead of the two tensor ops of torch.randint(...).item() (24 calls per forward pass on
 # a host-bound forward).
 _SEED_STATE = [None, 0]
+# Optional per-step seed base ON THE DEVICE (an int64 tensor of one element), added to every call's
+# seed by the kernels: a captured HIP graph bakes the per-call seeds in, so the replays of a step
+# differ only through this value, which the graph itself advances (``graph_step.GraphedStep``).
+_SEED_BASE = [None]
+
+
+def set_seed_base(tensor):
+    """Install (or with None remove) the device-side dropout seed base."""
+    if tensor is not None:
+        assert tensor.is_cuda and tensor.dtype == torch.int64 and tensor.numel() == 1
+    _SEED_BASE[0] = tensor
 
 
 def _next_seed():
@@ -459,10 +470,12 @@ class _AddDropoutNorm(Function):
             seed = _next_seed() if p > 0 else 0
             check(lib().ubv_add_dropout_layernorm_forward(_p(x2), _p(id2), _p(g), _p(b), _p(y), _p(mean),
                                                           _p(rstd), R, C, float(eps), float(p), seed,
-                                                          _dt(x2), _DT[sdt], _stream()),
+                                                          _p(_SEED_BASE[0]), _dt(x2), _DT[sdt],
+                                                          _stream()),
                   'add_dropout_layernorm_forward')
             ctx.save_for_backward(x2, id2, g, mean, rstd)
             ctx.p, ctx.seed, ctx.shape = float(p), seed, x.shape
+            ctx.seed_base = _SEED_BASE[0]
             ctx.dts = (identity.dtype, gamma.dtype, beta.dtype)
             return y.view(x.shape)
 
@@ -479,8 +492,9 @@ class _AddDropoutNorm(Function):
             dxs = zeros_f32(C, x2.device)
             check(lib().ubv_add_dropout_layernorm_backward(_p(gy), _p(x2), _p(id2), _p(g), _p(mean),
                                                            _p(rstd), _p(gx), _p(gid), _p(dg), _p(db),
-                                                           _p(dxs), R, C, ctx.p, ctx.seed, _dt(x2),
-                                                           _dt(id2), _stream()),
+                                                           _p(dxs), R, C, ctx.p, ctx.seed,
+                                                           _p(ctx.seed_base), _dt(x2), _dt(id2),
+                                                           _stream()),
                   'add_dropout_layernorm_backward')
             gx = gx.view(ctx.shape)
             # column sums of grad_x ride along: if x came straight out of a Linear, its backward takes
@@ -546,8 +560,9 @@ class _ReluDropout(Function):
             xc = x.contiguous()
             y = torch.empty_like(xc)
             seed = _next_seed() if p > 0 else 0
-            check(lib().ubv_relu_dropout_forward(_p(xc), _p(y), xc.numel(), float(p), seed, _dt(xc),
-                                                 _stream()), 'relu_dropout_forward')
+            check(lib().ubv_relu_dropout_forward(_p(xc), _p(y), xc.numel(), float(p), seed,
+                                                 _p(_SEED_BASE[0]), _dt(xc), _stream()),
+                  'relu_dropout_forward')
             ctx.save_for_backward(y)
             ctx.p = float(p)
             return y

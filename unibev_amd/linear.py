@@ -25,6 +25,7 @@ from torch.autograd import Function
 from torch.optim.optimizer import register_optimizer_step_post_hook
 
 import contextlib
+import os
 
 # (param ids, dtype) -> (concatenated low-precision buffer, per-parameter views, parameters)
 _SHADOWS = {}
@@ -157,6 +158,15 @@ class _Linear(Function):
             y = UF.linear_forward(xc, w, b)
         if y is None:
             y = F.linear(xc, w, b)
+        emu = os.environ.get('UBV_GEMM_EMU', '')
+        if emu and xc.dtype == torch.float32 and not (emu.endswith('-keep-offlog') and n == 2):
+            # precision study only: what a split-bf16 MFMA GEMM (3 products, f32 accumulation) would return
+            def split(t):
+                hi = t.bfloat16().float()
+                return hi, (t - hi).bfloat16().float()
+            xh, xl = split(xc)
+            wh, wl = split(w)
+            y = F.linear(xh, wh, b) + F.linear(xh, wl) + F.linear(xl, wh)
         return (y, x.view_as(x)) if passthru else y
 
     @staticmethod

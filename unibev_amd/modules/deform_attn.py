@@ -46,10 +46,31 @@ def static_hw(spatial_shapes):
     return hw
 
 
+_SHAPE_TENSORS = {}
+
+
 def shapes_tensor(hw, device):
-    """(L, 2) int64 device tensor carrying its own host copy."""
-    t = torch.as_tensor(hw, dtype=torch.long, device=device)
-    t._ubv_hw = [tuple(int(v) for v in r) for r in hw]
+    """(L, 2) int64 device tensor carrying its own host copy.  Cached per (shapes, device): the
+    upload happens once, so a later forward pass issues no host-to-device copy (none is allowed
+    while a HIP graph is being captured)."""
+    key = (tuple(tuple(int(v) for v in r) for r in hw), str(device))
+    t = _SHAPE_TENSORS.get(key)
+    if t is None:
+        t = torch.as_tensor(hw, dtype=torch.long, device=device)
+        t._ubv_hw = [tuple(int(v) for v in r) for r in hw]
+        if len(_SHAPE_TENSORS) > 64:
+            _SHAPE_TENSORS.clear()
+        _SHAPE_TENSORS[key] = t
+    return t
+
+
+def index_tensor(values, device):
+    """Cached int64 device tensor of a small host list (level start indices)."""
+    key = ('idx', tuple(int(v) for v in values), str(device))
+    t = _SHAPE_TENSORS.get(key)
+    if t is None:
+        t = torch.as_tensor([int(v) for v in values], dtype=torch.long, device=device)
+        _SHAPE_TENSORS[key] = t
     return t
 
 

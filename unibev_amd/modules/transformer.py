@@ -26,7 +26,7 @@ from ..linear import lowp_step_cache
 from ..registry import (TRANSFORMER, TRANSFORMER_LAYER_SEQUENCE,
                         build_transformer_layer_sequence)
 from .bricks import BaseModule, cast_keep_expand, xavier_init
-from .deform_attn import _DeformAttnBase, shapes_tensor
+from .deform_attn import _DeformAttnBase, index_tensor, shapes_tensor
 
 _UNSUPPORTED_NORMS = ('MLP_ChannelNormWeights', 'Leaky_ReLU_MLP_ChannelNormWeights',
                       'ELU_MLP_ChannelNormWeights', 'Sigmoid_MLP_ChannelNormWeights',
@@ -155,7 +155,7 @@ class UniBEVTransformer(BaseModule):
         flat = flat[0] if len(flat) == 1 else torch.cat(flat, 2)
         spatial_shapes = shapes_tensor(shapes, bev_queries.device)
         starts = np.concatenate(([0], np.cumsum([h * w for h, w in shapes])[:-1]))
-        level_start_index = torch.as_tensor(starts, dtype=torch.long, device=bev_queries.device)
+        level_start_index = index_tensor(starts, bev_queries.device)
         return flat.permute(1, 2, 0, 3), spatial_shapes, level_start_index
 
     def _pre_process_pts_feats(self, mlvl_pts_feats, bev_queries):
@@ -168,7 +168,7 @@ class UniBEVTransformer(BaseModule):
         bs, c, h, w = feat.shape
         tok = UF.flatten_embed(feat.reshape(bs, c, h * w), None, self.pts_level_embeds[0])
         spatial_shapes = shapes_tensor([(h, w)], bev_queries.device)
-        level_start_index = torch.zeros(1, dtype=torch.long, device=bev_queries.device)
+        level_start_index = index_tensor([0], bev_queries.device)
         return tok.permute(1, 0, 2), spatial_shapes, level_start_index
 
     # -- fusion ----------------------------------------------------------------------------------
@@ -210,9 +210,11 @@ class UniBEVTransformer(BaseModule):
                            cat=self.fusion_method == 'cat')
 
     # -- forward ---------------------------------------------------------------------------------
-    def _draw_modality_flags(self, img_mlvl_feats, pts_mlvl_feats):
-        self.l_flag = 1
-        self.c_flag = 1
+    def sample_modality_flags(self, has_img=True, has_pts=True):
+        """(c_flag, l_flag) of one forward pass: the modality-dropout draw of
+        transformer_fusion.py:463-477 (two ``np.random`` draws at most, in the reference's order)
+        followed by the missing-modality rule (:482-489).  Does not touch the module."""
+        l_flag = c_flag = 1
         if self.drop_modality is not None and self.training is True:
             if isinstance(self.drop_modality, dict):
                 dropout_prob = self.drop_modality['dropout_prob']
@@ -222,14 +224,22 @@ class UniBEVTransformer(BaseModule):
             else:
                 raise ValueError('Unrecognized type: {}'.format(type(self.drop_modality)))
             if self.get_probability(dropout_prob):
-                self.l_flag = self.get_probability(lidar_prob) * 1
-                self.c_flag = 1 - self.l_flag
-        if img_mlvl_feats is None:
-            self.c_flag = 0
-            return pts_mlvl_feats[0].size(0)
-        if pts_mlvl_feats is None:
-            self.l_flag = 0
-        return img_mlvl_feats[0].size(0)
+                l_flag = self.get_probability(lidar_prob) * 1
+                c_flag = 1 - l_flag
+        if not has_img:
+            c_flag = 0
+        elif not has_pts:
+            l_flag = 0
+        return c_flag, l_flag
+
+    def _draw_modality_flags(self, img_mlvl_feats, pts_mlvl_feats):
+        # ``forced_flags``: the caller drew (graph_step.GraphedStep replays one captured graph per
+        # flag combination and draws on the host with ``sample_modality_flags``)
+        forced = getattr(self, 'forced_flags', None)
+        self.c_flag, self.l_flag = forced if forced is not None else self.sample_modality_flags(
+            img_mlvl_feats is not None, pts_mlvl_feats is not None)
+        ref = img_mlvl_feats if img_mlvl_feats is not None else pts_mlvl_feats
+        return ref[0].size(0)
 
     def encode(self, img_mlvl_feats, pts_mlvl_feats, bev_queries, bev_h, bev_w, bev_pos=None,
                return_parts=False, **kwargs):
@@ -301,5 +311,5 @@ class UniBEVTransformer(BaseModule):
             reference_points=reference_points, reg_branches=reg_branches,
             cls_branches=cls_branches,
             spatial_shapes=shapes_tensor([(bev_h, bev_w)], query.device),
-            level_start_index=torch.zeros(1, dtype=torch.long, device=query.device), **kwargs)
+            level_start_index=index_tensor([0], query.device), **kwargs)
         return fused_bev_embed, inter_states, init_reference_out, inter_references
