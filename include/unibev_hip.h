@@ -275,6 +275,29 @@ int ubv_linear_forward(const void* x, const void* w, const void* bias, void* y, 
                        int K, int dtype, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Hand-written MFMA GEMM of the same Linear layers:
+ *   y[M, N] = x[M, K] . w[N, K]^T (+ bias[N]) (+ residual[M, N])
+ * forward ([ext] torch.nn.functional.linear), and with w := the transposed weight the input gradient
+ * dX = dY . W with the residual branch's gradient added in the epilogue.
+ *   dtype UBV_F32: x, y, residual f32; the weight comes SPLIT into bf16 halves w_hi + w_lo (both
+ *     [N, K], ubv_split_weight) and the product runs on the matrix cores as x_hi w_hi + x_hi w_lo +
+ *     x_lo w_hi with f32 accumulation: ~2^-17 per product instead of f32's 2^-24, the BEV features
+ *     of the full-size fixture stay at 3e-4 of the reference's (bar 1e-3) and the GEMM becomes
+ *     HBM-bound instead of bound by the f32 MFMA rate.
+ *   dtype UBV_F16 / UBV_BF16: x, w_hi, y, residual in that type, w_lo NULL, one product.
+ *   bias f32 [N] or NULL; residual may alias y; ldx / ldw / ldy row strides in elements.
+ * Needs K % 32 == 0, N % 32 == 0, 16-byte aligned rows; otherwise UBV_ERR_UNSUPPORTED (callers fall
+ * back to ubv_linear_forward / the framework GEMM).
+ */
+int ubv_gemm_nt(const void* x, int64_t ldx, const void* w_hi, const void* w_lo, int64_t ldw,
+                const float* bias, const void* residual, void* y, int64_t ldy, int64_t M, int N, int K,
+                int dtype, void* stream);
+/* f32 w [N, K] -> bf16 halves w_hi, w_lo [N, K] and (unless NULL) their transposes wt_hi, wt_lo
+ * [K, N] for the input-gradient GEMM.  One launch per Linear per step. */
+int ubv_split_weight(const float* w, int N, int K, void* w_hi, void* w_lo, void* wt_hi, void* wt_lo,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Reductions behind the gradients of the encoder's Linear layers (value_proj, sampling_offsets,
  * attention_weights, output_proj, FFN; [ext] torch.nn.Linear backward in the reference), one launch
  * per Linear:

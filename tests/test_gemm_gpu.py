@@ -1,0 +1,66 @@
+"""The hand-written MFMA GEMM (ubv_gemm_nt) against f64 products: split-bf16 arithmetic on f32 data
+(x_hi w_hi + x_hi w_lo + x_lo w_hi, ~2^-17 per product), single product on 16-bit data; bias, residual
+(aliasing the output), ragged row counts, every column tiling."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.mark.parametrize('M,N,K', [(1000, 256, 256), (4099, 192, 256), (130, 96, 512), (777, 512, 256),
+                                   (64, 32, 64), (2112, 128, 320)])
+def test_gemm_nt_split_f32(M, N, K):
+    from unibev_amd.functional import gemm_nt, split_weight
+    g = torch.Generator(device='cpu').manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    wh, wl, wth, wtl = split_weight(w.to(DEV))
+    # the halves reassemble the weight to 2^-17, in both orientations
+    torch.testing.assert_close(wh.float() + wl.float(), w.to(DEV), rtol=2.0 ** -16, atol=1e-7)
+    assert torch.equal(wth, wh.t().contiguous()) and torch.equal(wtl, wl.t().contiguous())
+    ref = x.double() @ w.double().t()
+    scale = float(ref.abs().max())
+    y = gemm_nt(x.to(DEV), wh, wl)
+    assert y is not None and y.dtype == torch.float32
+    assert float((y.cpu().double() - ref).abs().max()) < 3e-5 * scale
+    y = gemm_nt(x.to(DEV), wh, wl, bias=b.to(DEV), residual=r.to(DEV))
+    assert float((y.cpu().double() - (ref + b.double() + r.double())).abs().max()) < 3e-5 * scale
+    # residual aliasing the output (the in-place accumulation of the input-gradient GEMM)
+    acc = r.to(DEV).clone()
+    y = gemm_nt(x.to(DEV), wh, wl, residual=acc, out=acc)
+    assert y.data_ptr() == acc.data_ptr()
+    assert float((acc.cpu().double() - (ref + r.double())).abs().max()) < 3e-5 * scale
+    # input gradient: dX = dY . W through the transposed halves
+    gy = torch.randn(M, N, generator=g)
+    gx = gemm_nt(gy.to(DEV), wth, wtl)
+    assert gx is not None
+    if True:
+        refx = gy.double() @ w.double()
+        assert float((gx.cpu().double() - refx).abs().max()) < 3e-5 * float(refx.abs().max())
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_gemm_nt_16bit(dtype):
+    from unibev_amd.functional import gemm_nt
+    g = torch.Generator(device='cpu').manual_seed(3)
+    M, N, K = 3001, 192, 256
+    x = torch.randn(M, K, generator=g).to(dtype)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype)
+    b = torch.randn(N, generator=g)
+    y = gemm_nt(x.to(DEV), w.to(DEV), bias=b.to(DEV))
+    assert y.dtype == dtype
+    ref = x.double() @ w.double().t() + b.double()
+    tol = 2.0 ** (-8 if dtype == torch.bfloat16 else -11)          # one rounding of the output
+    assert float((y.cpu().double() - ref).abs().max()) < tol * float(ref.abs().max())
+
+
+def test_gemm_nt_declines_shapes_it_cannot_tile():
+    from unibev_amd.functional import gemm_nt, split_weight
+    wh, wl, _, _ = split_weight(torch.randn(24, 64, device=DEV), transposed=False)
+    assert gemm_nt(torch.randn(10, 64, device=DEV), wh, wl) is None          # N % 32 != 0
+    wh, wl, _, _ = split_weight(torch.randn(32, 48, device=DEV), transposed=False)
+    assert gemm_nt(torch.randn(10, 48, device=DEV), wh, wl) is None          # K % 32 != 0

@@ -1,0 +1,298 @@
+// Hand-written MFMA GEMMs of the encoder's Linear layers (gfx950).
+//
+//   Y[M, N] = X[M, K] . W[N, K]^T (+ bias[N]) (+ R[M, N])        "NT": both operands K-contiguous
+//
+// is the forward of every Linear (value_proj, sampling_offsets | attention_weights, output_proj, FFN)
+// and, with W := the transposed weight, its input gradient (dX = dY . W, the residual branch's
+// gradient R added in the epilogue).  M = bs x 40 000 rows, N, K in {96 .. 512}: tall and skinny,
+// bound by streaming X in and Y out.
+//
+// f32 data runs on the matrix cores as a SPLIT-bf16 product: x = x_hi + x_lo, w = w_hi + w_lo with
+// bf16 halves, y = x_hi w_hi + x_hi w_lo + x_lo w_hi accumulated in f32.  The dropped x_lo w_lo term
+// and the roundings of the lo halves leave ~2^-17 per product — the BEV features of the full-size
+// fixture move from 6.0e-5 (IEEE f32 GEMMs) to 3.2e-4 of the reference's, inside the 1e-3 bar —
+// while three bf16 MFMAs cost 3/16 of one f32 MFMA pass: the kernel is HBM-bound (164 MB per
+// 80 000 x 256 x 256 GEMM) where the f32 library GEMM is MFMA-bound (88 - 180 us measured).
+// Weights arrive pre-split (ubv_split_weight: once per step per Linear); activations are split in
+// registers on their way into LDS.  16-bit data takes the same kernel with one product.
+//
+// Block = 4 waves = 128 rows x NT columns (NT = 32 NB <= 256), K in chunks of 32 through LDS
+// ([rows][32 + 8] bf16: 80-byte rows keep the 16-byte fragment reads conflict-free; 60 KB per block,
+// two blocks per CU); the next chunk's global loads are issued before the MFMAs of the current one.  Operand roles are swapped
+// (A = W fragment, B = X fragment) so that a lane ends up with 4 CONSECUTIVE columns of one output
+// row: bias / residual / store are 16-byte (8-byte for 16-bit outputs) vectors.
+#include <type_traits>
+
+#include "ubv_common.h"
+
+namespace ubv {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 gbf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 gf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float gf32x16_t;
+
+constexpr int kGemmBM = 128, kGemmKC = 32, kGemmLd = kGemmKC + 8;   // 80-byte LDS rows: conflict-free 16-byte reads
+
+template <bool F16> __device__ __forceinline__ gf32x16_t gemm_mma(uint4 a, uint4 b, gf32x16_t c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gf16x8_t, a), __builtin_bit_cast(gf16x8_t, b),
+                                                  c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8_t, a),
+                                                   __builtin_bit_cast(gbf16x8_t, b), c, 0, 0, 0);
+}
+
+// SPLIT: X is f32, W is given as two bf16 matrices (hi, lo); else X, W are 16-bit (F16: f16, else bf16).
+// OUT16: Y (and R) in the 16-bit type, else f32.
+// Wave tiling: NB even -> 2 x 2 waves of (2 row blocks) x (NB / 2 column blocks): per 16-wide k step a
+// wave reads 2 + NB/2 fragment pairs from LDS for 2 * NB/2 MFMA groups (a 1-D split read 1 + NB for
+// NB groups and ran at a third of the speed); NB odd -> 4 x 1 waves of 1 x NB.
+template <int NB, bool SPLIT, bool F16, bool OUT16>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const void* __restrict__ Xv, long ldx,
+                                                      const uint16_t* __restrict__ Wh,
+                                                      const uint16_t* __restrict__ Wl, long ldw,
+                                                      const float* __restrict__ bias, const void* __restrict__ Rv,
+                                                      void* __restrict__ Yv, long ldy, long M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+  constexpr int NT = 32 * NB;
+  constexpr bool TWO_D = (NB % 2) == 0;
+  constexpr int WMB = TWO_D ? 2 : 1;                     // row blocks per wave
+  constexpr int WNB = TWO_D ? NB / 2 : NB;               // column blocks per wave
+  uint16_t* xh = lds;                                    // [128][40]
+  uint16_t* xl = xh + kGemmBM * kGemmLd;                 // (SPLIT only)
+  uint16_t* wh = xh + (SPLIT ? 2 : 1) * kGemmBM * kGemmLd;   // [NT][40]
+  uint16_t* wl = wh + NT * kGemmLd;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = TWO_D ? (wv >> 1) : wv, wn = TWO_D ? (wv & 1) : 0;
+  const long m0 = (long)blockIdx.x * kGemmBM;
+  const int n0 = blockIdx.y * NT;
+  // ---- staging maps.  X chunk [128 x 32]: f32 -> thread rows tid/8 + 32 i (i < 4), 4 columns
+  // (tid%8)*4; 16-bit -> rows tid/4 + 64 i (i < 2), 8 columns (tid%4)*8.  W chunk [NT x 32] 16-bit:
+  // rows tid/4 + 64 i, 8 columns.
+  const int xr = SPLIT ? tid >> 3 : tid >> 2, xc = SPLIT ? (tid & 7) * 4 : (tid & 3) * 8;
+  constexpr int XI = SPLIT ? 4 : 2;
+  constexpr int WI = (NT + 63) / 64;
+  const int wr = tid >> 2, wc = (tid & 3) * 8;
+  float4 xf[SPLIT ? 4 : 1];
+  uint4 xq[SPLIT ? 1 : 2];
+  uint4 wqh[WI], wql[SPLIT ? WI : 1];
+
+  auto load_chunk = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const long r = m0 + xr + (SPLIT ? 32 : 64) * i;
+      if constexpr (SPLIT)
+        xf[i] = r < M ? *reinterpret_cast<const float4*>((const float*)Xv + r * ldx + k0 + xc)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      else
+        xq[i] = r < M ? *reinterpret_cast<const uint4*>((const uint16_t*)Xv + r * ldx + k0 + xc)
+                      : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int r = wr + 64 * i;
+      const bool ok = r < NT && n0 + r < N;
+      wqh[i] = ok ? *reinterpret_cast<const uint4*>(Wh + (long)(n0 + r) * ldw + k0 + wc) : make_uint4(0u, 0u, 0u, 0u);
+      if constexpr (SPLIT)
+        wql[i] = ok ? *reinterpret_cast<const uint4*>(Wl + (long)(n0 + r) * ldw + k0 + wc) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      if constexpr (SPLIT) {
+        const float4 v = xf[i];
+        const uint32_t h0 = cvt_pk_bf16(v.x, v.y), h1 = cvt_pk_bf16(v.z, v.w);
+        const float r0 = v.x - __uint_as_float(h0 << 16), r1 = v.y - __uint_as_float(h0 & 0xffff0000u);
+        const float r2 = v.z - __uint_as_float(h1 << 16), r3 = v.w - __uint_as_float(h1 & 0xffff0000u);
+        const int o = (xr + 32 * i) * kGemmLd + xc;
+        *reinterpret_cast<uint2*>(xh + o) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(xl + o) = make_uint2(cvt_pk_bf16(r0, r1), cvt_pk_bf16(r2, r3));
+      } else {
+        *reinterpret_cast<uint4*>(xh + (xr + 64 * i) * kGemmLd + xc) = xq[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      if (wr + 64 * i < NT) {
+        *reinterpret_cast<uint4*>(wh + (wr + 64 * i) * kGemmLd + wc) = wqh[i];
+        if constexpr (SPLIT) *reinterpret_cast<uint4*>(wl + (wr + 64 * i) * kGemmLd + wc) = wql[i];
+      }
+    }
+  };
+
+  gf32x16_t acc[WMB][WNB];
+#pragma unroll
+  for (int i = 0; i < WMB; ++i)
+#pragma unroll
+    for (int j = 0; j < WNB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int fr = lane & 31, fk = (lane >> 5) * 8;         // fragment row within a 32-block, k offset
+  load_chunk(0);
+  for (int k0 = 0; k0 < K; k0 += kGemmKC) {
+    __syncthreads();                                      // previous chunk's fragments consumed
+    store_chunk();
+    __syncthreads();
+    if (k0 + kGemmKC < K) load_chunk(k0 + kGemmKC);       // in flight under the MFMAs below
+#pragma unroll
+    for (int ks = 0; ks < kGemmKC; ks += 16) {
+      uint4 bh[WMB], bl[WMB], ah[WNB], al[WNB];
+#pragma unroll
+      for (int i = 0; i < WMB; ++i) {
+        const int xo = ((wm * WMB + i) * 32 + fr) * kGemmLd + ks + fk;
+        bh[i] = *reinterpret_cast<const uint4*>(xh + xo);
+        if constexpr (SPLIT) bl[i] = *reinterpret_cast<const uint4*>(xl + xo);
+      }
+#pragma unroll
+      for (int j = 0; j < WNB; ++j) {
+        const int wo = ((wn * WNB + j) * 32 + fr) * kGemmLd + ks + fk;
+        ah[j] = *reinterpret_cast<const uint4*>(wh + wo);
+        if constexpr (SPLIT) al[j] = *reinterpret_cast<const uint4*>(wl + wo);
+      }
+#pragma unroll
+      for (int j = 0; j < WNB; ++j)
+#pragma unroll
+        for (int i = 0; i < WMB; ++i) {
+          acc[i][j] = gemm_mma<F16>(ah[j], bh[i], acc[i][j]);
+          if constexpr (SPLIT) {
+            acc[i][j] = gemm_mma<F16>(ah[j], bl[i], acc[i][j]);
+            acc[i][j] = gemm_mma<F16>(al[j], bh[i], acc[i][j]);
+          }
+        }
+    }
+  }
+  // ---- epilogue.  D[n][m]: column = this lane's row m, rows n = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  // within a column block: 4 consecutive output columns per (block, r >> 2)
+  const int half = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < WMB; ++i) {
+    const long m = m0 + (wm * WMB + i) * 32 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < WNB; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + (wn * WNB + j) * 32 + 8 * g + 4 * half;
+        if (n >= N) continue;                             // N is a multiple of 32 (checked by the host)
+        float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        if (bias != nullptr) {
+          const float4 b = *reinterpret_cast<const float4*>(bias + n);
+          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if constexpr (OUT16) {
+          using T = typename std::conditional<F16, f16_t, bf16_t>::type;
+          if (Rv != nullptr) {
+            float r[4];
+            vec_io<T, 4>::load((const T*)Rv + m * ldy + n, r);
+            v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+          }
+          vec_io<T, 4>::store((T*)Yv + m * ldy + n, v);
+        } else {
+          if (Rv != nullptr) {
+            const float4 r = *reinterpret_cast<const float4*>((const float*)Rv + m * ldy + n);
+            v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+          }
+          *reinterpret_cast<float4*>((float*)Yv + m * ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+  }
+}
+
+// f32 weight [N, K] -> bf16 hi / lo halves in both orientations: wh, wl [N, K] (forward) and
+// wth, wtl [K, N] (input gradient).  One launch per Linear per step.
+__global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ w, int N, int K,
+                                                           uint16_t* __restrict__ wh, uint16_t* __restrict__ wl,
+                                                           uint16_t* __restrict__ wth, uint16_t* __restrict__ wtl) {
+  __shared__ uint16_t th[32][33], tl[32][33];
+  const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + ty + 8 * i, k = k0 + tx;
+    uint16_t h = 0, l = 0;
+    if (n < N && k < K) {
+      const float v = w[(long)n * K + k];
+      h = (uint16_t)float_to_bf16_bits(v);
+      l = (uint16_t)float_to_bf16_bits(v - bf16_bits_to_float(h));
+      wh[(long)n * K + k] = h;
+      wl[(long)n * K + k] = l;
+    }
+    th[ty + 8 * i][tx] = h;
+    tl[ty + 8 * i][tx] = l;
+  }
+  __syncthreads();
+  if (wth == nullptr) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + ty + 8 * i, n = n0 + tx;
+    if (n < N && k < K) {
+      wth[(long)k * N + n] = th[tx][ty + 8 * i];
+      wtl[(long)k * N + n] = tl[tx][ty + 8 * i];
+    }
+  }
+}
+
+template <bool SPLIT, bool F16, bool OUT16>
+static int gemm_nt_launch(const void* X, long ldx, const void* Wh, const void* Wl, long ldw, const float* bias,
+                          const void* R, void* Y, long ldy, long M, int N, int K, hipStream_t st) {
+  // column tile: the largest of 256 / 192 / 128 / 96 / 64 / 32 that N fills evenly
+  int nt = 0;
+  for (int c : {256, 192, 128, 96, 64, 32})
+    if (N % c == 0) { nt = c; break; }
+  if (nt == 0) return UBV_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)((M + kGemmBM - 1) / kGemmBM), (unsigned)(N / nt)), blk(256);
+  const size_t lds = (size_t)((SPLIT ? 2 : 1) * (kGemmBM + nt) * kGemmLd) * sizeof(uint16_t);
+#define UBV_GEMM_NB(NBV)                                                                                     \
+  case NBV:                                                                                                  \
+    hipLaunchKernelGGL((gemm_nt_kernel<NBV, SPLIT, F16, OUT16>), grid, blk, lds, st, X, ldx, (const uint16_t*)Wh, \
+                       (const uint16_t*)Wl, ldw, bias, R, Y, ldy, M, N, K);                                  \
+    break;
+  switch (nt / 32) {
+    UBV_GEMM_NB(8) UBV_GEMM_NB(6) UBV_GEMM_NB(4) UBV_GEMM_NB(3) UBV_GEMM_NB(2) UBV_GEMM_NB(1)
+    default: return UBV_ERR_UNSUPPORTED;
+  }
+#undef UBV_GEMM_NB
+  return UBV_OK;
+}
+
+}  // namespace ubv
+
+extern "C" int ubv_split_weight(const float* w, int N, int K, void* wh, void* wl, void* wth, void* wtl,
+                                void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(w && wh && wl && N > 0 && K > 0, "split_weight: bad arguments");
+  UBV_CHECK_ARG((wth == nullptr) == (wtl == nullptr), "split_weight: give both transposed halves or neither");
+  hipLaunchKernelGGL(split_weight_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, as_stream(stream), w,
+                     N, K, (uint16_t*)wh, (uint16_t*)wl, (uint16_t*)wth, (uint16_t*)wtl);
+  UBV_CHECK_LAUNCH("split_weight");
+  return UBV_OK;
+}
+
+extern "C" int ubv_gemm_nt(const void* x, int64_t ldx, const void* w_hi, const void* w_lo, int64_t ldw,
+                           const float* bias, const void* residual, void* y, int64_t ldy, int64_t M, int N,
+                           int K, int dtype, void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(x && w_hi && y && M >= 0 && N > 0 && K > 0, "gemm_nt: bad arguments");
+  UBV_CHECK_ARG(dtype >= 0 && dtype <= 2, "gemm_nt: unknown dtype %d", dtype);
+  UBV_CHECK_ARG((dtype == UBV_F32) == (w_lo != nullptr), "gemm_nt: f32 data takes split weights (hi, lo), 16-bit data one");
+  if (M == 0) return UBV_OK;
+  const int al = dtype == UBV_F32 ? 4 : 8;
+  if (K % kGemmKC != 0 || N % 32 != 0 || ldx % al != 0 || ldw % 8 != 0 || ldy % 4 != 0 ||
+      ((uintptr_t)x % 16) != 0 || ((uintptr_t)w_hi % 16) != 0 || ((uintptr_t)y % 16) != 0 ||
+      (residual != nullptr && ((uintptr_t)residual % 16) != 0) || (bias != nullptr && ((uintptr_t)bias % 16) != 0)) {
+    set_error("gemm_nt: shape M=%lld N=%d K=%d needs K %% 32 == 0, N %% 32 == 0 and 16-byte aligned rows",
+              (long long)M, N, K);
+    return UBV_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = as_stream(stream);
+  int rc;
+  if (dtype == UBV_F32) rc = gemm_nt_launch<true, false, false>(x, ldx, w_hi, w_lo, ldw, bias, residual, y, ldy, M, N, K, st);
+  else if (dtype == UBV_F16) rc = gemm_nt_launch<false, true, true>(x, ldx, w_hi, nullptr, ldw, bias, residual, y, ldy, M, N, K, st);
+  else rc = gemm_nt_launch<false, false, true>(x, ldx, w_hi, nullptr, ldw, bias, residual, y, ldy, M, N, K, st);
+  if (rc != UBV_OK) { set_error("gemm_nt: no kernel for N=%d", N); return rc; }
+  UBV_CHECK_LAUNCH("gemm_nt");
+  return UBV_OK;
+}

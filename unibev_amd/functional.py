@@ -612,6 +612,43 @@ def linear_forward(x, weight, bias=None):
     return y
 
 
+# ----------------------------------------------------------------------------------------------- MFMA GEMM
+@torch.no_grad()
+def split_weight(w, transposed=True):
+    """f32 (N, K) -> bf16 halves (w_hi, w_lo, wt_hi, wt_lo) for ``gemm_nt`` (``ubv_split_weight``);
+    the transposed pair (K, N) serves the input-gradient GEMM."""
+    with _need_cuda(w):
+        w = w.detach().float().contiguous()
+        N, K = w.shape
+        wh = torch.empty(N, K, dtype=torch.bfloat16, device=w.device)
+        wl = torch.empty_like(wh)
+        wth = torch.empty(K, N, dtype=torch.bfloat16, device=w.device) if transposed else None
+        wtl = torch.empty_like(wth) if transposed else None
+        check(lib().ubv_split_weight(_p(w), N, K, _p(wh), _p(wl), _p(wth), _p(wtl), _stream()), 'split_weight')
+        return wh, wl, wth, wtl
+
+
+@torch.no_grad()
+def gemm_nt(x, w_hi, w_lo=None, bias=None, residual=None, out=None):
+    """y = x @ w^T (+ bias) (+ residual) on the matrix cores (``ubv_gemm_nt``).  f32 ``x`` takes the
+    split weight (w_hi, w_lo); 16-bit ``x`` takes w_hi of its own type.  Returns None when the shape
+    is outside the kernel's reach (K % 32, N % 32)."""
+    with _need_cuda(x, w_hi, w_lo, bias, residual, out):
+        K = x.shape[-1]
+        M = x.numel() // K
+        N = w_hi.shape[0]
+        if K % 32 != 0 or N % 32 != 0 or not x.is_contiguous():
+            return None
+        y = out if out is not None else torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+        b = None if bias is None else bias.float().contiguous()
+        rc = lib().ubv_gemm_nt(_p(x), K, _p(w_hi), _p(w_lo), K, _p(b), _p(residual), _p(y), N, M, N, K,
+                               _dt(x), _stream())
+        if rc == -3:
+            return None
+        check(rc, 'gemm_nt')
+        return y
+
+
 # ----------------------------------------------------------------------------------------------- linear grads
 @torch.no_grad()
 def linear_grad_reduce(grad_out=None, partials=None):

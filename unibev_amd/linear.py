@@ -93,6 +93,7 @@ def lowp_step_cache():
         return
     from . import functional as UF
     UF.new_step()                     # backward accumulators of this pass come from a fresh arena
+    _SPLIT_PASS.clear()
     if _SHADOWS and _masters_changed():
         plan = _refresh_plan()
         with torch.no_grad():
@@ -111,6 +112,38 @@ def clear_lowp_cache():
     _SHADOWS.clear()
     _PLAN.update(n=-1, groups=[], params=[], versions=None)
     _DIRTY[0] = True
+
+
+# f32 Linear layers on the matrix cores: per forward pass, the weight of a Linear is split once into
+# bf16 halves (both orientations) for functional.gemm_nt; fresh buffers per pass, so the copies a
+# pass saved for its backward stay valid when a later pass starts (gradient accumulation).
+_SPLIT_PASS = {}
+_MFMA_F32 = os.environ.get('UBV_F32_GEMM', 'mfma') != 'library'
+
+
+def set_f32_gemm(mode):
+    """'mfma': f32 Linear layers as split-bf16 products on the matrix cores (default; ~2^-17 per
+    product, BEV features 3e-4 from the reference's at full size).  'library': IEEE f32 GEMMs
+    (hipBLASLt; 6e-5), 1.7x slower.  Returns the previous mode."""
+    global _MFMA_F32
+    if mode not in ('mfma', 'library'):
+        raise ValueError("mode must be 'mfma' or 'library'")
+    prev = 'mfma' if _MFMA_F32 else 'library'
+    _MFMA_F32 = mode == 'mfma'
+    return prev
+_MFMA_16_MAXN = 192          # 16-bit data: the MFMA kernel wins for narrow outputs, the library for wide ones
+
+
+def _split_weights(weights):
+    key = tuple(id(p) for p in weights)
+    hit = _SPLIT_PASS.get(key) if _ACTIVE else None
+    if hit is None:
+        from . import functional as UF
+        w = weights[0] if len(weights) == 1 else torch.cat([p.detach() for p in weights], 0)
+        hit = UF.split_weight(w)
+        if _ACTIVE:
+            _SPLIT_PASS[key] = hit
+    return hit
 
 
 def _cached_lowp(params, dtype):
@@ -148,34 +181,68 @@ class _Linear(Function):
         w = _cached_lowp(weights, dtype)
         b = _cached_lowp(biases, dtype) if has_bias else None
         xc = x.to(dtype)
-        ctx.save_for_backward(xc, w)
         ctx.meta = (x.dtype, n, has_bias, [p.shape[0] for p in weights], [p.dtype for p in params])
         y = None
-        if xc.is_cuda and xc.dtype == w.dtype and (b is None or b.dtype == w.dtype) and \
+        split = None
+        ok = xc.is_cuda and xc.is_contiguous() and xc.numel() > 0 and xc.shape[-1] % 32 == 0 and \
+            w.shape[0] % 32 == 0
+        from . import functional as UF
+        if ok and dtype == torch.float32 and _MFMA_F32 and w.dtype == torch.float32:
+            # split-bf16 product on the matrix cores (ubv_gemm_nt): HBM-bound where the f32 library
+            # GEMM is MFMA-bound (61 vs 103 us at 80 000 x 256 x 256)
+            split = _split_weights(weights)
+            y = UF.gemm_nt(xc, split[0], split[1], bias=b)
+        elif ok and dtype != torch.float32 and w.dtype == dtype and w.shape[0] <= _MFMA_16_MAXN and \
+                w.is_contiguous():
+            b32 = None
+            if has_bias:                  # the kernel adds the bias in f32: hand it the master values
+                b32 = biases[0].detach() if n == 1 else torch.cat([p.detach() for p in biases])
+            y = UF.gemm_nt(xc, w, bias=b32)
+        if y is None and xc.is_cuda and xc.dtype == w.dtype and (b is None or b.dtype == w.dtype) and \
                 xc.is_contiguous() and w.is_contiguous() and xc.numel() > 0:
             # hipBLASLt with a cached plan (ubv_linear_forward): same GEMM, a third of the host time
-            from . import functional as UF
             y = UF.linear_forward(xc, w, b)
         if y is None:
             y = F.linear(xc, w, b)
         emu = os.environ.get('UBV_GEMM_EMU', '')
         if emu and xc.dtype == torch.float32 and not (emu.endswith('-keep-offlog') and n == 2):
             # precision study only: what a split-bf16 MFMA GEMM (3 products, f32 accumulation) would return
-            def split(t):
+            def split_(t):
                 hi = t.bfloat16().float()
                 return hi, (t - hi).bfloat16().float()
-            xh, xl = split(xc)
-            wh, wl = split(w)
+            xh, xl = split_(xc)
+            wh, wl = split_(w)
             y = F.linear(xh, wh, b) + F.linear(xh, wl) + F.linear(xl, wh)
+        if split is not None:
+            ctx.save_for_backward(xc, w, split[2], split[3])
+        else:
+            ctx.save_for_backward(xc, w)
         return (y, x.view_as(x)) if passthru else y
 
     @staticmethod
     def backward(ctx, grad_out, grad_alias=None):
-        xc, w = ctx.saved_tensors
+        xc, w = ctx.saved_tensors[:2]
+        wt = ctx.saved_tensors[2:]                    # transposed split halves (f32 MFMA path) or ()
         x_dtype, n, has_bias, outs, pdt = ctx.meta
         go2 = grad_out.reshape(-1, grad_out.shape[-1])
         gx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and wt and go2.dtype == torch.float32 and x_dtype == torch.float32 and \
+                go2.is_contiguous() and go2.shape[1] % 32 == 0 and xc.shape[-1] % 32 == 0:
+            # dX = dY . W on the matrix cores, the residual branch's gradient added in the epilogue
+            # (in place when that tensor was produced for this edge alone)
+            from . import functional as UF
+            ga = None
+            if grad_alias is not None and grad_alias.dtype == torch.float32:
+                ga = grad_alias.reshape(-1, xc.shape[-1])
+                ga = ga if ga.is_contiguous() else ga.contiguous()
+            own = ga is not None and getattr(grad_alias, '_ubv_owned', False) and \
+                ga.data_ptr() == grad_alias.data_ptr()
+            gx = UF.gemm_nt(go2, wt[0], wt[1], residual=ga, out=ga if own else None)
+            if gx is not None:
+                gx = gx.view(xc.shape)
+                if grad_alias is not None and ga is None:
+                    gx = gx + grad_alias.to(x_dtype)
+        if gx is None and ctx.needs_input_grad[0]:
             if grad_alias is not None and grad_alias.dtype == go2.dtype == x_dtype:
                 ga = grad_alias.reshape(-1, xc.shape[-1])
                 if getattr(grad_alias, '_ubv_owned', False) and ga.is_contiguous():
