@@ -41,12 +41,19 @@ def encoder_case(name):
     g = golden('encoder_' + name)
     cfg = json.loads(str(g['cfg_json']))
     case = mg.ENCODER_CASES[name] if name in mg.ENCODER_CASES else None
-    if name == 'fullsize':
-        case = (dict(embed_dims=256, num_layers=3), 200, 200, 1, (8, 22), (180, 180), (256, 704), 31)
-        tag = 'full'
-    else:
-        tag = name
+    if name in mg.FULLSIZE_CASES:
+        case = mg.FULLSIZE_CASES[name][0]
+        kw, bev_h, bev_w, bs, img_hw_f, pts_hw_f, img_hw, seed = case
+        img, pts, bev_q, bev_pos, oq, metas = mg.fullsize_inputs(name)
+        named = [(n, tuple(json.loads(s))) for n, s in zip(g['param_names'], g['param_shapes'])]
+        sd = mg.fullsize_state_dict(name, named)
+        np.testing.assert_array_equal(checksum(img[0]), g['img_ck'])
+        np.testing.assert_array_equal(checksum(pts[0]), g['pts_ck'])
+        inputs = dict(img=img, pts=pts, bev_q=bev_q, bev_pos=bev_pos, metas=metas, bev_h=bev_h,
+                      bev_w=bev_w, bs=bs)
+        return cfg, sd, inputs, g
     kw, bev_h, bev_w, bs, img_hw_f, pts_hw_f, img_hw, seed = case
+    tag = name
     img, pts, bev_q, bev_pos, oq, metas = mg.encoder_inputs(tag, *case)
     named = [(n, tuple(json.loads(s))) for n, s in zip(g['param_names'], g['param_shapes'])]
     sd = syn.seeded_state_dict(named, seed)

@@ -260,21 +260,66 @@ def gen_encoders(mods):
         save('encoder_' + name, **arrays)
 
 
-def gen_fullsize(mods):
-    """cfg4 shapes at bs=1 (6 x 8x22 image feats, 180x180 LiDAR feats, 200x200 BEV, C=256, 3 layers):
-    statistics + a strided subsample of the reference's output."""
-    case = (dict(embed_dims=256, num_layers=3), 200, 200, 1, (8, 22), (180, 180), (256, 704), 31)
-    cfg, named, fused, parts, (img, pts, bev_q, bev_pos, metas) = \
-        run_reference_transformer(mods, 'full', case)
-    f = fused.numpy().reshape(-1)
-    idx = np.arange(0, f.size, 2503)
-    save('encoder_fullsize', cfg_json=np.array(json.dumps(cfg)),
-         param_names=np.array([n for n, _ in named]),
-         param_shapes=np.array([json.dumps(list(s)) for _, s in named]),
-         fused_idx=idx, fused_sub=f[idx], fused_ck=checksum(f),
-         fused_std=np.array([f.std()]),
-         img_bev_ck=checksum(parts['img'].numpy()), pts_bev_ck=checksum(parts['pts'].numpy()),
-         img_ck=checksum(img[0]), pts_ck=checksum(pts[0]))
+FULLSIZE_CASES = {
+    # name: (case, profile).  profile 'random': i.i.d. maps + seeded random sampling weights (offsets of
+    # a few pixels driven by the queries: every rounding upstream moves sampling points — the
+    # adversarial case); 'init': the reference's initial sampling parameters + box-filtered maps.
+    'fullsize': ((dict(embed_dims=256, num_layers=3), 200, 200, 1, (8, 22), (180, 180), (256, 704), 31), 'random'),
+    'fullsize_init': ((dict(embed_dims=256, num_layers=3), 200, 200, 1, (8, 22), (180, 180), (256, 704), 33), 'init'),
+    # cfg5: cat fusion, C = 128, 800x1440 images -> 25x45 maps
+    'fullsize_cat128': ((dict(embed_dims=128, num_layers=3, fusion_method='cat', feature_norm=None),
+                         200, 200, 1, (25, 45), (180, 180), (800, 1440), 32), 'random'),
+}
+
+
+def fullsize_inputs(name):
+    """(img, pts, bev_q, bev_pos, oq, metas) of a full-size case, profile applied."""
+    case, profile = FULLSIZE_CASES[name]
+    img, pts, bev_q, bev_pos, oq, metas = encoder_inputs('full' if name == 'fullsize' else name, *case)
+    if profile == 'init':
+        img = [syn.smooth_maps(x) for x in img]
+        pts = [syn.smooth_maps(x) for x in pts]
+    return img, pts, bev_q, bev_pos, oq, metas
+
+
+def fullsize_state_dict(name, named):
+    case, profile = FULLSIZE_CASES[name]
+    sd = syn.seeded_state_dict(named, case[-1])
+    return syn.init_like_state_dict(sd) if profile == 'init' else sd
+
+
+def gen_fullsize(mods, only=None):
+    """BASELINE shapes at bs=1 (200x200 BEV, 3 layers): statistics + a strided subsample of the
+    reference's output."""
+    T = mods['transformer_fusion'].UniBEVTransformer
+    for name, (case, profile) in FULLSIZE_CASES.items():
+        if only is not None and name not in only:
+            continue
+        kw, bev_h, bev_w, bs = case[:4]
+        cfg = cfgs.transformer_cfg(**kw)
+        args = dict(cfg)
+        args.pop('type')
+        model = T(**args)
+        model.init_weights()
+        named = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+        model.load_state_dict({k: t(v) for k, v in fullsize_state_dict(name, named).items()})
+        model.eval()
+        img, pts, bev_q, bev_pos, oq, metas = fullsize_inputs(name)
+        parts = {}
+        model.img_bev_encoder.register_forward_hook(lambda m, i, o: parts.__setitem__('img', o))
+        model.pts_bev_encoder.register_forward_hook(lambda m, i, o: parts.__setitem__('pts', o))
+        with torch.no_grad():
+            fused, _, _, _ = model([t(x) for x in img], [t(x) for x in pts], t(bev_q), t(oq), bev_h, bev_w,
+                                   bev_pos=t(bev_pos), img_metas=metas)
+        f = fused.numpy().reshape(-1)
+        idx = np.arange(0, f.size, 2503)
+        save('encoder_' + name, cfg_json=np.array(json.dumps(cfg)),
+             param_names=np.array([n for n, _ in named]),
+             param_shapes=np.array([json.dumps(list(s)) for _, s in named]),
+             fused_idx=idx, fused_sub=f[idx], fused_ck=checksum(f),
+             fused_std=np.array([f.std()]),
+             img_bev_ck=checksum(parts['img'].numpy()), pts_bev_ck=checksum(parts['pts'].numpy()),
+             img_ck=checksum(img[0]), pts_ck=checksum(pts[0]))
 
 
 def gen_modality_dropout(mods):

@@ -176,10 +176,12 @@ def test_sca_modules_vs_reference_vectors():
     np.testing.assert_allclose(out.cpu().numpy(), g['pts_out'], rtol=1e-4, atol=1e-4)
 
 
-def test_encoder_fullsize_vs_reference_statistics():
-    """cfg4 shapes at bs=1 (6 x 8x22 image feats, 180x180 LiDAR feats, 200x200 BEV, C=256, 3 layers):
-    a strided sample and checksums of the reference's fused_bev_embed."""
-    cfg, sd, inp, g = encoder_case('fullsize')
+@pytest.mark.parametrize('fixture', ['fullsize', 'fullsize_init', 'fullsize_cat128'])
+def test_encoder_fullsize_vs_reference_statistics(fixture):
+    """BASELINE shapes at bs=1 (200x200 BEV, 3 layers, 180x180 LiDAR feats): cfg4 (6 x 8x22 image
+    feats, C=256, CNW) with adversarial and with initial-state sampling parameters, and cfg5 (6 x 25x45
+    image feats, C=128, cat): a strided sample and checksums of the reference's fused_bev_embed."""
+    cfg, sd, inp, g = encoder_case(fixture)
     model = _build(cfg).to(DEV).eval()
     _load(model, sd)
     with torch.no_grad():
@@ -187,9 +189,41 @@ def test_encoder_fullsize_vs_reference_statistics():
     f = fused.cpu().numpy().reshape(-1)
     scale = np.abs(g['fused_sub']).max()
     np.testing.assert_allclose(f[g['fused_idx']], g['fused_sub'], rtol=1e-3, atol=1e-3 * scale)
+    err = np.linalg.norm(f[g['fused_idx']] - g['fused_sub']) / np.linalg.norm(g['fused_sub'])
+    assert err < 6e-4, err            # split-bf16 GEMMs: 3.2e-4 measured on the adversarial fixture
     np.testing.assert_allclose(checksum(f)[1], g['fused_ck'][1], rtol=1e-4)
     np.testing.assert_allclose(checksum(img_bev.cpu().numpy())[1], g['img_bev_ck'][1], rtol=1e-4)
     np.testing.assert_allclose(checksum(pts_bev.cpu().numpy())[1], g['pts_bev_ck'][1], rtol=1e-4)
+
+
+# Full-size distance of the 16-bit autocast paths to the REFERENCE-recorded vectors (normwise, on the
+# recorded subsample), measured on MI355X and asserted with ~1.4x headroom (tools/precision_study.py):
+#   fixture            fp16 (16-bit stream)   bf16 (16-bit stream)   fp32
+#   fullsize_init      7.3e-4  < 1e-3 bar     5.8e-3                 7e-6    initial sampling parameters,
+#                                                                            spatially correlated maps
+#   fullsize           2.8e-2                 1.9e-1                 3.2e-4  i.i.d. maps, random offset
+#                                                                            weights: every rounding moves
+#                                                                            sampling points by O(1) values
+#   fullsize_cat128    6.1e-3                 4.7e-2                 6.5e-5  cfg5 (C = 128, 25x45 maps)
+# The adversarial fixtures amplify a unit round-off ~1000x (f32: 6e-8 -> 6e-5), so no 16-bit storage of
+# activations can hold 1e-3 there; on the operating point the bench runs at (and training starts
+# from) fp16 is inside the bar.
+LOWP_DISTANCE = {('fullsize_init', torch.float16): 1.0e-3, ('fullsize_init', torch.bfloat16): 8e-3,
+                 ('fullsize', torch.float16): 4e-2, ('fullsize', torch.bfloat16): 0.26,
+                 ('fullsize_cat128', torch.float16): 9e-3, ('fullsize_cat128', torch.bfloat16): 6.5e-2}
+
+
+@pytest.mark.parametrize('fixture,dtype', sorted(LOWP_DISTANCE, key=str))
+def test_fullsize_16bit_distance_to_reference_vectors(fixture, dtype):
+    cfg, sd, inp, g = encoder_case(fixture)
+    model = _build(cfg).to(DEV).eval()
+    _load(model, sd)
+    with torch.no_grad(), torch.autocast('cuda', dtype=dtype):
+        fused, _, _ = _run(model, inp)
+    assert fused.dtype == dtype
+    f = fused.float().cpu().numpy().reshape(-1)[g['fused_idx']]
+    err = np.linalg.norm(f - g['fused_sub']) / np.linalg.norm(g['fused_sub'])
+    assert err < LOWP_DISTANCE[(fixture, dtype)], err
 
 
 @pytest.mark.parametrize('lowp_stream', [True, False])

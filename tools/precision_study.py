@@ -18,7 +18,12 @@ DEV = 'cuda:0'
 
 
 def main():
-    cfg, sd, inp, g = encoder_case('fullsize')
+    for fx in (sys.argv[1:] or ['fullsize', 'fullsize_init', 'fullsize_cat128']):
+        study(fx)
+
+
+def study(fixture):
+    cfg, sd, inp, g = encoder_case(fixture)
     model = build_transformer(json.loads(json.dumps(cfg))).to(DEV).eval()
     model.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
     idx, sub = g['fused_idx'], g['fused_sub']
@@ -41,7 +46,7 @@ def main():
                                  inp['bev_h'], inp['bev_w'], bev_pos=t(inp['bev_pos'], device=DEV),
                                  img_metas=inp['metas'])
         f = fused.float().cpu().numpy().reshape(-1)[idx]
-        print(json.dumps({'mode': name, 'normwise': float(np.linalg.norm(f - sub) / np.linalg.norm(sub)),
+        print(json.dumps({'fixture': fixture, 'mode': name, 'normwise': float(np.linalg.norm(f - sub) / np.linalg.norm(sub)),
                           'max_abs_over_max': float(np.abs(f - sub).max() / scale),
                           'p99_abs_over_max': float(np.quantile(np.abs(f - sub), 0.99) / scale)}), flush=True)
 

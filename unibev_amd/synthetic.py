@@ -110,3 +110,42 @@ def lidar_points(n=30000, seed=0, frac_outside=0.02, pc_range=PC_RANGE):
         idx = rs.choice(n, n_out, replace=False)
         pts[idx, 0] = pc_range[3] + 1.0 + rs.random_sample(n_out) * 10.0
     return pts.astype(np.float32)
+
+
+def init_like_state_dict(sd, num_heads=8):
+    """Parameters as the reference leaves the sampling layers at initialisation
+    (spatial_cross_attention_img.py:293-311, decoder.py:208-226): ``sampling_offsets`` weight 0 and
+    bias = the compass-direction grid scaled by the point index, ``attention_weights`` all 0 — the
+    operating point of the first training steps (and of bench.py).  Everything else is kept."""
+    out = dict(sd)
+    for name, a in sd.items():
+        leaf = name.split('.')[-1]
+        if 'attention_weights' in name:
+            out[name] = np.zeros_like(a)
+        elif 'sampling_offsets' in name and leaf == 'weight':
+            out[name] = np.zeros_like(a)
+        elif 'sampling_offsets' in name and leaf == 'bias':
+            P = a.size // (num_heads * 2)
+            th = np.arange(num_heads, dtype=np.float32) * np.float32(2.0 * math.pi / num_heads)
+            g = np.stack([np.cos(th), np.sin(th)], -1).astype(np.float32)
+            g = g / np.abs(g).max(-1, keepdims=True)
+            g = np.tile(g[:, None, :], (1, P, 1)) * np.arange(1, P + 1, dtype=np.float32)[None, :, None]
+            out[name] = g.reshape(-1).astype(np.float32)
+    return out
+
+
+def smooth_maps(x, k=5):
+    """Box filter over the last two axes (window k, mean over the in-range part, times k): feature
+    maps with the spatial correlation backbone outputs have, instead of i.i.d. pixels."""
+    x = np.asarray(x, np.float64)
+    h, w = x.shape[-2:]
+    r = k // 2
+
+    def box(a, axis, n):
+        c = np.cumsum(np.concatenate([np.zeros_like(np.take(a, [0], axis)), a], axis), axis)
+        hi = np.minimum(np.arange(n) + r + 1, n)
+        lo = np.maximum(np.arange(n) - r, 0)
+        return np.take(c, hi, axis) - np.take(c, lo, axis), (hi - lo)
+    s, ch = box(x, x.ndim - 2, h)
+    s, cw = box(s, x.ndim - 1, w)
+    return (s / (ch[:, None] * cw[None, :]) * k).astype(np.float32)
