@@ -1148,17 +1148,39 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     // overflowed a bucket (normally nothing: both kernels exit at once), then the query gradients
     // and the owner tiles, each of which stores its finished pixels exactly once
     const int tiles = t.tiles_x * t.tiles_y;
+    // Diagnostic only (UBV_LIFT_TWO_STREAM=1): the grad_value chain (bins -> overflow -> owner tiles)
+    // on a side stream next to the query-gradient kernel, forked and joined with events inside this
+    // call.  Not faster (both chains are issue-bound); kept to reproduce and
+    // test the concurrent residency of the two kernels (tests/test_lift_gpu.py).
+    const char* two_env = getenv("UBV_LIFT_TWO_STREAM");
+    const bool two = two_env != nullptr && atoi(two_env) != 0;
+    hipStream_t s2 = st;
+    static hipStream_t side_stream[64] = {};
+    static hipEvent_t side_fork[64] = {}, side_join[64] = {};
+    int dev = 0;
+    if (two) {
+      (void)hipGetDevice(&dev);
+      dev &= 63;
+      if (side_stream[dev] == nullptr) {
+        (void)hipStreamCreateWithFlags(&side_stream[dev], hipStreamNonBlocking);
+        (void)hipEventCreateWithFlags(&side_fork[dev], hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&side_join[dev], hipEventDisableTiming);
+      }
+      s2 = side_stream[dev];
+      (void)hipEventRecord(side_fork[dev], st);
+      (void)hipStreamWaitEvent(s2, side_fork[dev], 0);
+    }
     {
       const long waves = (long)a.total_tiles * a.H;
-      ProfScope ps(name("bev_lift_bwd_bins"), st, nb.offlog + nb.ref + nb.rec);
+      ProfScope ps(name("bev_lift_bwd_bins"), s2, nb.offlog + nb.ref + nb.rec);
       hipLaunchKernelGGL((lift_bin_kernel<T, DH, P>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
-                         st, a, t.tiles_x, tiles);
+                         s2, a, t.tiles_x, tiles);
     }
     {
       const long tw = (long)a.B * a.H * tiles;
-      hipLaunchKernelGGL(lift_ovf_zero_kernel, dim3((unsigned)((tw + 3) / 4)), dim3(256), 0, st, a,
+      hipLaunchKernelGGL(lift_ovf_zero_kernel, dim3((unsigned)((tw + 3) / 4)), dim3(256), 0, s2, a,
                          t.tiles_x, tiles, DH);
-      hipLaunchKernelGGL((lift_ovf_scatter_kernel<T, DH>), dim3(1024), dim3(256), 0, st, a, t.tiles_x,
+      hipLaunchKernelGGL((lift_ovf_scatter_kernel<T, DH>), dim3(1024), dim3(256), 0, s2, a, t.tiles_x,
                          tiles);
     }
     {
@@ -1170,10 +1192,16 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     }
     constexpr int RB = 2;
     const size_t lds = (size_t)t.waves * TileLds<T, DH, RB>::kWords * sizeof(uint16_t);
-    ProfScope ps(name("bev_lift_bwd_value_grid"), st,
-                 nb.rec + nb.out + (a.gvalue_lp != nullptr ? nb.value : nb.value_f32));
-    hipLaunchKernelGGL((lift_bwd_value_kernel<T, DH, P, RB>), dim3(8 * t.chunk), dim3(64 * t.waves),
-                       lds, st, a, t);
+    {
+      ProfScope ps(name("bev_lift_bwd_value_grid"), s2,
+                   nb.rec + nb.out + (a.gvalue_lp != nullptr ? nb.value : nb.value_f32));
+      hipLaunchKernelGGL((lift_bwd_value_kernel<T, DH, P, RB>), dim3(8 * t.chunk), dim3(64 * t.waves),
+                         lds, s2, a, t);
+    }
+    if (two) {
+      (void)hipEventRecord(side_join[dev], s2);
+      (void)hipStreamWaitEvent(st, side_join[dev], 0);
+    }
   } else {
     if (!a.ext_list)
       hipLaunchKernelGGL(compact_visible_kernel, dim3(a.Nc), dim3(1024), 0, st, a.vis0, a.Nq,
