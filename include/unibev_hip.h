@@ -292,6 +292,16 @@ int ubv_linear_forward(const void* x, const void* w, const void* bias, void* y, 
 int ubv_gemm_nt(const void* x, int64_t ldx, const void* w_hi, const void* w_lo, int64_t ldw,
                 const float* bias, const void* residual, void* y, int64_t ldy, int64_t M, int N, int K,
                 int dtype, void* stream);
+/* Weight gradient of the same layers ([ext] torch.nn.Linear backward):
+ *   dW[N, K] = sum_m grad_out[m, n] x[m, k],  db[n] = sum_m grad_out[m, n]
+ * as a split-K MFMA product over `splits` slabs of rows (ubv_gemm_wgrad_splits picks the count that
+ * fills the chip).  grad_out [M, N] and x [M, K] share `dtype` (f32: split-bf16 products as above).
+ * partials [splits, N*K + N] f32: scratch (slab s holds its dW part followed by its N bias sums);
+ * grad_wb [N*K + N] f32, WRITTEN: dW row-major, then db — the slabs summed by a second launch.
+ * N % 4 == 0 and K % 4 == 0, else UBV_ERR_UNSUPPORTED. */
+int ubv_gemm_wgrad_splits(int64_t M, int N, int K);
+int ubv_gemm_wgrad(const void* grad_out, const void* x, float* partials, float* grad_wb, int64_t M, int N,
+                   int K, int splits, int dtype, void* stream);
 /* f32 w [N, K] -> bf16 halves w_hi, w_lo [N, K] and (unless NULL) their transposes wt_hi, wt_lo
  * [K, N] for the input-gradient GEMM.  One launch per Linear per step. */
 int ubv_split_weight(const float* w, int N, int K, void* w_hi, void* w_lo, void* wt_hi, void* wt_lo,

@@ -64,3 +64,25 @@ def test_gemm_nt_declines_shapes_it_cannot_tile():
     assert gemm_nt(torch.randn(10, 64, device=DEV), wh, wl) is None          # N % 32 != 0
     wh, wl, _, _ = split_weight(torch.randn(32, 48, device=DEV), transposed=False)
     assert gemm_nt(torch.randn(10, 48, device=DEV), wh, wl) is None          # K % 32 != 0
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('M,N,K', [(5000, 256, 256), (4099, 192, 256), (777, 96, 128), (9000, 512, 256),
+                                   (300, 64, 36), (12345, 256, 512)])
+def test_gemm_wgrad(M, N, K, dtype):
+    """dW = dY^T X and db = column sums of dY in one pass (ubv_gemm_wgrad + the slab sum) against f64:
+    split-bf16 products for f32 data (~2^-17 each), exact products of the stored values for 16-bit data;
+    ragged row counts, partial tiles in N and K."""
+    from unibev_amd.functional import gemm_wgrad
+    g = torch.Generator(device='cpu').manual_seed(M + N)
+    gy = torch.randn(M, N, generator=g).to(dtype)
+    x = torch.randn(M, K, generator=g).to(dtype)
+    res = gemm_wgrad(gy.to(DEV), x.to(DEV))
+    assert res is not None
+    gw, gb = res
+    assert gw.shape == (N, K) and gb.shape == (N,) and gw.dtype == torch.float32
+    refw = gy.double().t() @ x.double()
+    refb = gy.double().sum(0)
+    tol = 3e-5 if dtype == torch.float32 else 2e-6           # 16-bit inputs multiply exactly; f32 accumulation
+    assert float((gw.cpu().double() - refw).abs().max()) < max(tol * float(refw.abs().max()), 1e-3 * tol * M ** 0.5 * 30)
+    assert float((gb.cpu().double() - refb).abs().max()) < 1e-5 * max(1.0, float(refb.abs().max())) * (1 if dtype == torch.float32 else 1)

@@ -35,3 +35,20 @@ for dt in (torch.float32, torch.bfloat16):
         nbytes = (M * K + M * N) * x.element_size()
         print(f'{str(dt):16s} N={N:4d} K={K:4d}  mfma kernel {mine:7.1f} us ({nbytes / mine / 1e3:6.0f} GB/s)   '
               f'library {lib:7.1f} us ({nbytes / lib / 1e3:6.0f} GB/s)')
+
+print('--- weight gradient (dW + db): MFMA split-K kernel + slab sum vs strided-batched library GEMM + reduce')
+from unibev_amd.linear import _splits
+for dt in (torch.float32, torch.bfloat16):
+    for N, K in ((256, 256), (192, 256), (96, 256), (512, 256), (256, 512)):
+        gy = torch.randn(M, N, device='cuda').to(dt)
+        x = torch.randn(M, K, device='cuda').to(dt)
+        mine = timeit(lambda: UF.gemm_wgrad(gy, x))
+        s = _splits(M)
+
+        def lib():
+            part = torch.bmm(gy.view(s, M // s, -1).transpose(1, 2), x.view(s, M // s, -1))
+            return UF.linear_grad_reduce(gy, part)
+        libt = timeit(lib)
+        nbytes = (M * K + M * N) * x.element_size()
+        print(f'{str(dt):16s} N={N:4d} K={K:4d}  mfma wgrad {mine:7.1f} us ({nbytes / mine / 1e3:6.0f} GB/s)   '
+              f'library {libt:7.1f} us')

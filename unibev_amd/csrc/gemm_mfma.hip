@@ -296,3 +296,252 @@ extern "C" int ubv_gemm_nt(const void* x, int64_t ldx, const void* w_hi, const v
   UBV_CHECK_LAUNCH("gemm_nt");
   return UBV_OK;
 }
+
+namespace ubv {
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient:  dW[N, K] = sum_m dY[m, n] X[m, k],   db[n] = sum_m dY[m, n]
+// — a product that REDUCES over the M = bs x 40 000 rows into a 256 x 256 .. 512 x 256 output.  Both
+// operands are row-major with the reduction index outermost, the opposite of what MFMA fragments want
+// (8 consecutive reduction steps per lane), so the staging pass transposes: a lane loads elements
+// (m, c), (m + 1, c) of its two columns c and stores each PAIR as one dword of T[c][m .. m + 1] in LDS
+// (rows of 34 halves = 17 dwords: the 64 lanes of a store hit 32 different banks).  Fragments are then
+// 4 dword reads per 8 reduction steps.  f32 data is split into bf16 halves on the way in
+// (dY_hi X_hi + dY_hi X_lo + dY_lo X_hi, f32 accumulation), 16-bit data takes one product.
+//
+// A block owns a 128 x 128 tile of dW for one slab of rows (split-K over M); its 4 waves hold 64 x 64
+// each in registers.  Roles are swapped (A = X^T fragment, B = dY^T fragment) so that a lane ends up
+// with 4 consecutive k of one output row n: 16-byte stores.  The slabs' partial tiles go to
+// `partials` [S][N*K + N] (f32; the last N entries of a slab are its bias sums, written by the
+// k-tile-0 blocks from the same dY fragments), summed by ubv_linear_grad_reduce — one read of dY and
+// X instead of the strided-batched library GEMM + a separate column-sum pass.
+constexpr int kWgTile = 128, kWgMC = 64, kWgLd = kWgMC + 2;   // LDS rows: 64 reduction steps + 2 (halves): 33 dwords
+
+template <bool SPLIT, bool F16>
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restrict__ dYv, const void* __restrict__ Xv,
+                                                            float* __restrict__ partials, long M, int N, int K,
+                                                            int tiles_k, int rows_per_split) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+  uint16_t* ty_h = lds;                                   // [128 n][66]
+  uint16_t* tx_h = ty_h + kWgTile * kWgLd;                // [128 k][66]
+  uint16_t* ty_l = tx_h + kWgTile * kWgLd;                // (SPLIT only)
+  uint16_t* tx_l = ty_l + kWgTile * kWgLd;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tile = blockIdx.x, tn = tile / tiles_k, tk = tile - tn * tiles_k;
+  const int n0 = tn * kWgTile, k0 = tk * kWgTile;
+  const long mbeg = (long)blockIdx.y * rows_per_split;
+  const long mend = mbeg + rows_per_split < M ? mbeg + rows_per_split : M;
+  const int wk = wv >> 1, wn = wv & 1;                    // wave tile: k rows [64 wk, +64), n cols [64 wn, +64)
+
+  gf32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  float bsum[2] = {0.0f, 0.0f};
+
+  // staging: wave w takes rows m = 16 w + 2 p + {0, 1} (p < 8) of the chunk; lane l <-> the column pair
+  // (2 l, 2 l + 1): one 8-byte (f32) / 4-byte (16-bit) load per row, 512 / 256 contiguous bytes per wave
+  constexpr int NP = kWgMC / 8;                           // row pairs per wave
+  uint2 fy[SPLIT ? NP : 1][2], fx[SPLIT ? NP : 1][2];
+  uint32_t hy[SPLIT ? 1 : NP][2], hx[SPLIT ? 1 : NP][2];
+  const bool nok = n0 + 2 * lane < N, kok = k0 + 2 * lane < K;      // N, K even (host check)
+  auto load_chunk = [&](long mc) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const long m = mc + wv * (kWgMC / 4) + 2 * p + q;
+        const bool mok = m < mend;
+        if constexpr (SPLIT) {
+          fy[p][q] = (mok && nok) ? *reinterpret_cast<const uint2*>((const float*)dYv + m * N + n0 + 2 * lane) : make_uint2(0u, 0u);
+          fx[p][q] = (mok && kok) ? *reinterpret_cast<const uint2*>((const float*)Xv + m * K + k0 + 2 * lane) : make_uint2(0u, 0u);
+        } else {
+          hy[p][q] = (mok && nok) ? *reinterpret_cast<const uint32_t*>((const uint16_t*)dYv + m * N + n0 + 2 * lane) : 0u;
+          hx[p][q] = (mok && kok) ? *reinterpret_cast<const uint32_t*>((const uint16_t*)Xv + m * K + k0 + 2 * lane) : 0u;
+        }
+      }
+    }
+  };
+  // f32 pair (value at row m, value at row m+1) -> hi and lo bf16 pairs of one column
+  auto split_store = [&](uint16_t* th, uint16_t* tl, int col, int mo, uint32_t a_bits, uint32_t b_bits) {
+    const float a = __uint_as_float(a_bits), b = __uint_as_float(b_bits);
+    const uint32_t h = cvt_pk_bf16(a, b);
+    const uint32_t l = cvt_pk_bf16(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u));
+    *reinterpret_cast<uint32_t*>(th + col * kWgLd + mo) = h;
+    *reinterpret_cast<uint32_t*>(tl + col * kWgLd + mo) = l;
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int mo = wv * (kWgMC / 4) + 2 * p;            // even: the pair is one aligned dword
+      if constexpr (SPLIT) {
+        split_store(ty_h, ty_l, 2 * lane, mo, fy[p][0].x, fy[p][1].x);
+        split_store(ty_h, ty_l, 2 * lane + 1, mo, fy[p][0].y, fy[p][1].y);
+        split_store(tx_h, tx_l, 2 * lane, mo, fx[p][0].x, fx[p][1].x);
+        split_store(tx_h, tx_l, 2 * lane + 1, mo, fx[p][0].y, fx[p][1].y);
+      } else {
+        // rows m, m+1 hold columns (2l, 2l+1): regroup into (m, m+1) pairs per column
+        const uint32_t a = hy[p][0], b = hy[p][1];
+        *reinterpret_cast<uint32_t*>(ty_h + (2 * lane) * kWgLd + mo) = (a & 0xffffu) | (b << 16);
+        *reinterpret_cast<uint32_t*>(ty_h + (2 * lane + 1) * kWgLd + mo) = (a >> 16) | (b & 0xffff0000u);
+        const uint32_t c = hx[p][0], d = hx[p][1];
+        *reinterpret_cast<uint32_t*>(tx_h + (2 * lane) * kWgLd + mo) = (c & 0xffffu) | (d << 16);
+        *reinterpret_cast<uint32_t*>(tx_h + (2 * lane + 1) * kWgLd + mo) = (c >> 16) | (d & 0xffff0000u);
+      }
+    }
+  };
+  auto frag = [&](const uint16_t* t, int row, int ks) -> uint4 {   // 8 reduction steps of one row: 4 dwords
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(t + row * kWgLd + ks);
+    return make_uint4(p[0], p[1], p[2], p[3]);
+  };
+
+  const int fr = lane & 31, fk = (lane >> 5) * 8;
+  load_chunk(mbeg);
+  for (long mc = mbeg; mc < mend; mc += kWgMC) {
+    __syncthreads();
+    store_chunk();
+    __syncthreads();
+    if (mc + kWgMC < mend) load_chunk(mc + kWgMC);
+#pragma unroll
+    for (int ks = 0; ks < kWgMC; ks += 16) {
+      uint4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = frag(tx_h, wk * 64 + i * 32 + fr, ks + fk);
+        if constexpr (SPLIT) al[i] = frag(tx_l, wk * 64 + i * 32 + fr, ks + fk);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bh[j] = frag(ty_h, wn * 64 + j * 32 + fr, ks + fk);
+        if constexpr (SPLIT) bl[j] = frag(ty_l, wn * 64 + j * 32 + fr, ks + fk);
+        if (tk == 0 && wk == 0) {                         // bias: this lane's 8 values of column n
+          float s = 0.0f;
+          const uint32_t w4[4] = {bh[j].x, bh[j].y, bh[j].z, bh[j].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (F16) {
+              s += (float)__builtin_bit_cast(_Float16, (uint16_t)(w4[e] & 0xffffu)) +
+                   (float)__builtin_bit_cast(_Float16, (uint16_t)(w4[e] >> 16));
+            } else {
+              s += __uint_as_float(w4[e] << 16) + __uint_as_float(w4[e] & 0xffff0000u);
+            }
+          }
+          if constexpr (SPLIT) {
+            const uint32_t l4[4] = {bl[j].x, bl[j].y, bl[j].z, bl[j].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += __uint_as_float(l4[e] << 16) + __uint_as_float(l4[e] & 0xffff0000u);
+          }
+          bsum[j] += s;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = gemm_mma<F16>(ah[i], bh[j], acc[i][j]);
+          if constexpr (SPLIT) {
+            acc[i][j] = gemm_mma<F16>(ah[i], bl[j], acc[i][j]);
+            acc[i][j] = gemm_mma<F16>(al[i], bh[j], acc[i][j]);
+          }
+        }
+    }
+  }
+  // ---- partial tile.  D[k][n]: column n = this lane's, rows k = (r & 3) + 8 (r >> 2) + 4 half
+  float* part = partials + (long)blockIdx.y * ((long)N * K + N);
+  const int half = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + fr;
+    if (n >= N) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int k = k0 + wk * 64 + i * 32 + 8 * g + 4 * half;
+        if (k >= K) continue;                             // K is a multiple of 4 (host check)
+        *reinterpret_cast<float4*>(part + (long)n * K + k) =
+            make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+      }
+    }
+    if (tk == 0 && wk == 0) {                             // one wave row per column block owns the bias sum
+      const float s = bsum[j] + __shfl_xor(bsum[j], 32, 64);
+      if (half == 0) part[(long)N * K + n] = s;
+    }
+  }
+}
+
+// out[i] = sum over the S slabs of partials[s][i] (i < len, len % 4 == 0).  A block is 32 columns of 4
+// elements x 8 slab groups: every thread sums S / 8 slabs with independent 16-byte loads, the groups
+// meet in LDS.  (One thread walking all S slabs — the shape of ubv_linear_grad_reduce, built for 32
+// slabs — is a 128-deep chain of dependent loads on 16 blocks.)
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ part, int S, long len,
+                                                       float* __restrict__ out) {
+  __shared__ float4 red[8][32];
+  const int c = threadIdx.x & 31, gq = threadIdx.x >> 5;
+  const long i = ((long)blockIdx.x * 32 + c) * 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < len) {
+    for (int s0 = gq; s0 < S; s0 += 32) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int sl = s0 + 8 * u;
+        v[u] = sl < S ? *reinterpret_cast<const float4*>(part + (long)sl * len + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    }
+  }
+  red[gq][c] = a;
+  __syncthreads();
+  if (gq == 0 && i < len) {
+#pragma unroll
+    for (int g = 1; g < 8; ++g) { const float4 b = red[g][c]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    *reinterpret_cast<float4*>(out + i) = a;
+  }
+}
+
+}  // namespace ubv
+
+extern "C" int ubv_gemm_wgrad_splits(int64_t M, int N, int K) {
+  const int tiles = ((N + ubv::kWgTile - 1) / ubv::kWgTile) * ((K + ubv::kWgTile - 1) / ubv::kWgTile);
+  long s = (512 + tiles - 1) / tiles;                     // two blocks per CU
+  const long max_s = (M + 255) / 256;                     // at least 256 rows per split
+  if (s > max_s) s = max_s;
+  if (s > 256) s = 256;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+extern "C" int ubv_gemm_wgrad(const void* grad_out, const void* x, float* partials, float* grad_wb, int64_t M,
+                              int N, int K, int splits, int dtype, void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(grad_out && x && partials && grad_wb && M > 0 && N > 0 && K > 0 && splits > 0,
+                "gemm_wgrad: bad arguments");
+  UBV_CHECK_ARG(dtype >= 0 && dtype <= 2, "gemm_wgrad: unknown dtype %d", dtype);
+  if (N % 4 != 0 || K % 4 != 0 || ((uintptr_t)grad_out % 8) != 0 || ((uintptr_t)x % 8) != 0 ||
+      ((uintptr_t)partials % 16) != 0 || ((uintptr_t)grad_wb % 16) != 0) {
+    set_error("gemm_wgrad: N=%d, K=%d must be multiples of 4 with aligned buffers", N, K);
+    return UBV_ERR_UNSUPPORTED;
+  }
+  const int tiles_k = (K + kWgTile - 1) / kWgTile, tiles_n = (N + kWgTile - 1) / kWgTile;
+  long rps = (M + splits - 1) / splits;
+  rps = (rps + kWgMC - 1) / kWgMC * kWgMC;                // whole chunks (and even row pairs)
+  const dim3 grid(tiles_n * tiles_k, splits), blk(256);
+  const size_t lds = (size_t)(dtype == UBV_F32 ? 4 : 2) * kWgTile * kWgLd * sizeof(uint16_t);
+  hipStream_t st = as_stream(stream);
+  if (dtype == UBV_F32)
+    hipLaunchKernelGGL((gemm_wgrad_kernel<true, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, (int)rps);
+  else if (dtype == UBV_F16)
+    hipLaunchKernelGGL((gemm_wgrad_kernel<false, true>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, (int)rps);
+  else
+    hipLaunchKernelGGL((gemm_wgrad_kernel<false, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, (int)rps);
+  const long len = (long)N * K + N;
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((len / 4 + 31) / 32)), dim3(256), 0, st, partials, splits, len,
+                     grad_wb);
+  UBV_CHECK_LAUNCH("gemm_wgrad");
+  return UBV_OK;
+}

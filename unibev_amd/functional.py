@@ -649,6 +649,27 @@ def gemm_nt(x, w_hi, w_lo=None, bias=None, residual=None, out=None):
         return y
 
 
+@torch.no_grad()
+def gemm_wgrad(grad_out, x):
+    """(grad_weight f32 [N, K], grad_bias f32 [N]) of a Linear from grad_out [M, N] and x [M, K] (one
+    dtype) on the matrix cores (``ubv_gemm_wgrad``: split-K slabs + their sum).  None when the
+    shape is outside the kernel's reach."""
+    with _need_cuda(grad_out, x):
+        M, N = grad_out.shape
+        K = x.shape[1]
+        if N % 4 != 0 or K % 4 != 0 or grad_out.dtype != x.dtype or M == 0 or \
+                not (grad_out.is_contiguous() and x.is_contiguous()):
+            return None
+        S = int(lib().ubv_gemm_wgrad_splits(M, N, K))
+        part = _workspace(4 * S * (N * K + N), x.device)      # scratch: consumed inside the call
+        out = torch.empty(N * K + N, dtype=torch.float32, device=x.device)
+        rc = lib().ubv_gemm_wgrad(_p(grad_out), _p(x), _p(part), _p(out), M, N, K, S, _dt(x), _stream())
+        if rc == -3:
+            return None
+        check(rc, 'gemm_wgrad')
+        return out[:N * K].view(N, K), out[N * K:]
+
+
 # ----------------------------------------------------------------------------------------------- linear grads
 @torch.no_grad()
 def linear_grad_reduce(grad_out=None, partials=None):

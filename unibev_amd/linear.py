@@ -131,6 +131,7 @@ def set_f32_gemm(mode):
     prev = 'mfma' if _MFMA_F32 else 'library'
     _MFMA_F32 = mode == 'mfma'
     return prev
+_MFMA_WGRAD = os.environ.get('UBV_WGRAD', 'mfma') != 'library'
 _MFMA_16_MAXN = 192          # 16-bit data: the MFMA kernel wins for narrow outputs, the library for wide ones
 
 
@@ -263,6 +264,26 @@ class _Linear(Function):
         need_w = any(ctx.needs_input_grad[5:5 + n])
         need_b = has_bias and any(ctx.needs_input_grad[5 + n:])
         part = None
+        if (need_w or need_b) and go2.is_cuda and _MFMA_WGRAD and go2.dtype == x2.dtype and \
+                go2.is_contiguous() and x2.is_contiguous() and \
+                (go2.dtype == torch.float32 or go2.shape[1] * x2.shape[1] <= 65536):
+            # (16-bit data with a 512-wide side: the strided-batched library GEMM is as fast)
+            # one pass over grad_out and x on the matrix cores: dW and the bias sums together
+            from . import functional as UF
+            res = UF.gemm_wgrad(go2, x2)
+            if res is not None:
+                gw, gb = res
+                need_w = need_b_left = False
+                grads = []
+                off = 0
+                for i in range(n):
+                    grads.append(gw[off:off + outs[i]].to(pdt[i]) if ctx.needs_input_grad[5 + i] else None)
+                    off += outs[i]
+                off = 0
+                for i in range(n if has_bias else 0):
+                    grads.append(gb[off:off + outs[i]].to(pdt[n + i]))
+                    off += outs[i]
+                return (gx, None, None, None, None, *grads)
         if need_w:
             s = _splits(rows)
             if s > 1:
