@@ -1211,8 +1211,22 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     {
       ProfScope ps(name("bev_lift_bwd_value_camera"), st,
                    nb.offlog + nb.ref + nb.vis + nb.out + nb.value_f32);
-      hipLaunchKernelGGL((lift_bwd_value_camera_kernel<T, DH, P, RB>), dim3(8 * t.chunk),
-                         dim3(64 * t.waves), lds, st, a, t);
+      bool done = false;
+      if constexpr (DH == 32 && P == 8 && sizeof(T) == 2) {
+        if (cam_mfma && t.tiles_y == 1) {          // whole padded map per wave, one MFMA round per batch
+          const CamArgs c = cam_args(a, nullptr);
+          const int mbt = (c.KB + 1) / 2;
+          const size_t l2 = (size_t)t.waves * (mbt * 32 * kCamVStride + 64 * 32) * sizeof(uint16_t);
+          if (mbt == 7)
+            hipLaunchKernelGGL((lift_cam_bwd_value_kernel<T, 8, 7>), dim3(8 * t.chunk), dim3(64 * t.waves), l2, st, a, t, c);
+          else
+            hipLaunchKernelGGL((lift_cam_bwd_value_kernel<T, 8, 8>), dim3(8 * t.chunk), dim3(64 * t.waves), l2, st, a, t, c);
+          done = true;
+        }
+      }
+      if (!done)
+        hipLaunchKernelGGL((lift_bwd_value_camera_kernel<T, DH, P, RB>), dim3(8 * t.chunk),
+                           dim3(64 * t.waves), lds, st, a, t);
     }
     {
       const long n = (long)a.B * a.Nc * a.H * a.fh * a.fw * DH;

@@ -388,3 +388,154 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     store_ol<T, 2 * PG>(a.goff, bq * a.goff_stride + h * 2 * P + g * 2 * PG, OL16, gofs);
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Backward, value side, same padded-map coefficients: grad_value[pix, :] = sum_q A[q][pix] G[q, :]
+// over a camera's visible queries (G = grad_out / count).  As in lift_bwd_value_camera_kernel a wave
+// walks its share of the camera's compacted list 64 queries at a time, keeps the partial map in
+// registers and writes one slab; but all 8 points of a query go into ONE coefficient matrix
+// A^T[slot][query] (read-modify-write in the lane's own column, no per-corner masks thanks to the zero
+// border), so a batch is one MFMA round over the touched 32-slot row blocks instead of eight rounds
+// of scatter / ballot / multiply / clear.
+constexpr int kCamVStride = 72;      // u16 per A^T row: 64 query columns + 8 (144 B: conflict-free 16-byte reads)
+
+template <typename T, int P, int MBT>
+__global__ __launch_bounds__(256) void lift_cam_bwd_value_kernel(const LiftArgs a, const TileArgs t, const CamArgs c) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds_all[];
+  using M = mma_traits<T>;
+  using CV = cam_cvt<T>;
+  constexpr int DH = 32;
+  constexpr int NV = DH * elem<T>::kBytes / 16;
+  constexpr int kA = MBT * 32 * kCamVStride, kG = 64 * DH;
+  TileGeom g;
+  if (!tile_decode(a, t, g)) return;
+  const int lane = threadIdx.x & 63;
+  const int cq = cam_chunk_len(a.cam_n[g.cam], t.chunks);
+  const int l0 = g.ck * cq;
+  const int ncand = min(cq, a.cam_n[g.cam] - l0);
+  if (ncand <= 0) return;
+  uint16_t* A = lds_all + (threadIdx.x >> 6) * (kA + kG);
+  uint16_t* G = A + kA;
+  for (int i = lane; i < kA / 8; i += 64) reinterpret_cast<uint4*>(A)[i] = make_uint4(0u, 0u, 0u, 0u);
+  f32x16_t acc[MBT];
+#pragma unroll
+  for (int mb = 0; mb < MBT; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mb][r] = 0.0f;
+  const long row = (long)a.H * DH;
+  const T* __restrict__ gout = (const T*)a.gout;
+  const float fwf = (float)a.fw, fhf = (float)a.fh;
+  const float inv_fw = __builtin_amdgcn_rcpf(fwf), inv_fh = __builtin_amdgcn_rcpf(fhf);
+  const int n = lane & 31, kg = lane >> 5;
+  const int fh1 = c.fh1;
+  uint16_t* acol = A + lane;
+
+  struct Raw {
+    float off[2 * P], lg[P];
+    float2 ref[P];
+    float cnt;
+    uint4 grow[NV];
+    bool valid;
+  };
+  auto fetch_q = [&](int c0, bool& valid) -> int {
+    const int cc = c0 + lane;
+    valid = cc < ncand;
+    return a.cam_list[(long)g.cam * a.Nq + l0 + (valid ? cc : 0)];
+  };
+  auto fetch_raw = [&](int q, bool valid, Raw& rw) {
+    rw.valid = valid;
+    const long bq = (long)g.b * a.Nq + q;
+    load_ol<T, P>(a.logits, bq * a.log_stride + g.h * P, a.ol16, rw.lg);
+    load_ol<T, 2 * P>(a.offsets, bq * a.off_stride + g.h * 2 * P, a.ol16, rw.off);
+    const float* rp = a.ref + (((long)g.cam * a.B + g.b) * a.Nq + q) * a.Z * 2;
+    int zi = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      rw.ref[p] = *reinterpret_cast<const float2*>(rp + zi * 2);
+      zi = (zi + 1 == a.Z) ? 0 : zi + 1;
+    }
+    rw.cnt = (a.count != nullptr) ? a.count[bq] : 1.0f;
+    const uint4* gp = reinterpret_cast<const uint4*>(gout + bq * row + g.h * DH);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) rw.grow[i] = gp[i];
+  };
+
+  bool v1, v2;
+  Raw cur, nxt;
+  const int q1 = fetch_q(0, v1);
+  fetch_raw(q1, v1, nxt);
+  int q2 = fetch_q(64, v2);
+  for (int c0 = 0; c0 < ncand; c0 += 64) {
+    cur = nxt;
+    if (c0 + 64 < ncand) {
+      fetch_raw(q2, v2, nxt);
+      q2 = fetch_q(c0 + 128, v2);
+    }
+    // grad_out rows of the 64 queries -> LDS, then this lane's B fragments (8 queries x its channel)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) reinterpret_cast<uint4*>(G + lane * DH)[i] = cur.grow[i];
+    uint4 bfr[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      uint16_t bh[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bh[j] = G[(kb * 16 + kg * 8 + j) * DH + n];
+      bfr[kb] = make_uint4(bh[0] | ((uint32_t)bh[1] << 16), bh[2] | ((uint32_t)bh[3] << 16),
+                           bh[4] | ((uint32_t)bh[5] << 16), bh[6] | ((uint32_t)bh[7] << 16));
+    }
+    float w[P];
+    softmax_row<P, true>(cur.lg, w);
+    const float sc = cur.valid ? __builtin_amdgcn_rcpf(cur.cnt) : 0.0f;     // 1 / count, 0 for the list's tail
+    unsigned mbmask = 0u;
+    int k0s[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const PadFoot f = pad_foot(cur.ref[p].x + cur.off[2 * p] * inv_fw, cur.ref[p].y + cur.off[2 * p + 1] * inv_fh,
+                                 fwf, fhf, a.fw, a.fh, fh1);
+      const float wp = w[p] * sc;
+      const float wl = wp * f.lx, wh = wp - wl;
+      const float c11 = wl * f.ly, c01 = wl - c11, c10 = wh * f.ly, c00 = wh - c10;
+      uint16_t* e = acol + f.k0 * kCamVStride;
+      const uint16_t u00 = e[0], u10 = e[kCamVStride], u01 = e[fh1 * kCamVStride], u11 = e[(fh1 + 1) * kCamVStride];
+      e[0] = CV::enc(CV::dec(u00) + c00);
+      e[kCamVStride] = CV::enc(CV::dec(u10) + c10);
+      e[fh1 * kCamVStride] = CV::enc(CV::dec(u01) + c01);
+      e[(fh1 + 1) * kCamVStride] = CV::enc(CV::dec(u11) + c11);
+      k0s[p] = f.k0;
+      mbmask |= (1u << (f.k0 >> 5)) | (1u << ((f.k0 + fh1 + 1) >> 5));
+    }
+    __builtin_amdgcn_wave_barrier();
+    // (written out per row block: a loop with the wave-uniform skip inside is not unrolled and would
+    // index acc[] dynamically)
+#define UBV_CAM_MB_STEP(mb)                                                                               \
+    if ((mb) < MBT && __ballot((mbmask >> (mb)) & 1u) != 0ull) {                                          \
+      _Pragma("unroll") for (int kb = 0; kb < 4; ++kb) {                                                  \
+        const uint4 af = *reinterpret_cast<const uint4*>(A + ((mb) * 32 + n) * kCamVStride + kb * 16 + kg * 8); \
+        acc[(mb) < MBT ? (mb) : 0] = M::mma(af, bfr[kb], acc[(mb) < MBT ? (mb) : 0]);                     \
+      }                                                                                                   \
+    }
+    UBV_CAM_MB_STEP(0) UBV_CAM_MB_STEP(1) UBV_CAM_MB_STEP(2) UBV_CAM_MB_STEP(3)
+    UBV_CAM_MB_STEP(4) UBV_CAM_MB_STEP(5) UBV_CAM_MB_STEP(6) UBV_CAM_MB_STEP(7)
+#undef UBV_CAM_MB_STEP
+    static_assert(MBT <= 8, "row-block steps are written out for 8 blocks");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      uint16_t* e = acol + k0s[p] * kCamVStride;
+      e[0] = 0; e[kCamVStride] = 0; e[fh1 * kCamVStride] = 0; e[(fh1 + 1) * kCamVStride] = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- this share's partial map -> its slab ([b][cam][h][chunk][S][Dh], plain stores).  D: column =
+  // channel lane & 31, row = padded slot (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of block mb
+  float* __restrict__ slab = a.slab + ((((long)g.b * a.Nc + g.cam) * a.H + g.h) * t.chunks + g.ck) *
+                                          ((long)a.fh * a.fw * DH);
+#pragma unroll
+  for (int mb = 0; mb < MBT; ++mb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int pix;
+      if (cam_pixel(mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg, a.fh, a.fw, pix)) slab[(long)pix * DH + n] = acc[mb][r];
+    }
+  }
+}
