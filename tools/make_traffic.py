@@ -1,50 +1,67 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from the FETCH_SIZE / WRITE_SIZE PMC summary of tools/bench_lift.py.
+"""profiles/traffic.json: HBM-side bytes per launch of every sampling OP, from rocprofv3 PMC passes.
 
-    rocprofv3 --pmc FETCH_SIZE -d A ... -- python tools/bench_lift.py --iters 3      (own pass)
-    rocprofv3 --pmc WRITE_SIZE -d B ... -- python tools/bench_lift.py --iters 3      (own pass)
-    python tools/pmc_summary.py <dir> ubv:: > profiles/r01_v6_pmc_fetch_write.txt
-    python tools/make_traffic.py profiles/r01_v6_pmc_fetch_write.txt > profiles/traffic.json
+Run on the GPU box (tools/collect_traffic.sh): for each op instance of tools/bench_lift.py (self, pts,
+img; bs = 2, bf16) one pass with --pmc FETCH_SIZE and one with --pmc WRITE_SIZE (separate runs, with
+--kernel-trace only, as MI355X_MICROARCH.md section HBM prescribes).  Both counters are in KB; on
+gfx950 FETCH_SIZE under-counts wide coalesced reads by 2x: fetch_corrected = 2 x raw (same guide).
+Kernels are grouped into the op's forward (lift_fwd / lift_cam_fwd / value_frags) and backward
+(everything else of the lift family) and summed per launch of the op.
 
-Both counters are reported in KB.  Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE under-counts
-wide coalesced reads by 2x on gfx950: fetch_corrected = 2 x raw.  Keys are the library's profile
-names up to the sampling-point count (``bev_lift_fwd<P=4``), which is how bench.py looks them up.
+    python tools/make_traffic.py <dir with {op}_{FETCH_SIZE,WRITE_SIZE}_results.db> > profiles/traffic.json
 """
+import collections
 import json
-import re
+import os
+import sqlite3
 import sys
 
-NAMES = [   # (kernel symbol regex, profile-name key with {P})
-    (r'lift_fwd_kernel<[^,]+, \d+, \d+, (\d+)', 'bev_lift_fwd<P={P}'),
-    (r'lift_bin_kernel<[^,]+, \d+, (\d+)', 'bev_lift_bwd_bins<P={P}'),
-    (r'lift_bwd_query_kernel<[^,]+, \d+, \d+, (\d+)', 'bev_lift_bwd_query<P={P}'),
-    (r'lift_bwd_value_kernel<[^,]+, \d+, (\d+)', 'bev_lift_bwd_value_grid<P={P}'),
-    (r'lift_bwd_value_camera_kernel<[^,]+, \d+, (\d+)', 'bev_lift_bwd_value_camera<P={P}'),
-]
+OPS = {'self': 'self_attn', 'pts': 'sca_pts', 'img': 'sca_img'}
+FWD = ('lift_fwd_kernel', 'lift_cam_fwd_kernel', 'value_frags_kernel')
+
+
+def per_kernel(db_path, counter):
+    """kernel symbol -> (mean counter total per dispatch, dispatches)"""
+    db = sqlite3.connect(db_path)
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    T = lambda p: [t for t in tabs if t.startswith(p)][0]      # noqa: E731
+    q = f'''select s.kernel_name, sum(e.value), count(distinct d.id) from {T('rocpd_pmc_event')} e
+            join {T('rocpd_info_pmc')} p on e.pmc_id = p.id
+            join {T('rocpd_kernel_dispatch')} d on e.event_id = d.event_id
+            join {T('rocpd_info_kernel_symbol')} s on d.kernel_id = s.id
+            where p.name = ? group by s.kernel_name'''
+    return {name: (tot / nd, nd) for name, tot, nd in cur.execute(q, (counter,))}
 
 
 def main():
-    out = {'_note': 'HBM-side bytes per launch from rocprofv3 PMC passes over tools/bench_lift.py '
-                    '(bs=2, bf16, gfx950): FETCH_SIZE and WRITE_SIZE in separate runs, KB -> bytes, '
-                    'fetch_corrected = 2 x raw (gfx950 under-count of wide reads, '
-                    'MI355X_MICROARCH.md HBM section).  P=8 forward / query entries average the '
-                    'SCA-pts and SCA-img instances (same kernel symbol).  Source: ' + sys.argv[1]}
-    cur = None
-    for line in open(sys.argv[1]):
-        if not line.startswith(' '):
-            cur = None
-            for pat, key in NAMES:
-                m = re.search(pat, line)
-                if m:
-                    cur = out.setdefault(key.format(P=m.group(1)), {})
-                    break
-        elif cur is not None:
-            f = line.split()
-            if f[0] == 'FETCH_SIZE':
-                cur['fetch_raw'] = int(float(f[1]) * 1024)
-                cur['fetch_corrected'] = 2 * cur['fetch_raw']
-            elif f[0] == 'WRITE_SIZE':
-                cur['write'] = int(float(f[1]) * 1024)
+    d = sys.argv[1]
+    out = {'_note': 'HBM-side bytes per op launch from rocprofv3 PMC passes over tools/bench_lift.py (bs=2, bf16, '
+                    'gfx950): FETCH_SIZE and WRITE_SIZE in separate runs, KB -> bytes, fetch_corrected = 2 x raw '
+                    '(gfx950 under-count of wide reads, MI355X_MICROARCH.md HBM section); kernels grouped per op '
+                    'and pass, summed per launch of the op.', 'ops': {}, 'kernels': {}}
+    for key, op in OPS.items():
+        fetch = per_kernel(os.path.join(d, f'{key}_FETCH_SIZE_results.db'), 'FETCH_SIZE')
+        write = per_kernel(os.path.join(d, f'{key}_WRITE_SIZE_results.db'), 'WRITE_SIZE')
+        launches = max(nd for name, (_, nd) in fetch.items() if 'lift_' in name and 'fwd' in name)
+        agg = collections.defaultdict(lambda: [0.0, 0.0])
+        for name in set(fetch) | set(write):
+            if 'ubv' not in name or not ('lift_' in name or 'value_frags' in name or 'slab_reduce' in name
+                                         or 'compact_visible' in name):
+                continue
+            f, nf = fetch.get(name, (0.0, 0))
+            w, nw = write.get(name, (0.0, 0))
+            # per launch of the op: total over the run / op launches
+            fb = 2.0 * f * 1024 * nf / launches
+            wb = w * 1024 * nw / launches
+            side = 'fwd' if any(k in name for k in FWD) else 'bwd'
+            agg[side][0] += fb
+            agg[side][1] += wb
+            short = name.split('(')[0].replace('ubv::', '').replace('void ', '')[:70]
+            out['kernels'][f'{op}:{short}'] = {'fetch_corrected': int(fb), 'write': int(wb), 'per_op_launch': True}
+        for side, (fb, wb) in agg.items():
+            out['ops'][f'{op}:{side}'] = {'fetch_corrected': int(fb), 'write': int(wb),
+                                          'hbm_bytes_per_launch': int(fb + wb)}
     json.dump(out, sys.stdout, indent=1)
     print()
 
