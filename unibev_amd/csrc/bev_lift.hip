@@ -1047,6 +1047,7 @@ __global__ __launch_bounds__(256) void narrow_kernel(const float* __restrict__ s
 }
 
 #include "bev_lift_cam.inl"
+#include "bev_lift_shared.inl"
 
 // ---- dispatch ----------------------------------------------------------------------------------------
 // Algorithmic (compulsory) bytes of each kernel: every operand read once, every result written
@@ -1119,6 +1120,14 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
         return;
       }
     }
+    static const int shared_env = getenv("UBV_LIFT_SHARED") ? atoi(getenv("UBV_LIFT_SHARED")) : 1;
+    if (shared_env) {            // per-point arithmetic shared inside the lane group (bev_lift_shared.inl)
+      if (sizeof(T) == 2 && a.ol16)
+        hipLaunchKernelGGL((lift_fwd_shared_kernel<T, DH, VEC, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((lift_fwd_shared_kernel<T, DH, VEC, P, false>), dim3(blocks), dim3(256), 0, st, a);
+      return;
+    }
     if (sizeof(T) == 2 && a.ol16)
       hipLaunchKernelGGL((lift_fwd_kernel<T, DH, VEC, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
     else
@@ -1186,9 +1195,9 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     {
       ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes);
       if (sizeof(T) == 2 && a.ol16)
-        hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomNone, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
       else
-        hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomNone, false>), dim3(blocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, false>), dim3(blocks), dim3(256), 0, st, a);
     }
     constexpr int RB = 2;
     const size_t lds = (size_t)t.waves * TileLds<T, DH, RB>::kWords * sizeof(uint16_t);
@@ -1246,9 +1255,9 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
       }
     }
     if (sizeof(T) == 2 && a.ol16)
-      hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomNone, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
     else
-      hipLaunchKernelGGL((lift_bwd_query_kernel<T, DH, VEC, P, kAtomNone, false>), dim3(blocks), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, false>), dim3(blocks), dim3(256), 0, st, a);
   }
 }
 
