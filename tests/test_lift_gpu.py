@@ -205,6 +205,46 @@ def test_lift_backward_camera_mode_bands_and_chunks():
         assert bad.sum() <= 1e-5 * bad.size + 1, int(bad.sum())       # pixel-boundary discontinuities
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_lift_backward_maps_plan_heavy_buckets(dtype):
+    """Large per-camera maps (25x45: the MAPS plan, exact CSR buckets + work items).  All reference
+    points sit in a 3-pixel patch, so a few buckets hold tens of thousands of records and are cut into
+    many work items whose partial tiles are summed in order: grad_value vs the fp64 oracle, and two
+    launches against each other."""
+    from unibev_amd.functional import bev_lift
+    B, Nc, fh, fw, H, Dh, qh, qw, P, Z = 1, 2, 25, 45, 8, 16, 48, 48, 8, 4
+    rs = np.random.RandomState(3)
+    Nq, C, S = qh * qw, H * Dh, fh * fw
+    value = rs.standard_normal((B * Nc, S, C))
+    offlog = np.concatenate([rs.standard_normal((B, Nq, H * P * 2)) * 1.5,
+                             rs.standard_normal((B, Nq, H * P))], -1)
+    ref = 0.45 + 0.06 * rs.random_sample((Nc, B, Nq, Z, 2))
+    ref[1] += 0.3                                           # camera 1: a second patch
+    vis0 = (rs.random_sample((Nc, Nq)) < 0.8)
+    vis0[0, :64] = False                                     # a whole 8x8 query tile invisible in camera 0
+    count = np.maximum(vis0.sum(0), 1).astype(np.float32)[None].repeat(B, 0)
+    gout = rs.standard_normal((B, Nq, C))
+    if dtype != torch.float32:
+        value = t(value).to(dtype).double().numpy()
+        gout = t(gout).to(dtype).double().numpy()
+    v64, ol64 = t(value).requires_grad_(), t(offlog).requires_grad_()
+    o_ref = oracle_lift(v64, ol64, t(ref), t(vis0.astype(np.uint8)), t(count).double(), Nc, fh, fw, H, P)
+    o_ref.backward(t(gout))
+    got = []
+    for _ in range(2):
+        v = t(value, dtype, DEV).requires_grad_()
+        ol = t(offlog, torch.float32, DEV).requires_grad_()
+        out = bev_lift(v, ol, t(ref, torch.float32, DEV), Nc, (fh, fw), H, P,
+                       vis0=t(vis0.astype(np.uint8), device=DEV), count=t(count, device=DEV), query_grid=(qh, qw))
+        out.backward(t(gout, dtype, DEV))
+        got.append(v.grad.clone())
+    # records enter a bucket in arrival order (as on the GRID plan): launches agree to the order of the f32 sums
+    torch.testing.assert_close(got[0].float(), got[1].float(), rtol=2.0 ** -7 if dtype != torch.float32 else 1e-4, atol=1e-3)
+    tol = 2e-4 if dtype == torch.float32 else 2e-2
+    scale = np.abs(v64.grad.numpy()).max()
+    np.testing.assert_allclose(got[0].float().cpu().numpy(), v64.grad.numpy(), rtol=tol, atol=tol * scale)
+
+
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('mode', ['grid', 'centred', 'atomics', 'camera'])
 def test_lift_16bit_offsets_logits_read_directly(mode, dtype):

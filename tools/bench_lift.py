@@ -17,8 +17,8 @@ from unibev_amd import functional as UF      # noqa: E402
 from unibev_amd import synthetic as syn      # noqa: E402
 
 
-def instance(name, B, dtype, dev, init_like=True, img_hw=(256, 704)):
-    H, Dh, qh, qw = 8, 32, 200, 200
+def instance(name, B, dtype, dev, init_like=True, img_hw=(256, 704), Dh=32):
+    H, qh, qw = 8, 200, 200
     Nq, C = qh * qw, H * Dh
     g = torch.Generator(device='cpu').manual_seed(0)
     ys, xs = torch.meshgrid(torch.arange(qh), torch.arange(qw), indexing='ij')
@@ -64,12 +64,14 @@ def main():
     ap.add_argument('--only', default='self,pts,img')
     ap.add_argument('--no-center', action='store_true')
     ap.add_argument('--f32-offlog', action='store_true')
+    ap.add_argument('--img-hw', type=int, nargs=2, default=[256, 704], help='cat-128 config: 800 1440')
+    ap.add_argument('--dh', type=int, default=32, help='channels per head (cat-128 config: 16)')
     a = ap.parse_args()
     dev = 'cuda'
     dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[a.dtype]
     for name in a.only.split(','):
         value, offlog, ref, vis0, count, gout, geom, is_grid, center = instance(
-            name, a.bs, dtype, dev, not a.random_offsets)
+            name, a.bs, dtype, dev, not a.random_offsets, tuple(a.img_hw), a.dh)
         B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh = geom
         if dtype != torch.float32 and not a.f32_offlog:
             offlog = offlog.to(dtype)        # what the sampling_offsets Linear emits under autocast

@@ -44,6 +44,13 @@ struct LiftArgs {
   int* cam_list; int* cam_n;                     // per-camera compacted visible queries or null
   int ext_list;                                  // lists supplied by the caller (ubv_compact_visible)
   float* slab;                                   // CAMERA: per-chunk partial maps or null
+  // MAPS backward (large per-camera maps): exact CSR buckets + work items (bev_lift_maps.inl)
+  int* bin_cur;                                  // fill cursors per bucket
+  int* bin_start;                                // [buckets + 1] first record of each bucket
+  int* item_first;                               // [buckets + 1] first work item of each bucket
+  int* item_bucket;                              // [items] bucket of each work item
+  int* n_items;                                  // device scalar
+  int max_items;
 };
 
 // Decode (b, q, valid) of the query this lane works on in iteration `it`.
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (P == 8 
 // The launcher names its three plans with the same enum: kAtomAll (this kernel scatters), kPlanGrid
 // (points binned by owner tile: lift_bin_kernel + lift_bwd_value_kernel) and kAtomNone for the
 // CAMERA plan (per-camera lists: lift_bwd_value_camera_kernel).
-enum { kAtomAll = 0, kPlanGrid = 1, kAtomNone = 2 };
+enum { kAtomAll = 0, kPlanGrid = 1, kAtomNone = 2, kPlanMaps = 3 };
 
 
 // v + (v of the lane whose index differs in bit log2(M)): DPP quad permutes inside a quad (the
@@ -375,7 +382,12 @@ __global__ __launch_bounds__(256, ((ATOMICS == kAtomNone && P == 4) ? 3 : 1)) vo
 // overflow list that lift_ovf_* scatter atomically, so the result is exact for ANY offsets.
 struct TileArgs;
 
-template <typename T, int DH, int P>
+// MODE 0: fixed-capacity buckets + overflow list (GRID).  MODE 1 / 2: the two passes of an exact CSR
+// build for the MAPS plan (count the records per bucket; after the scan, write them at
+// bin_start[bucket] + cursor) — per-camera maps, where the load per tile varies 100:1 (the rows at the
+// horizon receive 85 % of the projected pillars) and no fixed capacity fits.  The cameras are walked in
+// the wave; one that none of the wave's 64 queries sees costs a ballot.
+template <typename T, int DH, int P, int MODE>
 __global__ __launch_bounds__(256) void lift_bin_kernel(const LiftArgs a, int tiles_x, int tiles) {
   // per wave: an 8x8 torus of tile slots — occupant tile, local count, global base
   __shared__ int slot_tile[4][64], slot_cnt[4][64], slot_base[4][64];
@@ -395,17 +407,24 @@ __global__ __launch_bounds__(256) void lift_bin_kernel(const LiftArgs a, int til
   load_ol<T, 2 * P>(a.offsets, bq * a.off_stride + h * 2 * P, a.ol16, off);
   softmax_row<P>(lg, w);
   const float cnt = (a.count != nullptr) ? a.count[bq] : 1.0f;
-  const float* rp = a.ref + bq * a.Z * 2;              // one map per sample (Nc == 1)
-  int* __restrict__ cntp = a.bin_cnt + ((long)b * a.H + h) * tiles;
-  float4* __restrict__ binp = a.bins + ((long)b * a.H + h) * tiles * a.cap;
-  const int tile_base = (b * a.H + h) * tiles;
+  for (int cam = 0; cam < a.Nc; ++cam) {
+  const bool vis = valid && (a.vis0 == nullptr || a.vis0[(long)cam * a.Nq + q] != 0);
+  if (a.Nc > 1 && __ballot(vis) == 0ull) continue;    // wave-uniform
+  const float* rp = a.ref + (((long)cam * a.B + b) * a.Nq + q) * a.Z * 2;
+  const int tile_base = ((b * a.Nc + cam) * a.H + h) * tiles;     // first bucket of this (map, head)
+  int* __restrict__ cntp = (MODE == 2 ? a.bin_cur : a.bin_cnt) + tile_base;
+  float4* __restrict__ binp = MODE == 0 ? a.bins + (long)tile_base * a.cap : a.bins;
 
   auto put = [&](int tile, int idx, const float4& rec) {
-    if (idx < a.cap) {
-      binp[(long)tile * a.cap + idx] = rec;
-    } else {
-      const int o = atomicAdd(a.ovf_n, 1);
-      if (o < a.ovf_cap) { a.ovf_rec[o] = rec; a.ovf_tile[o] = tile_base + tile; }
+    if constexpr (MODE == 0) {
+      if (idx < a.cap) {
+        binp[(long)tile * a.cap + idx] = rec;
+      } else {
+        const int o = atomicAdd(a.ovf_n, 1);
+        if (o < a.ovf_cap) { a.ovf_rec[o] = rec; a.ovf_tile[o] = tile_base + tile; }
+      }
+    } else if constexpr (MODE == 2) {
+      binp[idx] = rec;                                // idx already includes bin_start
     }
   };
 
@@ -424,7 +443,7 @@ __global__ __launch_bounds__(256) void lift_bin_kernel(const LiftArgs a, int til
     bool nz[4], lead[4], local[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      nz[k] = valid && wn != 0.0f && f.w[k] != 0.0f;
+      nz[k] = vis && wn != 0.0f && f.w[k] != 0.0f;
       const int tx = f.xc[k & 1] >> 3, ty = f.yc[k >> 1] >> 3;
       tk[k] = ty * tiles_x + tx;
       hs[k] = ((ty & 7) << 3) | (tx & 7);
@@ -445,20 +464,30 @@ __global__ __launch_bounds__(256) void lift_bin_kernel(const LiftArgs a, int til
         const int prev = atomicCAS(&slot_tile[wv][hs[k]], -1, tk[k]);
         local[k] = (prev == -1) || (prev == tk[k]);
         if (local[k]) rank[k] = atomicAdd(&slot_cnt[wv][hs[k]], 1);
-        else put(tk[k], atomicAdd(cntp + tk[k], 1), rec);
+        else {
+          const int i = atomicAdd(cntp + tk[k], 1);
+          put(tk[k], MODE == 2 ? a.bin_start[tile_base + tk[k]] + i : i, rec);
+        }
       }
     }
     // 2. ONE global atomic per occupied slot, all slots in parallel (lane = slot)
     {
       const int c = slot_cnt[wv][lane];
-      if (c > 0) slot_base[wv][lane] = atomicAdd(cntp + slot_tile[wv][lane], c);
+      if (c > 0) {
+        const int st = slot_tile[wv][lane];
+        const int i = atomicAdd(cntp + st, c);
+        slot_base[wv][lane] = MODE == 2 ? a.bin_start[tile_base + st] + i : i;
+      }
     }
     // 3. write the records
+    if constexpr (MODE != 1) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (lead[k] && local[k]) put(tk[k], slot_base[wv][hs[k]] + rank[k], rec);
+      for (int k = 0; k < 4; ++k)
+        if (lead[k] && local[k]) put(tk[k], slot_base[wv][hs[k]] + rank[k], rec);
+    }
     slot_tile[wv][lane] = -1;
     slot_cnt[wv][lane] = 0;
+  }
   }
 }
 
@@ -835,6 +864,8 @@ __global__ __launch_bounds__(256, 3) void lift_bwd_value_kernel(const LiftArgs a
   }
 }
 
+#include "bev_lift_maps.inl"
+
 // ------------------------------------------------------------------------------------------------
 // CAMERA owner tiles, one lane per QUERY: a round trip to memory fetches everything 64 queries need
 // (list entry -> offsets, logits, anchors, count, grad_out row), double-buffered in registers, and
@@ -1182,7 +1213,7 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     {
       const long waves = (long)a.total_tiles * a.H;
       ProfScope ps(name("bev_lift_bwd_bins"), s2, nb.offlog + nb.ref + nb.rec);
-      hipLaunchKernelGGL((lift_bin_kernel<T, DH, P>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+      hipLaunchKernelGGL((lift_bin_kernel<T, DH, P, 0>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
                          s2, a, t.tiles_x, tiles);
     }
     {
@@ -1210,6 +1241,37 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     if (two) {
       (void)hipEventRecord(side_join[dev], s2);
       (void)hipStreamWaitEvent(st, side_join[dev], 0);
+    }
+  } else if (bwd_mode == kPlanMaps) {
+    // exact CSR of the sampling points by owner tile (count, scan, fill), one wave per work item,
+    // slabs of multi-item buckets summed in order (bev_lift_maps.inl); counters zeroed by the caller
+    const int tiles = t.tiles_x * t.tiles_y;
+    const int nb_ = a.B * a.Nc * a.H * tiles;
+    const long waves = (long)a.total_tiles * a.H;
+    {
+      ProfScope ps(name("bev_lift_bwd_bins"), st, 2 * (nb.offlog + nb.ref) + nb.rec);
+      hipLaunchKernelGGL((lift_bin_kernel<T, DH, P, 1>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a,
+                         t.tiles_x, tiles);
+      hipLaunchKernelGGL(maps_scan_kernel, dim3(1), dim3(1024), 0, st, a, nb_);
+      hipLaunchKernelGGL((lift_bin_kernel<T, DH, P, 2>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a,
+                         t.tiles_x, tiles);
+    }
+    {
+      ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes);
+      if (sizeof(T) == 2 && a.ol16)
+        hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, false>), dim3(blocks), dim3(256), 0, st, a);
+    }
+    constexpr int RB = 2;
+    const size_t lds = (size_t)4 * TileLds<T, DH, RB>::kWords * sizeof(uint16_t);
+    {
+      ProfScope ps(name("bev_lift_bwd_value_maps"), st,
+                   nb.rec + nb.out + (a.gvalue_lp != nullptr ? nb.value : nb.value_f32));
+      hipLaunchKernelGGL((lift_bwd_value_items_kernel<T, DH, P, RB>), dim3((unsigned)((a.max_items + 3) / 4)),
+                         dim3(256), lds, st, a, t);
+      hipLaunchKernelGGL((maps_reduce_kernel<T, DH>), dim3((unsigned)((nb_ + 3) / 4)), dim3(256), 0, st, a,
+                         t.tiles_x, tiles, nb_);
     }
   } else {
     if (!a.ext_list)
@@ -1305,10 +1367,21 @@ static int plan_backward(const LiftArgs& a, int Dh, int P, int dtype, int ref_is
     // CAMERA: bands of full rows, at most 6 MFMA row blocks (192 pixels) per band, and few enough
     // bands that re-walking the visible queries once per band stays cheap
     int band = 192 / a.fw;
-    if (band < 1) return kAtomAll;
     if (band > a.fh) band = a.fh;
-    const int bands = (a.fh + band - 1) / band;
-    if (bands > 8) return kAtomAll;
+    const int bands = band >= 1 ? (a.fh + band - 1) / band : 0;
+    static const int maps_env = getenv("UBV_LIFT_MAPS") ? atoi(getenv("UBV_LIFT_MAPS")) : 1;
+    if (bands != 1 && (maps_env || band < 1 || bands > 8)) {
+      // MAPS: maps of more than one band (bev_lift_maps.inl); UBV_LIFT_MAPS=0 keeps the band walk for A/B runs
+      t.mode = 3;
+      t.tile_w = t.tile_h = 8;
+      t.tiles_x = (a.fw + 7) / 8;
+      t.tiles_y = (a.fh + 7) / 8;
+      t.chunks = 1;
+      t.waves = 4;
+      t.total = a.B * a.Nc * t.tiles_y * t.tiles_x * a.H;
+      t.chunk = ((t.total + t.waves - 1) / t.waves + 7) / 8;
+      return kPlanMaps;
+    }
     t.mode = 2;
     t.tile_w = a.fw;
     t.tile_h = band;
@@ -1349,8 +1422,29 @@ static GridWs grid_ws(const LiftArgs& a, const TileArgs& t, int P) {
   w.total = w.ovf_tile_off + (((size_t)w.ovf_cap * sizeof(int) + 255) & ~(size_t)255);
   return w;
 }
+// MAPS workspace: [counts | cursors | n_items] (zeroed per call) [starts][first items][item buckets]
+// [records][slabs].  Records and items are sized for the worst case — every query visible in every
+// camera, every point in 4 tiles — which the host cannot narrow without reading the visibility back
+// (2 GB of the 288 at the reference's 6 x 25x45 shape and bs = 2; only what is used is touched).
+struct MapsWs { size_t zero_bytes, start_off, first_off, ibucket_off, bins_off, slab_off, total; long buckets, max_rec, max_items; };
+static MapsWs maps_ws(const LiftArgs& a, const TileArgs& t, int Dh, int P) {
+  MapsWs w;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  w.buckets = (long)a.B * a.Nc * a.H * t.tiles_x * t.tiles_y;
+  w.max_rec = 4L * a.B * a.Nc * a.Nq * a.H * P;
+  w.max_items = w.buckets + w.max_rec / kItemRecs;
+  w.zero_bytes = al((2 * (size_t)w.buckets + 1) * sizeof(int));
+  w.start_off = w.zero_bytes;
+  w.first_off = w.start_off + al(((size_t)w.buckets + 1) * sizeof(int));
+  w.ibucket_off = w.first_off + al(((size_t)w.buckets + 1) * sizeof(int));
+  w.bins_off = w.ibucket_off + al((size_t)w.max_items * sizeof(int));
+  w.slab_off = w.bins_off + al((size_t)w.max_rec * sizeof(float4));
+  w.total = w.slab_off + al((size_t)w.max_items * 64 * Dh * sizeof(float));
+  return w;
+}
 static size_t lift_ws_bytes(int mode, const LiftArgs& a, const TileArgs& t, int Dh, int P) {
   if (mode == kPlanGrid) return grid_ws(a, t, P).total;
+  if (mode == kPlanMaps) return maps_ws(a, t, Dh, P).total;
   if (mode == kAtomNone)     // visible-query lists + one partial map per (b, cam, head, chunk)
     return lift_list_bytes(a) +
            (size_t)a.B * a.Nc * a.H * t.chunks * a.fh * a.fw * Dh * sizeof(float);
@@ -1415,6 +1509,23 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_g
       a.cap = t.cap;
       a.ovf_cap = (int)min(w.ovf_cap, (long)INT_MAX);
       if (hipMemsetAsync(ws, 0, w.cnt_bytes, st) != hipSuccess) {
+        set_error("bev_lift_backward: memset failed");
+        return UBV_ERR_LAUNCH;
+      }
+    }
+    if (mode == kPlanMaps) {
+      const MapsWs w = maps_ws(a, t, Dh, P);
+      UBV_CHECK_ARG(w.max_rec < (1L << 31) && w.max_items < (1L << 31), "bev_lift_backward: too many sampling points for the MAPS plan");
+      a.bin_cnt = (int*)ws;
+      a.bin_cur = a.bin_cnt + w.buckets;
+      a.n_items = a.bin_cur + w.buckets;
+      a.bin_start = (int*)((char*)ws + w.start_off);
+      a.item_first = (int*)((char*)ws + w.first_off);
+      a.item_bucket = (int*)((char*)ws + w.ibucket_off);
+      a.bins = (float4*)((char*)ws + w.bins_off);
+      a.slab = (float*)((char*)ws + w.slab_off);
+      a.max_items = (int)w.max_items;
+      if (hipMemsetAsync(ws, 0, w.zero_bytes, st) != hipSuccess) {
         set_error("bev_lift_backward: memset failed");
         return UBV_ERR_LAUNCH;
       }

@@ -30,6 +30,8 @@ namespace ubv {
 typedef __attribute__((ext_vector_type(8))) __bf16 gbf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 gf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float gf32x16_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t gu32x4_t;   // staging registers: native vectors (a HIP
+typedef __attribute__((ext_vector_type(4))) float gf32x4_t;      // uint4 / float4 struct copy ended up in scratch)
 
 constexpr int kGemmBM = 128, kGemmKC = 32, kGemmLd = kGemmKC + 8;   // 80-byte LDS rows: conflict-free 16-byte reads
 
@@ -47,8 +49,8 @@ template <bool F16> __device__ __forceinline__ gf32x16_t gemm_mma(uint4 a, uint4
 // Wave tiling: NB even -> 2 x 2 waves of (2 row blocks) x (NB / 2 column blocks): per 16-wide k step a
 // wave reads 2 + NB/2 fragment pairs from LDS for 2 * NB/2 MFMA groups (a 1-D split read 1 + NB for
 // NB groups and ran at a third of the speed); NB odd -> 4 x 1 waves of 1 x NB.
-template <int NB, bool SPLIT, bool F16, bool OUT16>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const void* __restrict__ Xv, long ldx,
+template <int NB, bool SPLIT, bool F16, bool OUT16, int XD>
+__global__ __launch_bounds__(256, ((NB <= 4 && XD == 1) ? 3 : 2)) void gemm_nt_kernel(const void* __restrict__ Xv, long ldx,
                                                       const uint16_t* __restrict__ Wh,
                                                       const uint16_t* __restrict__ Wl, long ldw,
                                                       const float* __restrict__ bias, const void* __restrict__ Rv,
@@ -64,8 +66,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const void* __restrict_
   uint16_t* wl = wh + NT * kGemmLd;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = TWO_D ? (wv >> 1) : wv, wn = TWO_D ? (wv & 1) : 0;
-  const long m0 = (long)blockIdx.x * kGemmBM;
-  const int n0 = blockIdx.y * NT;
+  // 1-D grid, XCD-aware: block ids go round-robin over the 8 XCDs, so the column tiles of one row tile
+  // are given consecutive slots of ONE XCD — they run together and share the X rows through its L2
+  const int ny = N / NT, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const long m0 = ((long)(slot / ny) * 8 + xcd) * kGemmBM;
+  const int n0 = (slot % ny) * NT;
+  if (m0 >= M) return;
   // ---- staging maps.  X chunk [128 x 32]: f32 -> thread rows tid/8 + 32 i (i < 4), 4 columns
   // (tid%8)*4; 16-bit -> rows tid/4 + 64 i (i < 2), 8 columns (tid%4)*8.  W chunk [NT x 32] 16-bit:
   // rows tid/4 + 64 i, 8 columns.
@@ -73,35 +79,48 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const void* __restrict_
   constexpr int XI = SPLIT ? 4 : 2;
   constexpr int WI = (NT + 63) / 64;
   const int wr = tid >> 2, wc = (tid & 3) * 8;
-  float4 xf[SPLIT ? 4 : 1];
-  uint4 xq[SPLIT ? 1 : 2];
-  uint4 wqh[WI], wql[SPLIT ? WI : 1];
+  // X chunks are fetched XD chunks ahead (register sets xf[0..XD)), W chunks — L2 hits — one ahead:
+  // the bytes in flight per CU, not the MFMA or LDS rate, set the speed of this kernel
+  gf32x4_t xf[XD][SPLIT ? 4 : 1];
+  gu32x4_t xq[XD][SPLIT ? 1 : 2];
+  gu32x4_t wqh[WI], wql[SPLIT ? WI : 1];
 
-  auto load_chunk = [&](int k0) {
+  // (rows past M are clamped, not predicated — their results are never stored — so that the loads are
+  //  straight-line code and the compiler can count them: a predicated load made it wait for vmcnt(0) at
+  //  the top of every chunk, which put the whole prefetch back in series with the MFMAs)
+  long xrow[XI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const long r = m0 + xr + (SPLIT ? 32 : 64) * i;
+    xrow[i] = (r < M ? r : M - 1) * ldx + xc;
+  }
+  long wrow[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int r = wr + 64 * i;
+    wrow[i] = (long)(n0 + (r < NT ? r : NT - 1)) * ldw + wc;          // N % NT == 0 (host)
+  }
+  auto load_x = [&](int k0, auto setc) {
+    constexpr int set = decltype(setc)::value;
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      const long r = m0 + xr + (SPLIT ? 32 : 64) * i;
-      if constexpr (SPLIT)
-        xf[i] = r < M ? *reinterpret_cast<const float4*>((const float*)Xv + r * ldx + k0 + xc)
-                      : make_float4(0.f, 0.f, 0.f, 0.f);
-      else
-        xq[i] = r < M ? *reinterpret_cast<const uint4*>((const uint16_t*)Xv + r * ldx + k0 + xc)
-                      : make_uint4(0u, 0u, 0u, 0u);
-    }
-#pragma unroll
-    for (int i = 0; i < WI; ++i) {
-      const int r = wr + 64 * i;
-      const bool ok = r < NT && n0 + r < N;
-      wqh[i] = ok ? *reinterpret_cast<const uint4*>(Wh + (long)(n0 + r) * ldw + k0 + wc) : make_uint4(0u, 0u, 0u, 0u);
-      if constexpr (SPLIT)
-        wql[i] = ok ? *reinterpret_cast<const uint4*>(Wl + (long)(n0 + r) * ldw + k0 + wc) : make_uint4(0u, 0u, 0u, 0u);
+      if constexpr (SPLIT) xf[set][i] = *reinterpret_cast<const gf32x4_t*>((const float*)Xv + xrow[i] + k0);
+      else xq[set][i] = *reinterpret_cast<const gu32x4_t*>((const uint16_t*)Xv + xrow[i] + k0);
     }
   };
-  auto store_chunk = [&]() {
+  auto load_w = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      wqh[i] = *reinterpret_cast<const gu32x4_t*>(Wh + wrow[i] + k0);
+      if constexpr (SPLIT) wql[i] = *reinterpret_cast<const gu32x4_t*>(Wl + wrow[i] + k0);
+    }
+  };
+  auto store_chunk = [&](auto setc) {
+    constexpr int set = decltype(setc)::value;
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       if constexpr (SPLIT) {
-        const float4 v = xf[i];
+        const gf32x4_t v = xf[set][i];
         const uint32_t h0 = cvt_pk_bf16(v.x, v.y), h1 = cvt_pk_bf16(v.z, v.w);
         const float r0 = v.x - __uint_as_float(h0 << 16), r1 = v.y - __uint_as_float(h0 & 0xffff0000u);
         const float r2 = v.z - __uint_as_float(h1 << 16), r3 = v.w - __uint_as_float(h1 & 0xffff0000u);
@@ -109,18 +128,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const void* __restrict_
         *reinterpret_cast<uint2*>(xh + o) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(xl + o) = make_uint2(cvt_pk_bf16(r0, r1), cvt_pk_bf16(r2, r3));
       } else {
-        *reinterpret_cast<uint4*>(xh + (xr + 64 * i) * kGemmLd + xc) = xq[i];
+        *reinterpret_cast<gu32x4_t*>(xh + (xr + 64 * i) * kGemmLd + xc) = xq[set][i];
       }
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
       if (wr + 64 * i < NT) {
-        *reinterpret_cast<uint4*>(wh + (wr + 64 * i) * kGemmLd + wc) = wqh[i];
-        if constexpr (SPLIT) *reinterpret_cast<uint4*>(wl + (wr + 64 * i) * kGemmLd + wc) = wql[i];
+        *reinterpret_cast<gu32x4_t*>(wh + (wr + 64 * i) * kGemmLd + wc) = wqh[i];
+        if constexpr (SPLIT) *reinterpret_cast<gu32x4_t*>(wl + (wr + 64 * i) * kGemmLd + wc) = wql[i];
       }
     }
   };
 
+  const int fr = lane & 31, fk = (lane >> 5) * 8;         // fragment row within a 32-block, k offset
   gf32x16_t acc[WMB][WNB];
 #pragma unroll
   for (int i = 0; i < WMB; ++i)
@@ -129,13 +149,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const void* __restrict_
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int fr = lane & 31, fk = (lane >> 5) * 8;         // fragment row within a 32-block, k offset
-  load_chunk(0);
-  for (int k0 = 0; k0 < K; k0 += kGemmKC) {
-    __syncthreads();                                      // previous chunk's fragments consumed
-    store_chunk();
-    __syncthreads();
-    if (k0 + kGemmKC < K) load_chunk(k0 + kGemmKC);       // in flight under the MFMAs below
+  auto mfma_chunk = [&]() {
 #pragma unroll
     for (int ks = 0; ks < kGemmKC; ks += 16) {
       uint4 bh[WMB], bl[WMB], ah[WNB], al[WNB];
@@ -162,6 +176,36 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const void* __restrict_
           }
         }
     }
+  };
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, XD - 1>;
+  // one pipeline step: chunk c (held in register set `setc`) -> LDS -> MFMAs, with the W chunk one ahead
+  // and the X chunk XD ahead issued in between.  W first: loads return in order, so the next step's wait
+  // for W leaves the later X loads in flight.  The prefetches are compile-time flags (main loop / tail).
+  auto step = [&](int c, auto setc, auto lw, auto lx) {
+    __syncthreads();                                      // previous chunk's fragments consumed
+    store_chunk(setc);
+    __syncthreads();
+    if constexpr (decltype(lw)::value) load_w((c + 1) * kGemmKC);
+    if constexpr (decltype(lx)::value) load_x((c + XD) * kGemmKC, setc);
+    mfma_chunk();
+  };
+  using Yes = std::true_type;
+  using No = std::false_type;
+  const int nch = K / kGemmKC;
+  load_w(0);
+  load_x(0, Set0{});
+  int c = 0;
+  if constexpr (XD == 2) {
+    if (nch > 1) load_x(kGemmKC, Set1{});
+    for (; c + 3 < nch; c += 2) { step(c, Set0{}, Yes{}, Yes{}); step(c + 1, Set1{}, Yes{}, Yes{}); }
+    const int rem = nch - c;
+    if (rem == 3) { step(c, Set0{}, Yes{}, Yes{}); step(c + 1, Set1{}, Yes{}, No{}); step(c + 2, Set0{}, No{}, No{}); }
+    else if (rem == 2) { step(c, Set0{}, Yes{}, No{}); step(c + 1, Set1{}, No{}, No{}); }
+    else step(c, Set0{}, No{}, No{});
+  } else {
+    for (; c + 1 < nch; ++c) step(c, Set0{}, Yes{}, Yes{});
+    step(c, Set0{}, No{}, No{});
   }
   // ---- epilogue.  D[n][m]: column = this lane's row m, rows n = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   // within a column block: 4 consecutive output columns per (block, r >> 2)
@@ -239,16 +283,26 @@ template <bool SPLIT, bool F16, bool OUT16>
 static int gemm_nt_launch(const void* X, long ldx, const void* Wh, const void* Wl, long ldw, const float* bias,
                           const void* R, void* Y, long ldy, long M, int N, int K, hipStream_t st) {
   // column tile: the largest of 256 / 192 / 128 / 96 / 64 / 32 that N fills evenly
+  // study knobs.  128-column tiles: 64 accumulator registers per lane -> 3 blocks per CU (49 vs 62 us at N = K = 256,
+  // f32); the column tiles of a row tile share X through L2 (block order above).  A second X register set in flight
+  // (depth 2) spills under hipcc and measures slower.
+  static const int nt_cap = getenv("UBV_GEMM_NT") ? atoi(getenv("UBV_GEMM_NT")) : 128;
+  static const int depth = getenv("UBV_GEMM_DEPTH") ? atoi(getenv("UBV_GEMM_DEPTH")) : 1;
   int nt = 0;
   for (int c : {256, 192, 128, 96, 64, 32})
-    if (N % c == 0) { nt = c; break; }
+    if (c <= nt_cap && N % c == 0) { nt = c; break; }
   if (nt == 0) return UBV_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)((M + kGemmBM - 1) / kGemmBM), (unsigned)(N / nt)), blk(256);
+  const long row_tiles = (M + kGemmBM - 1) / kGemmBM;
+  const dim3 grid((unsigned)((row_tiles + 7) / 8 * 8 * (N / nt))), blk(256);
   const size_t lds = (size_t)((SPLIT ? 2 : 1) * (kGemmBM + nt) * kGemmLd) * sizeof(uint16_t);
 #define UBV_GEMM_NB(NBV)                                                                                     \
   case NBV:                                                                                                  \
-    hipLaunchKernelGGL((gemm_nt_kernel<NBV, SPLIT, F16, OUT16>), grid, blk, lds, st, X, ldx, (const uint16_t*)Wh, \
-                       (const uint16_t*)Wl, ldw, bias, R, Y, ldy, M, N, K);                                  \
+    if (depth == 2)                                                                                          \
+      hipLaunchKernelGGL((gemm_nt_kernel<NBV, SPLIT, F16, OUT16, 2>), grid, blk, lds, st, X, ldx,            \
+                         (const uint16_t*)Wh, (const uint16_t*)Wl, ldw, bias, R, Y, ldy, M, N, K);           \
+    else                                                                                                     \
+      hipLaunchKernelGGL((gemm_nt_kernel<NBV, SPLIT, F16, OUT16, 1>), grid, blk, lds, st, X, ldx,            \
+                         (const uint16_t*)Wh, (const uint16_t*)Wl, ldw, bias, R, Y, ldy, M, N, K);           \
     break;
   switch (nt / 32) {
     UBV_GEMM_NB(8) UBV_GEMM_NB(6) UBV_GEMM_NB(4) UBV_GEMM_NB(3) UBV_GEMM_NB(2) UBV_GEMM_NB(1)
