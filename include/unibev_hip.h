@@ -298,7 +298,8 @@ int ubv_gemm_nt(const void* x, int64_t ldx, const void* w_hi, const void* w_lo, 
  * fills the chip).  grad_out [M, N] and x [M, K] share `dtype` (f32: split-bf16 products as above).
  * partials [splits, N*K + N] f32: scratch (slab s holds its dW part followed by its N bias sums);
  * grad_wb [N*K + N] f32, WRITTEN: dW row-major, then db — the slabs summed by a second launch.
- * N % 4 == 0 and K % 4 == 0, else UBV_ERR_UNSUPPORTED. */
+ * Rows are read 16 bytes at a time: N and K multiples of 4 (f32) / 8 (16-bit), buffers 16-byte aligned,
+ * else UBV_ERR_UNSUPPORTED. */
 int ubv_gemm_wgrad_splits(int64_t M, int N, int K);
 int ubv_gemm_wgrad(const void* grad_out, const void* x, float* partials, float* grad_wb, int64_t M, int N,
                    int K, int splits, int dtype, void* stream);

@@ -68,8 +68,10 @@ def test_gemm_nt_declines_shapes_it_cannot_tile():
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('M,N,K', [(5000, 256, 256), (4099, 192, 256), (777, 96, 128), (9000, 512, 256),
-                                   (300, 64, 36), (12345, 256, 512)])
+                                   (300, 64, 40), (12345, 256, 512)])
 def test_gemm_wgrad(M, N, K, dtype):
+    if K == 40 and dtype == torch.float32:
+        K = 36                                              # f32 rows load 4 columns at a time, 16-bit rows 8
     """dW = dY^T X and db = column sums of dY in one pass (ubv_gemm_wgrad + the slab sum) against f64:
     split-bf16 products for f32 data (~2^-17 each), exact products of the stored values for 16-bit data;
     ragged row counts, partial tiles in N and K."""

@@ -357,102 +357,129 @@ namespace ubv {
 // Weight gradient:  dW[N, K] = sum_m dY[m, n] X[m, k],   db[n] = sum_m dY[m, n]
 // — a product that REDUCES over the M = bs x 40 000 rows into a 256 x 256 .. 512 x 256 output.  Both
 // operands are row-major with the reduction index outermost, the opposite of what MFMA fragments want
-// (8 consecutive reduction steps per lane), so the staging pass transposes: a lane loads elements
-// (m, c), (m + 1, c) of its two columns c and stores each PAIR as one dword of T[c][m .. m + 1] in LDS
-// (rows of 34 halves = 17 dwords: the 64 lanes of a store hit 32 different banks).  Fragments are then
-// 4 dword reads per 8 reduction steps.  f32 data is split into bf16 halves on the way in
-// (dY_hi X_hi + dY_hi X_lo + dY_lo X_hi, f32 accumulation), 16-bit data takes one product.
+// (8 consecutive reduction steps per lane).  The transposition is done by the LDS read:
+// ds_read_b64_tr_b16 hands lane l of a 16-lane group column l of a [4 rows][16 columns] block whose
+// 16 pieces of 4 columns the lanes address (probed in tools/ubench/tr16_probe.hip).  So a chunk of
+// 64 rows is staged row-major, as it arrives — 16-byte loads, 16-byte LDS stores, no shuffling — in
+// column groups: T[column / 16][row][16] (+ 32 bytes per group, which puts the 8 groups of a row on 8
+// different bank octets for the stores and groups c / c + 4 on opposite bank halves for the reads),
+// and a fragment is two transposing reads.  An MFMA block takes its 32 rows / columns from groups
+// (c, c + 4): the tile's rows are permuted, which only the epilogue has to know.
+// f32 data is split into bf16 halves on the way in (dY_hi X_hi + dY_hi X_lo + dY_lo X_hi, f32
+// accumulation), 16-bit data takes one product.  db comes from the same dY fragments and an all-ones
+// A operand (one more MFMA per column block in the blocks of k tile 0): no VALU work at all.
 //
 // A block owns a 128 x 128 tile of dW for one slab of rows (split-K over M); its 4 waves hold 64 x 64
 // each in registers.  Roles are swapped (A = X^T fragment, B = dY^T fragment) so that a lane ends up
 // with 4 consecutive k of one output row n: 16-byte stores.  The slabs' partial tiles go to
-// `partials` [S][N*K + N] (f32; the last N entries of a slab are its bias sums, written by the
-// k-tile-0 blocks from the same dY fragments), summed by ubv_linear_grad_reduce — one read of dY and
-// X instead of the strided-batched library GEMM + a separate column-sum pass.
-constexpr int kWgTile = 128, kWgMC = 64, kWgLd = kWgMC + 2;   // LDS rows: 64 reduction steps + 2 (halves): 33 dwords
+// `partials` [S][N*K + N] (f32; the last N entries of a slab are its bias sums), summed by
+// slab_sum_kernel — one read of dY and X instead of the strided-batched library GEMM + a separate
+// column-sum pass.
+constexpr int kWgTile = 128, kWgMC = 64;
+constexpr int kWgCS = kWgMC * 16 + 16;                    // halves per column group (64 rows x 16 + 32 B)
+constexpr int kWgPlane = 8 * kWgCS;                       // halves per operand plane (128 columns)
+
+typedef short gi16x4_t __attribute__((ext_vector_type(4)));
+
+// 8 reduction steps (rows m0 .. m0 + 7 of this lane's half) of one column: two transposing reads
+__device__ __forceinline__ uint4 wg_frag(const uint16_t* p) {
+  typedef __attribute__((address_space(3))) gi16x4_t lds_v4;
+  const gi16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)p);
+  const gi16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p + 4 * 16));
+  const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+  return make_uint4(ua.x, ua.y, ub.x, ub.y);
+}
 
 template <bool SPLIT, bool F16>
 __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restrict__ dYv, const void* __restrict__ Xv,
                                                             float* __restrict__ partials, long M, int N, int K,
-                                                            int tiles_k, int rows_per_split) {
+                                                            int tiles_k, int tiles, int splits, int rows_per_split) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-  uint16_t* ty_h = lds;                                   // [128 n][66]
-  uint16_t* tx_h = ty_h + kWgTile * kWgLd;                // [128 k][66]
-  uint16_t* ty_l = tx_h + kWgTile * kWgLd;                // (SPLIT only)
-  uint16_t* tx_l = ty_l + kWgTile * kWgLd;
+  uint16_t* ty_h = lds;
+  uint16_t* tx_h = ty_h + kWgPlane;
+  uint16_t* ty_l = tx_h + kWgPlane;                       // (SPLIT only)
+  uint16_t* tx_l = ty_l + kWgPlane;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int tile = blockIdx.x, tn = tile / tiles_k, tk = tile - tn * tiles_k;
+  // 1-D grid, XCD-aware: block ids go round-robin over the 8 XCDs; the tiles of one slab take consecutive
+  // slots of ONE XCD, so the slab's rows of dY and X (each read by 2 - 4 tiles) come from HBM once
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int split = (slot / tiles) * 8 + xcd, tile = slot % tiles;
+  if (split >= splits) return;
+  const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
   const int n0 = tn * kWgTile, k0 = tk * kWgTile;
-  const long mbeg = (long)blockIdx.y * rows_per_split;
+  const long mbeg = (long)split * rows_per_split;
   const long mend = mbeg + rows_per_split < M ? mbeg + rows_per_split : M;
-  const int wk = wv >> 1, wn = wv & 1;                    // wave tile: k rows [64 wk, +64), n cols [64 wn, +64)
+  const int wk = wv >> 1, wn = wv & 1;                    // wave: k groups {wk, wk+2} (+4), n groups {wn, wn+2} (+4)
+  const bool want_bias = tk == 0 && wk == 0;
 
-  gf32x16_t acc[2][2];
+  gf32x16_t acc[2][2], accb[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[i][r] = 0.0f;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  float bsum[2] = {0.0f, 0.0f};
+  }
 
-  // staging: wave w takes rows m = 16 w + 2 p + {0, 1} (p < 8) of the chunk; lane l <-> the column pair
-  // (2 l, 2 l + 1): one 8-byte (f32) / 4-byte (16-bit) load per row, 512 / 256 contiguous bytes per wave
-  constexpr int NP = kWgMC / 8;                           // row pairs per wave
-  uint2 fy[SPLIT ? NP : 1][2], fx[SPLIT ? NP : 1][2];
-  uint32_t hy[SPLIT ? 1 : NP][2], hx[SPLIT ? 1 : NP][2];
-  const bool nok = n0 + 2 * lane < N, kok = k0 + 2 * lane < K;      // N, K even (host check)
+  // ---- staging maps.  16-bit: thread t <-> columns 8 (t % 16) .. + 7 of rows t / 16 + 16 i (i < 4);
+  // f32: columns 4 (t % 32) .. + 3 of rows t / 32 + 8 i (i < 8).  Rows past the slab and columns past
+  // N / K are clamped for the load and zeroed by a select (straight-line loads, see gemm_nt_kernel).
+  constexpr int NI = SPLIT ? 8 : 4;                       // loads per operand per thread per chunk
+  constexpr int CW = SPLIT ? 4 : 8;                       // columns per load
+  constexpr int TPR = 128 / CW;                           // threads per row
+  const int sc = (tid % TPR) * CW, sr = tid / TPR;        // column within the tile, first row
+  const bool yok = n0 + sc < N, xok = k0 + sc < K;        // N, K multiples of CW (host check)
+  const long ycol = yok ? n0 + sc : 0, xcol = xok ? k0 + sc : 0;
+  const int soff = (sc >> 4) * kWgCS + (sc & 15);         // LDS offset of (row 0, column sc)
+  gf32x4_t fy[SPLIT ? NI : 1], fx[SPLIT ? NI : 1];
+  gu32x4_t hy[SPLIT ? 1 : NI], hx[SPLIT ? 1 : NI];
   auto load_chunk = [&](long mc) {
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const long m = mc + wv * (kWgMC / 4) + 2 * p + q;
-        const bool mok = m < mend;
-        if constexpr (SPLIT) {
-          fy[p][q] = (mok && nok) ? *reinterpret_cast<const uint2*>((const float*)dYv + m * N + n0 + 2 * lane) : make_uint2(0u, 0u);
-          fx[p][q] = (mok && kok) ? *reinterpret_cast<const uint2*>((const float*)Xv + m * K + k0 + 2 * lane) : make_uint2(0u, 0u);
-        } else {
-          hy[p][q] = (mok && nok) ? *reinterpret_cast<const uint32_t*>((const uint16_t*)dYv + m * N + n0 + 2 * lane) : 0u;
-          hx[p][q] = (mok && kok) ? *reinterpret_cast<const uint32_t*>((const uint16_t*)Xv + m * K + k0 + 2 * lane) : 0u;
-        }
+    for (int i = 0; i < NI; ++i) {
+      const long m = mc + sr + (256 / TPR) * i;
+      const long mm = m < mend ? m : mend - 1;
+      if constexpr (SPLIT) {
+        fy[i] = *reinterpret_cast<const gf32x4_t*>((const float*)dYv + mm * N + ycol);
+        fx[i] = *reinterpret_cast<const gf32x4_t*>((const float*)Xv + mm * K + xcol);
+        if (!(m < mend && yok)) fy[i] = gf32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (!(m < mend && xok)) fx[i] = gf32x4_t{0.f, 0.f, 0.f, 0.f};
+      } else {
+        hy[i] = *reinterpret_cast<const gu32x4_t*>((const uint16_t*)dYv + mm * N + ycol);
+        hx[i] = *reinterpret_cast<const gu32x4_t*>((const uint16_t*)Xv + mm * K + xcol);
+        if (!(m < mend && yok)) hy[i] = gu32x4_t{0u, 0u, 0u, 0u};
+        if (!(m < mend && xok)) hx[i] = gu32x4_t{0u, 0u, 0u, 0u};
       }
     }
   };
-  // f32 pair (value at row m, value at row m+1) -> hi and lo bf16 pairs of one column
-  auto split_store = [&](uint16_t* th, uint16_t* tl, int col, int mo, uint32_t a_bits, uint32_t b_bits) {
-    const float a = __uint_as_float(a_bits), b = __uint_as_float(b_bits);
-    const uint32_t h = cvt_pk_bf16(a, b);
-    const uint32_t l = cvt_pk_bf16(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u));
-    *reinterpret_cast<uint32_t*>(th + col * kWgLd + mo) = h;
-    *reinterpret_cast<uint32_t*>(tl + col * kWgLd + mo) = l;
+  auto split_store = [&](uint16_t* th, uint16_t* tl, int o, const gf32x4_t v) {
+    const uint32_t h0 = cvt_pk_bf16(v.x, v.y), h1 = cvt_pk_bf16(v.z, v.w);
+    const float r0 = v.x - __uint_as_float(h0 << 16), r1 = v.y - __uint_as_float(h0 & 0xffff0000u);
+    const float r2 = v.z - __uint_as_float(h1 << 16), r3 = v.w - __uint_as_float(h1 & 0xffff0000u);
+    *reinterpret_cast<uint2*>(th + o) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(tl + o) = make_uint2(cvt_pk_bf16(r0, r1), cvt_pk_bf16(r2, r3));
   };
   auto store_chunk = [&]() {
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int mo = wv * (kWgMC / 4) + 2 * p;            // even: the pair is one aligned dword
+    for (int i = 0; i < NI; ++i) {
+      const int o = soff + (sr + (256 / TPR) * i) * 16;
       if constexpr (SPLIT) {
-        split_store(ty_h, ty_l, 2 * lane, mo, fy[p][0].x, fy[p][1].x);
-        split_store(ty_h, ty_l, 2 * lane + 1, mo, fy[p][0].y, fy[p][1].y);
-        split_store(tx_h, tx_l, 2 * lane, mo, fx[p][0].x, fx[p][1].x);
-        split_store(tx_h, tx_l, 2 * lane + 1, mo, fx[p][0].y, fx[p][1].y);
+        split_store(ty_h, ty_l, o, fy[i]);
+        split_store(tx_h, tx_l, o, fx[i]);
       } else {
-        // rows m, m+1 hold columns (2l, 2l+1): regroup into (m, m+1) pairs per column
-        const uint32_t a = hy[p][0], b = hy[p][1];
-        *reinterpret_cast<uint32_t*>(ty_h + (2 * lane) * kWgLd + mo) = (a & 0xffffu) | (b << 16);
-        *reinterpret_cast<uint32_t*>(ty_h + (2 * lane + 1) * kWgLd + mo) = (a >> 16) | (b & 0xffff0000u);
-        const uint32_t c = hx[p][0], d = hx[p][1];
-        *reinterpret_cast<uint32_t*>(tx_h + (2 * lane) * kWgLd + mo) = (c & 0xffffu) | (d << 16);
-        *reinterpret_cast<uint32_t*>(tx_h + (2 * lane + 1) * kWgLd + mo) = (c >> 16) | (d & 0xffff0000u);
+        *reinterpret_cast<gu32x4_t*>(ty_h + o) = hy[i];
+        *reinterpret_cast<gu32x4_t*>(tx_h + o) = hx[i];
       }
     }
   };
-  auto frag = [&](const uint16_t* t, int row, int ks) -> uint4 {   // 8 reduction steps of one row: 4 dwords
-    const uint32_t* p = reinterpret_cast<const uint32_t*>(t + row * kWgLd + ks);
-    return make_uint4(p[0], p[1], p[2], p[3]);
-  };
 
-  const int fr = lane & 31, fk = (lane >> 5) * 8;
+  // fragment base of this lane inside an MFMA block whose first column group is c: group (lane >> 4) & 1
+  // selects c / c + 4, lane >> 5 the reduction half (rows 8 .. 15), lane & 15 the piece
+  const int fbase = ((lane >> 4) & 1) * 4 * kWgCS + (lane >> 5) * 8 * 16 + (lane & 15) * 4;
+  const uint32_t one2 = F16 ? 0x3C003C00u : 0x3F803F80u;
+  const uint4 ones = make_uint4(one2, one2, one2, one2);
+
   load_chunk(mbeg);
   for (long mc = mbeg; mc < mend; mc += kWgMC) {
     __syncthreads();
@@ -464,32 +491,15 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
       uint4 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        ah[i] = frag(tx_h, wk * 64 + i * 32 + fr, ks + fk);
-        if constexpr (SPLIT) al[i] = frag(tx_l, wk * 64 + i * 32 + fr, ks + fk);
+        const int o = (wk + 2 * i) * kWgCS + fbase + ks * 16;
+        ah[i] = wg_frag(tx_h + o);
+        if constexpr (SPLIT) al[i] = wg_frag(tx_l + o);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        bh[j] = frag(ty_h, wn * 64 + j * 32 + fr, ks + fk);
-        if constexpr (SPLIT) bl[j] = frag(ty_l, wn * 64 + j * 32 + fr, ks + fk);
-        if (tk == 0 && wk == 0) {                         // bias: this lane's 8 values of column n
-          float s = 0.0f;
-          const uint32_t w4[4] = {bh[j].x, bh[j].y, bh[j].z, bh[j].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if constexpr (F16) {
-              s += (float)__builtin_bit_cast(_Float16, (uint16_t)(w4[e] & 0xffffu)) +
-                   (float)__builtin_bit_cast(_Float16, (uint16_t)(w4[e] >> 16));
-            } else {
-              s += __uint_as_float(w4[e] << 16) + __uint_as_float(w4[e] & 0xffff0000u);
-            }
-          }
-          if constexpr (SPLIT) {
-            const uint32_t l4[4] = {bl[j].x, bl[j].y, bl[j].z, bl[j].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s += __uint_as_float(l4[e] << 16) + __uint_as_float(l4[e] & 0xffff0000u);
-          }
-          bsum[j] += s;
-        }
+        const int o = (wn + 2 * j) * kWgCS + fbase + ks * 16;
+        bh[j] = wg_frag(ty_h + o);
+        if constexpr (SPLIT) bl[j] = wg_frag(ty_l + o);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -501,29 +511,35 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
             acc[i][j] = gemm_mma<F16>(al[i], bh[j], acc[i][j]);
           }
         }
+      if (want_bias) {                                    // column sums of dY: an all-ones A operand
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          accb[j] = gemm_mma<F16>(ones, bh[j], accb[j]);
+          if constexpr (SPLIT) accb[j] = gemm_mma<F16>(ones, bl[j], accb[j]);
+        }
+      }
     }
   }
-  // ---- partial tile.  D[k][n]: column n = this lane's, rows k = (r & 3) + 8 (r >> 2) + 4 half
-  float* part = partials + (long)blockIdx.y * ((long)N * K + N);
-  const int half = lane >> 5;
+  // ---- partial tile.  D[k][n]: column u = lane & 31 of block j, rows u' = (r & 3) + 8 (r >> 2) + 4 half of
+  // block i; block-local index u -> tile index 16 (c + 4 (u >> 4)) + (u & 15) with c the block's first group
+  float* part = partials + (long)split * ((long)N * K + N);
+  const int half = lane >> 5, u = lane & 31;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + fr;
+    const int n = n0 + 16 * (wn + 2 * j + 4 * (u >> 4)) + (u & 15);
     if (n >= N) continue;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int k = k0 + wk * 64 + i * 32 + 8 * g + 4 * half;
+        const int uk = 8 * g + 4 * half;                  // 4 consecutive rows, inside one 16-group
+        const int k = k0 + 16 * (wk + 2 * i + 4 * (uk >> 4)) + (uk & 15);
         if (k >= K) continue;                             // K is a multiple of 4 (host check)
         *reinterpret_cast<float4*>(part + (long)n * K + k) =
             make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
       }
     }
-    if (tk == 0 && wk == 0) {                             // one wave row per column block owns the bias sum
-      const float s = bsum[j] + __shfl_xor(bsum[j], 32, 64);
-      if (half == 0) part[(long)N * K + n] = s;
-    }
+    if (want_bias && half == 0) part[(long)N * K + n] = accb[j][0];   // every row of the ones product is the sum
   }
 }
 
@@ -576,23 +592,25 @@ extern "C" int ubv_gemm_wgrad(const void* grad_out, const void* x, float* partia
   UBV_CHECK_ARG(grad_out && x && partials && grad_wb && M > 0 && N > 0 && K > 0 && splits > 0,
                 "gemm_wgrad: bad arguments");
   UBV_CHECK_ARG(dtype >= 0 && dtype <= 2, "gemm_wgrad: unknown dtype %d", dtype);
-  if (N % 4 != 0 || K % 4 != 0 || ((uintptr_t)grad_out % 8) != 0 || ((uintptr_t)x % 8) != 0 ||
+  const int cw = dtype == UBV_F32 ? 4 : 8;                // columns per 16-byte load
+  if (N % cw != 0 || K % cw != 0 || ((uintptr_t)grad_out % 16) != 0 || ((uintptr_t)x % 16) != 0 ||
       ((uintptr_t)partials % 16) != 0 || ((uintptr_t)grad_wb % 16) != 0) {
-    set_error("gemm_wgrad: N=%d, K=%d must be multiples of 4 with aligned buffers", N, K);
+    set_error("gemm_wgrad: N=%d, K=%d must be multiples of %d with 16-byte aligned buffers", N, K, cw);
     return UBV_ERR_UNSUPPORTED;
   }
   const int tiles_k = (K + kWgTile - 1) / kWgTile, tiles_n = (N + kWgTile - 1) / kWgTile;
   long rps = (M + splits - 1) / splits;
   rps = (rps + kWgMC - 1) / kWgMC * kWgMC;                // whole chunks (and even row pairs)
-  const dim3 grid(tiles_n * tiles_k, splits), blk(256);
-  const size_t lds = (size_t)(dtype == UBV_F32 ? 4 : 2) * kWgTile * kWgLd * sizeof(uint16_t);
+  const int tiles = tiles_n * tiles_k;
+  const dim3 grid((unsigned)((splits + 7) / 8 * 8 * tiles)), blk(256);
+  const size_t lds = (size_t)(dtype == UBV_F32 ? 4 : 2) * kWgPlane * sizeof(uint16_t);
   hipStream_t st = as_stream(stream);
   if (dtype == UBV_F32)
-    hipLaunchKernelGGL((gemm_wgrad_kernel<true, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, (int)rps);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<true, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps);
   else if (dtype == UBV_F16)
-    hipLaunchKernelGGL((gemm_wgrad_kernel<false, true>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, (int)rps);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<false, true>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps);
   else
-    hipLaunchKernelGGL((gemm_wgrad_kernel<false, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, (int)rps);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<false, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps);
   const long len = (long)N * K + N;
   hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((len / 4 + 31) / 32)), dim3(256), 0, st, partials, splits, len,
                      grad_wb);

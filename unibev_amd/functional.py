@@ -657,7 +657,8 @@ def gemm_wgrad(grad_out, x):
     with _need_cuda(grad_out, x):
         M, N = grad_out.shape
         K = x.shape[1]
-        if N % 4 != 0 or K % 4 != 0 or grad_out.dtype != x.dtype or M == 0 or \
+        cw = 4 if x.dtype == torch.float32 else 8              # columns per 16-byte load
+        if N % cw != 0 or K % cw != 0 or grad_out.dtype != x.dtype or M == 0 or \
                 not (grad_out.is_contiguous() and x.is_contiguous()):
             return None
         S = int(lib().ubv_gemm_wgrad_splits(M, N, K))
