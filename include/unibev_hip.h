@@ -292,6 +292,18 @@ int ubv_linear_forward(const void* x, const void* w, const void* bias, void* y, 
 int ubv_gemm_nt(const void* x, int64_t ldx, const void* w_hi, const void* w_lo, int64_t ldw,
                 const float* bias, const void* residual, void* y, int64_t ldy, int64_t M, int N, int K,
                 int dtype, void* stream);
+/* The two GEMMs around the FFN activation ([ext] mmcv FFN: Sequential(Linear, ReLU, Dropout) -> Linear,
+ * mmcv/cnn/bricks/transformer.py; configured at projects/UniBEV/configs/unibev/
+ * unibev_nus_LC_cnw_256_modality_dropout.py:281-291, ffn_dropout 0.1) with the activation in the epilogue:
+ *   act 1: y = dropout(relu(x w^T + bias), p)      — the keep mask of ubv_relu_dropout_forward for the same
+ *          (seed, seed_dev) and the element's index in the contiguous [M, N] output (ldy == N);
+ *   act 2: y = (x w^T) * 1/(1-p) where mask[m][n] != 0, else 0  — the input gradient of the Linear that
+ *          FOLLOWS the activation (x = its grad_out, w = its transposed weight), already multiplied by the
+ *          activation's derivative; mask [M, ldy] is the activation's saved output, in `dtype`.
+ * Same shapes, dtypes and return codes as ubv_gemm_nt. */
+int ubv_gemm_nt_act(const void* x, int64_t ldx, const void* w_hi, const void* w_lo, int64_t ldw,
+                    const float* bias, void* y, int64_t ldy, int64_t M, int N, int K, int dtype,
+                    int act, const void* mask, float p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 /* Weight gradient of the same layers ([ext] torch.nn.Linear backward):
  *   dW[N, K] = sum_m grad_out[m, n] x[m, k],  db[n] = sum_m grad_out[m, n]
  * as a split-K MFMA product over `splits` slabs of rows (ubv_gemm_wgrad_splits picks the count that

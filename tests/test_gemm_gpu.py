@@ -88,3 +88,52 @@ def test_gemm_wgrad(M, N, K, dtype):
     tol = 3e-5 if dtype == torch.float32 else 2e-6           # 16-bit inputs multiply exactly; f32 accumulation
     assert float((gw.cpu().double() - refw).abs().max()) < max(tol * float(refw.abs().max()), 1e-3 * tol * M ** 0.5 * 30)
     assert float((gb.cpu().double() - refb).abs().max()) < 1e-5 * max(1.0, float(refb.abs().max())) * (1 if dtype == torch.float32 else 1)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('p', [0.0, 0.1])
+def test_ffn_activation_in_gemm_epilogues(dtype, p, monkeypatch):
+    """FFN (Linear -> ReLU -> Dropout -> Linear): the activation in the first GEMM's epilogue and its
+    derivative in the second GEMM's input-gradient epilogue (ubv_gemm_nt_act) against the same module with
+    the separate relu_dropout kernels (UBV_FFN_FUSE=0) — same seeds, so the same keep mask — and, without
+    dropout, against plain torch in f64."""
+    import contextlib
+    from unibev_amd.registry import build_feedforward_network
+    from unibev_amd import functional as UF
+    torch.manual_seed(5)
+    ffn = build_feedforward_network(dict(type='FFN', embed_dims=64, feedforward_channels=128, ffn_drop=p,
+                                         add_identity=True)).to(DEV).train()
+    x0 = torch.randn(2, 700, 64, device=DEV)
+    gy = torch.randn(2, 700, 64, device=DEV)
+    ctx = contextlib.nullcontext() if dtype == torch.float32 else torch.autocast('cuda', dtype=dtype)
+
+    def run(fuse):
+        monkeypatch.setenv('UBV_FFN_FUSE', '1' if fuse else '0')
+        torch.manual_seed(11)
+        UF.new_step()
+        for q in ffn.parameters():
+            q.grad = None
+        x = x0.clone().requires_grad_()
+        with ctx:
+            parts = ffn.forward_parts(x)
+            assert parts is not None
+            out = parts[0]
+        out.float().backward(gy)
+        return [out.float().detach(), x.grad.clone()] + [q.grad.clone() for q in ffn.parameters()]
+
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        if dtype == torch.float32:
+            torch.testing.assert_close(u, v, rtol=1e-4, atol=1e-5)
+        else:       # the fused path rounds the hidden activation once instead of twice: compare in norm
+            assert float((u - v).norm() / v.norm().clamp_min(1e-6)) < 2e-2
+    if p == 0.0 and dtype == torch.float32:
+        lin1, lin2 = ffn.layers[0][0], ffn.layers[1]
+        x = x0.double().clone().requires_grad_()
+        w1, b1, w2, b2 = [t.detach().double().requires_grad_() for t in (lin1.weight, lin1.bias, lin2.weight, lin2.bias)]
+        ref = torch.relu(x @ w1.t() + b1) @ w2.t() + b2
+        ref.backward(gy.double())
+        torch.testing.assert_close(a[0].double(), ref.detach(), rtol=2e-4, atol=2e-4)
+        torch.testing.assert_close(a[1].double(), x.grad, rtol=2e-4, atol=2e-4)
+        for got, want in zip(a[2:], (w1.grad, b1.grad, w2.grad, b2.grad)):
+            torch.testing.assert_close(got.double(), want, rtol=2e-4, atol=2e-3)

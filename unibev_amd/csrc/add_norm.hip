@@ -15,14 +15,6 @@ namespace ubv {
 
 constexpr int kNormChunks = 4;      // C <= 64 lanes * 4 floats * 4 chunks = 1024
 
-// Stateless 32-bit mix of (seed, element index): keep iff hash >= threshold.
-__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t idx) {
-  uint64_t z = idx + seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return (uint32_t)((z ^ (z >> 31)) >> 16);
-}
-
 template <typename T>
 __device__ __forceinline__ void load4(const T* p, float (&v)[4]) { vec_io<T, 4>::load(p, v); }
 template <typename T>
@@ -352,10 +344,14 @@ __global__ __launch_bounds__(256) void relu_dropout_fwd_kernel(const T* __restri
     float v[VEC];
     vec_io<T, VEC>::load(x + i, v);
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-      float r = fmaxf(v[k], 0.0f);
-      if (thresh != 0u) r = (drop_hash(seed, (uint64_t)(i + k)) >= thresh) ? r * scale : 0.0f;
-      v[k] = r;
+    for (int k4 = 0; k4 < VEC; k4 += 4) {
+      const uint64_t mix = thresh != 0u ? drop_mix64(seed, (uint64_t)(i + k4) >> 2) : 0ull;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float r = fmaxf(v[k4 + e], 0.0f);
+        if (thresh != 0u) r = drop_keep16(mix, e, thresh) ? r * scale : 0.0f;
+        v[k4 + e] = r;
+      }
     }
     vec_io<T, VEC>::store(y + i, v);
   }
@@ -385,13 +381,6 @@ static int norm_check(long R, int C, int dtype, int stream_dtype, const char* wh
   UBV_CHECK_ARG(stream_dtype == UBV_F32 || stream_dtype == dtype,
                 "%s: stream_dtype %d must be f32 or equal dtype %d", who, stream_dtype, dtype);
   return UBV_OK;
-}
-
-static void drop_params(float p, uint32_t& thresh, float& scale) {
-  if (p <= 0.0f) { thresh = 0u; scale = 1.0f; return; }
-  const double t = (double)p * 4294967296.0;
-  thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
-  scale = 1.0f / (1.0f - p);
 }
 
 // Packed-rows kernels where a row is 16, 32 or 64 lanes of 16-byte vectors, else one row per wave.

@@ -33,6 +33,12 @@ typedef __attribute__((ext_vector_type(16))) float gf32x16_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t gu32x4_t;   // staging registers: native vectors (a HIP
 typedef __attribute__((ext_vector_type(4))) float gf32x4_t;      // uint4 / float4 struct copy ended up in scratch)
 
+// Optional epilogue of the FFN GEMMs (ubv_gemm_nt_act): mode 1 y = dropout(relu(acc + bias)) with the
+// keep mask of ubv_relu_dropout_forward (hash of seed and the element's index in the [M, N] output);
+// mode 2 y = acc * scale where mask[m][n] != 0, else 0 — the backward of that activation applied to the
+// input gradient of the NEXT Linear (mask = the activation's saved output).
+struct GemmAct { int mode; const void* mask; uint32_t thresh; float scale; uint64_t seed; const uint64_t* seed_dev; };
+
 constexpr int kGemmBM = 128, kGemmKC = 32, kGemmLd = kGemmKC + 8;   // 80-byte LDS rows: conflict-free 16-byte reads
 
 template <bool F16> __device__ __forceinline__ gf32x16_t gemm_mma(uint4 a, uint4 b, gf32x16_t c) {
@@ -54,7 +60,8 @@ __global__ __launch_bounds__(256, ((NB <= 4 && XD == 1) ? 3 : 2)) void gemm_nt_k
                                                       const uint16_t* __restrict__ Wh,
                                                       const uint16_t* __restrict__ Wl, long ldw,
                                                       const float* __restrict__ bias, const void* __restrict__ Rv,
-                                                      void* __restrict__ Yv, long ldy, long M, int N, int K) {
+                                                      void* __restrict__ Yv, long ldy, long M, int N, int K,
+                                                      const GemmAct act) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   constexpr int NT = 32 * NB;
   constexpr bool TWO_D = (NB % 2) == 0;
@@ -210,6 +217,7 @@ __global__ __launch_bounds__(256, ((NB <= 4 && XD == 1) ? 3 : 2)) void gemm_nt_k
   // ---- epilogue.  D[n][m]: column = this lane's row m, rows n = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   // within a column block: 4 consecutive output columns per (block, r >> 2)
   const int half = lane >> 5;
+  const uint64_t act_seed = act.seed + ((act.mode == 1 && act.seed_dev != nullptr) ? *act.seed_dev : 0ull);
 #pragma unroll
   for (int i = 0; i < WMB; ++i) {
     const long m = m0 + (wm * WMB + i) * 32 + fr;
@@ -224,6 +232,26 @@ __global__ __launch_bounds__(256, ((NB <= 4 && XD == 1) ? 3 : 2)) void gemm_nt_k
         if (bias != nullptr) {
           const float4 b = *reinterpret_cast<const float4*>(bias + n);
           v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (act.mode == 1) {
+          const uint64_t mix = act.thresh != 0u ? drop_mix64(act_seed, (uint64_t)(m * ldy + n) >> 2) : 0ull;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float r = fmaxf(v[e], 0.0f);
+            if (act.thresh != 0u) r = drop_keep16(mix, e, act.thresh) ? r * act.scale : 0.0f;
+            v[e] = r;
+          }
+        } else if (act.mode == 2) {
+          float k4[4];
+          if constexpr (OUT16) {
+            using T = typename std::conditional<F16, f16_t, bf16_t>::type;
+            vec_io<T, 4>::load((const T*)act.mask + m * ldy + n, k4);
+          } else {
+            const float4 t4 = *reinterpret_cast<const float4*>((const float*)act.mask + m * ldy + n);
+            k4[0] = t4.x; k4[1] = t4.y; k4[2] = t4.z; k4[3] = t4.w;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (k4[e] != 0.0f) ? v[e] * act.scale : 0.0f;
         }
         if constexpr (OUT16) {
           using T = typename std::conditional<F16, f16_t, bf16_t>::type;
@@ -281,7 +309,7 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
 
 template <bool SPLIT, bool F16, bool OUT16>
 static int gemm_nt_launch(const void* X, long ldx, const void* Wh, const void* Wl, long ldw, const float* bias,
-                          const void* R, void* Y, long ldy, long M, int N, int K, hipStream_t st) {
+                          const void* R, void* Y, long ldy, long M, int N, int K, const GemmAct& act, hipStream_t st) {
   // column tile: the largest of 256 / 192 / 128 / 96 / 64 / 32 that N fills evenly
   // study knobs.  128-column tiles: 64 accumulator registers per lane -> 3 blocks per CU (49 vs 62 us at N = K = 256,
   // f32); the column tiles of a row tile share X through L2 (block order above).  A second X register set in flight
@@ -299,10 +327,10 @@ static int gemm_nt_launch(const void* X, long ldx, const void* Wh, const void* W
   case NBV:                                                                                                  \
     if (depth == 2)                                                                                          \
       hipLaunchKernelGGL((gemm_nt_kernel<NBV, SPLIT, F16, OUT16, 2>), grid, blk, lds, st, X, ldx,            \
-                         (const uint16_t*)Wh, (const uint16_t*)Wl, ldw, bias, R, Y, ldy, M, N, K);           \
+                         (const uint16_t*)Wh, (const uint16_t*)Wl, ldw, bias, R, Y, ldy, M, N, K, act);      \
     else                                                                                                     \
       hipLaunchKernelGGL((gemm_nt_kernel<NBV, SPLIT, F16, OUT16, 1>), grid, blk, lds, st, X, ldx,            \
-                         (const uint16_t*)Wh, (const uint16_t*)Wl, ldw, bias, R, Y, ldy, M, N, K);           \
+                         (const uint16_t*)Wh, (const uint16_t*)Wl, ldw, bias, R, Y, ldy, M, N, K, act);      \
     break;
   switch (nt / 32) {
     UBV_GEMM_NB(8) UBV_GEMM_NB(6) UBV_GEMM_NB(4) UBV_GEMM_NB(3) UBV_GEMM_NB(2) UBV_GEMM_NB(1)
@@ -325,30 +353,51 @@ extern "C" int ubv_split_weight(const float* w, int N, int K, void* wh, void* wl
   return UBV_OK;
 }
 
-extern "C" int ubv_gemm_nt(const void* x, int64_t ldx, const void* w_hi, const void* w_lo, int64_t ldw,
-                           const float* bias, const void* residual, void* y, int64_t ldy, int64_t M, int N,
-                           int K, int dtype, void* stream) {
+static int gemm_nt_run(const void* x, int64_t ldx, const void* w_hi, const void* w_lo, int64_t ldw,
+                       const float* bias, const void* residual, void* y, int64_t ldy, int64_t M, int N, int K,
+                       int dtype, const ubv::GemmAct& act, void* stream, const char* who) {
   using namespace ubv;
-  UBV_CHECK_ARG(x && w_hi && y && M >= 0 && N > 0 && K > 0, "gemm_nt: bad arguments");
-  UBV_CHECK_ARG(dtype >= 0 && dtype <= 2, "gemm_nt: unknown dtype %d", dtype);
-  UBV_CHECK_ARG((dtype == UBV_F32) == (w_lo != nullptr), "gemm_nt: f32 data takes split weights (hi, lo), 16-bit data one");
+  UBV_CHECK_ARG(x && w_hi && y && M >= 0 && N > 0 && K > 0, "%s: bad arguments", who);
+  UBV_CHECK_ARG(dtype >= 0 && dtype <= 2, "%s: unknown dtype %d", who, dtype);
+  UBV_CHECK_ARG((dtype == UBV_F32) == (w_lo != nullptr), "%s: f32 data takes split weights (hi, lo), 16-bit data one", who);
   if (M == 0) return UBV_OK;
   const int al = dtype == UBV_F32 ? 4 : 8;
   if (K % kGemmKC != 0 || N % 32 != 0 || ldx % al != 0 || ldw % 8 != 0 || ldy % 4 != 0 ||
       ((uintptr_t)x % 16) != 0 || ((uintptr_t)w_hi % 16) != 0 || ((uintptr_t)y % 16) != 0 ||
-      (residual != nullptr && ((uintptr_t)residual % 16) != 0) || (bias != nullptr && ((uintptr_t)bias % 16) != 0)) {
-    set_error("gemm_nt: shape M=%lld N=%d K=%d needs K %% 32 == 0, N %% 32 == 0 and 16-byte aligned rows",
+      (residual != nullptr && ((uintptr_t)residual % 16) != 0) || (bias != nullptr && ((uintptr_t)bias % 16) != 0) ||
+      (act.mode == 2 && ((uintptr_t)act.mask % 8) != 0)) {
+    set_error("%s: shape M=%lld N=%d K=%d needs K %% 32 == 0, N %% 32 == 0 and 16-byte aligned rows", who,
               (long long)M, N, K);
     return UBV_ERR_UNSUPPORTED;
   }
   hipStream_t st = as_stream(stream);
   int rc;
-  if (dtype == UBV_F32) rc = gemm_nt_launch<true, false, false>(x, ldx, w_hi, w_lo, ldw, bias, residual, y, ldy, M, N, K, st);
-  else if (dtype == UBV_F16) rc = gemm_nt_launch<false, true, true>(x, ldx, w_hi, nullptr, ldw, bias, residual, y, ldy, M, N, K, st);
-  else rc = gemm_nt_launch<false, false, true>(x, ldx, w_hi, nullptr, ldw, bias, residual, y, ldy, M, N, K, st);
-  if (rc != UBV_OK) { set_error("gemm_nt: no kernel for N=%d", N); return rc; }
-  UBV_CHECK_LAUNCH("gemm_nt");
+  if (dtype == UBV_F32) rc = gemm_nt_launch<true, false, false>(x, ldx, w_hi, w_lo, ldw, bias, residual, y, ldy, M, N, K, act, st);
+  else if (dtype == UBV_F16) rc = gemm_nt_launch<false, true, true>(x, ldx, w_hi, nullptr, ldw, bias, residual, y, ldy, M, N, K, act, st);
+  else rc = gemm_nt_launch<false, false, true>(x, ldx, w_hi, nullptr, ldw, bias, residual, y, ldy, M, N, K, act, st);
+  if (rc != UBV_OK) { set_error("%s: no kernel for N=%d", who, N); return rc; }
+  UBV_CHECK_LAUNCH(who);
   return UBV_OK;
+}
+
+extern "C" int ubv_gemm_nt(const void* x, int64_t ldx, const void* w_hi, const void* w_lo, int64_t ldw,
+                           const float* bias, const void* residual, void* y, int64_t ldy, int64_t M, int N,
+                           int K, int dtype, void* stream) {
+  return gemm_nt_run(x, ldx, w_hi, w_lo, ldw, bias, residual, y, ldy, M, N, K, dtype, ubv::GemmAct{}, stream, "gemm_nt");
+}
+
+extern "C" int ubv_gemm_nt_act(const void* x, int64_t ldx, const void* w_hi, const void* w_lo, int64_t ldw,
+                               const float* bias, void* y, int64_t ldy, int64_t M, int N, int K, int dtype,
+                               int act, const void* mask, float p, uint64_t seed, const uint64_t* seed_dev,
+                               void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(act == 1 || act == 2, "gemm_nt_act: act must be 1 (relu + dropout) or 2 (masked gradient)");
+  UBV_CHECK_ARG(act != 2 || mask != nullptr, "gemm_nt_act: act 2 needs the activation's output as mask");
+  UBV_CHECK_ARG(p >= 0.0f && p < 1.0f, "gemm_nt_act: dropout probability %f outside [0, 1)", (double)p);
+  GemmAct a{};
+  a.mode = act; a.mask = mask; a.seed = seed; a.seed_dev = seed_dev;
+  drop_params(p, a.thresh, a.scale);
+  return gemm_nt_run(x, ldx, w_hi, w_lo, ldw, bias, nullptr, y, ldy, M, N, K, dtype, a, stream, "gemm_nt_act");
 }
 
 namespace ubv {

@@ -200,4 +200,32 @@ class ProfScope {
   hipStream_t st_;
 };
 
+// ---- dropout: stateless keep mask (shared by add_norm.hip and the GEMM epilogues) -----------------
+// 32-bit mix of (seed, element index): keep iff hash >= threshold.
+__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t idx) {
+  uint64_t z = idx + seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (uint32_t)((z ^ (z >> 31)) >> 16);
+}
+// The FFN activation (relu_dropout kernels and the GEMM epilogue) draws FOUR 16-bit decisions from one
+// 64-bit mix, for the 4-element group the index belongs to: a quarter of the 64-bit multiplies, which a
+// GEMM epilogue cannot hide behind memory time the way a streaming kernel does.  keep4(...)[e] for
+// element 4 g + e; thresh16 = thresh >> 16 (p at a resolution of 2^-16).
+__device__ __forceinline__ uint64_t drop_mix64(uint64_t seed, uint64_t group) {
+  uint64_t z = group + seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ bool drop_keep16(uint64_t mix, int e, uint32_t thresh) {
+  return (uint32_t)((mix >> (16 * e)) & 0xffffull) >= (thresh >> 16);
+}
+static inline void drop_params(float p, uint32_t& thresh, float& scale) {
+  if (p <= 0.0f) { thresh = 0u; scale = 1.0f; return; }
+  const double t = (double)p * 4294967296.0;
+  thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+  scale = 1.0f / (1.0f - p);
+}
+
 }  // namespace ubv

@@ -649,6 +649,53 @@ def gemm_nt(x, w_hi, w_lo=None, bias=None, residual=None, out=None):
         return y
 
 
+def gemm_nt_act(x, w_hi, w_lo=None, bias=None, act=1, mask=None, p=0.0, seed=0):
+    """``ubv_gemm_nt_act``: act 1 -> dropout(relu(x @ w^T + bias), p) with the keep mask of
+    ``relu_dropout`` for ``seed``; act 2 -> (x @ w^T) / (1 - p) where ``mask`` != 0, else 0.  None when the
+    shape is outside the kernel's reach."""
+    with _need_cuda(x, w_hi, w_lo, bias, mask):
+        K = x.shape[-1]
+        M = x.numel() // K
+        N = w_hi.shape[0]
+        if K % 32 != 0 or N % 32 != 0 or not x.is_contiguous() or \
+                (mask is not None and not (mask.is_contiguous() and mask.dtype == x.dtype and mask.numel() == M * N)):
+            return None
+        y = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+        b = None if bias is None else bias.float().contiguous()
+        rc = lib().ubv_gemm_nt_act(_p(x), K, _p(w_hi), _p(w_lo), K, _p(b), _p(y), N, M, N, K, _dt(x), int(act),
+                                   _p(mask), float(p), int(seed), _p(_SEED_BASE[0]), _stream())
+        if rc == -3:
+            return None
+        check(rc, 'gemm_nt_act')
+        return y
+
+
+@torch.no_grad()
+def relu_dropout_raw(x, p, seed):
+    """dropout(relu(x), p) without an autograd node (``ubv_relu_dropout_forward``)."""
+    with _need_cuda(x):
+        xc = x.contiguous()
+        y = torch.empty_like(xc)
+        check(lib().ubv_relu_dropout_forward(_p(xc), _p(y), xc.numel(), float(p), int(seed), _p(_SEED_BASE[0]),
+                                             _dt(xc), _stream()), 'relu_dropout_forward')
+        return y
+
+
+@torch.no_grad()
+def relu_dropout_grad_raw(grad_y, y, p):
+    """grad of ``relu_dropout`` from its output ``y`` (``ubv_relu_dropout_backward``)."""
+    with _need_cuda(grad_y, y):
+        gy = grad_y.to(y.dtype).contiguous()
+        gx = torch.empty_like(y)
+        check(lib().ubv_relu_dropout_backward(_p(gy), _p(y), _p(gx), y.numel(), float(p), _dt(y), _stream()),
+              'relu_dropout_backward')
+        return gx
+
+
+def next_dropout_seed():
+    return _next_seed()
+
+
 @torch.no_grad()
 def gemm_wgrad(grad_out, x):
     """(grad_weight f32 [N, K], grad_bias f32 [N]) of a Linear from grad_out [M, N] and x [M, K] (one

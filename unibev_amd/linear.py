@@ -177,8 +177,9 @@ class _Linear(Function):
     (``addmm``: D = grad_alias + grad_out @ W in the GEMM epilogue)."""
 
     @staticmethod
-    def forward(ctx, x, dtype, n, has_bias, passthru, *params):
+    def forward(ctx, x, dtype, n, has_bias, passthru, act, *params):
         weights, biases = params[:n], params[n:]
+        ctx.act = act
         w = _cached_lowp(weights, dtype)
         b = _cached_lowp(biases, dtype) if has_bias else None
         xc = x.to(dtype)
@@ -188,17 +189,31 @@ class _Linear(Function):
         ok = xc.is_cuda and xc.is_contiguous() and xc.numel() > 0 and xc.shape[-1] % 32 == 0 and \
             w.shape[0] % 32 == 0
         from . import functional as UF
+        # act = ('relu_drop', p): this Linear's output goes through ReLU + Dropout(p) — applied in the
+        # GEMM epilogue (ubv_gemm_nt_act), the pre-activation is never written; act = ('masked_in', p):
+        # this Linear's INPUT is such an activation's output (see backward).
+        fuse = act is not None and act[0] == 'relu_drop'
+        seed = UF.next_dropout_seed() if (fuse and act[1] > 0) else 0
+        fused = False
         if ok and dtype == torch.float32 and _MFMA_F32 and w.dtype == torch.float32:
             # split-bf16 product on the matrix cores (ubv_gemm_nt): HBM-bound where the f32 library
             # GEMM is MFMA-bound (61 vs 103 us at 80 000 x 256 x 256)
             split = _split_weights(weights)
-            y = UF.gemm_nt(xc, split[0], split[1], bias=b)
-        elif ok and dtype != torch.float32 and w.dtype == dtype and w.shape[0] <= _MFMA_16_MAXN and \
-                w.is_contiguous():
+            if fuse:
+                y = UF.gemm_nt_act(xc, split[0], split[1], bias=b, act=1, p=act[1], seed=seed)
+                fused = y is not None
+            if y is None:
+                y = UF.gemm_nt(xc, split[0], split[1], bias=b)
+        elif ok and dtype != torch.float32 and w.dtype == dtype and w.is_contiguous() and \
+                (fuse or w.shape[0] <= _MFMA_16_MAXN):
             b32 = None
             if has_bias:                  # the kernel adds the bias in f32: hand it the master values
                 b32 = biases[0].detach() if n == 1 else torch.cat([p.detach() for p in biases])
-            y = UF.gemm_nt(xc, w, bias=b32)
+            if fuse:
+                y = UF.gemm_nt_act(xc, w, bias=b32, act=1, p=act[1], seed=seed)
+                fused = y is not None
+            elif w.shape[0] <= _MFMA_16_MAXN:
+                y = UF.gemm_nt(xc, w, bias=b32)
         if y is None and xc.is_cuda and xc.dtype == w.dtype and (b is None or b.dtype == w.dtype) and \
                 xc.is_contiguous() and w.is_contiguous() and xc.numel() > 0:
             # hipBLASLt with a cached plan (ubv_linear_forward): same GEMM, a third of the host time
@@ -214,24 +229,49 @@ class _Linear(Function):
             xh, xl = split_(xc)
             wh, wl = split_(w)
             y = F.linear(xh, wh, b) + F.linear(xh, wl) + F.linear(xl, wh)
-        if split is not None:
-            ctx.save_for_backward(xc, w, split[2], split[3])
-        else:
-            ctx.save_for_backward(xc, w)
+        if fuse and not fused:
+            y = UF.relu_dropout_raw(y, act[1], seed) if y.is_cuda else \
+                F.dropout(torch.relu(y), act[1], training=act[1] > 0)
+        ctx.n_wt = 2 if split is not None else 0
+        keep = (xc, w) + ((split[2], split[3]) if split is not None else ()) + ((y,) if fuse else ())
+        ctx.save_for_backward(*keep)
         return (y, x.view_as(x)) if passthru else y
 
     @staticmethod
     def backward(ctx, grad_out, grad_alias=None):
         xc, w = ctx.saved_tensors[:2]
-        wt = ctx.saved_tensors[2:]                    # transposed split halves (f32 MFMA path) or ()
+        wt = ctx.saved_tensors[2:2 + ctx.n_wt]        # transposed split halves (f32 MFMA path) or ()
         x_dtype, n, has_bias, outs, pdt = ctx.meta
+        act = ctx.act
+        from . import functional as UF
+        if act is not None and act[0] == 'relu_drop' and not getattr(grad_out, '_ubv_masked', False):
+            # the consumer did not fold the activation's derivative into its input gradient
+            a_out = ctx.saved_tensors[2 + ctx.n_wt]
+            if a_out.is_cuda:
+                grad_out = UF.relu_dropout_grad_raw(grad_out, a_out, act[1])
+            else:
+                grad_out = grad_out * (a_out != 0).to(grad_out.dtype) / (1.0 - act[1])
         go2 = grad_out.reshape(-1, grad_out.shape[-1])
         gx = None
-        if ctx.needs_input_grad[0] and wt and go2.dtype == torch.float32 and x_dtype == torch.float32 and \
+        if act is not None and act[0] == 'masked_in' and ctx.needs_input_grad[0]:
+            # dX = (dY . W) * relu'/keep mask of the activation that produced this Linear's input, in the
+            # GEMM epilogue (ubv_gemm_nt_act, act 2); the producing Linear then takes the gradient as is
+            a2 = xc.reshape(-1, xc.shape[-1])
+            if go2.is_cuda and go2.is_contiguous() and go2.dtype == xc.dtype == x_dtype and grad_alias is None:
+                if wt and go2.dtype == torch.float32:
+                    gx = UF.gemm_nt_act(go2, wt[0], wt[1], act=2, mask=a2, p=act[1])
+                elif go2.dtype != torch.float32 and w.dtype == go2.dtype:
+                    gx = UF.gemm_nt_act(go2, w.t().contiguous(), act=2, mask=a2, p=act[1])
+            if gx is None:
+                g = (go2 @ w).to(x_dtype)
+                gx = UF.relu_dropout_grad_raw(g, a2, act[1]) if g.is_cuda else \
+                    g * (a2 != 0).to(g.dtype) / (1.0 - act[1])
+            gx = gx.view(xc.shape)
+            gx._ubv_masked = True
+        if gx is None and ctx.needs_input_grad[0] and wt and go2.dtype == torch.float32 and x_dtype == torch.float32 and \
                 go2.is_contiguous() and go2.shape[1] % 32 == 0 and xc.shape[-1] % 32 == 0:
             # dX = dY . W on the matrix cores, the residual branch's gradient added in the epilogue
             # (in place when that tensor was produced for this edge alone)
-            from . import functional as UF
             ga = None
             if grad_alias is not None and grad_alias.dtype == torch.float32:
                 ga = grad_alias.reshape(-1, xc.shape[-1])
@@ -261,8 +301,8 @@ class _Linear(Function):
         x2 = xc.reshape(-1, xc.shape[-1])
         rows = x2.shape[0]
         gw = gb = None
-        need_w = any(ctx.needs_input_grad[5:5 + n])
-        need_b = has_bias and any(ctx.needs_input_grad[5 + n:])
+        need_w = any(ctx.needs_input_grad[6:6 + n])
+        need_b = has_bias and any(ctx.needs_input_grad[6 + n:])
         part = None
         if (need_w or need_b) and go2.is_cuda and _MFMA_WGRAD and go2.dtype == x2.dtype and \
                 go2.is_contiguous() and x2.is_contiguous() and \
@@ -277,13 +317,13 @@ class _Linear(Function):
                 grads = []
                 off = 0
                 for i in range(n):
-                    grads.append(gw[off:off + outs[i]].to(pdt[i]) if ctx.needs_input_grad[5 + i] else None)
+                    grads.append(gw[off:off + outs[i]].to(pdt[i]) if ctx.needs_input_grad[6 + i] else None)
                     off += outs[i]
                 off = 0
                 for i in range(n if has_bias else 0):
                     grads.append(gb[off:off + outs[i]].to(pdt[n + i]))
                     off += outs[i]
-                return (gx, None, None, None, None, *grads)
+                return (gx, None, None, None, None, None, *grads)
         if need_w:
             s = _splits(rows)
             if s > 1:
@@ -316,25 +356,38 @@ class _Linear(Function):
         for i in range(n if has_bias else 0):
             grads.append(None if gb is None else gb[off:off + outs[i]].to(pdt[n + i]))
             off += outs[i]
-        return (gx, None, None, None, None, *grads)
+        return (gx, None, None, None, None, None, *grads)
 
 
-def _run(x, weights, biases, passthru=False):
+def _run(x, weights, biases, passthru=False, act=None):
     has_bias = biases[0] is not None
     params = list(weights) + (list(biases) if has_bias else [])
     if x.is_cuda and torch.is_autocast_enabled('cuda'):
         # no autocast(enabled=False) scope here: every operand of the GEMM inside is already in the
         # autocast dtype, so the ambient policy has nothing to cast (and the context manager costs
         # ~1 us x 3 per call on a host-bound forward)
-        return _Linear.apply(x, torch.get_autocast_dtype('cuda'), len(weights), has_bias, passthru,
+        return _Linear.apply(x, torch.get_autocast_dtype('cuda'), len(weights), has_bias, passthru, act,
                              *params)
     return _Linear.apply(x, x.dtype if x.dtype == weights[0].dtype else weights[0].dtype,
-                         len(weights), has_bias, passthru, *params)
+                         len(weights), has_bias, passthru, act, *params)
 
 
 def linear(x, weight, bias=None):
     """``F.linear(x, weight, bias)``; follows the ambient autocast dtype."""
     return _run(x, [weight], [bias])
+
+
+def linear_relu_dropout(x, weight, bias=None, p=0.0, training=False, passthru=False):
+    """``dropout(relu(F.linear(x, weight, bias)), p)`` with the activation in the GEMM epilogue (the first
+    half of an FFN).  Feed the result ONLY to ``linear_after_relu_dropout`` with the same ``p`` /
+    ``training``: that Linear's input gradient comes back already multiplied by the activation's
+    derivative.  ``passthru``: as ``linear_pass``."""
+    return _run(x, [weight], [bias], passthru=passthru, act=('relu_drop', float(p) if training else 0.0))
+
+
+def linear_after_relu_dropout(a, weight, bias=None, p=0.0, training=False):
+    """``F.linear(a, weight, bias)`` for ``a = linear_relu_dropout(...)`` (the second half of an FFN)."""
+    return _run(a, [weight], [bias], act=('masked_in', float(p) if training else 0.0))
 
 
 def linear_cat(x, weights, biases):

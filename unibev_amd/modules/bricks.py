@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from .. import functional as UF
 from ..linear import linear as ubv_linear
-from ..linear import linear_pass
+from ..linear import linear_pass, linear_relu_dropout, linear_after_relu_dropout
 from ..registry import (ATTENTION, FEEDFORWARD_NETWORK, POSITIONAL_ENCODING, TRANSFORMER_LAYER,
                         TRANSFORMER_LAYER_SEQUENCE, build_attention, build_feedforward_network,
                         build_transformer_layer)
@@ -93,6 +93,9 @@ class FFN(BaseModule):
         """One entry of ``self.layers``: a Linear, the closing Dropout, or a
         Sequential(Linear, act, Dropout) whose ReLU + Dropout run as one kernel on the GPU."""
         if isinstance(layer, nn.Linear):
+            p_act = getattr(x, '_ubv_ffn_act', None)
+            if p_act is not None:      # x = linear_relu_dropout(...): its derivative folds into this dgrad
+                return linear_after_relu_dropout(x, layer.weight, layer.bias, p_act, True)
             return ubv_linear(x, layer.weight, layer.bias)
         if not isinstance(layer, nn.Sequential):
             return layer(x)
@@ -100,7 +103,12 @@ class FFN(BaseModule):
         i = start
         while i < len(subs):
             sub = subs[i]
-            if isinstance(sub, nn.Linear):
+            if isinstance(sub, nn.Linear) and self._is_relu_dropout(subs, i + 1) and x.is_cuda:
+                # Linear -> ReLU -> Dropout: the activation runs in the GEMM epilogue
+                x = linear_relu_dropout(x, sub.weight, sub.bias, subs[i + 2].p, self.training)
+                x._ubv_ffn_act = subs[i + 2].p if self.training else 0.0
+                i += 2
+            elif isinstance(sub, nn.Linear):
                 x = ubv_linear(x, sub.weight, sub.bias)
             elif isinstance(sub, nn.ReLU):
                 nxt = subs[i + 1] if i + 1 < len(subs) else None
@@ -113,6 +121,13 @@ class FFN(BaseModule):
                 x = sub(x)
             i += 1
         return x
+
+    @staticmethod
+    def _is_relu_dropout(subs, i):
+        import os
+        if os.environ.get('UBV_FFN_FUSE', '1') == '0':       # study knob: the separate relu_dropout kernels
+            return False
+        return i + 1 < len(subs) and isinstance(subs[i], nn.ReLU) and isinstance(subs[i + 1], nn.Dropout)
 
     def forward_parts(self, x, identity=None):
         """(pre-dropout output, identity, p) for a caller that fuses the tail with the next norm;
@@ -127,8 +142,14 @@ class FFN(BaseModule):
         if identity is None and x.is_cuda and isinstance(first, nn.Sequential) and \
                 isinstance(first[0], nn.Linear):
             # x feeds the first Linear AND the residual: pass-through (linear.linear_pass)
-            h, identity = linear_pass(x, first[0].weight, first[0].bias)
-            h = self._block(h, first, start=1)
+            if self._is_relu_dropout(list(first), 1):
+                h, identity = linear_relu_dropout(x, first[0].weight, first[0].bias, first[2].p, self.training,
+                                                  passthru=True)
+                h._ubv_ffn_act = first[2].p if self.training else 0.0
+                h = self._block(h, first, start=3)
+            else:
+                h, identity = linear_pass(x, first[0].weight, first[0].bias)
+                h = self._block(h, first, start=1)
             blocks = blocks[1:]
         for layer in blocks:
             h = self._block(h, layer)
