@@ -39,7 +39,10 @@ typedef __attribute__((ext_vector_type(4))) float gf32x4_t;      // uint4 / floa
 // input gradient of the NEXT Linear (mask = the activation's saved output).
 struct GemmAct { int mode; const void* mask; uint32_t thresh; float scale; uint64_t seed; const uint64_t* seed_dev; };
 
-constexpr int kGemmBM = 128, kGemmKC = 32, kGemmLd = kGemmKC + 8;   // 80-byte LDS rows: conflict-free 16-byte reads
+constexpr int kGemmBM = 128;
+// K is walked in chunks of KC = 32 (f32 data: the hi + lo images double the LDS) or 64 (16-bit data, where
+// a 32-wide chunk is 8 MFMAs per wave between two barriers); LDS rows of KC + 8 halves (80 / 144 bytes)
+// keep the 16-byte fragment reads conflict-free.
 
 template <bool F16> __device__ __forceinline__ gf32x16_t gemm_mma(uint4 a, uint4 b, gf32x16_t c) {
   if constexpr (F16)
@@ -55,8 +58,8 @@ template <bool F16> __device__ __forceinline__ gf32x16_t gemm_mma(uint4 a, uint4
 // Wave tiling: NB even -> 2 x 2 waves of (2 row blocks) x (NB / 2 column blocks): per 16-wide k step a
 // wave reads 2 + NB/2 fragment pairs from LDS for 2 * NB/2 MFMA groups (a 1-D split read 1 + NB for
 // NB groups and ran at a third of the speed); NB odd -> 4 x 1 waves of 1 x NB.
-template <int NB, bool SPLIT, bool F16, bool OUT16, int XD>
-__global__ __launch_bounds__(256, ((NB <= 4 && XD == 1) ? 3 : 2)) void gemm_nt_kernel(const void* __restrict__ Xv, long ldx,
+template <int NB, bool SPLIT, bool F16, bool OUT16, int KC>
+__global__ __launch_bounds__(256, (NB <= 4 ? 3 : 2)) void gemm_nt_kernel(const void* __restrict__ Xv, long ldx,
                                                       const uint16_t* __restrict__ Wh,
                                                       const uint16_t* __restrict__ Wl, long ldw,
                                                       const float* __restrict__ bias, const void* __restrict__ Rv,
@@ -64,6 +67,8 @@ __global__ __launch_bounds__(256, ((NB <= 4 && XD == 1) ? 3 : 2)) void gemm_nt_k
                                                       const GemmAct act) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   constexpr int NT = 32 * NB;
+  constexpr int XD = 1;                                   // register sets of X in flight (2 spills under hipcc)
+  constexpr int kGemmKC = KC, kGemmLd = KC + 8;
   constexpr bool TWO_D = (NB % 2) == 0;
   constexpr int WMB = TWO_D ? 2 : 1;                     // row blocks per wave
   constexpr int WNB = TWO_D ? NB / 2 : NB;               // column blocks per wave
@@ -79,17 +84,16 @@ __global__ __launch_bounds__(256, ((NB <= 4 && XD == 1) ? 3 : 2)) void gemm_nt_k
   const long m0 = ((long)(slot / ny) * 8 + xcd) * kGemmBM;
   const int n0 = (slot % ny) * NT;
   if (m0 >= M) return;
-  // ---- staging maps.  X chunk [128 x 32]: f32 -> thread rows tid/8 + 32 i (i < 4), 4 columns
-  // (tid%8)*4; 16-bit -> rows tid/4 + 64 i (i < 2), 8 columns (tid%4)*8.  W chunk [NT x 32] 16-bit:
-  // rows tid/4 + 64 i, 8 columns.
-  const int xr = SPLIT ? tid >> 3 : tid >> 2, xc = SPLIT ? (tid & 7) * 4 : (tid & 3) * 8;
-  constexpr int XI = SPLIT ? 4 : 2;
-  constexpr int WI = (NT + 63) / 64;
-  const int wr = tid >> 2, wc = (tid & 3) * 8;
+  // ---- staging maps.  X chunk [128 x KC]: a row is KC/4 (f32) or KC/8 (16-bit) threads of 16 bytes;
+  // W chunk [NT x KC] 16-bit: KC/8 threads per row.
+  constexpr int TPRX = SPLIT ? KC / 4 : KC / 8, XSTEP = 256 / TPRX, XI = kGemmBM / XSTEP;
+  constexpr int TPRW = KC / 8, WSTEP = 256 / TPRW, WI = (NT + WSTEP - 1) / WSTEP;
+  const int xr = tid / TPRX, xc = (tid % TPRX) * (SPLIT ? 4 : 8);
+  const int wr = tid / TPRW, wc = (tid % TPRW) * 8;
   // X chunks are fetched XD chunks ahead (register sets xf[0..XD)), W chunks — L2 hits — one ahead:
   // the bytes in flight per CU, not the MFMA or LDS rate, set the speed of this kernel
-  gf32x4_t xf[XD][SPLIT ? 4 : 1];
-  gu32x4_t xq[XD][SPLIT ? 1 : 2];
+  gf32x4_t xf[XD][SPLIT ? XI : 1];
+  gu32x4_t xq[XD][SPLIT ? 1 : XI];
   gu32x4_t wqh[WI], wql[SPLIT ? WI : 1];
 
   // (rows past M are clamped, not predicated — their results are never stored — so that the loads are
@@ -98,13 +102,13 @@ __global__ __launch_bounds__(256, ((NB <= 4 && XD == 1) ? 3 : 2)) void gemm_nt_k
   long xrow[XI];
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
-    const long r = m0 + xr + (SPLIT ? 32 : 64) * i;
+    const long r = m0 + xr + XSTEP * i;
     xrow[i] = (r < M ? r : M - 1) * ldx + xc;
   }
   long wrow[WI];
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
-    const int r = wr + 64 * i;
+    const int r = wr + WSTEP * i;
     wrow[i] = (long)(n0 + (r < NT ? r : NT - 1)) * ldw + wc;          // N % NT == 0 (host)
   }
   auto load_x = [&](int k0, auto setc) {
@@ -131,18 +135,18 @@ __global__ __launch_bounds__(256, ((NB <= 4 && XD == 1) ? 3 : 2)) void gemm_nt_k
         const uint32_t h0 = cvt_pk_bf16(v.x, v.y), h1 = cvt_pk_bf16(v.z, v.w);
         const float r0 = v.x - __uint_as_float(h0 << 16), r1 = v.y - __uint_as_float(h0 & 0xffff0000u);
         const float r2 = v.z - __uint_as_float(h1 << 16), r3 = v.w - __uint_as_float(h1 & 0xffff0000u);
-        const int o = (xr + 32 * i) * kGemmLd + xc;
+        const int o = (xr + XSTEP * i) * kGemmLd + xc;
         *reinterpret_cast<uint2*>(xh + o) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(xl + o) = make_uint2(cvt_pk_bf16(r0, r1), cvt_pk_bf16(r2, r3));
       } else {
-        *reinterpret_cast<gu32x4_t*>(xh + (xr + 64 * i) * kGemmLd + xc) = xq[set][i];
+        *reinterpret_cast<gu32x4_t*>(xh + (xr + XSTEP * i) * kGemmLd + xc) = xq[set][i];
       }
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-      if (wr + 64 * i < NT) {
-        *reinterpret_cast<gu32x4_t*>(wh + (wr + 64 * i) * kGemmLd + wc) = wqh[i];
-        if constexpr (SPLIT) *reinterpret_cast<gu32x4_t*>(wl + (wr + 64 * i) * kGemmLd + wc) = wql[i];
+      if (wr + WSTEP * i < NT) {
+        *reinterpret_cast<gu32x4_t*>(wh + (wr + WSTEP * i) * kGemmLd + wc) = wqh[i];
+        if constexpr (SPLIT) *reinterpret_cast<gu32x4_t*>(wl + (wr + WSTEP * i) * kGemmLd + wc) = wql[i];
       }
     }
   };
@@ -311,26 +315,29 @@ template <bool SPLIT, bool F16, bool OUT16>
 static int gemm_nt_launch(const void* X, long ldx, const void* Wh, const void* Wl, long ldw, const float* bias,
                           const void* R, void* Y, long ldy, long M, int N, int K, const GemmAct& act, hipStream_t st) {
   // column tile: the largest of 256 / 192 / 128 / 96 / 64 / 32 that N fills evenly
-  // study knobs.  128-column tiles: 64 accumulator registers per lane -> 3 blocks per CU (49 vs 62 us at N = K = 256,
-  // f32); the column tiles of a row tile share X through L2 (block order above).  A second X register set in flight
-  // (depth 2) spills under hipcc and measures slower.
+  // 128-column tiles: 64 accumulator registers per lane -> 3 blocks per CU (49 vs 62 us at N = K = 256, f32); the
+  // column tiles of a row tile share X through L2 (block order above).  UBV_GEMM_NT: study knob.
   static const int nt_cap = getenv("UBV_GEMM_NT") ? atoi(getenv("UBV_GEMM_NT")) : 128;
-  static const int depth = getenv("UBV_GEMM_DEPTH") ? atoi(getenv("UBV_GEMM_DEPTH")) : 1;
+  static const int kc_cap = getenv("UBV_GEMM_KC") ? atoi(getenv("UBV_GEMM_KC")) : 64;
+  const int kc = (!SPLIT && K % 64 == 0 && kc_cap >= 64) ? 64 : 32;
   int nt = 0;
   for (int c : {256, 192, 128, 96, 64, 32})
     if (c <= nt_cap && N % c == 0) { nt = c; break; }
   if (nt == 0) return UBV_ERR_UNSUPPORTED;
   const long row_tiles = (M + kGemmBM - 1) / kGemmBM;
   const dim3 grid((unsigned)((row_tiles + 7) / 8 * 8 * (N / nt))), blk(256);
-  const size_t lds = (size_t)((SPLIT ? 2 : 1) * (kGemmBM + nt) * kGemmLd) * sizeof(uint16_t);
+  const size_t lds = (size_t)((SPLIT ? 2 : 1) * (kGemmBM + nt) * (kc + 8)) * sizeof(uint16_t);
 #define UBV_GEMM_NB(NBV)                                                                                     \
   case NBV:                                                                                                  \
-    if (depth == 2)                                                                                          \
-      hipLaunchKernelGGL((gemm_nt_kernel<NBV, SPLIT, F16, OUT16, 2>), grid, blk, lds, st, X, ldx,            \
-                         (const uint16_t*)Wh, (const uint16_t*)Wl, ldw, bias, R, Y, ldy, M, N, K, act);      \
-    else                                                                                                     \
-      hipLaunchKernelGGL((gemm_nt_kernel<NBV, SPLIT, F16, OUT16, 1>), grid, blk, lds, st, X, ldx,            \
-                         (const uint16_t*)Wh, (const uint16_t*)Wl, ldw, bias, R, Y, ldy, M, N, K, act);      \
+    if constexpr (!SPLIT) {                                                                                  \
+      if (kc == 64) {                                                                                        \
+        hipLaunchKernelGGL((gemm_nt_kernel<NBV, SPLIT, F16, OUT16, 64>), grid, blk, lds, st, X, ldx,         \
+                           (const uint16_t*)Wh, (const uint16_t*)Wl, ldw, bias, R, Y, ldy, M, N, K, act);    \
+        break;                                                                                               \
+      }                                                                                                      \
+    }                                                                                                        \
+    hipLaunchKernelGGL((gemm_nt_kernel<NBV, SPLIT, F16, OUT16, 32>), grid, blk, lds, st, X, ldx,             \
+                       (const uint16_t*)Wh, (const uint16_t*)Wl, ldw, bias, R, Y, ldy, M, N, K, act);        \
     break;
   switch (nt / 32) {
     UBV_GEMM_NB(8) UBV_GEMM_NB(6) UBV_GEMM_NB(4) UBV_GEMM_NB(3) UBV_GEMM_NB(2) UBV_GEMM_NB(1)
@@ -362,7 +369,7 @@ static int gemm_nt_run(const void* x, int64_t ldx, const void* w_hi, const void*
   UBV_CHECK_ARG((dtype == UBV_F32) == (w_lo != nullptr), "%s: f32 data takes split weights (hi, lo), 16-bit data one", who);
   if (M == 0) return UBV_OK;
   const int al = dtype == UBV_F32 ? 4 : 8;
-  if (K % kGemmKC != 0 || N % 32 != 0 || ldx % al != 0 || ldw % 8 != 0 || ldy % 4 != 0 ||
+  if (K % 32 != 0 || N % 32 != 0 || ldx % al != 0 || ldw % 8 != 0 || ldy % 4 != 0 ||
       ((uintptr_t)x % 16) != 0 || ((uintptr_t)w_hi % 16) != 0 || ((uintptr_t)y % 16) != 0 ||
       (residual != nullptr && ((uintptr_t)residual % 16) != 0) || (bias != nullptr && ((uintptr_t)bias % 16) != 0) ||
       (act.mode == 2 && ((uintptr_t)act.mask % 8) != 0)) {
