@@ -499,9 +499,9 @@ class _AddDropoutNorm(Function):
             gx = gx.view(ctx.shape)
             # column sums of grad_x ride along: if x came straight out of a Linear, its backward takes
             # them as the bias gradient instead of reducing grad_x again (linear._Linear.backward)
-            gx._ubv_colsum = dxs
+            tag_grad(gx, '_ubv_colsum', dxs)
             gid = gid.view(ctx.shape).to(ctx.dts[0])
-            gid._ubv_owned = True         # fresh, single consumer: linear._Linear may accumulate into it
+            tag_grad(gid, '_ubv_owned', True)   # fresh, single consumer: linear._Linear may accumulate into it
             return (gx, gid, dg.to(ctx.dts[1]), db.to(ctx.dts[2]), None, None)
 
 
@@ -747,6 +747,37 @@ def linear_grad_reduce(grad_out=None, partials=None):
 
 # ----------------------------------------------------------------------------------------------- voxels
 _WS = {}
+
+
+def release_workspaces():
+    """Drops the cached scratch buffers (per device and stream; the lifting backward's binning workspace
+    is the large one: it is sized for the worst case).  They are re-created on the next call."""
+    _WS.clear()
+
+
+# ---- tags on gradient tensors ------------------------------------------------------------------
+# A producer's backward may hand its consumer more than the gradient itself (the column sums it already
+# has, the fact that the tensor is fresh and may be accumulated into, ...).  The hint travels as a Python
+# attribute on the gradient tensor, together with the tensor's version counter and address at tagging
+# time: autograd accumulates a second consumer's gradient IN PLACE into the first one's tensor (and keeps
+# its attributes), which bumps the version — the reader then sees a stale tag and ignores it.
+def tag_grad(t, name, value):
+    setattr(t, name, (value, t._version, t.data_ptr()))
+    return t
+
+
+def grad_tag(t, name):
+    """The value tagged on ``t`` under ``name``, or None when absent or stale."""
+    rec = getattr(t, name, None)
+    if rec is None:
+        return None
+    value, version, ptr = rec
+    return value if (t._version == version and t.data_ptr() == ptr) else None
+
+
+def grad_tag_stale(t, name):
+    rec = getattr(t, name, None)
+    return rec is not None and not (t._version == rec[1] and t.data_ptr() == rec[2])
 
 
 def _workspace(nbytes, device):

@@ -164,6 +164,9 @@ def _cached_lowp(params, dtype):
             _SHADOWS.clear()
         views = list(torch.split(buf, [p.shape[0] for p in params], 0))
         _SHADOWS[key] = (buf, views, list(params))
+        # the refresh plan holds the old buffers: rebuild it (a shadow REPLACED under its key, or the table
+        # cleared and refilled to the same size, leaves len(_SHADOWS) unchanged)
+        _PLAN['n'] = -1
         _PLAN['versions'] = None      # a shadow created mid-pass: its versions are taken at the next refresh
     return buf
 
@@ -244,7 +247,10 @@ class _Linear(Function):
         x_dtype, n, has_bias, outs, pdt = ctx.meta
         act = ctx.act
         from . import functional as UF
-        if act is not None and act[0] == 'relu_drop' and not getattr(grad_out, '_ubv_masked', False):
+        if act is not None and act[0] == 'relu_drop' and UF.grad_tag_stale(grad_out, '_ubv_masked'):
+            raise RuntimeError('linear_relu_dropout: the activation fed something besides '
+                               'linear_after_relu_dropout (its gradient arrived partly pre-multiplied)')
+        if act is not None and act[0] == 'relu_drop' and not UF.grad_tag(grad_out, '_ubv_masked'):
             # the consumer did not fold the activation's derivative into its input gradient
             a_out = ctx.saved_tensors[2 + ctx.n_wt]
             if a_out.is_cuda:
@@ -267,7 +273,7 @@ class _Linear(Function):
                 gx = UF.relu_dropout_grad_raw(g, a2, act[1]) if g.is_cuda else \
                     g * (a2 != 0).to(g.dtype) / (1.0 - act[1])
             gx = gx.view(xc.shape)
-            gx._ubv_masked = True
+            UF.tag_grad(gx, '_ubv_masked', True)
         if gx is None and ctx.needs_input_grad[0] and wt and go2.dtype == torch.float32 and x_dtype == torch.float32 and \
                 go2.is_contiguous() and go2.shape[1] % 32 == 0 and xc.shape[-1] % 32 == 0:
             # dX = dY . W on the matrix cores, the residual branch's gradient added in the epilogue
@@ -276,7 +282,7 @@ class _Linear(Function):
             if grad_alias is not None and grad_alias.dtype == torch.float32:
                 ga = grad_alias.reshape(-1, xc.shape[-1])
                 ga = ga if ga.is_contiguous() else ga.contiguous()
-            own = ga is not None and getattr(grad_alias, '_ubv_owned', False) and \
+            own = ga is not None and UF.grad_tag(grad_alias, '_ubv_owned') and \
                 ga.data_ptr() == grad_alias.data_ptr()
             gx = UF.gemm_nt(go2, wt[0], wt[1], residual=ga, out=ga if own else None)
             if gx is not None:
@@ -286,7 +292,7 @@ class _Linear(Function):
         if gx is None and ctx.needs_input_grad[0]:
             if grad_alias is not None and grad_alias.dtype == go2.dtype == x_dtype:
                 ga = grad_alias.reshape(-1, xc.shape[-1])
-                if getattr(grad_alias, '_ubv_owned', False) and ga.is_contiguous():
+                if UF.grad_tag(grad_alias, '_ubv_owned') and ga.is_contiguous():
                     # a fresh tensor produced for this edge alone (functional._AddDropoutNorm marks
                     # its grad_identity): accumulate in place — out-of-place addmm would first copy
                     # it into the result.  Untagged gradients may be shared (AddBackward hands ONE
@@ -305,9 +311,7 @@ class _Linear(Function):
         need_b = has_bias and any(ctx.needs_input_grad[6 + n:])
         part = None
         if (need_w or need_b) and go2.is_cuda and _MFMA_WGRAD and go2.dtype == x2.dtype and \
-                go2.is_contiguous() and x2.is_contiguous() and \
-                (go2.dtype == torch.float32 or go2.shape[1] * x2.shape[1] <= 65536):
-            # (16-bit data with a 512-wide side: the strided-batched library GEMM is as fast)
+                go2.is_contiguous() and x2.is_contiguous():
             # one pass over grad_out and x on the matrix cores: dW and the bias sums together
             from . import functional as UF
             res = UF.gemm_wgrad(go2, x2)
@@ -331,7 +335,7 @@ class _Linear(Function):
             else:
                 gw = (go2.t() @ x2).float()
         vec = 16 // go2.element_size()
-        colsum = getattr(grad_out, '_ubv_colsum', None)
+        colsum = UF.grad_tag(grad_out, '_ubv_colsum')
         if need_b and colsum is not None and colsum.numel() == go2.shape[1]:
             gb, need_b = colsum, False          # summed by the kernel that produced grad_out
         if go2.is_cuda and (need_b or part is not None) and go2.shape[1] % vec == 0 and \
