@@ -71,6 +71,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP graphs')
+    ap.add_argument('--single-stream', action='store_true',
+                    help='both encoders on one stream (default: image and point-cloud encoders on two)')
     ap.add_argument('--no-extras', action='store_true', help='skip the gemm / voxel records')
     ap.add_argument('--eval-mode', action='store_true', help='dropout / modality dropout off')
     ap.add_argument('--fp32-stream', action='store_true',
@@ -261,6 +263,11 @@ def run_mode(args, name, head, world, rank, device, want_ops):
     # ---- per-op roofline: the same step, eager, HIP events on the launch stream around every
     # sampling kernel / op (events cannot be read back from inside a captured graph)
     if want_ops and not args.no_kernel_timing:
+        # (one stream: a kernel's duration is its own, not its share of a chip it splits with the other
+        #  encoder's kernels — the timed steps above run the two encoders on two streams)
+        from unibev_amd.modules import transformer as _tr
+        two = _tr._TWO_STREAMS[0]
+        _tr.set_two_streams(False)
         UF.set_seed_base(None)
         UF.kernel_profile(True)
         for _ in range(min(args.steps, 10)):
@@ -268,6 +275,7 @@ def run_mode(args, name, head, world, rank, device, want_ops):
         torch.cuda.synchronize()
         prof = UF.kernel_profile()
         UF.kernel_profile(False)
+        _tr.set_two_streams(two)
         pairs = args.bs * 40000
         if 'C' in mods:
             from unibev_amd.modules.encoders import pillar_axes, _lidar2img_tensor
@@ -354,6 +362,11 @@ def voxel_record(device):
             'note': 'hard voxelize + VFE mean, 7 launches: latency-bound, not bandwidth-bound'}
 
 
+def _two_streams():
+    from unibev_amd.modules import transformer as _tr
+    return bool(_tr._TWO_STREAMS[0])
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -368,6 +381,9 @@ def main():
     # everything runs on one non-default stream: HIP-graph capture needs the gradient accumulation of
     # every parameter pinned to the capturing stream (graph_step.GraphedStep.capture)
     torch.cuda.set_stream(torch.cuda.Stream(device))
+    if args.single_stream:
+        from unibev_amd.modules import transformer as _tr
+        _tr.set_two_streams(False)
     from unibev_amd import dp
     dp.init_distributed('nccl', device)                       # RCCL over xGMI (no-op for N = 1)
 
@@ -393,6 +409,7 @@ def main():
                        'residual_stream': main_rec['residual_stream'],
                        'step': 'fwd + bwd (HIP graphs) + flat-gradient all-reduce + clip + AdamW'
                                if main_rec['hip_graphs'] else 'fwd + bwd + flat-gradient all-reduce + clip + AdamW',
+                       'streams': 'image / point-cloud encoders on 2 HIP streams' if _two_streams() else '1 stream',
                        'parallelism': f'dp{world}', 'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
                        'parity': main_rec['parity']},
             'roofline': main_rec.get('roofline'),

@@ -87,11 +87,22 @@ def test_encoder_fusion_vs_reference_vectors(name):
     np.testing.assert_allclose(fused.cpu().numpy(), g['fused'], rtol=1e-4, atol=1e-4 * scale)
 
 
+@pytest.mark.parametrize('streams', [2, 1])
 @pytest.mark.parametrize('name', ['cnw', 'cat'])
-def test_encoder_gradients_vs_oracle(name):
+def test_encoder_gradients_vs_oracle(name, streams):
     """Backward of the whole path: d(sum(fused * cot)) w.r.t. inputs and every parameter vs torch
-    autograd through the oracle."""
+    autograd through the oracle — with the two encoders on two HIP streams (the default) and on one."""
     from oracle import unibev_ref as R
+    from unibev_amd.modules import transformer as TR
+    was = TR._TWO_STREAMS[0]
+    TR.set_two_streams(streams == 2)
+    try:
+        _encoder_gradients_vs_oracle(name, R)
+    finally:
+        TR.set_two_streams(was)
+
+
+def _encoder_gradients_vs_oracle(name, R):
     cfg, sd, inp, g = encoder_case(name)
     cot = syn.seeded_array('cot:' + name, g['fused'].shape, 5)
     # oracle

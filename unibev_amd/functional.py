@@ -537,18 +537,23 @@ class _ZeroArena:
         return out
 
 
-_ARENA = _ZeroArena()
+_ARENAS = {}            # one arena per (device, stream): the fill and its users stay in stream order
 
 
 def zeros_f32(n, device):
-    """Zeroed f32 vector of ``n`` elements from the per-step arena."""
-    return _ARENA.take(int(n), device)
+    """Zeroed f32 vector of ``n`` elements from the per-step arena of the current stream."""
+    key = (device.index, torch._C._cuda_getCurrentRawStream(device.index)) if device.type == 'cuda' else None
+    arena = _ARENAS.get(key)
+    if arena is None:
+        arena = _ARENAS[key] = _ZeroArena()
+    return arena.take(int(n), device)
 
 
 def new_step():
     """Called once per forward pass (``linear.lowp_step_cache``): later backward accumulators come
     from a fresh zero buffer."""
-    _ARENA.reset()
+    for arena in _ARENAS.values():
+        arena.reset()
     _SEED_STATE[0] = None             # dropout seeds of this pass: one fresh draw from torch's generator
 
 

@@ -33,6 +33,24 @@ _UNSUPPORTED_NORMS = ('MLP_ChannelNormWeights', 'Leaky_ReLU_MLP_ChannelNormWeigh
                       'ModalityProjection')
 
 
+import os as _os
+
+# Image and point-cloud encoders on two HIP streams (UBV_TWO_STREAMS=0 or set_two_streams(False): one).
+# Measured at bs = 2, L+C CNW: 95.8 -> 106.3 samples/s in fp32, 173.9 -> 197.3 in bf16.
+_TWO_STREAMS = [_os.environ.get('UBV_TWO_STREAMS', '1') != '0']
+_SIDE_STREAMS = {}
+
+
+def set_two_streams(on):
+    _TWO_STREAMS[0] = bool(on)
+
+
+def _side_streams(device):
+    key = device.index
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+    return _SIDE_STREAMS[key]
+
 @TRANSFORMER.register_module()
 class UniBEVTransformer(BaseModule):
     def __init__(self, num_feature_levels=4, num_cams=6, two_stage_num_proposals=300,
@@ -273,16 +291,42 @@ class UniBEVTransformer(BaseModule):
         else:
             q_img = q_pts = bev_queries.unsqueeze(1).expand(-1, bs, -1)
         img_bev_embed = pts_bev_embed = None
-        if img_mlvl_feats is not None:
+
+        def run_img():
             flat, ss, lsi = self._pre_process_img_feats(img_mlvl_feats, q_img)
-            img_bev_embed = self.img_bev_encoder(q_img, flat, flat, bev_h=bev_h, bev_w=bev_w,
-                                                 bev_pos=bev_pos, spatial_shapes=ss,
-                                                 level_start_index=lsi, **kwargs)
-        if pts_mlvl_feats is not None:
+            return self.img_bev_encoder(q_img, flat, flat, bev_h=bev_h, bev_w=bev_w, bev_pos=bev_pos,
+                                        spatial_shapes=ss, level_start_index=lsi, **kwargs)
+
+        def run_pts():
             flat, ss, lsi = self._pre_process_pts_feats(pts_mlvl_feats, q_pts)
-            pts_bev_embed = self.pts_bev_encoder(q_pts, flat, flat, bev_h=bev_h, bev_w=bev_w,
-                                                 bev_pos=bev_pos, spatial_shapes=ss,
-                                                 level_start_index=lsi, **kwargs)
+            return self.pts_bev_encoder(q_pts, flat, flat, bev_h=bev_h, bev_w=bev_w, bev_pos=bev_pos,
+                                        spatial_shapes=ss, level_start_index=lsi, **kwargs)
+
+        ref_q = q_img if img_mlvl_feats is not None else q_pts
+        if img_mlvl_feats is not None and pts_mlvl_feats is not None and ref_q.is_cuda and _TWO_STREAMS[0]:
+            # The two encoders are independent until the fusion: each on its own HIP stream, forked
+            # from and joined into the caller's (autograd replays every backward op on its forward
+            # op's stream, so the backward forks the same way).  Most kernels of the path leave part
+            # of the chip idle — tails of 1.2 - 1.6 block rounds, latency-bound GEMM phases next to
+            # issue-bound sampling kernels — and the other encoder's kernels fill it.
+            dev = ref_q.device
+            cur = torch.cuda.current_stream(dev)
+            sa, sb = _side_streams(dev)
+            sa.wait_stream(cur)
+            sb.wait_stream(cur)
+            with torch.cuda.stream(sa):
+                img_bev_embed = run_img()
+            with torch.cuda.stream(sb):
+                pts_bev_embed = run_pts()
+            cur.wait_stream(sa)
+            cur.wait_stream(sb)
+            img_bev_embed.record_stream(cur)
+            pts_bev_embed.record_stream(cur)
+        else:
+            if img_mlvl_feats is not None:
+                img_bev_embed = run_img()
+            if pts_mlvl_feats is not None:
+                pts_bev_embed = run_pts()
         fused = self.fuse(img_bev_embed, pts_bev_embed)
         if return_parts:
             return fused, img_bev_embed, pts_bev_embed
