@@ -192,13 +192,15 @@ def op_roofline(prof, ops):
     return out
 
 
-def traffic_of(op_rec):
+def traffic_of(op_rec, dtype_name, workload, bs):
     """HBM bytes per launch of an op from the committed PMC passes (profiles/traffic.json, made by
-    tools/make_traffic.py with the corrections of MI355X_MICROARCH.md section HBM), or None."""
+    tools/make_traffic.py with the corrections of MI355X_MICROARCH.md section HBM; taken at bs = 2 on the
+    256x704 shapes, bf16 and fp32), or None."""
     tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if not os.path.exists(tfile):
+    if not os.path.exists(tfile) or bs != 2 or workload == 'LC_cat128':
         return None
-    rec = json.load(open(tfile)).get('ops', {}).get(f"{op_rec['op']}:{op_rec['pass']}")
+    ops = json.load(open(tfile)).get('ops', {}).get({'fp16': 'bf16'}.get(dtype_name, dtype_name), {})
+    rec = ops.get(f"{op_rec['op']}:{op_rec['pass']}")
     return None if rec is None else rec.get('hbm_bytes_per_launch')
 
 
@@ -286,7 +288,7 @@ def run_mode(args, name, head, world, rank, device, want_ops):
             pairs = args.bs * int(vis0.sum().item())         # rows of sample 0's visibility (quirk q1) per sample
         ops = op_roofline(prof, sampling_ops(args.workload, args.bs, 4 if name == 'fp32' else 2, pairs))
         for o in ops:
-            o['traffic'] = traffic_of(o) if name != 'fp32' else None
+            o['traffic'] = traffic_of(o, name, args.workload, args.bs)
         rec['roofline_ops'] = ops
         if ops:
             dom = ops[0]
@@ -304,33 +306,44 @@ def run_mode(args, name, head, world, rank, device, want_ops):
 
 
 def gemm_record(device, bs):
-    """The projection GEMMs of one encoder layer (M = bs x 40 000 rows): time per call, TFLOP/s
-    against the dense MFMA peak, operand GB/s — through the same entry point the layers use."""
+    """The projection GEMMs of one encoder layer (M = bs x 40 000 rows) through the entry point the layers
+    use (unibev_amd.linear.linear: the hand-written MFMA kernels — split-bf16 for f32 data — or hipBLASLt
+    where that is faster), forward and weight gradient: time per call, TFLOP/s against the dense bf16 MFMA
+    peak (f32 rows: 3 bf16 products per multiply are counted as ONE), operand GB/s."""
     from unibev_amd import functional as UF
+    from unibev_amd.linear import linear as ubv_linear
     M, C = bs * 40000, 256
     shapes = [('value_proj / output_proj', C, C), ('offsets+logits (P=8)', 192, C),
               ('offsets+logits (P=4)', 96, C), ('ffn up', 2 * C, C), ('ffn down', C, 2 * C)]
+
+    def clock(fn, n=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return 1e3 * e0.elapsed_time(e1) / n
+
     out = []
     for dname, dt in (('bf16', torch.bfloat16), ('fp32', torch.float32)):
         for label, N, K in shapes:
             x = torch.randn(M, K, device=device, dtype=dt)
-            w = torch.randn(N, K, device=device, dtype=dt) / K ** 0.5
-            b = torch.zeros(N, device=device, dtype=dt)
-            for _ in range(3):
-                y = UF.linear_forward(x, w, b)
-            if y is None:
-                continue
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
-                UF.linear_forward(x, w, b)
-            e1.record()
-            torch.cuda.synchronize()
-            us = 1e3 * e0.elapsed_time(e1) / 20
-            flops, nbytes = 2.0 * M * N * K, (M * K + N * K + M * N) * x.element_size()
+            w = torch.randn(N, K, device=device) / K ** 0.5          # f32 master weights, as in the model
+            b = torch.zeros(N, device=device)
+            gy = torch.randn(M, N, device=device, dtype=dt)
+            with torch.no_grad(), torch.autocast('cuda', dtype=dt, enabled=dt != torch.float32):
+                us = clock(lambda: ubv_linear(x, w, b))
+            us_w = clock(lambda: UF.gemm_wgrad(gy, x))
+            flops = 2.0 * M * N * K
+            nb_f, nb_w = (M * K + M * N) * x.element_size(), (M * K + M * N) * x.element_size()
             out.append({'gemm': label, 'dtype': dname, 'M': M, 'N': N, 'K': K, 'us': us,
-                        'TFLOPs': flops / us / 1e6, 'mfma_frac': flops / us / 1e6 / MFMA_PEAK_TFLOPS[dname],
-                        'GBps': nbytes / us / 1e3, 'hbm_frac': nbytes / us / 1e3 / HBM_PEAK_GBS})
+                        'TFLOPs': flops / us / 1e6, 'mfma_frac': flops / us / 1e6 / MFMA_PEAK_TFLOPS['bf16'],
+                        'GBps': nb_f / us / 1e3, 'hbm_frac': nb_f / us / 1e3 / HBM_PEAK_GBS,
+                        'wgrad_us': us_w, 'wgrad_GBps': nb_w / us_w / 1e3,
+                        'wgrad_hbm_frac': nb_w / us_w / 1e3 / HBM_PEAK_GBS})
     return out
 
 
