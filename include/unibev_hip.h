@@ -394,6 +394,42 @@ int ubv_voxel_mean(const float* voxels, const int32_t* num_points, const int32_t
 int ubv_sparse_to_dense(const float* feats, const int32_t* coors, const int32_t* m_dev, int m,
                         float* dense, int B, int C, int D, int Hs, int Ws, void* stream);
 
+/* ---- sparse 3-D convolutions of the LiDAR middle encoder -----------------
+ * [ext] mmdet3d 0.18.1 SparseEncoder -> spconv SubMConv3d / SparseConv3d (un-vendored; configured at
+ * projects/UniBEV/configs/unibev/unibev_nus_LC_cnw_256_modality_dropout.py:194-208).  These entry points
+ * replace spconv's ops.get_indice_pairs (the rulebook) and ops.indice_conv / indice_conv_backward (gather -
+ * GEMM - scatter).  Voxel coordinates are int32 rows (batch, z, y, x), mmdet3d's `coors`.
+ *
+ * Rulebook = a dense neighbour map nbr[k][row] (int32, -1 = inactive; k = (kz * ky_size + ky) * kx_size + kx)
+ * looked up in an open-addressing hash of the active voxels' keys:
+ *   ubv_spconv_table_slots(n)        power-of-two slot count for n voxels
+ *   ubv_spconv_hash_build            coors [n, 4] of a (D, H, W) map -> table_keys [slots] / table_vals [slots]
+ *   ubv_spconv_neighbors             rows of `row_dims` looked up in the table of `target_dims`:
+ *        transposed = 0: target = row * stride - pad + k      (output rows -> inputs; SubM: stride 1, pad k/2)
+ *        transposed = 1: target = (row + pad - k) / stride where divisible (input rows -> outputs: the map
+ *                        of the input gradient)
+ *   ubv_spconv_candidates            cand [kvol, n] int64: key of the output each (input, offset) reaches or -1
+ *                                    (a strided convolution's output set = the unique keys, ascending)
+ *   ubv_spconv_keys_to_coors         keys [n] of a (D, H, W) map -> coors [n, 4]
+ * Product:
+ *   ubv_spconv_gather_mma            out[row, :] = sum_k feats[nbr[k][row], :] . w[k]^T on the matrix cores.
+ *        feats [*, Cin] (dtype), w_hi (and w_lo for f32: split-bf16 halves) [kvol, 32*ceil(Cout/32), Cin] in the
+ *        16-bit operand type, rows past Cout zero; out [rows, Cout] (dtype), WRITTEN.  Cin % 16 == 0,
+ *        Cout <= 128.  The same call computes the input gradient (feats = grad_out, nbr = the transposed map,
+ *        w = the [k][Cin][Cout] weight as stored). */
+int64_t ubv_spconv_table_slots(int64_t n);
+int ubv_spconv_hash_build(const int32_t* coors, int64_t n, int D, int H, int W, int64_t* table_keys,
+                          int32_t* table_vals, int64_t slots, void* stream);
+int ubv_spconv_neighbors(const int32_t* coors, int64_t rows, int B, const int* row_dims, const int* target_dims,
+                         const int* ksize, const int* stride, const int* pad, int transposed,
+                         const int64_t* table_keys, const int32_t* table_vals, int64_t slots, int32_t* nbr,
+                         int64_t ld, void* stream);
+int ubv_spconv_candidates(const int32_t* coors, int64_t n, int B, const int* in_dims, const int* out_dims,
+                          const int* ksize, const int* stride, const int* pad, int64_t* cand, void* stream);
+int ubv_spconv_keys_to_coors(const int64_t* keys, int64_t n, int D, int H, int W, int32_t* coors, void* stream);
+int ubv_spconv_gather_mma(const void* feats, const int32_t* nbr, int64_t ld, int64_t rows, const void* w_hi,
+                          const void* w_lo, void* out, int Cin, int Cout, int kvol, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,335 @@
+// Sparse 3-D convolutions of the LiDAR middle encoder for gfx950.
+//
+// [ext] mmdet3d 0.18.1 `SparseEncoder` (configured at projects/UniBEV/configs/unibev/
+// unibev_nus_LC_cnw_256_modality_dropout.py:194-208) is built from spconv's SubMConv3d / SparseConv3d:
+//        out[o, :] = sum_k  in[ nbr(k, o), : ] . W_k          (k: the kz x ky x kx kernel offsets)
+// over the ACTIVE voxels only.  spconv materialises, per offset, (input, output) index pairs with atomic
+// counters, gathers both sides into dense buffers, multiplies and scatter-adds.  Here:
+//
+//   * the rulebook is a dense NEIGHBOUR MAP nbr[k][row] (-1 = no active voxel there), built by one lookup
+//     per (row, offset) in an open-addressing hash of the voxel keys — no atomics beyond the key CAS, no
+//     compaction, nothing order-dependent.  Forward maps output rows to inputs (in = out*stride - pad + k),
+//     the input gradient uses the transposed map (out = (in + pad - k) / stride where divisible): BOTH passes
+//     are gathers, so neither needs float atomics and both are bit-reproducible.
+//   * the product is ONE kernel (spconv_gather_mma_kernel): a wave owns 32 output rows x all output
+//     channels; for every offset with at least one neighbour in the wave it loads its MFMA A fragment
+//     straight from the gathered rows (a lane = one row x 8 consecutive channels: exactly the operand
+//     layout of v_mfma_f32_32x32x16, no LDS), the B fragments from the weight block W_k (K-contiguous copy
+//     made once per step), and accumulates in registers over all 27 offsets.  f32 features run as split-bf16
+//     products (hi.hi + hi.lo + lo.hi, f32 accumulation) like the Linear layers (gemm_mfma.hip).
+//
+// Keys: ((b * D + z) * H + y) * W + x as int64.  Coordinates are (batch, z, y, x) int32 rows, the layout of
+// mmdet3d's voxel `coors`.
+#include "ubv_common.h"
+
+namespace ubv {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 sbf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 sf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float sf32x16_t;
+
+struct SpGeom {
+  int B;
+  int in_dims[3];       // D, H, W of the map the QUERY rows live in
+  int tgt_dims[3];      // D, H, W of the map that is looked up
+  int ksize[3], stride[3], pad[3];
+  int mode;             // 0: target = row * stride - pad + k   (outputs -> inputs; SubM: stride 1)
+                        // 1: target = (row + pad - k) / stride where divisible (inputs -> outputs)
+};
+
+__device__ __forceinline__ uint64_t spc_hash(uint64_t k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+  return k;
+}
+
+// table: tkeys[cap] (int64, -1 = empty), tvals[cap]; cap a power of two >= 2 n.  Keys are unique.
+__global__ __launch_bounds__(256) void spc_insert_kernel(const int32_t* __restrict__ coors, long n, int D, int H,
+                                                         int W, long long* __restrict__ tkeys,
+                                                         int32_t* __restrict__ tvals, long cap_mask) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int32_t* c = coors + i * 4;
+  const long long key = (((long long)c[0] * D + c[1]) * H + c[2]) * W + c[3];
+  long slot = (long)(spc_hash((uint64_t)key) & (uint64_t)cap_mask);
+  for (;;) {
+    const unsigned long long prev = atomicCAS((unsigned long long*)(tkeys + slot), ~0ull, (unsigned long long)key);
+    if (prev == ~0ull || prev == (unsigned long long)key) { tvals[slot] = (int32_t)i; return; }
+    slot = (slot + 1) & cap_mask;
+  }
+}
+
+__device__ __forceinline__ int spc_lookup(const long long* __restrict__ tkeys, const int32_t* __restrict__ tvals,
+                                          long cap_mask, long long key) {
+  long slot = (long)(spc_hash((uint64_t)key) & (uint64_t)cap_mask);
+  for (;;) {
+    const long long k = tkeys[slot];
+    if (k == key) return tvals[slot];
+    if (k == -1) return -1;
+    slot = (slot + 1) & cap_mask;
+  }
+}
+
+// target coordinate of (row coordinate c, kernel offset kk) or false
+__device__ __forceinline__ bool spc_target(const SpGeom& g, const int32_t* c, int kz, int ky, int kx, int (&t)[3]) {
+  const int kk[3] = {kz, ky, kx};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    int v;
+    if (g.mode == 0) {
+      v = c[1 + d] * g.stride[d] - g.pad[d] + kk[d];
+    } else {
+      const int num = c[1 + d] + g.pad[d] - kk[d];
+      if (num < 0 || num % g.stride[d] != 0) return false;
+      v = num / g.stride[d];
+    }
+    if (v < 0 || v >= g.tgt_dims[d]) return false;
+    t[d] = v;
+  }
+  return true;
+}
+
+// nbr[k][row] = index of the active voxel at the target of (row, k) in the hashed map, or -1
+__global__ __launch_bounds__(256) void spc_neighbors_kernel(const int32_t* __restrict__ coors, long rows,
+                                                            const SpGeom g, const long long* __restrict__ tkeys,
+                                                            const int32_t* __restrict__ tvals, long cap_mask,
+                                                            int32_t* __restrict__ nbr, long ld) {
+  const int kvol = g.ksize[0] * g.ksize[1] * g.ksize[2];
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= rows * kvol) return;
+  const long row = t % rows;                     // consecutive threads: consecutive rows of one offset
+  const int k = (int)(t / rows);
+  const int kx = k % g.ksize[2], ky = (k / g.ksize[2]) % g.ksize[1], kz = k / (g.ksize[2] * g.ksize[1]);
+  const int32_t* c = coors + row * 4;
+  int tc[3];
+  int idx = -1;
+  if (spc_target(g, c, kz, ky, kx, tc)) {
+    const long long key = (((long long)c[0] * g.tgt_dims[0] + tc[0]) * g.tgt_dims[1] + tc[1]) * g.tgt_dims[2] + tc[2];
+    idx = spc_lookup(tkeys, tvals, cap_mask, key);
+  }
+  nbr[(long)k * ld + row] = idx;
+}
+
+// Candidate output keys of a strided convolution: cand[k][i] = key of the output that input i reaches
+// through offset k, or -1.  (The host sorts / uniques them: the output set in ascending key order.)
+__global__ __launch_bounds__(256) void spc_candidates_kernel(const int32_t* __restrict__ coors, long n,
+                                                             const SpGeom g, long long* __restrict__ cand) {
+  const int kvol = g.ksize[0] * g.ksize[1] * g.ksize[2];
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * kvol) return;
+  const long row = t % n;
+  const int k = (int)(t / n);
+  const int kx = k % g.ksize[2], ky = (k / g.ksize[2]) % g.ksize[1], kz = k / (g.ksize[2] * g.ksize[1]);
+  const int32_t* c = coors + row * 4;
+  int tc[3];
+  long long key = -1;
+  if (spc_target(g, c, kz, ky, kx, tc))
+    key = (((long long)c[0] * g.tgt_dims[0] + tc[0]) * g.tgt_dims[1] + tc[1]) * g.tgt_dims[2] + tc[2];
+  cand[t] = key;
+}
+
+__global__ __launch_bounds__(256) void spc_keys_to_coors_kernel(const long long* __restrict__ keys, long n, int D,
+                                                                int H, int W, int32_t* __restrict__ coors) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  long long k = keys[i];
+  const int x = (int)(k % W); k /= W;
+  const int y = (int)(k % H); k /= H;
+  const int z = (int)(k % D); k /= D;
+  reinterpret_cast<int4*>(coors)[i] = make_int4((int)k, z, y, x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[row, :] = sum_k in[nbr[k][row], :] . W_k^T      W given as [kvol][CoutP][Cin] (Cin contiguous)
+// T: feature element type (float: split-bf16 products, W as hi + lo bf16 arrays).  NB = CoutP / 32.
+template <typename T> struct spc_mma;
+template <> struct spc_mma<bf16_t> {
+  static __device__ __forceinline__ sf32x16_t run(uint4 a, uint4 b, sf32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sbf16x8_t, a), __builtin_bit_cast(sbf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct spc_mma<f16_t> {
+  static __device__ __forceinline__ sf32x16_t run(uint4 a, uint4 b, sf32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sf16x8_t, a), __builtin_bit_cast(sf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct spc_mma<float> : spc_mma<bf16_t> {};
+
+template <typename T, int NB>
+__global__ __launch_bounds__(256) void spconv_gather_mma_kernel(const T* __restrict__ feats, const int32_t* __restrict__ nbr,
+                                                                long ld, long rows, const uint16_t* __restrict__ w_hi,
+                                                                const uint16_t* __restrict__ w_lo, T* __restrict__ out,
+                                                                int Cin, int Cout, int kvol) {
+  constexpr bool SPLIT = sizeof(T) == 4;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long row0 = ((long)blockIdx.x * 4 + wv) * 32;
+  if (row0 >= rows) return;
+  const int m = lane & 31, kg = lane >> 5;
+  const long row = row0 + m;
+  const bool rok = row < rows;
+  sf32x16_t acc[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+  for (int k = 0; k < kvol; ++k) {
+    const int idx = rok ? nbr[(long)k * ld + row] : -1;
+    if (__ballot(idx >= 0) == 0ull) continue;             // no row of this wave has a neighbour at offset k
+    const T* frow = feats + (long)(idx >= 0 ? idx : 0) * Cin + kg * 8;
+    const uint16_t* wk_hi = w_hi + ((long)k * NB * 32 + m) * Cin + kg * 8;
+    const uint16_t* wk_lo = SPLIT ? w_lo + ((long)k * NB * 32 + m) * Cin + kg * 8 : nullptr;
+    for (int c0 = 0; c0 < Cin; c0 += 16) {
+      uint4 a_hi = make_uint4(0u, 0u, 0u, 0u), a_lo = make_uint4(0u, 0u, 0u, 0u);
+      if (idx >= 0) {
+        if constexpr (SPLIT) {
+          const float4 v0 = *reinterpret_cast<const float4*>(frow + c0);
+          const float4 v1 = *reinterpret_cast<const float4*>(frow + c0 + 4);
+          a_hi.x = cvt_pk_bf16(v0.x, v0.y); a_hi.y = cvt_pk_bf16(v0.z, v0.w);
+          a_hi.z = cvt_pk_bf16(v1.x, v1.y); a_hi.w = cvt_pk_bf16(v1.z, v1.w);
+          a_lo.x = cvt_pk_bf16(v0.x - __uint_as_float(a_hi.x << 16), v0.y - __uint_as_float(a_hi.x & 0xffff0000u));
+          a_lo.y = cvt_pk_bf16(v0.z - __uint_as_float(a_hi.y << 16), v0.w - __uint_as_float(a_hi.y & 0xffff0000u));
+          a_lo.z = cvt_pk_bf16(v1.x - __uint_as_float(a_hi.z << 16), v1.y - __uint_as_float(a_hi.z & 0xffff0000u));
+          a_lo.w = cvt_pk_bf16(v1.z - __uint_as_float(a_hi.w << 16), v1.w - __uint_as_float(a_hi.w & 0xffff0000u));
+        } else {
+          a_hi = *reinterpret_cast<const uint4*>(frow + c0);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const uint4 b_hi = *reinterpret_cast<const uint4*>(wk_hi + (long)j * 32 * Cin + c0);
+        acc[j] = spc_mma<T>::run(a_hi, b_hi, acc[j]);
+        if constexpr (SPLIT) {
+          const uint4 b_lo = *reinterpret_cast<const uint4*>(wk_lo + (long)j * 32 * Cin + c0);
+          acc[j] = spc_mma<T>::run(a_hi, b_lo, acc[j]);
+          acc[j] = spc_mma<T>::run(a_lo, b_hi, acc[j]);
+        }
+      }
+    }
+  }
+  // D[i][n]: this lane holds column n = lane & 31 (output channel within block j), rows i = (r & 3) + 8 (r >> 2) + 4 kg
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = j * 32 + m;
+    if (n >= Cout) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long orow = row0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+      if (orow < rows) out[orow * Cout + n] = elem<T>::from_float(acc[j][r]);
+    }
+  }
+}
+
+template <typename T>
+static int spconv_launch(const void* feats, const int32_t* nbr, long ld, long rows, const void* w_hi, const void* w_lo,
+                         void* out, int Cin, int Cout, int kvol, hipStream_t st) {
+  const int nb = (Cout + 31) / 32;
+  const dim3 grid((unsigned)((rows + 127) / 128)), blk(256);
+#define UBV_SPC(NBV)                                                                                            \
+  case NBV:                                                                                                     \
+    hipLaunchKernelGGL((spconv_gather_mma_kernel<T, NBV>), grid, blk, 0, st, (const T*)feats, nbr, ld, rows,    \
+                       (const uint16_t*)w_hi, (const uint16_t*)w_lo, (T*)out, Cin, Cout, kvol);                 \
+    break;
+  switch (nb) {
+    UBV_SPC(1) UBV_SPC(2) UBV_SPC(3) UBV_SPC(4)
+    default: return UBV_ERR_UNSUPPORTED;
+  }
+#undef UBV_SPC
+  return UBV_OK;
+}
+
+static bool sp_geom(SpGeom& g, int B, const int* in_dims, const int* tgt_dims, const int* ksize, const int* stride,
+                    const int* pad, int mode) {
+  g.B = B; g.mode = mode;
+  for (int d = 0; d < 3; ++d) {
+    g.in_dims[d] = in_dims[d]; g.tgt_dims[d] = tgt_dims[d]; g.ksize[d] = ksize[d]; g.stride[d] = stride[d];
+    g.pad[d] = pad[d];
+    if (in_dims[d] <= 0 || tgt_dims[d] <= 0 || ksize[d] <= 0 || stride[d] <= 0 || pad[d] < 0) return false;
+  }
+  return B > 0;
+}
+
+}  // namespace ubv
+
+extern "C" int64_t ubv_spconv_table_slots(int64_t n) {
+  int64_t cap = 64;
+  while (cap < 2 * n) cap <<= 1;
+  return cap;
+}
+
+extern "C" int ubv_spconv_hash_build(const int32_t* coors, int64_t n, int D, int H, int W, int64_t* table_keys,
+                                     int32_t* table_vals, int64_t slots, void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(coors && table_keys && table_vals && n >= 0 && D > 0 && H > 0 && W > 0, "spconv_hash_build: bad arguments");
+  UBV_CHECK_ARG(slots >= 2 * n && (slots & (slots - 1)) == 0, "spconv_hash_build: slots must be a power of two >= 2 n");
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(table_keys, 0xff, (size_t)slots * sizeof(int64_t), st) != hipSuccess) {
+    set_error("spconv_hash_build: memset failed");
+    return UBV_ERR_LAUNCH;
+  }
+  if (n > 0)
+    hipLaunchKernelGGL(spc_insert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, coors, (long)n, D, H, W,
+                       (long long*)table_keys, table_vals, (long)(slots - 1));
+  UBV_CHECK_LAUNCH("spconv_hash_build");
+  return UBV_OK;
+}
+
+extern "C" int ubv_spconv_neighbors(const int32_t* coors, int64_t rows, int B, const int* row_dims,
+                                    const int* target_dims, const int* ksize, const int* stride, const int* pad,
+                                    int transposed, const int64_t* table_keys, const int32_t* table_vals,
+                                    int64_t slots, int32_t* nbr, int64_t ld, void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(coors && table_keys && table_vals && nbr && rows >= 0 && ld >= rows, "spconv_neighbors: bad arguments");
+  SpGeom g;
+  UBV_CHECK_ARG(sp_geom(g, B, row_dims, target_dims, ksize, stride, pad, transposed ? 1 : 0), "spconv_neighbors: bad geometry");
+  if (rows == 0) return UBV_OK;
+  const long total = (long)rows * ksize[0] * ksize[1] * ksize[2];
+  hipLaunchKernelGGL(spc_neighbors_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), coors,
+                     (long)rows, g, (const long long*)table_keys, table_vals, (long)(slots - 1), nbr, (long)ld);
+  UBV_CHECK_LAUNCH("spconv_neighbors");
+  return UBV_OK;
+}
+
+extern "C" int ubv_spconv_candidates(const int32_t* coors, int64_t n, int B, const int* in_dims, const int* out_dims,
+                                     const int* ksize, const int* stride, const int* pad, int64_t* cand, void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(coors && cand && n >= 0, "spconv_candidates: bad arguments");
+  SpGeom g;
+  UBV_CHECK_ARG(sp_geom(g, B, in_dims, out_dims, ksize, stride, pad, 1), "spconv_candidates: bad geometry");
+  if (n == 0) return UBV_OK;
+  const long total = (long)n * ksize[0] * ksize[1] * ksize[2];
+  hipLaunchKernelGGL(spc_candidates_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), coors,
+                     (long)n, g, (long long*)cand);
+  UBV_CHECK_LAUNCH("spconv_candidates");
+  return UBV_OK;
+}
+
+extern "C" int ubv_spconv_keys_to_coors(const int64_t* keys, int64_t n, int D, int H, int W, int32_t* coors, void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(keys && coors && n >= 0 && D > 0 && H > 0 && W > 0, "spconv_keys_to_coors: bad arguments");
+  if (n == 0) return UBV_OK;
+  hipLaunchKernelGGL(spc_keys_to_coors_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     (const long long*)keys, (long)n, D, H, W, coors);
+  UBV_CHECK_LAUNCH("spconv_keys_to_coors");
+  return UBV_OK;
+}
+
+extern "C" int ubv_spconv_gather_mma(const void* feats, const int32_t* nbr, int64_t ld, int64_t rows, const void* w_hi,
+                                     const void* w_lo, void* out, int Cin, int Cout, int kvol, int dtype, void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(feats && nbr && w_hi && out && rows >= 0 && ld >= rows && kvol > 0, "spconv_gather_mma: bad arguments");
+  UBV_CHECK_ARG(dtype >= 0 && dtype <= 2, "spconv_gather_mma: unknown dtype %d", dtype);
+  UBV_CHECK_ARG((dtype == UBV_F32) == (w_lo != nullptr), "spconv_gather_mma: f32 features take split weights (hi, lo)");
+  if (Cin % 16 != 0 || Cout <= 0 || Cout > 128 || ((uintptr_t)feats % 16) != 0 || ((uintptr_t)w_hi % 16) != 0) {
+    set_error("spconv_gather_mma: Cin=%d must be a multiple of 16, Cout=%d at most 128, buffers 16-byte aligned", Cin, Cout);
+    return UBV_ERR_UNSUPPORTED;
+  }
+  if (rows == 0) return UBV_OK;
+  hipStream_t st = as_stream(stream);
+  int rc;
+  if (dtype == UBV_F32) rc = spconv_launch<float>(feats, nbr, ld, rows, w_hi, w_lo, out, Cin, Cout, kvol, st);
+  else if (dtype == UBV_F16) rc = spconv_launch<f16_t>(feats, nbr, ld, rows, w_hi, nullptr, out, Cin, Cout, kvol, st);
+  else rc = spconv_launch<bf16_t>(feats, nbr, ld, rows, w_hi, nullptr, out, Cin, Cout, kvol, st);
+  if (rc != UBV_OK) { set_error("spconv_gather_mma: no kernel for Cout=%d", Cout); return rc; }
+  UBV_CHECK_LAUNCH("spconv_gather_mma");
+  return UBV_OK;
+}

@@ -888,3 +888,103 @@ def sparse_to_dense(feats, coors, batch_size, spatial_shape, m_dev=None):
                                         _p(m_dev), M, _p(dense), batch_size, C, D, Hs, Ws, _stream()),
               'sparse_to_dense')
         return dense
+
+
+# ----------------------------------------------------------------------------------------------- sparse 3-D convolution
+def _i3(v):
+    import ctypes
+    return (ctypes.c_int * 3)(*[int(x) for x in v])
+
+
+def spconv_out_dims(in_dims, ksize, stride, pad):
+    """Output (D, H, W) of a strided sparse convolution (dilation 1): floor((d + 2 p - k) / s) + 1."""
+    return tuple((int(d) + 2 * int(p) - int(k)) // int(s) + 1 for d, k, s, p in zip(in_dims, ksize, stride, pad))
+
+
+@torch.no_grad()
+def spconv_hash(coors, dims):
+    """Hash table of the active voxels ``coors`` [N, 4] int32 (b, z, y, x) of a (D, H, W) map."""
+    with _need_cuda(coors):
+        N = coors.shape[0]
+        slots = int(lib().ubv_spconv_table_slots(N))
+        keys = torch.empty(slots, dtype=torch.int64, device=coors.device)
+        vals = torch.empty(slots, dtype=torch.int32, device=coors.device)
+        check(lib().ubv_spconv_hash_build(_p(coors), N, int(dims[0]), int(dims[1]), int(dims[2]), _p(keys), _p(vals),
+                                          slots, _stream()), 'spconv_hash_build')
+        return keys, vals
+
+
+@torch.no_grad()
+def spconv_neighbors(coors, batch_size, row_dims, target_dims, ksize, stride, pad, table, transposed=False):
+    """Neighbour map [kvol, rows] int32 (``ubv_spconv_neighbors``): the index, in the hashed map, of the voxel
+    each (row, kernel offset) reaches, or -1."""
+    with _need_cuda(coors, *table):
+        rows = coors.shape[0]
+        kvol = int(ksize[0]) * int(ksize[1]) * int(ksize[2])
+        nbr = torch.empty(kvol, rows, dtype=torch.int32, device=coors.device)
+        check(lib().ubv_spconv_neighbors(_p(coors), rows, int(batch_size), _i3(row_dims), _i3(target_dims), _i3(ksize),
+                                         _i3(stride), _i3(pad), 1 if transposed else 0, _p(table[0]), _p(table[1]),
+                                         table[0].numel(), _p(nbr), rows, _stream()), 'spconv_neighbors')
+        return nbr
+
+
+@torch.no_grad()
+def spconv_subm_map(coors, batch_size, dims, ksize):
+    """Neighbour map of a submanifold convolution (outputs = the inputs' sites, stride 1, padding k // 2)."""
+    coors = coors.contiguous()
+    table = spconv_hash(coors, dims)
+    pad = [int(k) // 2 for k in ksize]
+    return spconv_neighbors(coors, batch_size, dims, dims, ksize, (1, 1, 1), pad, table)
+
+
+@torch.no_grad()
+def spconv_strided_maps(coors, batch_size, in_dims, ksize, stride, pad):
+    """Rulebook of a strided sparse convolution: (out_coors [M, 4] in ascending key order, out_dims,
+    nbr_fwd [kvol, M] (inputs of each output), nbr_bwd [kvol, N] (outputs of each input)).  Reads the
+    output count back (one host sync, as spconv's get_indice_pairs does)."""
+    with _need_cuda(coors):
+        coors = coors.contiguous()
+        N = coors.shape[0]
+        out_dims = spconv_out_dims(in_dims, ksize, stride, pad)
+        kvol = int(ksize[0]) * int(ksize[1]) * int(ksize[2])
+        cand = torch.empty(kvol * N, dtype=torch.int64, device=coors.device)
+        check(lib().ubv_spconv_candidates(_p(coors), N, int(batch_size), _i3(in_dims), _i3(out_dims), _i3(ksize),
+                                          _i3(stride), _i3(pad), _p(cand), _stream()), 'spconv_candidates')
+        keys = torch.unique(cand[cand >= 0])                   # ascending; the host learns M here
+        M = keys.numel()
+        out_coors = torch.empty(M, 4, dtype=torch.int32, device=coors.device)
+        check(lib().ubv_spconv_keys_to_coors(_p(keys), M, int(out_dims[0]), int(out_dims[1]), int(out_dims[2]),
+                                             _p(out_coors), _stream()), 'spconv_keys_to_coors')
+        t_in = spconv_hash(coors, in_dims)
+        t_out = spconv_hash(out_coors, out_dims)
+        nbr_fwd = spconv_neighbors(out_coors, batch_size, out_dims, in_dims, ksize, stride, pad, t_in)
+        nbr_bwd = spconv_neighbors(coors, batch_size, in_dims, out_dims, ksize, stride, pad, t_out, transposed=True)
+        return out_coors, out_dims, nbr_fwd, nbr_bwd
+
+
+@torch.no_grad()
+def spconv_operand(w):
+    """Weight blocks [kvol, Cout, Cin] (any float dtype) -> the kernel's operand: rows padded to a multiple of
+    32 per block; f32 -> (hi, lo) bf16 halves, 16-bit -> (w, None)."""
+    kvol, cout, cin = w.shape
+    coutp = (cout + 31) // 32 * 32
+    if coutp != cout:
+        w = torch.nn.functional.pad(w, (0, 0, 0, coutp - cout))
+    w = w.contiguous()
+    if w.dtype == torch.float32:
+        hi, lo, _, _ = split_weight(w.view(kvol * coutp, cin), transposed=False)
+        return hi, lo
+    return w, None
+
+
+@torch.no_grad()
+def spconv_gather_mma(feats, nbr, w_hi, w_lo, cout):
+    """out[row] = sum_k feats[nbr[k][row]] . w[k]^T (``ubv_spconv_gather_mma``)."""
+    with _need_cuda(feats, nbr, w_hi, w_lo):
+        feats = feats.contiguous()
+        kvol, rows = nbr.shape
+        cin = feats.shape[1]
+        out = torch.empty(rows, cout, dtype=feats.dtype, device=feats.device)
+        check(lib().ubv_spconv_gather_mma(_p(feats), _p(nbr), rows, rows, _p(w_hi), _p(w_lo), _p(out), cin, int(cout),
+                                          kvol, _dt(feats), _stream()), 'spconv_gather_mma')
+        return out

@@ -1,0 +1,308 @@
+"""LiDAR middle encoder: ``SparseEncoder`` and the sparse 3-D convolutions under it.
+
+Reference surface: [ext] mmdet3d 0.18.1 ``mmdet3d/models/middle_encoders/sparse_encoder.py`` (``SparseEncoder``),
+``mmdet3d/ops/sparse_block.py`` (``SparseBasicBlock``, ``make_sparse_convmodule``) and the spconv 1.x layers
+``SubMConv3d`` / ``SparseConv3d`` they build — none of them vendored in the reference repository, which
+configures them at projects/UniBEV/configs/unibev/unibev_nus_LC_cnw_256_modality_dropout.py:194-208 and calls
+them at models/detectors/unibev_detector.py (``extract_pts_feat``: voxelize -> voxel encoder -> middle encoder).
+Registry key, constructor kwargs, state-dict keys (``conv_input.0.weight``, ``encoder_layers.encoder_layer1.0.
+conv1.weight``, ``...bn1.weight``, ``conv_out.0.weight`` ...) and the weight layout (kz, ky, kx, Cin, Cout) follow
+the published code; there are no reference vectors (parity unpinned by the reference).
+
+MI355X form (csrc/sparse_conv.hip): the rulebook is a dense neighbour map per indice key (one hash lookup per
+(row, offset), no atomics), forward and input gradient are the same gather + MFMA kernel over that map and its
+transpose, the weight gradient is one batched GEMM over the gathered rows.  BatchNorm1d / ReLU / the residual
+add of the basic block are framework ops on the (N, C) feature matrix.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import functional as UF
+from ..registry import MIDDLE_ENCODERS
+
+
+def _triple(v):
+    return tuple(v) if isinstance(v, (list, tuple)) else (v, v, v)
+
+
+class SparseConvTensor:
+    """features [N, C], indices [N, 4] int32 (batch, z, y, x), spatial_shape (D, H, W), batch_size — the
+    fields of spconv.SparseConvTensor this path uses; ``indice_dict`` caches rulebooks per indice key."""
+
+    def __init__(self, features, indices, spatial_shape, batch_size, indice_dict=None):
+        self.features = features
+        self.indices = indices
+        self.spatial_shape = tuple(int(s) for s in spatial_shape)
+        self.batch_size = int(batch_size)
+        self.indice_dict = {} if indice_dict is None else indice_dict
+
+    def replace(self, features, indices=None, spatial_shape=None):
+        return SparseConvTensor(features, self.indices if indices is None else indices,
+                                self.spatial_shape if spatial_shape is None else spatial_shape, self.batch_size,
+                                self.indice_dict)
+
+    def dense(self):
+        """(B, C, D, H, W), zeros at inactive sites."""
+        return _Dense.apply(self.features, self.indices, self.batch_size, self.spatial_shape)
+
+
+class _Dense(Function):
+    @staticmethod
+    def forward(ctx, feats, coors, batch_size, shape):
+        ctx.save_for_backward(coors)
+        ctx.dt = feats.dtype
+        return UF.sparse_to_dense(feats, coors, batch_size, shape).to(feats.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        c, = ctx.saved_tensors
+        c = c.long()
+        return g[c[:, 0], :, c[:, 1], c[:, 2], c[:, 3]].to(ctx.dt), None, None, None
+
+
+class _SparseConv(Function):
+    """out = sum_k feats[nbr_fwd[k]] . W_k; the input gradient runs the same kernel over ``nbr_bwd``
+    (None: submanifold — the forward map read with mirrored offsets)."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, nbr_fwd, nbr_bwd):
+        kvol = nbr_fwd.shape[0]
+        cin, cout = weight.shape[-2], weight.shape[-1]
+        w = weight.detach().reshape(kvol, cin, cout).to(feats.dtype)
+        hi, lo = UF.spconv_operand(w.transpose(1, 2))          # [kvol, Cout, Cin]: K-contiguous blocks
+        out = UF.spconv_gather_mma(feats, nbr_fwd, hi, lo, cout)
+        ctx.save_for_backward(feats, weight, nbr_fwd, nbr_bwd if nbr_bwd is not None else nbr_fwd)
+        ctx.subm = nbr_bwd is None
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        feats, weight, nbr_fwd, nbr_bwd = ctx.saved_tensors
+        kvol = nbr_fwd.shape[0]
+        cin, cout = weight.shape[-2], weight.shape[-1]
+        g = g.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            w = weight.detach().reshape(kvol, cin, cout).to(g.dtype)
+            if ctx.subm:
+                w = w.flip(0)          # j is o's neighbour at offset k  <=>  o is j's neighbour at kvol - 1 - k
+            hi, lo = UF.spconv_operand(w)                      # [kvol, Cin (out), Cout (in)] as stored
+            gx = UF.spconv_gather_mma(g, nbr_bwd, hi, lo, cin)
+        if ctx.needs_input_grad[1]:
+            # dW_k = gathered_k^T . g: one batched GEMM per group of offsets over the gathered rows
+            fz = torch.cat((feats, feats.new_zeros(1, cin)), 0)
+            gw = torch.empty(kvol, cin, cout, dtype=torch.float32, device=g.device)
+            rows = nbr_fwd.shape[1]
+            step = max(1, min(kvol, (1 << 28) // max(1, rows * cin * feats.element_size())))
+            for k0 in range(0, kvol, step):
+                idx = nbr_fwd[k0:k0 + step].long()
+                idx = torch.where(idx < 0, torch.full_like(idx, feats.shape[0]), idx)
+                gathered = fz[idx]                             # [kc, rows, Cin]
+                gw[k0:k0 + step] = torch.matmul(gathered.transpose(1, 2), g.unsqueeze(0)).float()
+            gw = gw.view_as(weight).to(weight.dtype)
+        return gx, gw, None, None
+
+
+class _SparseConvBase(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=False, indice_key=None,
+                 subm=False):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = _triple(kernel_size), _triple(stride), _triple(padding)
+        self.indice_key, self.subm = indice_key, subm
+        self.weight = nn.Parameter(torch.empty(*self.kernel_size, in_channels, out_channels))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # spconv 1.x SparseConvolution.reset_parameters: kaiming_uniform_(a = sqrt(5)) on the
+        # (k..., Cin, Cout) tensor (its fan_in therefore computed from the trailing dims as torch does)
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = nn.init._calculate_fan_in_and_fan_out(self.weight)
+            bound = 1 / math.sqrt(fan_in)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def _maps(self, x):
+        hit = x.indice_dict.get(self.indice_key) if self.indice_key is not None else None
+        if hit is not None:
+            return hit
+        if self.subm:
+            rec = (x.indices, x.spatial_shape,
+                   UF.spconv_subm_map(x.indices, x.batch_size, x.spatial_shape, self.kernel_size), None)
+        else:
+            oc, od, nf, nb = UF.spconv_strided_maps(x.indices, x.batch_size, x.spatial_shape, self.kernel_size,
+                                                    self.stride, self.padding)
+            rec = (oc, od, nf, nb)
+        if self.indice_key is not None:
+            x.indice_dict[self.indice_key] = rec
+        return rec
+
+    def forward(self, x):
+        out_coors, out_dims, nbr_fwd, nbr_bwd = self._maps(x)
+        feats, w = x.features, self.weight
+        if torch.is_autocast_enabled('cuda') and feats.is_cuda:
+            feats = feats.to(torch.get_autocast_dtype('cuda'))
+        pad = (-self.in_channels) % 16                         # the MFMA K step (conv_input: 5 -> 16 channels)
+        if pad:
+            feats = F.pad(feats, (0, pad))
+            w = F.pad(w, (0, 0, 0, pad))
+        out = _SparseConv.apply(feats.contiguous(), w, nbr_fwd, nbr_bwd)
+        if self.bias is not None:
+            out = out + self.bias.to(out.dtype)
+        return x.replace(out, out_coors, out_dims)
+
+
+class SubMConv3d(_SparseConvBase):
+    """spconv.SubMConv3d: outputs only at the input's active sites (stride 1, padding k // 2)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        assert _triple(dilation) == (1, 1, 1) and groups == 1 and _triple(stride) == (1, 1, 1)
+        super().__init__(in_channels, out_channels, kernel_size, 1, padding, bias, indice_key, subm=True)
+
+
+class SparseConv3d(_SparseConvBase):
+    """spconv.SparseConv3d: an output site is active when any input in its receptive field is."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        assert _triple(dilation) == (1, 1, 1) and groups == 1
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, bias, indice_key, subm=False)
+
+
+class SparseSequential(nn.Sequential):
+    """spconv.SparseSequential: sparse layers take the tensor object, dense ones its feature matrix."""
+
+    def forward(self, x):
+        for m in self:
+            if isinstance(m, (_SparseConvBase, SparseBasicBlock, SparseSequential)):
+                x = m(x)
+            else:
+                x = x.replace(m(x.features))
+        return x
+
+
+def _norm(cfg, channels):
+    cfg = dict(cfg or dict(type='BN1d', eps=1e-3, momentum=0.01))
+    kind = cfg.pop('type')
+    assert kind in ('BN1d', 'BN'), kind
+    cfg.pop('requires_grad', None)
+    return nn.BatchNorm1d(channels, **cfg)
+
+
+def make_sparse_convmodule(in_channels, out_channels, kernel_size, indice_key, stride=1, padding=0,
+                           conv_type='SubMConv3d', norm_cfg=None, order=('conv', 'norm', 'act')):
+    """mmdet3d.ops.make_sparse_convmodule: SparseSequential of (conv, norm, act) in ``order``."""
+    assert set(order) <= {'conv', 'norm', 'act'}
+    layers = []
+    for layer in order:
+        if layer == 'conv':
+            if conv_type == 'SubMConv3d':
+                layers.append(SubMConv3d(in_channels, out_channels, kernel_size, bias=False, indice_key=indice_key))
+            else:
+                layers.append(SparseConv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                                           bias=False, indice_key=indice_key))
+        elif layer == 'norm':
+            layers.append(_norm(norm_cfg, out_channels))
+        else:
+            layers.append(nn.ReLU(inplace=True))
+    return SparseSequential(*layers)
+
+
+class SparseBasicBlock(nn.Module):
+    """mmdet3d.ops.SparseBasicBlock: two 3x3x3 submanifold convolutions with BatchNorm, a residual, ReLU."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, conv_cfg=None, norm_cfg=None):
+        super().__init__()
+        key = (conv_cfg or {}).get('indice_key')
+        self.conv1 = SubMConv3d(inplanes, planes, 3, bias=False, indice_key=key)
+        self.bn1 = _norm(norm_cfg, planes)
+        self.conv2 = SubMConv3d(planes, planes, 3, bias=False, indice_key=key)
+        self.bn2 = _norm(norm_cfg, planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x.features
+        out = self.conv1(x)
+        out = out.replace(self.relu(self.bn1(out.features)))
+        out = self.conv2(out)
+        f = self.bn2(out.features)
+        if self.downsample is not None:
+            identity = self.downsample(x).features
+        return out.replace(self.relu(f + identity.to(f.dtype)))
+
+
+@MIDDLE_ENCODERS.register_module()
+class SparseEncoder(nn.Module):
+    """mmdet3d ``SparseEncoder``: conv_input -> encoder stages -> conv_out -> dense -> (N, C * D, H, W)."""
+
+    def __init__(self, in_channels, sparse_shape, order=('conv', 'norm', 'act'),
+                 norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01), base_channels=16, output_channels=128,
+                 encoder_channels=((16,), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
+                 encoder_paddings=((1,), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)), block_type='conv_module'):
+        super().__init__()
+        assert block_type in ('conv_module', 'basicblock')
+        assert isinstance(order, (list, tuple)) and len(order) == 3 and set(order) == {'conv', 'norm', 'act'}
+        self.sparse_shape = tuple(sparse_shape)
+        self.in_channels, self.order = in_channels, tuple(order)
+        self.base_channels, self.output_channels = base_channels, output_channels
+        self.encoder_channels, self.encoder_paddings = encoder_channels, encoder_paddings
+        self.stage_num = len(encoder_channels)
+        self.fp16_enabled = False
+        if self.order[0] != 'conv':                 # pre-activation structure
+            self.conv_input = make_sparse_convmodule(in_channels, base_channels, 3, 'subm1', padding=1,
+                                                     norm_cfg=norm_cfg, order=('conv',))
+        else:
+            self.conv_input = make_sparse_convmodule(in_channels, base_channels, 3, 'subm1', padding=1,
+                                                     norm_cfg=norm_cfg)
+        out_c = self.make_encoder_layers(norm_cfg, base_channels, block_type)
+        self.conv_out = make_sparse_convmodule(out_c, output_channels, (3, 1, 1), 'spconv_down2', stride=(2, 1, 1),
+                                               padding=0, conv_type='SparseConv3d', norm_cfg=norm_cfg)
+
+    def make_encoder_layers(self, norm_cfg, in_channels, block_type='conv_module'):
+        self.encoder_layers = SparseSequential()
+        for i, blocks in enumerate(self.encoder_channels):
+            blocks_list = []
+            for j, out_channels in enumerate(tuple(blocks)):
+                padding = tuple(self.encoder_paddings[i])[j]
+                if i != 0 and j == 0 and block_type == 'conv_module':
+                    blocks_list.append(make_sparse_convmodule(
+                        in_channels, out_channels, 3, f'spconv{i + 1}', stride=2, padding=padding,
+                        conv_type='SparseConv3d', norm_cfg=norm_cfg))
+                elif block_type == 'basicblock':
+                    if j == len(blocks) - 1 and i != len(self.encoder_channels) - 1:
+                        blocks_list.append(make_sparse_convmodule(
+                            in_channels, out_channels, 3, f'spconv{i + 1}', stride=2, padding=padding,
+                            conv_type='SparseConv3d', norm_cfg=norm_cfg))
+                    else:
+                        blocks_list.append(SparseBasicBlock(out_channels, out_channels, norm_cfg=norm_cfg,
+                                                            conv_cfg=dict(type='SubMConv3d', indice_key=f'subm{i + 1}')))
+                else:
+                    blocks_list.append(make_sparse_convmodule(
+                        in_channels, out_channels, 3, f'subm{i + 1}', padding=padding, conv_type='SubMConv3d',
+                        norm_cfg=norm_cfg))
+                in_channels = out_channels
+            self.encoder_layers.add_module(f'encoder_layer{i + 1}', SparseSequential(*blocks_list))
+        return in_channels
+
+    def forward(self, voxel_features, coors, batch_size):
+        """voxel_features [N, in_channels], coors [N, 4] (batch, z, y, x) -> (batch, C * D, H, W)."""
+        coors = coors.int()
+        x = SparseConvTensor(voxel_features, coors.contiguous(), self.sparse_shape, batch_size)
+        x = self.conv_input(x)
+        for stage in self.encoder_layers:
+            x = stage(x)
+        out = self.conv_out(x)
+        dense = out.dense()
+        N, C, D, H, W = dense.shape
+        return dense.view(N, C * D, H, W)
