@@ -370,9 +370,51 @@ def voxel_record(device):
     us = 1e3 * e0.elapsed_time(e1) / 20
     m = int(vnum.item())
     nbytes = N * F * 4 + N * 3 * 4 + m * (F + 3 + 1) * 4
-    return {'points': N, 'voxels': m, 'us_per_cloud': us, 'points_per_s': N / us * 1e6,
-            'algorithmic_bytes': nbytes, 'GBps': nbytes / us / 1e3,
-            'note': 'hard voxelize + VFE mean, 7 launches: latency-bound, not bandwidth-bound'}
+    rec = {'points': N, 'voxels': m, 'us_per_cloud': us, 'points_per_s': N / us * 1e6,
+           'algorithmic_bytes': nbytes, 'GBps': nbytes / us / 1e3,
+           'note': 'hard voxelize + VFE mean, 7 launches: latency-bound, not bandwidth-bound'}
+    rec['middle_encoder'] = middle_encoder_record(device, mean[:m], coors[:m])
+    return rec
+
+
+def middle_encoder_record(device, feats, coors, bs=2):
+    """SparseEncoder of the shipped L / LC configs (41 x 1440 x 1440 grid, basic blocks) on `bs` copies of the
+    cloud: forward and forward + backward (training mode), per batch.  Rulebooks are rebuilt every pass."""
+    from unibev_amd.registry import MIDDLE_ENCODERS, build_from_cfg
+    cfg = dict(type='SparseEncoder', in_channels=5, sparse_shape=[41, 1440, 1440], output_channels=128,
+               order=('conv', 'norm', 'act'),
+               encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+               encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)), block_type='basicblock')
+    torch.manual_seed(0)
+    enc = build_from_cfg(cfg, MIDDLE_ENCODERS).to(device).train()
+    f = torch.cat([feats] * bs).float().contiguous()
+    zyx = coors[:, -3:]                                     # ubv_hard_voxelize: (z, y, x) rows
+    c = torch.cat([torch.cat((torch.full_like(zyx[:, :1], b), zyx), 1) for b in range(bs)]).contiguous()
+
+    def fwd():
+        with torch.no_grad():
+            return enc(f, c, bs)
+
+    def fwd_bwd():
+        for p in enc.parameters():
+            p.grad = None
+        enc(f, c, bs).sum().backward()
+
+    out = {}
+    for name, fn in (('forward_ms', fwd), ('forward_backward_ms', fwd_bwd)):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = e0.elapsed_time(e1) / 5
+    out.update(batch=bs, voxels_per_sample=int(feats.shape[0]), out_shape=list(fwd().shape),
+               note='SubM / strided sparse convs as gather + MFMA over neighbour maps; weight gradients as batched '
+                    'library GEMMs over gathered rows; 4 host syncs per pass (output counts of the strided convs)')
+    return out
 
 
 def _two_streams():

@@ -418,6 +418,14 @@ int ubv_sparse_to_dense(const float* feats, const int32_t* coors, const int32_t*
  *        Cout <= 128.  The same call computes the input gradient (feats = grad_out, nbr = the transposed map,
  *        w = the [k][Cin][Cout] weight as stored). */
 int64_t ubv_spconv_table_slots(int64_t n);
+/* Weight gradient: grad_w[k][co][ci] = sum_rows grad_out[row][co] * feats[nbr[k][row]][ci] — the split-K MFMA
+ * weight-gradient kernel of the Linear layers with gathered rows, one launch for all kernel offsets.
+ * partials [splits, kvol, Cout*Cin + Cout] f32 scratch (ubv_spconv_wgrad_splits picks `splits`);
+ * grad_w [kvol, Cout*Cin + Cout] f32 WRITTEN, each block's Cout trailing entries unused.  Cout, Cin <= 128,
+ * multiples of 4 (f32) / 8 (16-bit). */
+int ubv_spconv_wgrad_splits(int64_t rows, int kvol);
+int ubv_spconv_wgrad(const void* grad_out, const void* feats, const int32_t* nbr, int64_t ld, int64_t rows,
+                     float* partials, float* grad_w, int Cout, int Cin, int kvol, int splits, int dtype, void* stream);
 int ubv_spconv_hash_build(const int32_t* coors, int64_t n, int D, int H, int W, int64_t* table_keys,
                           int32_t* table_vals, int64_t slots, void* stream);
 int ubv_spconv_neighbors(const int32_t* coors, int64_t rows, int B, const int* row_dims, const int* target_dims,

@@ -128,3 +128,37 @@ def test_sparse_encoder_vs_dense_oracle(block_type):
         g = P[k].grad
         assert p.grad is not None and g is not None, k
         assert rel(p.grad, g) < 3e-2, (k, rel(p.grad, g))
+
+
+def test_lidar_front_end_end_to_end_at_the_reference_size():
+    """points -> ubv_hard_voxelize -> VFE mean -> SparseEncoder -> (B, 256, 180, 180): the LiDAR branch up to
+    the BEV feature map the point-cloud encoder consumes, at the shipped config's grid (41 x 1440 x 1440).
+    Shape, finiteness, run-to-run identity, and the active columns of the output against the voxels' own
+    (a stride-8 BEV cell can only be non-zero if a voxel lies within its receptive field)."""
+    from unibev_amd import functional as UF
+    from unibev_amd import synthetic as syn
+    from unibev_amd.registry import MIDDLE_ENCODERS, build_from_cfg
+    pts = torch.from_numpy(syn.lidar_points(30000, seed=2)).to(DEV)
+    voxels, coors, num, vnum = UF.hard_voxelize(pts, syn.VOXEL_SIZE, syn.PC_RANGE, 10, 90000)
+    m = int(vnum.item())
+    feats = UF.voxel_mean(voxels, num, vnum)[:m]
+    c = coors[:m]
+    c = torch.cat((torch.zeros_like(c[:, :1]), c[:, -3:]), 1) if c.shape[1] == 3 else c
+    cfg = dict(type='SparseEncoder', in_channels=5, sparse_shape=[41, 1440, 1440], output_channels=128,
+               order=('conv', 'norm', 'act'),
+               encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+               encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)), block_type='basicblock')
+    torch.manual_seed(0)
+    enc = build_from_cfg(cfg, MIDDLE_ENCODERS).to(DEV).eval()
+    with torch.no_grad():
+        a = enc(feats, c, 1)
+        b = enc(feats, c, 1)
+    assert a.shape == (1, 256, 180, 180) and torch.isfinite(a).all()
+    assert torch.equal(a, b)
+    # receptive field of a stride-8 cell: three stride-2 3x3 convs with padding 1 + the 3x3 submanifold ones
+    yx = (c[:, 2:].long() // 8)
+    occ = torch.zeros(180, 180, dtype=torch.bool, device=DEV)
+    occ[yx[:, 0].clamp(0, 179), yx[:, 1].clamp(0, 179)] = True
+    grown = torch.nn.functional.max_pool2d(occ[None, None].float(), 5, 1, 2)[0, 0] > 0
+    nz = (a[0].abs().sum(0) > 0)
+    assert nz.any() and not (nz & ~grown).any()

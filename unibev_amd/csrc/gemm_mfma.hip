@@ -446,10 +446,14 @@ __device__ __forceinline__ uint4 wg_frag(const uint16_t* p) {
   return make_uint4(ua.x, ua.y, ub.x, ub.y);
 }
 
-template <bool SPLIT, bool F16>
+// GATHER (the sparse convolutions' weight gradient, sparse_conv.hip): X rows are taken through an index map,
+// x_row(m) = xidx[kk * xld + m] (-1: a zero row), one 128 x 128 tile per kernel offset kk — the "tiles" of a
+// slab are then the kvol offsets, which share the slab's rows of dY through one XCD's L2.
+template <bool SPLIT, bool F16, bool GATHER>
 __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restrict__ dYv, const void* __restrict__ Xv,
                                                             float* __restrict__ partials, long M, int N, int K,
-                                                            int tiles_k, int tiles, int splits, int rows_per_split) {
+                                                            int tiles_k, int tiles, int splits, int rows_per_split,
+                                                            const int32_t* __restrict__ xidx, long xld) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   uint16_t* ty_h = lds;
   uint16_t* tx_h = ty_h + kWgPlane;
@@ -461,12 +465,13 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int split = (slot / tiles) * 8 + xcd, tile = slot % tiles;
   if (split >= splits) return;
-  const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
+  const int tn = GATHER ? 0 : tile / tiles_k, tk = GATHER ? 0 : tile - tn * tiles_k;
   const int n0 = tn * kWgTile, k0 = tk * kWgTile;
+  if (GATHER) xidx += (long)tile * xld;
   const long mbeg = (long)split * rows_per_split;
   const long mend = mbeg + rows_per_split < M ? mbeg + rows_per_split : M;
   const int wk = wv >> 1, wn = wv & 1;                    // wave: k groups {wk, wk+2} (+4), n groups {wn, wn+2} (+4)
-  const bool want_bias = tk == 0 && wk == 0;
+  const bool want_bias = !GATHER && tk == 0 && wk == 0;
 
   gf32x16_t acc[2][2], accb[2];
 #pragma unroll
@@ -496,16 +501,23 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
     for (int i = 0; i < NI; ++i) {
       const long m = mc + sr + (256 / TPR) * i;
       const long mm = m < mend ? m : mend - 1;
+      long xm = mm;
+      bool xrow_ok = m < mend;
+      if constexpr (GATHER) {
+        const int r = xidx[mm];
+        xrow_ok = xrow_ok && r >= 0;
+        xm = r >= 0 ? r : 0;
+      }
       if constexpr (SPLIT) {
         fy[i] = *reinterpret_cast<const gf32x4_t*>((const float*)dYv + mm * N + ycol);
-        fx[i] = *reinterpret_cast<const gf32x4_t*>((const float*)Xv + mm * K + xcol);
+        fx[i] = *reinterpret_cast<const gf32x4_t*>((const float*)Xv + xm * K + xcol);
         if (!(m < mend && yok)) fy[i] = gf32x4_t{0.f, 0.f, 0.f, 0.f};
-        if (!(m < mend && xok)) fx[i] = gf32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (!(xrow_ok && xok)) fx[i] = gf32x4_t{0.f, 0.f, 0.f, 0.f};
       } else {
         hy[i] = *reinterpret_cast<const gu32x4_t*>((const uint16_t*)dYv + mm * N + ycol);
-        hx[i] = *reinterpret_cast<const gu32x4_t*>((const uint16_t*)Xv + mm * K + xcol);
+        hx[i] = *reinterpret_cast<const gu32x4_t*>((const uint16_t*)Xv + xm * K + xcol);
         if (!(m < mend && yok)) hy[i] = gu32x4_t{0u, 0u, 0u, 0u};
-        if (!(m < mend && xok)) hx[i] = gu32x4_t{0u, 0u, 0u, 0u};
+        if (!(xrow_ok && xok)) hx[i] = gu32x4_t{0u, 0u, 0u, 0u};
       }
     }
   };
@@ -578,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
   }
   // ---- partial tile.  D[k][n]: column u = lane & 31 of block j, rows u' = (r & 3) + 8 (r >> 2) + 4 half of
   // block i; block-local index u -> tile index 16 (c + 4 (u >> 4)) + (u & 15) with c the block's first group
-  float* part = partials + (long)split * ((long)N * K + N);
+  float* part = partials + ((long)split * (GATHER ? tiles : 1) + (GATHER ? tile : 0)) * ((long)N * K + N);
   const int half = lane >> 5, u = lane & 31;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -662,14 +674,56 @@ extern "C" int ubv_gemm_wgrad(const void* grad_out, const void* x, float* partia
   const size_t lds = (size_t)(dtype == UBV_F32 ? 4 : 2) * kWgPlane * sizeof(uint16_t);
   hipStream_t st = as_stream(stream);
   if (dtype == UBV_F32)
-    hipLaunchKernelGGL((gemm_wgrad_kernel<true, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<true, false, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps, (const int32_t*)nullptr, 0L);
   else if (dtype == UBV_F16)
-    hipLaunchKernelGGL((gemm_wgrad_kernel<false, true>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<false, true, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps, (const int32_t*)nullptr, 0L);
   else
-    hipLaunchKernelGGL((gemm_wgrad_kernel<false, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<false, false, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps, (const int32_t*)nullptr, 0L);
   const long len = (long)N * K + N;
   hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((len / 4 + 31) / 32)), dim3(256), 0, st, partials, splits, len,
                      grad_wb);
   UBV_CHECK_LAUNCH("gemm_wgrad");
+  return UBV_OK;
+}
+
+// Weight gradient of a sparse convolution: for every kernel offset k, dW_k[Cout, Cin] = sum_rows grad_out[row, :]^T .
+// feats[nbr[k][row], :] (rows without a neighbour contribute nothing) — gemm_wgrad_kernel with gathered X rows, one
+// 128 x 128 tile per offset, split-K over the rows.  partials [splits, kvol, Cout*Cin + Cout] f32 scratch;
+// grad_w [kvol, Cout*Cin + Cout] f32, WRITTEN (the last Cout entries of each block are unused).
+extern "C" int ubv_spconv_wgrad_splits(int64_t rows, int kvol) {
+  long s = (768 + kvol - 1) / kvol;
+  const long max_s = (rows + 255) / 256;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+extern "C" int ubv_spconv_wgrad(const void* grad_out, const void* feats, const int32_t* nbr, int64_t ld, int64_t rows,
+                                float* partials, float* grad_w, int Cout, int Cin, int kvol, int splits, int dtype,
+                                void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(grad_out && feats && nbr && partials && grad_w && rows > 0 && ld >= rows && kvol > 0 && splits > 0,
+                "spconv_wgrad: bad arguments");
+  UBV_CHECK_ARG(dtype >= 0 && dtype <= 2, "spconv_wgrad: unknown dtype %d", dtype);
+  const int cw = dtype == UBV_F32 ? 4 : 8;
+  if (Cout % cw != 0 || Cin % cw != 0 || Cout > kWgTile || Cin > kWgTile || ((uintptr_t)grad_out % 16) != 0 ||
+      ((uintptr_t)feats % 16) != 0) {
+    set_error("spconv_wgrad: Cout=%d, Cin=%d must be multiples of %d and at most %d", Cout, Cin, cw, kWgTile);
+    return UBV_ERR_UNSUPPORTED;
+  }
+  long rps = (rows + splits - 1) / splits;
+  rps = (rps + kWgMC - 1) / kWgMC * kWgMC;
+  const dim3 grid((unsigned)((splits + 7) / 8 * 8 * kvol)), blk(256);
+  const size_t lds = (size_t)(dtype == UBV_F32 ? 4 : 2) * kWgPlane * sizeof(uint16_t);
+  hipStream_t st = as_stream(stream);
+  if (dtype == UBV_F32)
+    hipLaunchKernelGGL((gemm_wgrad_kernel<true, false, true>), grid, blk, lds, st, grad_out, feats, partials, (long)rows, Cout, Cin, 1, kvol, splits, (int)rps, nbr, (long)ld);
+  else if (dtype == UBV_F16)
+    hipLaunchKernelGGL((gemm_wgrad_kernel<false, true, true>), grid, blk, lds, st, grad_out, feats, partials, (long)rows, Cout, Cin, 1, kvol, splits, (int)rps, nbr, (long)ld);
+  else
+    hipLaunchKernelGGL((gemm_wgrad_kernel<false, false, true>), grid, blk, lds, st, grad_out, feats, partials, (long)rows, Cout, Cin, 1, kvol, splits, (int)rps, nbr, (long)ld);
+  const long len = (long)kvol * ((long)Cout * Cin + Cout);
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((len / 4 + 31) / 32)), dim3(256), 0, st, partials, splits, len, grad_w);
+  UBV_CHECK_LAUNCH("spconv_wgrad");
   return UBV_OK;
 }

@@ -11,7 +11,7 @@
 //     compaction, nothing order-dependent.  Forward maps output rows to inputs (in = out*stride - pad + k),
 //     the input gradient uses the transposed map (out = (in + pad - k) / stride where divisible): BOTH passes
 //     are gathers, so neither needs float atomics and both are bit-reproducible.
-//   * the product is ONE kernel (spconv_gather_mma_kernel): a wave owns 32 output rows x all output
+//   * the product is ONE kernel (spconv_gather_mma_kernel): a wave owns 64 output rows x all output
 //     channels; for every offset with at least one neighbour in the wave it loads its MFMA A fragment
 //     straight from the gathered rows (a lane = one row x 8 consecutive channels: exactly the operand
 //     layout of v_mfma_f32_32x32x16, no LDS), the B fragments from the weight block W_k (K-contiguous copy
@@ -154,79 +154,103 @@ template <> struct spc_mma<f16_t> {
 };
 template <> struct spc_mma<float> : spc_mma<bf16_t> {};
 
-template <typename T, int NB>
+// RB: 32-row blocks per wave.  Every B fragment (a slice of W_k, fetched from L2 by every wave that needs it)
+// then feeds RB MFMA groups: with one row block per wave the weight traffic — 1.8 MB of W per 32 output rows at
+// 128 x 128 channels — was the bound (9.6 TB/s of L2 reads measured).
+template <typename T, int NB, int RB>
 __global__ __launch_bounds__(256) void spconv_gather_mma_kernel(const T* __restrict__ feats, const int32_t* __restrict__ nbr,
                                                                 long ld, long rows, const uint16_t* __restrict__ w_hi,
                                                                 const uint16_t* __restrict__ w_lo, T* __restrict__ out,
                                                                 int Cin, int Cout, int kvol) {
   constexpr bool SPLIT = sizeof(T) == 4;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const long row0 = ((long)blockIdx.x * 4 + wv) * 32;
+  const long row0 = ((long)blockIdx.x * 4 + wv) * (32 * RB);
   if (row0 >= rows) return;
   const int m = lane & 31, kg = lane >> 5;
-  const long row = row0 + m;
-  const bool rok = row < rows;
-  sf32x16_t acc[NB];
+  sf32x16_t acc[RB][NB];
 #pragma unroll
-  for (int j = 0; j < NB; ++j)
+  for (int i = 0; i < RB; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   for (int k = 0; k < kvol; ++k) {
-    const int idx = rok ? nbr[(long)k * ld + row] : -1;
-    if (__ballot(idx >= 0) == 0ull) continue;             // no row of this wave has a neighbour at offset k
-    const T* frow = feats + (long)(idx >= 0 ? idx : 0) * Cin + kg * 8;
+    int idx[RB];
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const long row = row0 + i * 32 + m;
+      idx[i] = row < rows ? nbr[(long)k * ld + row] : -1;
+      any = any || idx[i] >= 0;
+    }
+    if (__ballot(any) == 0ull) continue;                  // no row of this wave has a neighbour at offset k
     const uint16_t* wk_hi = w_hi + ((long)k * NB * 32 + m) * Cin + kg * 8;
     const uint16_t* wk_lo = SPLIT ? w_lo + ((long)k * NB * 32 + m) * Cin + kg * 8 : nullptr;
     for (int c0 = 0; c0 < Cin; c0 += 16) {
-      uint4 a_hi = make_uint4(0u, 0u, 0u, 0u), a_lo = make_uint4(0u, 0u, 0u, 0u);
-      if (idx >= 0) {
-        if constexpr (SPLIT) {
-          const float4 v0 = *reinterpret_cast<const float4*>(frow + c0);
-          const float4 v1 = *reinterpret_cast<const float4*>(frow + c0 + 4);
-          a_hi.x = cvt_pk_bf16(v0.x, v0.y); a_hi.y = cvt_pk_bf16(v0.z, v0.w);
-          a_hi.z = cvt_pk_bf16(v1.x, v1.y); a_hi.w = cvt_pk_bf16(v1.z, v1.w);
-          a_lo.x = cvt_pk_bf16(v0.x - __uint_as_float(a_hi.x << 16), v0.y - __uint_as_float(a_hi.x & 0xffff0000u));
-          a_lo.y = cvt_pk_bf16(v0.z - __uint_as_float(a_hi.y << 16), v0.w - __uint_as_float(a_hi.y & 0xffff0000u));
-          a_lo.z = cvt_pk_bf16(v1.x - __uint_as_float(a_hi.z << 16), v1.y - __uint_as_float(a_hi.z & 0xffff0000u));
-          a_lo.w = cvt_pk_bf16(v1.z - __uint_as_float(a_hi.w << 16), v1.w - __uint_as_float(a_hi.w & 0xffff0000u));
-        } else {
-          a_hi = *reinterpret_cast<const uint4*>(frow + c0);
+      uint4 a_hi[RB], a_lo[RB];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        a_hi[i] = make_uint4(0u, 0u, 0u, 0u);
+        a_lo[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (idx[i] >= 0) {
+          const T* frow = feats + (long)idx[i] * Cin + kg * 8 + c0;
+          if constexpr (SPLIT) {
+            const float4 v0 = *reinterpret_cast<const float4*>(frow);
+            const float4 v1 = *reinterpret_cast<const float4*>(frow + 4);
+            uint4 h, l;
+            h.x = cvt_pk_bf16(v0.x, v0.y); h.y = cvt_pk_bf16(v0.z, v0.w);
+            h.z = cvt_pk_bf16(v1.x, v1.y); h.w = cvt_pk_bf16(v1.z, v1.w);
+            l.x = cvt_pk_bf16(v0.x - __uint_as_float(h.x << 16), v0.y - __uint_as_float(h.x & 0xffff0000u));
+            l.y = cvt_pk_bf16(v0.z - __uint_as_float(h.y << 16), v0.w - __uint_as_float(h.y & 0xffff0000u));
+            l.z = cvt_pk_bf16(v1.x - __uint_as_float(h.z << 16), v1.y - __uint_as_float(h.z & 0xffff0000u));
+            l.w = cvt_pk_bf16(v1.z - __uint_as_float(h.w << 16), v1.w - __uint_as_float(h.w & 0xffff0000u));
+            a_hi[i] = h; a_lo[i] = l;
+          } else {
+            a_hi[i] = *reinterpret_cast<const uint4*>(frow);
+          }
         }
       }
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         const uint4 b_hi = *reinterpret_cast<const uint4*>(wk_hi + (long)j * 32 * Cin + c0);
-        acc[j] = spc_mma<T>::run(a_hi, b_hi, acc[j]);
-        if constexpr (SPLIT) {
-          const uint4 b_lo = *reinterpret_cast<const uint4*>(wk_lo + (long)j * 32 * Cin + c0);
-          acc[j] = spc_mma<T>::run(a_hi, b_lo, acc[j]);
-          acc[j] = spc_mma<T>::run(a_lo, b_hi, acc[j]);
+        uint4 b_lo = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (SPLIT) b_lo = *reinterpret_cast<const uint4*>(wk_lo + (long)j * 32 * Cin + c0);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          acc[i][j] = spc_mma<T>::run(a_hi[i], b_hi, acc[i][j]);
+          if constexpr (SPLIT) {
+            acc[i][j] = spc_mma<T>::run(a_hi[i], b_lo, acc[i][j]);
+            acc[i][j] = spc_mma<T>::run(a_lo[i], b_hi, acc[i][j]);
+          }
         }
       }
     }
   }
-  // D[i][n]: this lane holds column n = lane & 31 (output channel within block j), rows i = (r & 3) + 8 (r >> 2) + 4 kg
+  // D[i][n]: this lane holds column n = lane & 31 (output channel within block j), rows (r & 3) + 8 (r >> 2) + 4 kg
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const int n = j * 32 + m;
-    if (n >= Cout) continue;
+  for (int i = 0; i < RB; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const long orow = row0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-      if (orow < rows) out[orow * Cout + n] = elem<T>::from_float(acc[j][r]);
+    for (int j = 0; j < NB; ++j) {
+      const int n = j * 32 + m;
+      if (n >= Cout) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long orow = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        if (orow < rows) out[orow * Cout + n] = elem<T>::from_float(acc[i][j][r]);
+      }
     }
-  }
 }
 
 template <typename T>
 static int spconv_launch(const void* feats, const int32_t* nbr, long ld, long rows, const void* w_hi, const void* w_lo,
                          void* out, int Cin, int Cout, int kvol, hipStream_t st) {
   const int nb = (Cout + 31) / 32;
-  const dim3 grid((unsigned)((rows + 127) / 128)), blk(256);
+  constexpr int RB = 2;
+  const dim3 grid((unsigned)((rows + 128 * RB - 1) / (128 * RB))), blk(256);
 #define UBV_SPC(NBV)                                                                                            \
   case NBV:                                                                                                     \
-    hipLaunchKernelGGL((spconv_gather_mma_kernel<T, NBV>), grid, blk, 0, st, (const T*)feats, nbr, ld, rows,    \
+    hipLaunchKernelGGL((spconv_gather_mma_kernel<T, NBV, RB>), grid, blk, 0, st, (const T*)feats, nbr, ld, rows, \
                        (const uint16_t*)w_hi, (const uint16_t*)w_lo, (T*)out, Cin, Cout, kvol);                 \
     break;
   switch (nb) {

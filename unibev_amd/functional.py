@@ -988,3 +988,25 @@ def spconv_gather_mma(feats, nbr, w_hi, w_lo, cout):
         check(lib().ubv_spconv_gather_mma(_p(feats), _p(nbr), rows, rows, _p(w_hi), _p(w_lo), _p(out), cin, int(cout),
                                           kvol, _dt(feats), _stream()), 'spconv_gather_mma')
         return out
+
+
+@torch.no_grad()
+def spconv_wgrad(grad_out, feats, nbr):
+    """[kvol, Cin, Cout] f32 weight gradient of a sparse convolution (``ubv_spconv_wgrad``), or None when
+    the channel counts are outside the kernel's reach."""
+    with _need_cuda(grad_out, feats, nbr):
+        kvol, rows = nbr.shape
+        cout, cin = grad_out.shape[1], feats.shape[1]
+        cw = 4 if feats.dtype == torch.float32 else 8
+        if rows == 0 or cout % cw or cin % cw or cout > 128 or cin > 128 or grad_out.dtype != feats.dtype:
+            return None
+        S = int(lib().ubv_spconv_wgrad_splits(rows, kvol))
+        blk = cout * cin + cout
+        part = _workspace(4 * S * kvol * blk, feats.device)
+        out = torch.empty(kvol, blk, dtype=torch.float32, device=feats.device)
+        rc = lib().ubv_spconv_wgrad(_p(grad_out.contiguous()), _p(feats.contiguous()), _p(nbr), rows, rows, _p(part),
+                                    _p(out), cout, cin, kvol, S, _dt(feats), _stream())
+        if rc == -3:
+            return None
+        check(rc, 'spconv_wgrad')
+        return out[:, :cout * cin].view(kvol, cout, cin).transpose(1, 2)

@@ -11,7 +11,7 @@ the published code; there are no reference vectors (parity unpinned by the refer
 
 MI355X form (csrc/sparse_conv.hip): the rulebook is a dense neighbour map per indice key (one hash lookup per
 (row, offset), no atomics), forward and input gradient are the same gather + MFMA kernel over that map and its
-transpose, the weight gradient is one batched GEMM over the gathered rows.  BatchNorm1d / ReLU / the residual
+transpose, the weight gradient is the Linear layers' split-K MFMA kernel with gathered rows (all offsets in one launch).  BatchNorm1d / ReLU / the residual
 add of the basic block are framework ops on the (N, C) feature matrix.
 """
 import math
@@ -96,7 +96,10 @@ class _SparseConv(Function):
             hi, lo = UF.spconv_operand(w)                      # [kvol, Cin (out), Cout (in)] as stored
             gx = UF.spconv_gather_mma(g, nbr_bwd, hi, lo, cin)
         if ctx.needs_input_grad[1]:
-            # dW_k = gathered_k^T . g: one batched GEMM per group of offsets over the gathered rows
+            gw = UF.spconv_wgrad(g, feats, nbr_fwd)             # [kvol, Cin, Cout] f32, all offsets in one launch
+            if gw is not None:
+                return gx, gw.reshape(weight.shape).to(weight.dtype), None, None
+            # channel counts outside the kernel's reach: batched library GEMMs over the gathered rows
             fz = torch.cat((feats, feats.new_zeros(1, cin)), 0)
             gw = torch.empty(kvol, cin, cout, dtype=torch.float32, device=g.device)
             rows = nbr_fwd.shape[1]
