@@ -113,7 +113,7 @@ def test_sparse_encoder_vs_dense_oracle(block_type):
     ref = R.sparse_encoder(P, cfg, f64, coors, B)
     assert out.shape == ref.shape == (B, 32 * 2, 4, 4)
     cot = torch.from_numpy(rs.standard_normal(tuple(ref.shape)))
-    scale = float(ref.abs().max())
+    scale = float(ref.detach().abs().max())
     assert float((out.detach().cpu().double() - ref.detach()).abs().max()) < 2e-4 * scale
     (ref * cot).sum().backward()
     (out.double() * cot.to(DEV)).sum().backward()
@@ -162,3 +162,26 @@ def test_lidar_front_end_end_to_end_at_the_reference_size():
     grown = torch.nn.functional.max_pool2d(occ[None, None].float(), 5, 1, 2)[0, 0] > 0
     nz = (a[0].abs().sum(0) > 0)
     assert nz.any() and not (nz & ~grown).any()
+
+
+def test_extract_pts_feat_connects_voxelization_vfe_and_middle_encoder():
+    """``extract_pts_feat`` (unibev_detector.py:111-123) over the three built pieces, two clouds of different
+    sizes: equals running each stage by hand, sample by sample."""
+    from unibev_amd import synthetic as syn
+    from unibev_amd.modules import HardSimpleVFE, Voxelization, extract_pts_feat
+    from unibev_amd.registry import MIDDLE_ENCODERS, build_from_cfg
+    clouds = [torch.from_numpy(syn.lidar_points(n, seed=s)).to(DEV) for n, s in ((20000, 1), (12000, 2))]
+    vox = Voxelization(syn.VOXEL_SIZE, syn.PC_RANGE, 10, (90000, 120000)).eval()
+    vfe = HardSimpleVFE(num_features=5)
+    torch.manual_seed(0)
+    enc = build_from_cfg(dict(type='SparseEncoder', in_channels=5, sparse_shape=[41, 1440, 1440], output_channels=128,
+                              order=('conv', 'norm', 'act'),
+                              encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+                              encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)),
+                              block_type='basicblock'), MIDDLE_ENCODERS).to(DEV).eval()
+    with torch.no_grad():
+        both = extract_pts_feat(clouds, vox, vfe, enc)
+        singles = [extract_pts_feat([c], vox, vfe, enc) for c in clouds]
+    assert both.shape == (2, 256, 180, 180)
+    for b in range(2):      # eval-mode BatchNorm: samples do not interact
+        torch.testing.assert_close(both[b], singles[b][0], rtol=1e-5, atol=1e-6)

@@ -7,6 +7,6 @@ from .head import UniBEV_Head, inverse_sigmoid  # noqa
 from .encoders import ImgEncoder, ImgLayer, PtsEncoder, PtsLayer  # noqa
 from .sca import SpatialCrossAttentionImg, SpatialCrossAttentionPts  # noqa
 from .transformer import UniBEVTransformer  # noqa
-from .voxel import HardSimpleVFE, Voxelization, sparse_to_dense, voxelize_batch  # noqa
+from .voxel import HardSimpleVFE, Voxelization, extract_pts_feat, sparse_to_dense, voxelize_batch  # noqa
 from .sparse_encoder import (SparseBasicBlock, SparseConv3d, SparseConvTensor, SparseEncoder,  # noqa
                              SparseSequential, SubMConv3d, make_sparse_convmodule)

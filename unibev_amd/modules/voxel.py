@@ -163,3 +163,18 @@ def sparse_to_dense(features, coors, batch_size, spatial_shape):
     dense = UF.sparse_to_dense(features, coors.int(), batch_size, spatial_shape)
     N, C, D, H, W = dense.shape
     return dense.view(N, C * D, H, W)
+
+
+def extract_pts_feat(points, voxel_layer, voxel_encoder, middle_encoder, backbone=None, neck=None):
+    """The LiDAR branch of ``UniBEV.extract_pts_feat`` (unibev_detector.py:111-123) up to — and, when given,
+    through — the 2-D backbone / neck: list of per-sample point clouds -> voxelize (``voxelize_batch``) ->
+    voxel encoder -> middle encoder (``SparseEncoder``: (B, 256, 180, 180) at the shipped configs).  The batch
+    size is taken from the list, not read back from ``coors[-1, 0]`` as the reference does."""
+    voxels, num_points, coors = voxelize_batch(voxel_layer, points)
+    voxel_features = voxel_encoder(voxels, num_points, coors)
+    x = middle_encoder(voxel_features, coors, len(points))
+    if backbone is not None:
+        x = backbone(x)
+        if neck is not None:
+            x = neck(x)
+    return x
