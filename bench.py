@@ -71,6 +71,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP graphs')
+    ap.add_argument('--torch-optimizer', dest='flat_optimizer', action='store_false',
+                    help='torch clip_grad_norm_ + fused AdamW instead of the flat-buffer kernels')
     ap.add_argument('--single-stream', action='store_true',
                     help='both encoders on one stream (default: image and point-cloud encoders on two)')
     ap.add_argument('--no-extras', action='store_true', help='skip the gemm / voxel records')
@@ -216,7 +218,7 @@ def run_mode(args, name, head, world, rank, device, want_ops):
     params = [p for p in head.parameters() if p.requires_grad]
     for p in params:
         p.grad = None
-    opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.01, fused=True)
+    opt = None if args.flat_optimizer else torch.optim.AdamW(params, lr=2e-4, weight_decay=0.01, fused=True)
     s = 2 if kw.get('fusion_method') == 'cat' else 1
     C = kw['embed_dims']
     cot = torch.randn(200 * 200, args.bs, C * s, device=device) / 200.0
@@ -224,9 +226,17 @@ def run_mode(args, name, head, world, rank, device, want_ops):
                      inputs=(img or []) + (pts or []), has_img='C' in mods, has_pts='L' in mods,
                      autocast_dtype=None if dtype == torch.float32 else dtype)
 
-    def finish():
-        torch.nn.utils.clip_grad_norm_(params, 35.0)
-        opt.step()
+    if args.flat_optimizer:
+        # clip (max_norm 35) + AdamW as two streaming passes over the flat parameter / gradient / moment buffers
+        from unibev_amd.optim import FlatAdamW
+        opt = FlatAdamW(params, gs.grads, lr=2e-4, weight_decay=0.01, max_grad_norm=35.0)
+
+        def finish():
+            opt.step()
+    else:
+        def finish():
+            torch.nn.utils.clip_grad_norm_(params, 35.0)
+            opt.step()
 
     graphed = not args.no_graph
     for _ in range(args.warmup):
@@ -464,6 +474,7 @@ def main():
                        'residual_stream': main_rec['residual_stream'],
                        'step': 'fwd + bwd (HIP graphs) + flat-gradient all-reduce + clip + AdamW'
                                if main_rec['hip_graphs'] else 'fwd + bwd + flat-gradient all-reduce + clip + AdamW',
+                       'optimizer': 'flat-buffer clip + AdamW kernels' if args.flat_optimizer else 'torch clip_grad_norm_ + fused AdamW',
                        'streams': 'image / point-cloud encoders on 2 HIP streams' if _two_streams() else '1 stream',
                        'parallelism': f'dp{world}', 'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
                        'parity': main_rec['parity']},

@@ -438,6 +438,18 @@ int ubv_spconv_keys_to_coors(const int64_t* keys, int64_t n, int D, int H, int W
 int ubv_spconv_gather_mma(const void* feats, const int32_t* nbr, int64_t ld, int64_t rows, const void* w_hi,
                           const void* w_lo, void* out, int Cin, int Cout, int kvol, int dtype, void* stream);
 
+/* ---- optimizer step over flat f32 buffers -----------------------------------------------------------
+ * [ext] mmcv OptimizerHook(grad_clip = dict(max_norm = 35, norm_type = 2)) -> torch.nn.utils.clip_grad_norm_, and
+ * torch.optim.AdamW (reference: projects/UniBEV/configs/unibev/unibev_nus_LC_cnw_256_modality_dropout.py:455-462).
+ *   ubv_sumsq_f32     out[0] = sum x[i]^2 (deterministic two-stage reduction; workspace of
+ *                     ubv_sumsq_workspace() bytes)
+ *   ubv_adamw_flat    *step += 1 (device-side int64), then AdamW on p / m / v [n] from g [n]; when `sumsq` is given
+ *                     the gradient is first scaled by min(1, max_norm / (sqrt(*sumsq) + 1e-6)) — nothing read back. */
+int64_t ubv_sumsq_workspace(void);
+int ubv_sumsq_f32(const float* x, int64_t n, float* out, void* workspace, void* stream);
+int ubv_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int64_t* step, const float* sumsq, float max_norm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,3 +137,33 @@ def test_ffn_activation_in_gemm_epilogues(dtype, p, monkeypatch):
         torch.testing.assert_close(a[1].double(), x.grad, rtol=2e-4, atol=2e-4)
         for got, want in zip(a[2:], (w1.grad, b1.grad, w2.grad, b2.grad)):
             torch.testing.assert_close(got.double(), want, rtol=2e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize('max_norm', [None, 0.5])
+def test_flat_adamw_matches_torch_adamw_with_clipping(max_norm):
+    """ubv_sumsq_f32 + ubv_adamw_flat over flat buffers against torch.nn.utils.clip_grad_norm_ +
+    torch.optim.AdamW, five steps, odd tensor sizes (tail handling)."""
+    from unibev_amd.dp import FlatGradients
+    from unibev_amd.optim import FlatAdamW
+    torch.manual_seed(2)
+    shapes = [(257, 33), (5,), (64, 64), (3, 7, 11), (1,)]
+    mine = [torch.nn.Parameter(torch.randn(*s, device=DEV)) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    fg = FlatGradients(mine)
+    fg.attach()
+    opt = FlatAdamW(mine, fg, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, max_grad_norm=max_norm)
+    topt = torch.optim.AdamW(ref, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    for it in range(5):
+        gs = [torch.randn(*s, device=DEV) * (0.1 + it) for s in shapes]
+        for p, r, g in zip(mine, ref, gs):
+            p.grad.copy_(g)
+            r.grad = g.clone()
+        if max_norm is not None:
+            tn = torch.nn.utils.clip_grad_norm_(ref, max_norm)
+        topt.step()
+        opt.step()
+        if max_norm is not None:
+            assert abs(opt.grad_norm() - float(tn)) < 1e-4 * float(tn)
+        for p, r in zip(mine, ref):
+            torch.testing.assert_close(p.detach(), r.detach(), rtol=2e-6, atol=2e-7)
+    assert all(p.data_ptr() >= opt.flat.data_ptr() for p in mine)      # parameters live in the flat buffer
