@@ -327,12 +327,19 @@ def gemm_record(device, bs):
               ('offsets+logits (P=4)', 96, C), ('ffn up', 2 * C, C), ('ffn down', C, 2 * C)]
 
     def clock(fn, n=20):
+        """Device time per call: n calls captured in one HIP graph (an eager loop is host-bound below ~25 us
+        per call), replayed and timed with events."""
         for _ in range(3):
             fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=torch.cuda.current_stream()):
+            for _ in range(n):
+                fn()
+        g.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(n):
-            fn()
+        g.replay()
         e1.record()
         torch.cuda.synchronize()
         return 1e3 * e0.elapsed_time(e1) / n
@@ -341,10 +348,12 @@ def gemm_record(device, bs):
     for dname, dt in (('bf16', torch.bfloat16), ('fp32', torch.float32)):
         for label, N, K in shapes:
             x = torch.randn(M, K, device=device, dtype=dt)
-            w = torch.randn(N, K, device=device) / K ** 0.5          # f32 master weights, as in the model
-            b = torch.zeros(N, device=device)
+            w = torch.nn.Parameter(torch.randn(N, K, device=device) / K ** 0.5)   # f32 master weights, as in the model
+            b = torch.nn.Parameter(torch.zeros(N, device=device))
             gy = torch.randn(M, N, device=device, dtype=dt)
-            with torch.no_grad(), torch.autocast('cuda', dtype=dt, enabled=dt != torch.float32):
+            from unibev_amd.linear import lowp_step_cache
+            # (inside the step cache: the 16-bit / split copies of the weights are made once per step, not per call)
+            with torch.no_grad(), torch.autocast('cuda', dtype=dt, enabled=dt != torch.float32), lowp_step_cache():
                 us = clock(lambda: ubv_linear(x, w, b))
             us_w = clock(lambda: UF.gemm_wgrad(gy, x))
             flops = 2.0 * M * N * K
@@ -422,8 +431,8 @@ def middle_encoder_record(device, feats, coors, bs=2):
         torch.cuda.synchronize()
         out[name] = e0.elapsed_time(e1) / 5
     out.update(batch=bs, voxels_per_sample=int(feats.shape[0]), out_shape=list(fwd().shape),
-               note='SubM / strided sparse convs as gather + MFMA over neighbour maps; weight gradients as batched '
-                    'library GEMMs over gathered rows; 4 host syncs per pass (output counts of the strided convs)')
+               note='SubM / strided sparse convs as gather + MFMA over neighbour maps; weight gradients on the split-K MFMA '
+                    'kernel over gathered rows; 4 host syncs per pass (output counts of the strided convs)')
     return out
 
 
