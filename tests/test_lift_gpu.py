@@ -205,8 +205,9 @@ def test_lift_backward_camera_mode_bands_and_chunks():
         assert bad.sum() <= 1e-5 * bad.size + 1, int(bad.sum())       # pixel-boundary discontinuities
 
 
+@pytest.mark.parametrize('grid', [True, False])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-def test_lift_backward_maps_plan_heavy_buckets(dtype):
+def test_lift_backward_maps_plan_heavy_buckets(dtype, grid):
     """Large per-camera maps (25x45: the MAPS plan, exact CSR buckets + work items).  All reference
     points sit in a 3-pixel patch, so a few buckets hold tens of thousands of records and are cut into
     many work items whose partial tiles are summed in order: grad_value vs the fp64 oracle, and two
@@ -235,7 +236,8 @@ def test_lift_backward_maps_plan_heavy_buckets(dtype):
         v = t(value, dtype, DEV).requires_grad_()
         ol = t(offlog, torch.float32, DEV).requires_grad_()
         out = bev_lift(v, ol, t(ref, torch.float32, DEV), Nc, (fh, fw), H, P,
-                       vis0=t(vis0.astype(np.uint8), device=DEV), count=t(count, device=DEV), query_grid=(qh, qw))
+                       vis0=t(vis0.astype(np.uint8), device=DEV), count=t(count, device=DEV),
+                       query_grid=(qh, qw) if grid else None)      # None: queries in list order (64 per wave)
         out.backward(t(gout, dtype, DEV))
         got.append(v.grad.clone())
     # records enter a bucket in arrival order (as on the GRID plan): launches agree to the order of the f32 sums
