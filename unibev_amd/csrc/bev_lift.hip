@@ -675,12 +675,17 @@ __device__ __forceinline__ bool tile_own(const Footprint& f, float w, bool valid
 
 constexpr int kAStride = 40;      // u16 per A row: 32 point slots + 8 pad (80 B: conflict-free b128 reads)
 
-// Per-wave LDS carve (u16 units): A_hi[32*RB][kAStride] (+ A_lo), G_hi[32][DH] (+ G_lo)
+// grad_out rows in LDS: DH + 8 halves per row.  With DH = 32 halves (64 bytes) a lane's row started on the same 4
+// bank groups as every 4th other lane's: PMC showed 46 % of the f32 owner-tile kernel's LDS cycles as bank
+// conflicts (8-way on the 8-byte hi / lo stores).  80-byte rows spread 16 consecutive rows over all 64 banks.
+template <int DH> struct GRow { static constexpr int kStride = DH + 8; };
+
+// Per-wave LDS carve (u16 units): A_hi[32*RB][kAStride] (+ A_lo), G_hi[32][DH + 8] (+ G_lo)
 template <typename T, int DH, int RB>
 struct TileLds {
   static constexpr bool kSplit = mma_traits<T>::kSplit;
   static constexpr int kA = 32 * RB * kAStride;
-  static constexpr int kG = 32 * DH;
+  static constexpr int kG = 32 * GRow<DH>::kStride;
   static constexpr int kWords = (kA + kG) * (kSplit ? 2 : 1);      // u16 per wave
 };
 
@@ -689,21 +694,25 @@ template <typename T, int DH, int NV>
 __device__ __forceinline__ void stage_row(uint16_t* __restrict__ g_hi, uint16_t* __restrict__ g_lo,
                                           int slot, const uint4 (&v)[NV]) {
   using M = mma_traits<T>;
+  constexpr int GS = GRow<DH>::kStride;
   if constexpr (!M::kSplit) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) reinterpret_cast<uint4*>(g_hi + slot * DH)[i] = v[i];
+    for (int i = 0; i < NV; ++i) reinterpret_cast<uint4*>(g_hi + slot * GS)[i] = v[i];
   } else {
+    static_assert(NV % 2 == 0, "pairs of 4-channel loads");
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const float f[4] = {__uint_as_float(v[i].x), __uint_as_float(v[i].y), __uint_as_float(v[i].z),
-                          __uint_as_float(v[i].w)};
-      uint16_t hi[4], lo[4];
+    for (int i = 0; i < NV; i += 2) {                    // 8 channels -> one 16-byte store per plane
+      const float f[8] = {__uint_as_float(v[i].x), __uint_as_float(v[i].y), __uint_as_float(v[i].z),
+                          __uint_as_float(v[i].w), __uint_as_float(v[i + 1].x), __uint_as_float(v[i + 1].y),
+                          __uint_as_float(v[i + 1].z), __uint_as_float(v[i + 1].w)};
+      uint32_t hi[4], lo[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { hi[k] = M::enc(f[k]); lo[k] = M::enc(f[k] - M::dec(hi[k])); }
-      reinterpret_cast<uint2*>(g_hi + slot * DH)[i] =
-          make_uint2(hi[0] | ((uint32_t)hi[1] << 16), hi[2] | ((uint32_t)hi[3] << 16));
-      reinterpret_cast<uint2*>(g_lo + slot * DH)[i] =
-          make_uint2(lo[0] | ((uint32_t)lo[1] << 16), lo[2] | ((uint32_t)lo[3] << 16));
+      for (int k = 0; k < 4; ++k) {
+        hi[k] = cvt_pk_bf16(f[2 * k], f[2 * k + 1]);
+        lo[k] = cvt_pk_bf16(f[2 * k] - __uint_as_float(hi[k] << 16), f[2 * k + 1] - __uint_as_float(hi[k] & 0xffff0000u));
+      }
+      reinterpret_cast<uint4*>(g_hi + slot * GS)[i / 2] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+      reinterpret_cast<uint4*>(g_lo + slot * GS)[i / 2] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     }
   }
 }
@@ -740,8 +749,8 @@ struct TileAcc {
       uint16_t bh[8], bl[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        bh[j] = g_hi[(kb * 16 + kg * 8 + j) * DH + nn];
-        if (M::kSplit) bl[j] = g_lo[(kb * 16 + kg * 8 + j) * DH + nn];
+        bh[j] = g_hi[(kb * 16 + kg * 8 + j) * GRow<DH>::kStride + nn];
+        if (M::kSplit) bl[j] = g_lo[(kb * 16 + kg * 8 + j) * GRow<DH>::kStride + nn];
       }
       uint4 b_hi, b_lo;
       b_hi.x = bh[0] | ((uint32_t)bh[1] << 16); b_hi.y = bh[2] | ((uint32_t)bh[3] << 16);
@@ -885,7 +894,7 @@ template <typename T, int DH, int RB>
 struct CamLds {
   static constexpr bool kSplit = mma_traits<T>::kSplit;
   static constexpr int kA = 32 * RB * kCStride;
-  static constexpr int kG = 64 * DH;
+  static constexpr int kG = 64 * GRow<DH>::kStride;
   static constexpr int kWords = (kA + kG) * (kSplit ? 2 : 1);      // u16 per wave
 };
 
@@ -970,8 +979,8 @@ __global__ __launch_bounds__(256) void lift_bwd_value_camera_kernel(const LiftAr
       uint16_t bh[8], bl[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        bh[j] = g_hi[(kb * 16 + kg * 8 + j) * DH + nn];
-        if (M::kSplit) bl[j] = g_lo[(kb * 16 + kg * 8 + j) * DH + nn];
+        bh[j] = g_hi[(kb * 16 + kg * 8 + j) * GRow<DH>::kStride + nn];
+        if (M::kSplit) bl[j] = g_lo[(kb * 16 + kg * 8 + j) * GRow<DH>::kStride + nn];
       }
       b_hi[kb] = make_uint4(bh[0] | ((uint32_t)bh[1] << 16), bh[2] | ((uint32_t)bh[3] << 16),
                             bh[4] | ((uint32_t)bh[5] << 16), bh[6] | ((uint32_t)bh[7] << 16));
