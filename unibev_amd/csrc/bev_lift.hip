@@ -261,6 +261,10 @@ __device__ __forceinline__ float add_xor(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
   else if constexpr (M == 2)
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+  else if constexpr (M == 4)
+    // third step of a 1-2-4 butterfly: the lanes of a quad already agree, so "the other quad of my 8 lanes" is
+    // as good as "lane ^ 4" — DPP row_half_mirror (lane i <- lane 7 - i) instead of a ds_bpermute through LDS
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));
   else
     return v + __shfl_xor(v, M, 64);
 }

@@ -44,6 +44,8 @@ template <int M> __device__ __forceinline__ float max_xor(float v) {
     return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true)));
   else if constexpr (M == 2)
     return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true)));
+  else if constexpr (M == 4)       // after the 1- and 2-steps: row_half_mirror (see add_xor)
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true)));
   else
     return fmaxf(v, __shfl_xor(v, M, 64));
 }
