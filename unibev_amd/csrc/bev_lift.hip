@@ -1136,6 +1136,13 @@ template <typename T, int DH, int P>
 static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool cam_mfma, void* fwd_ws,
                         hipStream_t st) {
   constexpr int VEC = 16 / elem<T>::kBytes;
+  // shared-footprint kernels on f32 data: 8 channels per lane (two 16-byte loads per corner, 4 lanes per (query, head),
+  // DPP broadcasts) for the camera instances — 183 -> 148 us forward, 196 -> 175 us backward at 6 x 8x22 — and 4
+  // (8 lanes, ds_swizzle broadcasts) for the single-map ones, which lose 5 % with the wider lanes.
+  // UBV_LIFT_F32_VEC = 4 | 8 forces one.
+  constexpr int VECS = 8;
+  static const int f32_vec = getenv("UBV_LIFT_F32_VEC") ? atoi(getenv("UBV_LIFT_F32_VEC")) : 0;
+  const bool wide = sizeof(T) == 2 || (f32_vec == 0 ? a.Nc > 1 : f32_vec == 8);
   const int blocks = 8 * a.chunk;
   const LiftBytes nb = lift_bytes(a, DH, P, elem<T>::kBytes);
   char tag[96];
@@ -1167,9 +1174,15 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     static const int shared_env = getenv("UBV_LIFT_SHARED") ? atoi(getenv("UBV_LIFT_SHARED")) : 1;
     if (shared_env) {            // per-point arithmetic shared inside the lane group (bev_lift_shared.inl)
       if (sizeof(T) == 2 && a.ol16)
-        hipLaunchKernelGGL((lift_fwd_shared_kernel<T, DH, VEC, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+        {
+          if (wide) hipLaunchKernelGGL((lift_fwd_shared_kernel<T, DH, VECS, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+          else hipLaunchKernelGGL((lift_fwd_shared_kernel<T, DH, VEC, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+        }
       else
-        hipLaunchKernelGGL((lift_fwd_shared_kernel<T, DH, VEC, P, false>), dim3(blocks), dim3(256), 0, st, a);
+        {
+          if (wide) hipLaunchKernelGGL((lift_fwd_shared_kernel<T, DH, VECS, P, false>), dim3(blocks), dim3(256), 0, st, a);
+          else hipLaunchKernelGGL((lift_fwd_shared_kernel<T, DH, VEC, P, false>), dim3(blocks), dim3(256), 0, st, a);
+        }
       return;
     }
     if (sizeof(T) == 2 && a.ol16)
@@ -1239,9 +1252,15 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     {
       ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes);
       if (sizeof(T) == 2 && a.ol16)
-        hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+        {
+          if (wide) hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VECS, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+          else hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+        }
       else
-        hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, false>), dim3(blocks), dim3(256), 0, st, a);
+        {
+          if (wide) hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VECS, P, false>), dim3(blocks), dim3(256), 0, st, a);
+          else hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, false>), dim3(blocks), dim3(256), 0, st, a);
+        }
     }
     constexpr int RB = 2;
     const size_t lds = (size_t)t.waves * TileLds<T, DH, RB>::kWords * sizeof(uint16_t);
@@ -1272,9 +1291,15 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     {
       ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes);
       if (sizeof(T) == 2 && a.ol16)
-        hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+        {
+          if (wide) hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VECS, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+          else hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+        }
       else
-        hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, false>), dim3(blocks), dim3(256), 0, st, a);
+        {
+          if (wide) hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VECS, P, false>), dim3(blocks), dim3(256), 0, st, a);
+          else hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, false>), dim3(blocks), dim3(256), 0, st, a);
+        }
     }
     constexpr int RB = 2;
     const size_t lds = (size_t)4 * TileLds<T, DH, RB>::kWords * sizeof(uint16_t);
@@ -1330,9 +1355,15 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
       }
     }
     if (sizeof(T) == 2 && a.ol16)
-      hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+      {
+        if (wide) hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VECS, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+      }
     else
-      hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, false>), dim3(blocks), dim3(256), 0, st, a);
+      {
+        if (wide) hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VECS, P, false>), dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, false>), dim3(blocks), dim3(256), 0, st, a);
+      }
   }
 }
 

@@ -76,6 +76,17 @@ template <> struct vec_io<float, 4> {
   }
 };
 
+template <> struct vec_io<float, 8> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+    const float4 t = *reinterpret_cast<const float4*>(p), u = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; v[4] = u.x; v[5] = u.y; v[6] = u.z; v[7] = u.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
+
 template <> struct vec_io<f16_t, 8> {
   static __device__ __forceinline__ void load(const f16_t* p, float (&v)[8]) {
     using h8 = __attribute__((ext_vector_type(8))) _Float16;
