@@ -1414,7 +1414,7 @@ static int plan_backward(const LiftArgs& a, int Dh, int P, int dtype, int ref_is
     if (band > a.fh) band = a.fh;
     const int bands = band >= 1 ? (a.fh + band - 1) / band : 0;
     static const int maps_env = getenv("UBV_LIFT_MAPS") ? atoi(getenv("UBV_LIFT_MAPS")) : 1;
-    if (bands != 1 && (maps_env || band < 1 || bands > 8)) {
+    if ((bands != 1 && (maps_env || band < 1 || bands > 8)) || (maps_env == 2 && a.Nc > 1 && !cam_mfma_ok(a, Dh, P, dtype))) {
       // MAPS: maps of more than one band (bev_lift_maps.inl); UBV_LIFT_MAPS=0 keeps the band walk for A/B runs
       t.mode = 3;
       t.tile_w = t.tile_h = 8;
@@ -1616,9 +1616,15 @@ extern "C" int64_t ubv_bev_lift_backward_workspace(int B, int Nc, int fh, int fw
   a.B = B; a.Nc = Nc; a.fh = fh; a.fw = fw; a.H = H; a.Nq = Nq;
   a.qw = (qgrid_w > 0 && (long)qgrid_w * qgrid_h == Nq) ? qgrid_w : 0;
   a.qh = a.qw ? qgrid_h : 0;
-  ubv::TileArgs t{};
-  const int mode = ubv::plan_backward(a, Dh, P, UBV_BF16, ref_is_grid, t);
-  return (int64_t)ubv::lift_ws_bytes(mode, a, t, Dh, P);
+  // the plan can depend on the dtype (the matrix-core CAMERA plan is 16-bit only): the larger of the two
+  size_t need = 0;
+  for (int dt : {UBV_BF16, UBV_F32}) {
+    ubv::TileArgs t{};
+    const int mode = ubv::plan_backward(a, Dh, P, dt, ref_is_grid, t);
+    const size_t b = ubv::lift_ws_bytes(mode, a, t, Dh, P);
+    need = b > need ? b : need;
+  }
+  return (int64_t)need;
 }
 
 extern "C" int64_t ubv_visible_lists_elems(int Nc, int Nq) { return (int64_t)Nc * Nq + Nc; }
