@@ -1,3 +1,4 @@
+"""Middle-encoder loop for rocprofv3: python tools/profile_middle_encoder.py fwd|bwd (shipped-config size, bs = 2)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench

@@ -1,3 +1,4 @@
+"""Traces the call sites of the large element-wise framework ops of one f32 training step (TorchDispatchMode)."""
 import os, sys, torch, traceback, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench as B
