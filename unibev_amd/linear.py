@@ -260,6 +260,7 @@ class _Linear(Function):
         go2 = grad_out.reshape(-1, grad_out.shape[-1])
         gx = None
         if act is not None and act[0] == 'masked_in' and ctx.needs_input_grad[0]:
+            assert grad_alias is None, 'linear_after_relu_dropout has no pass-through output'
             # dX = (dY . W) * relu'/keep mask of the activation that produced this Linear's input, in the
             # GEMM epilogue (ubv_gemm_nt_act, act 2); the producing Linear then takes the gradient as is
             a2 = xc.reshape(-1, xc.shape[-1])

@@ -300,6 +300,8 @@ class SparseEncoder(nn.Module):
 
     def forward(self, voxel_features, coors, batch_size):
         """voxel_features [N, in_channels], coors [N, 4] (batch, z, y, x) -> (batch, C * D, H, W)."""
+        if voxel_features.shape[0] == 0:
+            raise ValueError('SparseEncoder: no voxels (BatchNorm over an empty set is undefined)')
         coors = coors.int()
         x = SparseConvTensor(voxel_features, coors.contiguous(), self.sparse_shape, batch_size)
         x = self.conv_input(x)
