@@ -45,10 +45,10 @@ def set_two_streams(on):
     _TWO_STREAMS[0] = bool(on)
 
 
-def _side_streams(device):
+def _side_stream(device):
     key = device.index
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device)
     return _SIDE_STREAMS[key]
 
 @TRANSFORMER.register_module()
@@ -304,23 +304,22 @@ class UniBEVTransformer(BaseModule):
 
         ref_q = q_img if img_mlvl_feats is not None else q_pts
         if img_mlvl_feats is not None and pts_mlvl_feats is not None and ref_q.is_cuda and _TWO_STREAMS[0]:
-            # The two encoders are independent until the fusion: each on its own HIP stream, forked
+            # The two encoders are independent until the fusion: two HIP streams, forked
             # from and joined into the caller's (autograd replays every backward op on its forward
             # op's stream, so the backward forks the same way).  Most kernels of the path leave part
             # of the chip idle — tails of 1.2 - 1.6 block rounds, latency-bound GEMM phases next to
             # issue-bound sampling kernels — and the other encoder's kernels fill it.
             dev = ref_q.device
             cur = torch.cuda.current_stream(dev)
-            sa, sb = _side_streams(dev)
-            sa.wait_stream(cur)
-            sb.wait_stream(cur)
-            with torch.cuda.stream(sa):
-                img_bev_embed = run_img()
-            with torch.cuda.stream(sb):
+            side = _side_stream(dev)
+            # the image encoder stays on the caller's stream, the point-cloud encoder gets the side stream: two
+            # active streams (three — caller idle + one per encoder — measured the same, and a fourth stream of
+            # any kind, e.g. RCCL's, then falls back to the single-stream time)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
                 pts_bev_embed = run_pts()
-            cur.wait_stream(sa)
-            cur.wait_stream(sb)
-            img_bev_embed.record_stream(cur)
+            img_bev_embed = run_img()
+            cur.wait_stream(side)
             pts_bev_embed.record_stream(cur)
         else:
             if img_mlvl_feats is not None:
