@@ -40,3 +40,27 @@ def test_batch_norm_uses_only_active_sites():
     out = R.batch_norm(dense, mask, torch.ones(1), torch.zeros(1), 0.0)
     assert torch.allclose(out[0, 0, 0, 0, 0], torch.tensor(-1.0)) and torch.allclose(out[0, 0, 1, 1, 1], torch.tensor(1.0))
     assert float(out.abs().sum()) == 2.0
+
+
+def test_sparse_encoder_state_dict_follows_the_mmdet3d_layout():
+    """Key names and shapes of the shipped L / LC configs' middle encoder (mmdet3d 0.18.1 SparseEncoder with
+    basic blocks; spconv 1.x weight layout (kz, ky, kx, Cin, Cout)) — what a reference checkpoint holds."""
+    from unibev_amd.registry import MIDDLE_ENCODERS, build_from_cfg
+    enc = build_from_cfg(dict(type='SparseEncoder', in_channels=5, sparse_shape=[41, 1440, 1440], output_channels=128,
+                              order=('conv', 'norm', 'act'),
+                              encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+                              encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)),
+                              block_type='basicblock'), MIDDLE_ENCODERS)
+    sd = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    assert sd['conv_input.0.weight'] == (3, 3, 3, 5, 16)
+    assert sd['conv_input.1.weight'] == (16,) and 'conv_input.1.running_var' in sd
+    assert sd['encoder_layers.encoder_layer1.0.conv1.weight'] == (3, 3, 3, 16, 16)
+    assert sd['encoder_layers.encoder_layer1.0.bn2.bias'] == (16,)
+    assert sd['encoder_layers.encoder_layer1.2.0.weight'] == (3, 3, 3, 16, 32)       # strided SparseConv3d
+    assert sd['encoder_layers.encoder_layer3.2.0.weight'] == (3, 3, 3, 64, 128)
+    assert sd['encoder_layers.encoder_layer4.1.conv2.weight'] == (3, 3, 3, 128, 128)
+    assert 'encoder_layers.encoder_layer4.2.0.weight' not in sd                      # last stage: blocks only
+    assert sd['conv_out.0.weight'] == (3, 1, 1, 128, 128)
+    assert not any(k.endswith('.bias') and '.conv' in k for k in sd)                 # convolutions carry no bias
+    stage3 = enc.encoder_layers.encoder_layer3[2][0]
+    assert stage3.padding == (0, 1, 1) and stage3.stride == (2, 2, 2) and stage3.indice_key == 'spconv3'
