@@ -159,8 +159,9 @@ def test_sca_modules_vs_reference_vectors():
                   bev_mask=t(g['img_mask'], device=DEV), spatial_shapes=shapes_tensor([(fh, fw)], DEV),
                   level_start_index=torch.zeros(1, dtype=torch.long, device=DEV))
         np.testing.assert_allclose(out.cpu().numpy(), g['img_out'], rtol=1e-4, atol=1e-4)
-        # the padded re-batch path (what the reference literally does) gives the same answer
-        slots = sca._rebatch_path(query, value.permute(2, 0, 1, 3).reshape(bs * nc, fh * fw, C),
+        # the fallback for shapes the fused kernel rejects (k1 per camera over all queries, invisible rows
+        # masked) gives the same answer
+        slots = sca._masked_path(query, value.permute(2, 0, 1, 3).reshape(bs * nc, fh * fw, C),
                                   t(g['img_cam'], device=DEV), t(g['img_mask'], device=DEV),
                                   shapes_tensor([(fh, fw)], DEV),
                                   torch.zeros(1, dtype=torch.long, device=DEV))

@@ -81,37 +81,31 @@ class SpatialCrossAttentionImg(BaseModule):
                                 vis0=vis0, count=count, query_grid=kwargs.get('query_grid'),
                                 visible_lists=kwargs.get('cam_lists') if kwargs.get('cam_vis0') is not None else None)
         else:
-            slots = self._rebatch_path(query, value, reference_points_cam, bev_mask,
-                                       spatial_shapes, level_start_index)
+            slots = self._masked_path(query, value, reference_points_cam, bev_mask,
+                                      spatial_shapes, level_start_index)
         slots = ubv_linear(slots, self.output_proj.weight, self.output_proj.bias)
         if kwargs.get('return_parts'):            # the caller fuses dropout + residual + LayerNorm
             return slots, inp_residual, self.dropout.p
         return self.dropout(slots) + inp_residual
 
-    def _rebatch_path(self, query, value, reference_points_cam, bev_mask, spatial_shapes,
-                      level_start_index):
-        """The reference's algorithm verbatim in behaviour (spatial_cross_attention_img.py:141-212),
-        for shapes the fused kernel does not cover (multi-level maps, unusual head sizes).  Uses
-        the k1 operator through ``deformable_attention``; pays the reference's host syncs."""
-        bs, num_query, _ = query.size()
-        D = reference_points_cam.size(3)
-        indexes = [m[0].sum(-1).nonzero().squeeze(-1) for m in bev_mask]
-        max_len = max(len(i) for i in indexes)
+    def _masked_path(self, query, value, reference_points_cam, bev_mask, spatial_shapes,
+                     level_start_index):
+        """Shapes the fused kernel does not cover (multi-level maps, unusual head sizes): every camera samples
+        for EVERY query through the k1 operator, and the rows a camera does not see are zeroed afterwards.
+        The reference first gathers each camera's visible rows — chosen by batch element 0's mask, quirk q1 —
+        into padded per-camera batches (spatial_cross_attention_img.py:141-212), which needs their counts on the
+        host; masking gives the same sums without a read-back, at num_cams times the sampling work."""
+        bs, num_query, C = query.shape
+        seen = bev_mask.any(-1)                                          # (Nc, B, Nq)
+        per_cam = value.view(bs, self.num_cams, -1, C)
         slots = torch.zeros_like(query)
-        queries_rebatch = query.new_zeros([bs, self.num_cams, max_len, self.embed_dims])
-        ref_rebatch = reference_points_cam.new_zeros([bs, self.num_cams, max_len, D, 2])
-        for i, idx in enumerate(indexes):
-            queries_rebatch[:, i, :len(idx)] = query[:, idx]
-            ref_rebatch[:, i, :len(idx)] = reference_points_cam[i][:, idx]
-        out = self.deformable_attention(
-            query=queries_rebatch.view(bs * self.num_cams, max_len, self.embed_dims), key=value,
-            value=value, reference_points=ref_rebatch.view(bs * self.num_cams, max_len, D, 2),
-            spatial_shapes=spatial_shapes, level_start_index=level_start_index)
-        out = out.view(bs, self.num_cams, max_len, self.embed_dims)
-        for i, idx in enumerate(indexes):
-            slots[:, idx] += out[:, i, :len(idx)]
-        count = (bev_mask.sum(-1) > 0).permute(1, 2, 0).sum(-1)
-        count = torch.clamp(count, min=1.0)
+        for cam in range(self.num_cams):
+            v = per_cam[:, cam].contiguous()
+            out = self.deformable_attention(query=query, key=v, value=v,
+                                            reference_points=reference_points_cam[cam],
+                                            spatial_shapes=spatial_shapes, level_start_index=level_start_index)
+            slots = slots + out * seen[cam, 0].to(out.dtype)[None, :, None]
+        count = seen.sum(0).clamp(min=1).to(slots.dtype)                 # (B, Nq): cameras that see the query
         return slots / count[..., None]
 
 
