@@ -39,6 +39,20 @@ template <int LP> __device__ __forceinline__ float bcast_f(float v, int owner) {
   return __int_as_float(bcast_i<LP>(__float_as_int(v), owner));
 }
 
+// c + a.lo * b.lo + a.hi * b.hi on packed 16-bit pairs (v_dot2c_f32_bf16 / v_dot2c_f32_f16): the dot product of a
+// gathered value row with the grad_out slice without unpacking either (8 shifts / masks + 8 FMAs -> 4 dot2 per 8
+// channels).
+template <typename T> __device__ __forceinline__ float dot2_pk(uint32_t a, uint32_t b, float c);
+template <> __device__ __forceinline__ float dot2_pk<bf16_t>(uint32_t a, uint32_t b, float c) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a), __builtin_bit_cast(bf2, b), c, false);
+}
+template <> __device__ __forceinline__ float dot2_pk<f16_t>(uint32_t a, uint32_t b, float c) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b), c, false);
+}
+template <> __device__ __forceinline__ float dot2_pk<float>(uint32_t, uint32_t, float c) { return c; }   // unused
+
 template <int M> __device__ __forceinline__ float max_xor(float v) {
   if constexpr (M == 1)
     return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true)));
@@ -197,14 +211,23 @@ __global__ __launch_bounds__(256) void lift_bwd_query_shared_kernel(const LiftAr
     const long bq = (long)b * a.Nq + q;
     float ox[NOWN], oy[NOWN], w_own[NOWN];
     own_points<T, P, LP, OL16>(a, bq, h, cg, ox, oy, w_own);
+    // 16-bit data with 8 channels per lane: grad_out stays packed and the dots are v_dot2c; the 1 / count and
+    // validity factors are applied to the (group-uniform) dot afterwards
+    constexpr bool PK = sizeof(T) == 2 && VEC == 8;
     float go[VEC];
-    vec_io<T, VEC>::load(gout + bq * row + h * DH + cg * VEC, go);
+    uint4 gop = make_uint4(0u, 0u, 0u, 0u);
     const float inv = valid ? 1.0f : 0.0f;
     const float cnt = (a.count != nullptr) ? a.count[bq] : 1.0f;
     const float inv_cnt = 1.0f / cnt;
+    const float gscale = (a.count != nullptr ? inv_cnt : 1.0f) * inv;
+    if constexpr (PK) {
+      gop = *reinterpret_cast<const uint4*>(gout + bq * row + h * DH + cg * VEC);
+    } else {
+      vec_io<T, VEC>::load(gout + bq * row + h * DH + cg * VEC, go);
 #pragma unroll
-    for (int i = 0; i < VEC; ++i)
-      go[i] = (a.count != nullptr ? div_or_mul<FAST>(go[i], cnt, inv_cnt) : go[i]) * inv;
+      for (int i = 0; i < VEC; ++i)
+        go[i] = (a.count != nullptr ? div_or_mul<FAST>(go[i], cnt, inv_cnt) : go[i]) * inv;
+    }
     float gw[NOWN], gx[NOWN], gy[NOWN];
 #pragma unroll
     for (int s = 0; s < NOWN; ++s) { gw[s] = 0.0f; gx[s] = 0.0f; gy[s] = 0.0f; }
@@ -232,12 +255,19 @@ __global__ __launch_bounds__(256) void lift_bwd_query_shared_kernel(const LiftAr
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int idx = bcast_i<LP>(oi[s][k], owner);
-          float v[VEC];
-          vec_io<T, VEC>::load(vb + idx, v);
           float d = 0.0f;
+          if constexpr (PK) {
+            const uint4 vp = *reinterpret_cast<const uint4*>(vb + idx);
+            d = dot2_pk<T>(gop.x, vp.x, d); d = dot2_pk<T>(gop.y, vp.y, d);
+            d = dot2_pk<T>(gop.z, vp.z, d); d = dot2_pk<T>(gop.w, vp.w, d);
+            dot[k] = group_sum<LP>(d) * gscale;             // every lane of the group holds the full dot
+          } else {
+            float v[VEC];
+            vec_io<T, VEC>::load(vb + idx, v);
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) d = fmaf(go[i], v[i], d);
-          dot[k] = group_sum<LP>(d);                        // every lane of the group holds the full dot
+            for (int i = 0; i < VEC; ++i) d = fmaf(go[i], v[i], d);
+            dot[k] = group_sum<LP>(d);
+          }
         }
         // (measured: reducing the 4 dots per point and letting the owner combine them beats keeping 3P
         //  partial sums per lane and reducing those at the end — 61 vs 79 us on the self-attention shape)
