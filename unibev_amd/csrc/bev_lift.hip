@@ -1500,8 +1500,8 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_g
   UBV_CHECK_ARG(a.B > 0 && a.Nc > 0 && a.fh > 0 && a.fw > 0 && a.H > 0 && a.Nq > 0 && a.Z > 0,
                 "bev_lift: non-positive dimension");
   UBV_CHECK_ARG(P % a.Z == 0, "bev_lift: num_points %d not a multiple of Z %d", P, a.Z);
-  UBV_CHECK_ARG((long)a.fh * a.fw * a.H * Dh < (1L << 31),
-                "bev_lift: one value map must hold fewer than 2^31 elements");
+  UBV_CHECK_ARG((long)a.fh * a.fw * a.H * Dh < (1L << 30),
+                "bev_lift: one value map must hold fewer than 2^30 elements (32-bit byte offsets)");
   if (!lift_shape_ok(a.H, Dh, P, dtype)) {
     set_error("bev_lift: no kernel for H=%d Dh=%d P=%d dtype=%d", a.H, Dh, P, dtype);
     return UBV_ERR_UNSUPPORTED;

@@ -53,6 +53,12 @@ template <> __device__ __forceinline__ float dot2_pk<f16_t>(uint32_t a, uint32_t
 }
 template <> __device__ __forceinline__ float dot2_pk<float>(uint32_t, uint32_t, float c) { return c; }   // unused
 
+// base (wave-uniform) + element offset as a 32-bit BYTE offset (the host checks that one map stays below 4 GiB):
+// lets the backend emit global_load with a scalar base and a 32-bit vector offset
+template <typename T> __device__ __forceinline__ const T* gather_ptr(const T* base, unsigned elem_off) {
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (unsigned)(elem_off * (unsigned)sizeof(T)));
+}
+
 template <int M> __device__ __forceinline__ float max_xor(float v) {
   if constexpr (M == 1)
     return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true)));
@@ -133,7 +139,8 @@ __global__ __launch_bounds__(256) void lift_fwd_shared_kernel(const LiftArgs a) 
   for (int li0 = 0; li0 < 64; li0 += 4 * QW) {
     int b, q;
     const bool valid = lift_query(a, item, li0 + wv * QW + sub, b, q);
-    if (!valid) { b = 0; q = 0; }                   // keep every lane in the group operations
+    if (!valid) q = 0;                              // keep every lane in the group operations
+    b = __builtin_amdgcn_readfirstlane(b);          // a wave's queries share the sample: scalar base addresses
     const long bq = (long)b * a.Nq + q;
     float ox[NOWN], oy[NOWN], w_own[NOWN];
     own_points<T, P, LP, OL16>(a, bq, h, cg, ox, oy, w_own);
@@ -156,7 +163,10 @@ __global__ __launch_bounds__(256) void lift_fwd_shared_kernel(const LiftArgs a) 
 #pragma unroll
         for (int k = 0; k < 4; ++k) { oi[s][k] = f.idx[k] * rowi; oc[s][k] = w_own[s] * f.w[k]; }
       }
-      const T* vb = value + ((long)b * a.Nc + cam) * S * row + h * DH + cg * VEC;
+      // wave-uniform base (scalar registers) + 32-bit per-lane element offset: global_load with an SGPR base,
+      // no 64-bit address arithmetic per gather
+      const T* vb = value + ((long)b * a.Nc + cam) * S * row;
+      const unsigned lane_off = (unsigned)(h * DH + cg * VEC);
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         constexpr int dummy = 0; (void)dummy;
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(256) void lift_fwd_shared_kernel(const LiftArgs a) 
           const int idx = bcast_i<LP>(oi[s][k], owner);
           const float c = bcast_f<LP>(oc[s][k], owner);
           float v[VEC];
-          vec_io<T, VEC>::load(vb + idx, v);
+          vec_io<T, VEC>::load(gather_ptr(vb, (unsigned)idx + lane_off), v);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) acc[i] = fmaf(c, v[i], acc[i]);
         }
@@ -207,7 +217,8 @@ __global__ __launch_bounds__(256) void lift_bwd_query_shared_kernel(const LiftAr
   for (int li0 = 0; li0 < 64; li0 += 4 * QW) {
     int b, q;
     const bool valid = lift_query(a, item, li0 + wv * QW + sub, b, q);
-    if (!valid) { b = 0; q = 0; }
+    if (!valid) q = 0;
+    b = __builtin_amdgcn_readfirstlane(b);
     const long bq = (long)b * a.Nq + q;
     float ox[NOWN], oy[NOWN], w_own[NOWN];
     own_points<T, P, LP, OL16>(a, bq, h, cg, ox, oy, w_own);
@@ -247,7 +258,10 @@ __global__ __launch_bounds__(256) void lift_bwd_query_shared_kernel(const LiftAr
 #pragma unroll
         for (int k = 0; k < 4; ++k) { oi[s][k] = f.idx[k] * rowi; om[s][k] = f.m[k]; }
       }
-      const T* vb = value + ((long)b * a.Nc + cam) * S * row + h * DH + cg * VEC;
+      // wave-uniform base (scalar registers) + 32-bit per-lane element offset: global_load with an SGPR base,
+      // no 64-bit address arithmetic per gather
+      const T* vb = value + ((long)b * a.Nc + cam) * S * row;
+      const unsigned lane_off = (unsigned)(h * DH + cg * VEC);
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int s = p / LP, owner = p % LP;
@@ -257,13 +271,13 @@ __global__ __launch_bounds__(256) void lift_bwd_query_shared_kernel(const LiftAr
           const int idx = bcast_i<LP>(oi[s][k], owner);
           float d = 0.0f;
           if constexpr (PK) {
-            const uint4 vp = *reinterpret_cast<const uint4*>(vb + idx);
+            const uint4 vp = *reinterpret_cast<const uint4*>(gather_ptr(vb, (unsigned)idx + lane_off));
             d = dot2_pk<T>(gop.x, vp.x, d); d = dot2_pk<T>(gop.y, vp.y, d);
             d = dot2_pk<T>(gop.z, vp.z, d); d = dot2_pk<T>(gop.w, vp.w, d);
             dot[k] = group_sum<LP>(d) * gscale;             // every lane of the group holds the full dot
           } else {
             float v[VEC];
-            vec_io<T, VEC>::load(vb + idx, v);
+            vec_io<T, VEC>::load(gather_ptr(vb, (unsigned)idx + lane_off), v);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) d = fmaf(go[i], v[i], d);
             dot[k] = group_sum<LP>(d);
