@@ -333,7 +333,7 @@ def gemm_record(device, bs):
             fn()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=torch.cuda.current_stream()):
+        with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode='thread_local'):
             for _ in range(n):
                 fn()
         g.replay()

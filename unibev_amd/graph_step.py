@@ -94,7 +94,8 @@ class GraphedStep:
             self._clear_grads()
             UL.mark_weights_changed()                    # the refresh of the 16-bit weight shadows is part of the graph
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.pool, stream=self.stream):
+            # thread-local capture mode: other threads (RCCL's watchdog polling its events) stay free to call into HIP
+            with torch.cuda.graph(g, pool=self.pool, stream=self.stream, capture_error_mode='thread_local'):
                 self.out = self._fwd_bwd()
             if self.pool is None:
                 self.pool = g.pool()
