@@ -53,6 +53,11 @@ struct LiftArgs {
   int max_items;
 };
 
+// The wave's index inside its block as a SCALAR: threadIdx.x >> 6 is wave-uniform, but the compiler cannot know, and
+// everything decoded from it (tile, head, bucket, base addresses) would otherwise live in vector registers and be
+// computed with vector instructions.
+__device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 // Decode (b, q, valid) of the query this lane works on in iteration `it`.
 // n / d through the host-made reciprocal mg = floor(2^32 / d) + 1 (exact while n * d < 2^32; the host
 // passes 0 otherwise): an integer division is ~40 instructions, this is one.
@@ -395,7 +400,7 @@ template <typename T, int DH, int P, int MODE>
 __global__ __launch_bounds__(256) void lift_bin_kernel(const LiftArgs a, int tiles_x, int tiles) {
   // per wave: an 8x8 torus of tile slots — occupant tile, local count, global base
   __shared__ int slot_tile[4][64], slot_cnt[4][64], slot_base[4][64];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = wave_in_block(), lane = threadIdx.x & 63;
   slot_tile[wv][lane] = -1;
   slot_cnt[wv][lane] = 0;
   const long wave = (long)blockIdx.x * 4 + wv;
@@ -642,7 +647,7 @@ struct TileGeom {
 };
 
 __device__ __forceinline__ bool tile_decode(const LiftArgs& a, const TileArgs& t, TileGeom& g) {
-  const int item = xcd_remap(blockIdx.x, t.chunk) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+  const int item = xcd_remap(blockIdx.x, t.chunk) * (int)(blockDim.x >> 6) + wave_in_block();
   if (item >= t.total) return false;
   // item -> (b, cam, tile_y, tile_x, chunk, head); head fastest: neighbours share rows of grad_out
   int r = item;
@@ -827,7 +832,7 @@ __global__ __launch_bounds__(256, 3) void lift_bwd_value_kernel(const LiftArgs a
   TileGeom g;
   if (!tile_decode(a, t, g)) return;
   const int lane = threadIdx.x & 63;
-  uint16_t* __restrict__ lds = lds_all + (threadIdx.x >> 6) * L::kWords;
+  uint16_t* __restrict__ lds = lds_all + wave_in_block() * L::kWords;
   TileAcc<T, DH, RB> ta;
   ta.init(lds, lane);
   const long row = (long)a.H * DH;
@@ -855,22 +860,33 @@ __global__ __launch_bounds__(256, 3) void lift_bwd_value_kernel(const LiftArgs a
   // ---- store the tile: D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5);
   // tiles are 8 pixels wide, so the tile-local pixel index splits with a shift
   const bool rmw = cnt_raw > a.cap;                    // lift_ovf_* scattered part of this tile
+  // pixel (lx, ly) of accumulator element (rb, r): lx = (r & 3) + 4 (lane >> 5), ly = 4 rb + (r >> 2) — the lane
+  // part (column, its half's 4-pixel shift) is one 32-bit offset, the (rb, r) part is wave-uniform: scalar
+  // address arithmetic instead of a 64-bit multiply-add chain per element (it was a third of a self-attention
+  // tile's instructions)
   const long mbase = (long)g.b * a.fh * a.fw * row + g.h * DH;
-  float* __restrict__ gv = a.gvalue + mbase;
-  const int col = lane & 31;
+  const long tile0 = mbase + ((long)g.y0 * a.fw + g.x0) * row;         // wave-uniform
+  const int col = lane & 31, lxh = 4 * (lane >> 5);
   if (col < DH) {
+    const unsigned lane_off = (unsigned)(lxh * (int)row + col);
+    const unsigned rowstride = (unsigned)(a.fw * (int)row);
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int px = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int lx = px & 7, ly = px >> 3;
+        const int lx = (r & 3) + lxh, ly = 4 * rb + (r >> 2);
         if (lx < g.tw && ly < g.th) {
-          const long o = ((long)(g.y0 + ly) * a.fw + (g.x0 + lx)) * row + col;
+          const unsigned uo = (unsigned)ly * rowstride + (unsigned)(r & 3) * (unsigned)row;     // uniform
           float v = ta.acc[rb][r];
-          if (rmw) v += gv[o];
-          if (sizeof(T) == 2 && a.gvalue_lp != nullptr) ((T*)a.gvalue_lp)[mbase + o] = elem<T>::from_float(v);
-          else gv[o] = v;
+          if (sizeof(T) == 2 && a.gvalue_lp != nullptr) {
+            T* dst = (T*)a.gvalue_lp + tile0 + uo;
+            if (rmw) v += (a.gvalue + tile0 + uo)[lane_off];
+            dst[lane_off] = elem<T>::from_float(v);
+          } else {
+            float* dst = a.gvalue + tile0 + uo;
+            if (rmw) v += dst[lane_off];
+            dst[lane_off] = v;
+          }
         }
       }
     }

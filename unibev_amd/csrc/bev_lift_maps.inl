@@ -60,7 +60,7 @@ template <typename T, int DH, int P, int RB>
 __global__ __launch_bounds__(256, 3) void lift_bwd_value_items_kernel(const LiftArgs a, const TileArgs t) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds_all[];
   using L = TileLds<T, DH, RB>;
-  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int item = blockIdx.x * 4 + wave_in_block();
   if (item >= *a.n_items) return;
   const int lane = threadIdx.x & 63;
   const int tiles = t.tiles_x * t.tiles_y;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, 3) void lift_bwd_value_items_kernel(const Lift
     g.tw = min(8, a.fw - g.x0); g.th = min(8, a.fh - g.y0);
     g.npx = 64;
   }
-  uint16_t* __restrict__ lds = lds_all + (threadIdx.x >> 6) * L::kWords;
+  uint16_t* __restrict__ lds = lds_all + wave_in_block() * L::kWords;
   TileAcc<T, DH, RB> ta;
   ta.init(lds, lane);
   const long row = (long)a.H * DH;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, 3) void lift_bwd_value_items_kernel(const Lift
 // One wave per multi-item bucket: its slabs summed in item order -> grad_value.
 template <typename T, int DH>
 __global__ __launch_bounds__(256) void maps_reduce_kernel(const LiftArgs a, int tiles_x, int tiles, int n) {
-  const int bk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int bk = blockIdx.x * 4 + wave_in_block();
   if (bk >= n) return;
   const int first = a.item_first[bk], nit = min(a.item_first[bk + 1], a.max_items) - first;
   if (nit <= 1) return;
