@@ -58,6 +58,12 @@ struct LiftArgs {
 // computed with vector instructions.
 __device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
+// base (wave-uniform) + element offset as a 32-bit BYTE offset (the host checks that one map / one sample's rows
+// stay below 4 GiB): lets the backend emit global_load with a scalar base and a 32-bit vector offset
+template <typename T> __device__ __forceinline__ const T* gather_ptr(const T* base, unsigned elem_off) {
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (unsigned)(elem_off * (unsigned)sizeof(T)));
+}
+
 // Decode (b, q, valid) of the query this lane works on in iteration `it`.
 // n / d through the host-made reciprocal mg = floor(2^32 / d) + 1 (exact while n * d < 2^32; the host
 // passes 0 otherwise): an integer division is ~40 instructions, this is one.
@@ -786,8 +792,9 @@ struct TileAcc {
   }
 
   // Adds the owned points of one batch (one point per lane).
+  // grad_out row of the lane's record: grow_base (wave-uniform: sample, head) + grow_off elements (query * row)
   __device__ __forceinline__ void add(const int (&lp)[4], const float (&cwt)[4], bool any,
-                                      const T* __restrict__ grow_ptr, int lane) {
+                                      const T* __restrict__ grow_base, unsigned grow_off, int lane) {
     const unsigned long long m = __ballot(any);
     if (m == 0ull) return;
     // issue the grad_out row loads first: a pending MFMA round (flush) below overlaps their latency
@@ -795,7 +802,7 @@ struct TileAcc {
     uint4 grow[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-      grow[i] = any ? reinterpret_cast<const uint4*>(grow_ptr)[i] : make_uint4(0, 0, 0, 0);
+      grow[i] = any ? reinterpret_cast<const uint4*>(gather_ptr(grow_base, grow_off))[i] : make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const unsigned int hm = (unsigned int)(m >> (32 * half));
@@ -854,7 +861,7 @@ __global__ __launch_bounds__(256, 3) void lift_bwd_value_kernel(const LiftArgs a
     float cwt[4];
     const Footprint f = footprint_px(rec.x, rec.y, a.fh, a.fw);
     const bool any = tile_own(f, rec.z, valid, g, t.tile_w, lp, cwt);
-    ta.add(lp, cwt, any, gout + ((long)g.b * a.Nq + q) * row + g.h * DH, lane);
+    ta.add(lp, cwt, any, gout + (long)g.b * a.Nq * row + g.h * DH, (unsigned)q * (unsigned)row, lane);
   }
   if (ta.fill > 0) ta.flush(lane);
   // ---- store the tile: D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5);
@@ -1516,8 +1523,8 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_g
   UBV_CHECK_ARG(a.B > 0 && a.Nc > 0 && a.fh > 0 && a.fw > 0 && a.H > 0 && a.Nq > 0 && a.Z > 0,
                 "bev_lift: non-positive dimension");
   UBV_CHECK_ARG(P % a.Z == 0, "bev_lift: num_points %d not a multiple of Z %d", P, a.Z);
-  UBV_CHECK_ARG((long)a.fh * a.fw * a.H * Dh < (1L << 30),
-                "bev_lift: one value map must hold fewer than 2^30 elements (32-bit byte offsets)");
+  UBV_CHECK_ARG((long)a.fh * a.fw * a.H * Dh < (1L << 30) && (long)a.Nq * a.H * Dh < (1L << 30),
+                "bev_lift: one value map / one sample's query rows must hold fewer than 2^30 elements (32-bit byte offsets)");
   if (!lift_shape_ok(a.H, Dh, P, dtype)) {
     set_error("bev_lift: no kernel for H=%d Dh=%d P=%d dtype=%d", a.H, Dh, P, dtype);
     return UBV_ERR_UNSUPPORTED;

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 3) void lift_bwd_value_items_kernel(const Lift
     float cwt[4];
     const Footprint f = footprint_px(rec.x, rec.y, a.fh, a.fw);
     const bool any = tile_own(f, rec.z, valid, g, 8, lp, cwt);
-    ta.add(lp, cwt, any, gout + ((long)g.b * a.Nq + q) * row + g.h * DH, lane);
+    ta.add(lp, cwt, any, gout + (long)g.b * a.Nq * row + g.h * DH, (unsigned)q * (unsigned)row, lane);
   }
   if (ta.fill > 0) ta.flush(lane);
   // ---- D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)

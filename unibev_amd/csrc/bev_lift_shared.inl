@@ -53,12 +53,6 @@ template <> __device__ __forceinline__ float dot2_pk<f16_t>(uint32_t a, uint32_t
 }
 template <> __device__ __forceinline__ float dot2_pk<float>(uint32_t, uint32_t, float c) { return c; }   // unused
 
-// base (wave-uniform) + element offset as a 32-bit BYTE offset (the host checks that one map stays below 4 GiB):
-// lets the backend emit global_load with a scalar base and a 32-bit vector offset
-template <typename T> __device__ __forceinline__ const T* gather_ptr(const T* base, unsigned elem_off) {
-  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (unsigned)(elem_off * (unsigned)sizeof(T)));
-}
-
 template <int M> __device__ __forceinline__ float max_xor(float v) {
   if constexpr (M == 1)
     return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true)));
