@@ -219,59 +219,86 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 3 : 2)) void gemm_nt_kernel(const v
     step(c, Set0{}, No{}, No{});
   }
   // ---- epilogue.  D[n][m]: column = this lane's row m, rows n = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-  // within a column block: 4 consecutive output columns per (block, r >> 2)
+  // within a column block: 4 consecutive output columns per (block, r >> 2).
+  // Stored directly, that is 16 bytes per lane on 32 different rows per instruction: 32-byte pieces that L2 has to
+  // merge into lines (skipping the stores took the 256 x 256 f32 GEMM from 51 to 35 us; non-temporal stores: 107).
+  // So the tile goes through LDS (free after the K loop) in two halves of 64 rows and leaves as whole rows: a wave
+  // store is two full rows of the tile; the residual / mask operands are read with the same pattern.
   const int half = lane >> 5;
   const uint64_t act_seed = act.seed + ((act.mode == 1 && act.seed_dev != nullptr) ? *act.seed_dev : 0ull);
+  using TO = typename std::conditional<OUT16, typename std::conditional<F16, f16_t, bf16_t>::type, float>::type;
+  constexpr bool STAGE = NT <= 128;
+  constexpr int TLD = NT + 4;                              // f32 per staged row: 16-byte shifts per row
+  float* tile = reinterpret_cast<float*>(lds);
 #pragma unroll
-  for (int i = 0; i < WMB; ++i) {
-    const long m = m0 + (wm * WMB + i) * 32 + fr;
-    if (m >= M) continue;
+  for (int hh = 0; hh < (STAGE ? 2 : 1); ++hh) {
+    if constexpr (STAGE) __syncthreads();                 // fragments consumed / previous half stored
 #pragma unroll
-    for (int j = 0; j < WNB; ++j) {
+    for (int i = 0; i < WMB; ++i) {
+      const int mrow = (wm * WMB + i) * 32 + fr;          // row inside the block tile
+      if (STAGE && (mrow >> 6) != hh) continue;           // (wave-uniform: a wave's rows lie in one half)
+      const long m = m0 + mrow;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + (wn * WNB + j) * 32 + 8 * g + 4 * half;
-        if (n >= N) continue;                             // N is a multiple of 32 (checked by the host)
-        float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-        if (bias != nullptr) {
-          const float4 b = *reinterpret_cast<const float4*>(bias + n);
-          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-        }
-        if (act.mode == 1) {
-          const uint64_t mix = act.thresh != 0u ? drop_mix64(act_seed, (uint64_t)(m * ldy + n) >> 2) : 0ull;
+      for (int j = 0; j < WNB; ++j) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float r = fmaxf(v[e], 0.0f);
-            if (act.thresh != 0u) r = drop_keep16(mix, e, act.thresh) ? r * act.scale : 0.0f;
-            v[e] = r;
+        for (int g = 0; g < 4; ++g) {
+          const int nl = (wn * WNB + j) * 32 + 8 * g + 4 * half, n = n0 + nl;
+          float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          if (bias != nullptr) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + n);
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
           }
-        } else if (act.mode == 2) {
-          float k4[4];
-          if constexpr (OUT16) {
-            using T = typename std::conditional<F16, f16_t, bf16_t>::type;
-            vec_io<T, 4>::load((const T*)act.mask + m * ldy + n, k4);
+          if (act.mode == 1) {
+            const uint64_t mix = act.thresh != 0u ? drop_mix64(act_seed, (uint64_t)(m * ldy + n) >> 2) : 0ull;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float r = fmaxf(v[e], 0.0f);
+              if (act.thresh != 0u) r = drop_keep16(mix, e, act.thresh) ? r * act.scale : 0.0f;
+              v[e] = r;
+            }
+          }
+          if constexpr (STAGE) {
+            *reinterpret_cast<float4*>(tile + (mrow & 63) * TLD + nl) = make_float4(v[0], v[1], v[2], v[3]);
           } else {
-            const float4 t4 = *reinterpret_cast<const float4*>((const float*)act.mask + m * ldy + n);
-            k4[0] = t4.x; k4[1] = t4.y; k4[2] = t4.z; k4[3] = t4.w;
-          }
+            if (m >= M) continue;
+            if (act.mode == 2) {
+              float k4[4];
+              vec_io<TO, 4>::load((const TO*)act.mask + m * ldy + n, k4);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (k4[e] != 0.0f) ? v[e] * act.scale : 0.0f;
-        }
-        if constexpr (OUT16) {
-          using T = typename std::conditional<F16, f16_t, bf16_t>::type;
-          if (Rv != nullptr) {
-            float r[4];
-            vec_io<T, 4>::load((const T*)Rv + m * ldy + n, r);
-            v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+              for (int e = 0; e < 4; ++e) v[e] = (k4[e] != 0.0f) ? v[e] * act.scale : 0.0f;
+            }
+            if (Rv != nullptr) {
+              float r4[4];
+              vec_io<TO, 4>::load((const TO*)Rv + m * ldy + n, r4);
+              v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
+            }
+            vec_io<TO, 4>::store((TO*)Yv + m * ldy + n, v);
           }
-          vec_io<T, 4>::store((T*)Yv + m * ldy + n, v);
-        } else {
-          if (Rv != nullptr) {
-            const float4 r = *reinterpret_cast<const float4*>((const float*)Rv + m * ldy + n);
-            v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-          }
-          *reinterpret_cast<float4*>((float*)Yv + m * ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
         }
+      }
+    }
+    if constexpr (STAGE) {
+      __syncthreads();
+      constexpr int CPR = NT / 4;                          // 16-byte chunks per row
+      for (int e = tid; e < 64 * CPR; e += 256) {
+        const int rl = e / CPR, c4 = (e - rl * CPR) * 4;
+        const long m = m0 + hh * 64 + rl;
+        if (m >= M) continue;
+        const float4 t4 = *reinterpret_cast<const float4*>(tile + rl * TLD + c4);
+        float v[4] = {t4.x, t4.y, t4.z, t4.w};
+        const long o = m * ldy + n0 + c4;
+        if (act.mode == 2) {
+          float k4[4];
+          vec_io<TO, 4>::load((const TO*)act.mask + o, k4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = (k4[q] != 0.0f) ? v[q] * act.scale : 0.0f;
+        }
+        if (Rv != nullptr) {
+          float r4[4];
+          vec_io<TO, 4>::load((const TO*)Rv + o, r4);
+          v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
+        }
+        vec_io<TO, 4>::store((TO*)Yv + o, v);
       }
     }
   }
