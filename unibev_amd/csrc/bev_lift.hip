@@ -1339,7 +1339,8 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
       hipLaunchKernelGGL(compact_visible_kernel, dim3(a.Nc), dim3(1024), 0, st, a.vis0, a.Nq,
                          a.cam_list, a.cam_n);
     constexpr int RB = 6;
-    const size_t lds = (size_t)t.waves * CamLds<T, DH, RB>::kWords * sizeof(uint16_t);
+    const bool rb3 = sizeof(T) == 4 && t.tile_h * a.fw <= 96;      // f32, half-height bands: 3 row blocks
+    const size_t lds = (size_t)t.waves * (rb3 ? CamLds<T, DH, 3>::kWords : CamLds<T, DH, RB>::kWords) * sizeof(uint16_t);
     {
       ProfScope ps(name("bev_lift_bwd_value_camera"), st,
                    nb.offlog + nb.ref + nb.vis + nb.out + nb.value_f32);
@@ -1356,9 +1357,14 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
           done = true;
         }
       }
-      if (!done)
-        hipLaunchKernelGGL((lift_bwd_value_camera_kernel<T, DH, P, RB>), dim3(8 * t.chunk),
-                           dim3(64 * t.waves), lds, st, a, t);
+      if (!done) {
+        if (rb3)
+          hipLaunchKernelGGL((lift_bwd_value_camera_kernel<T, DH, P, 3>), dim3(8 * t.chunk),
+                             dim3(64 * t.waves), lds, st, a, t);
+        else
+          hipLaunchKernelGGL((lift_bwd_value_camera_kernel<T, DH, P, RB>), dim3(8 * t.chunk),
+                             dim3(64 * t.waves), lds, st, a, t);
+      }
     }
     {
       const long n = (long)a.B * a.Nc * a.H * a.fh * a.fw * DH;
@@ -1454,14 +1460,22 @@ static int plan_backward(const LiftArgs& a, int Dh, int P, int dtype, int ref_is
     t.tile_h = band;
     t.tiles_x = 1;
     t.tiles_y = bands;
+    // f32 data (hi + lo operand tiles: 65 KB of LDS per wave at 6 row blocks, two waves per CU): a single-band map
+    // is cut into two bands of 3 row blocks when it fits — half the LDS per wave, four waves per CU; each band
+    // re-walks the visible list (UBV_CAM_F32_BANDS=1 keeps one band)
+    static const int f32_bands = getenv("UBV_CAM_F32_BANDS") ? atoi(getenv("UBV_CAM_F32_BANDS")) : 2;
+    if (dtype == UBV_F32 && bands == 1 && f32_bands == 2) {        // (four quarter bands: 756 us)
+      const int half = (a.fh + 1) / 2;
+      if (half * a.fw <= 96) { t.tile_h = half; t.tiles_y = 2; }
+    }
     // each (sample, camera, band, head) list is dealt evenly (device side, cam_chunk_len) to
     // `chunks` waves, enough of them to give every SIMD of the chip one wave: a wave keeps its
     // partial map in registers across all of its batches and writes ONE slab
     static const int split_env = getenv("UBV_CAM_SPLIT") ? atoi(getenv("UBV_CAM_SPLIT")) : 0;
     // (one block per CU: its LDS holds 4 waves' operand tiles, or 2 with f32 data's hi + lo tiles;
     // one block too many would cost a whole second round, so round down)
-    t.waves = (dtype == UBV_F32) ? 2 : 4;
-    const int combos = a.B * a.Nc * bands * a.H;
+    t.waves = (dtype == UBV_F32 && t.tile_h * a.fw > 96) ? 2 : 4;
+    const int combos = a.B * a.Nc * t.tiles_y * a.H;
     int split = split_env > 0 ? split_env : (256 * t.waves) / combos;
     split = max(1, min(split, (a.Nq + 63) / 64));
     t.chunk_q = 0;
