@@ -450,6 +450,15 @@ int ubv_sumsq_f32(const float* x, int64_t n, float* out, void* workspace, void* 
 int ubv_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int64_t* step, const float* sumsq, float max_norm, void* stream);
 
+/* ---- GridMask (the device-side image augmentation) --------------------------
+ * Reference: models/utils/grid_mask.py:70-123 (GridMask.forward; built at models/detectors/unibev_detector.py:75):
+ * y = x * mask over `planes` = n*c images of h x w, mask = the centre crop of a (1.5 h x 1.5 w) grid of stripes
+ * of width l and period d starting at st_h / st_w (rows when use_h, columns when use_w), inverted when mode == 1.
+ * The five integers are the reference's np.random draws (the host keeps its draw order); no rotation (the
+ * detector's rotate = 1 always draws 0).  x may equal y. */
+int ubv_grid_mask(const void* x, void* y, int64_t planes, int h, int w, int d, int l, int st_h, int st_w,
+                  int use_h, int use_w, int mode, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,7 @@ The fixtures hold data only: explicit small inputs, seeds for the large ones (wi
 the regenerated arrays), and the reference's outputs.
 """
 import importlib
+import importlib.util
 import json
 import os
 import sys
@@ -426,6 +427,44 @@ def gen_head(mods):
          pos_untouched=np.array([float((head.positional_encoding.row_embed.weight == before).all())]))
 
 
+# --------------------------------------------------------------------------- GridMask (row f4, device part)
+GRID_MASK_CASES = [
+    # seed, (n, c, h, w), prob
+    (0, (6, 3, 32, 88), 1.0),
+    (1, (2, 3, 64, 64), 1.0),
+    (2, (1, 3, 20, 50), 1.0),
+    (3, (6, 3, 256, 704), 0.7),
+    (4, (6, 3, 256, 704), 0.7),
+    (5, (6, 3, 256, 704), 0.7),
+]
+
+
+def gen_grid_mask():
+    """models/utils/grid_mask.py GridMask.forward as the detector builds it (unibev_detector.py:75:
+    GridMask(True, True, rotate=1, offset=False, ratio=0.5, mode=1, prob=0.7)): the mask it multiplies with,
+    recorded by passing ones, and the next np.random draw (the RNG protocol)."""
+    stub.install()
+    spec = importlib.util.spec_from_file_location(
+        'ref_grid_mask', os.path.join(REF_MODULES, '..', 'utils', 'grid_mask.py'))
+    gm_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gm_mod)
+    cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self              # the reference moves its mask with .cuda()
+    out = {}
+    try:
+        for seed, shape, prob in GRID_MASK_CASES:
+            gm = gm_mod.GridMask(True, True, rotate=1, offset=False, ratio=0.5, mode=1, prob=prob).train()
+            np.random.seed(seed)
+            y = gm(torch.ones(*shape))
+            assert (y == y[:1, :1]).all()
+            out[f's{seed}_mask'] = y[0, 0].numpy().astype(np.uint8)
+            out[f's{seed}_next'] = np.array([np.random.rand()])
+            out[f's{seed}_meta'] = np.array(list(shape) + [int(round(prob * 100))])
+    finally:
+        torch.Tensor.cuda = cuda
+    save('grid_mask', **out)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -438,6 +477,7 @@ def main():
     gen_init(mods)
     gen_fullsize(mods)
     gen_head(mods)
+    gen_grid_mask()
 
 
 if __name__ == '__main__':

@@ -1010,3 +1010,16 @@ def spconv_wgrad(grad_out, feats, nbr):
             return None
         check(rc, 'spconv_wgrad')
         return out[:, :cout * cin].view(kvol, cout, cin).transpose(1, 2)
+
+
+# ----------------------------------------------------------------------------------------------- GridMask
+@torch.no_grad()
+def grid_mask(x, d, length, st_h, st_w, use_h=True, use_w=True, mode=1):
+    """x (..., h, w) times the GridMask stripe mask of (d, length, st_h, st_w) (``ubv_grid_mask``)."""
+    with _need_cuda(x):
+        x = x.contiguous()
+        h, w = x.shape[-2], x.shape[-1]
+        y = torch.empty_like(x)
+        check(lib().ubv_grid_mask(_p(x), _p(y), x.numel() // (h * w), h, w, int(d), int(length), int(st_h), int(st_w),
+                                  1 if use_h else 0, 1 if use_w else 0, int(mode), _dt(x), _stream()), 'grid_mask')
+        return y

@@ -10,3 +10,4 @@ from .transformer import UniBEVTransformer  # noqa
 from .voxel import HardSimpleVFE, Voxelization, extract_pts_feat, sparse_to_dense, voxelize_batch  # noqa
 from .sparse_encoder import (SparseBasicBlock, SparseConv3d, SparseConvTensor, SparseEncoder,  # noqa
                              SparseSequential, SubMConv3d, make_sparse_convmodule)
+from .grid_mask import GridMask  # noqa
