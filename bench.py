@@ -268,8 +268,20 @@ def run_mode(args, name, head, world, rank, device, want_ops):
     dt = time.perf_counter() - t0
     from unibev_amd import dp
     dt = dp.max_over_ranks(dt, device)
+    # pure launch cost: the same step enqueued on an IDLE device (host_dt above includes the time the host spends
+    # blocked on the full launch queue once it is steps ahead of the GPU)
+    launch_dt = 0.0
+    for _ in range(min(args.steps, 10)):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step()
+        finish()
+        launch_dt += time.perf_counter() - t1
+    torch.cuda.synchronize()
+    launch_dt /= min(args.steps, 10)
     rec = {'dtype': name, 'value': world * args.bs * args.steps / dt, 'ms_per_step': 1e3 * dt / args.steps,
-           'host_enqueue_ms_per_step': 1e3 * host_dt / args.steps, 'hip_graphs': graphed,
+           'host_enqueue_ms_per_step': 1e3 * launch_dt, 'host_loop_ms_per_step': 1e3 * host_dt / args.steps,
+           'hip_graphs': graphed,
            'residual_stream': 'f32' if (args.fp32_stream or name == 'fp32') else name,
            'parity': PARITY_NOTE[name]}
     # ---- per-op roofline: the same step, eager, HIP events on the launch stream around every
@@ -475,6 +487,7 @@ def main():
             'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': main_rec['ms_per_step'],
             'host_enqueue_ms_per_step': main_rec['host_enqueue_ms_per_step'],
+            'host_loop_ms_per_step': main_rec['host_loop_ms_per_step'],
             'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': main_rec['dtype'], 'data': 'synthetic',
             'config': {'workload': WORKLOADS[args.workload][3], 'per_gpu_batch': args.bs,

@@ -688,7 +688,14 @@ __device__ __forceinline__ bool tile_own(const Footprint& f, float w, bool valid
   return any;
 }
 
-constexpr int kAStride = 40;      // u16 per A row: 32 point slots + 8 pad (80 B: conflict-free b128 reads)
+// A rows are 32 point slots = 64 bytes with NO padding; the four 16-byte chunks of a row are XOR-swizzled with
+// bits 2..3 of the row index, so the b128 fragment reads of any 16 consecutive rows touch 16 distinct bank groups
+// (rows r and r + 4 share a 16-word window and get different chunks).  1 KB per plane less than 80-byte rows:
+// an f32 wave's carve drops from 15 to 13 KB, which is what lets 12 waves share a CU.
+constexpr int kAStride = 32;
+__device__ __forceinline__ int a_index(int row, int slot) {
+  return row * kAStride + ((((slot >> 3) ^ (row >> 2)) & 3) << 3) + (slot & 7);
+}
 
 // grad_out rows in LDS: DH + 8 halves per row.  With DH = 32 halves (64 bytes) a lane's row started on the same 4
 // bank groups as every 4th other lane's: PMC showed 46 % of the f32 owner-tile kernel's LDS cycles as bank
@@ -704,19 +711,16 @@ struct TileLds {
   static constexpr int kWords = (kA + kG) * (kSplit ? 2 : 1);      // u16 per wave
 };
 
-// Stages a grad_out row (held raw in `v`, Dh elements) in LDS as 16-bit MFMA operands.
-template <typename T, int DH, int NV>
-__device__ __forceinline__ void stage_row(uint16_t* __restrict__ g_hi, uint16_t* __restrict__ g_lo,
-                                          int slot, const uint4 (&v)[NV]) {
-  using M = mma_traits<T>;
-  constexpr int GS = GRow<DH>::kStride;
-  if constexpr (!M::kSplit) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) reinterpret_cast<uint4*>(g_hi + slot * GS)[i] = v[i];
-  } else {
+// A grad_out row (held raw in `v`, Dh elements) as 16-bit MFMA operands: for f32 data the row is split into bf16
+// hi + lo halves IN PLACE (v[0 .. NV/2) = hi, v[NV/2 .. NV) = lo; 8 channels per uint4) — register work the
+// callers do once per batch, outside the per-half staging; 16-bit data stays as it is.
+template <typename T, int NV>
+__device__ __forceinline__ void split_row(uint4 (&v)[NV]) {
+  if constexpr (mma_traits<T>::kSplit) {
     static_assert(NV % 2 == 0, "pairs of 4-channel loads");
+    uint4 hi4[NV / 2], lo4[NV / 2];
 #pragma unroll
-    for (int i = 0; i < NV; i += 2) {                    // 8 channels -> one 16-byte store per plane
+    for (int i = 0; i < NV; i += 2) {
       const float f[8] = {__uint_as_float(v[i].x), __uint_as_float(v[i].y), __uint_as_float(v[i].z),
                           __uint_as_float(v[i].w), __uint_as_float(v[i + 1].x), __uint_as_float(v[i + 1].y),
                           __uint_as_float(v[i + 1].z), __uint_as_float(v[i + 1].w)};
@@ -726,10 +730,39 @@ __device__ __forceinline__ void stage_row(uint16_t* __restrict__ g_hi, uint16_t*
         hi[k] = cvt_pk_bf16(f[2 * k], f[2 * k + 1]);
         lo[k] = cvt_pk_bf16(f[2 * k] - __uint_as_float(hi[k] << 16), f[2 * k + 1] - __uint_as_float(hi[k] & 0xffff0000u));
       }
-      reinterpret_cast<uint4*>(g_hi + slot * GS)[i / 2] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-      reinterpret_cast<uint4*>(g_lo + slot * GS)[i / 2] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+      hi4[i / 2] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+      lo4[i / 2] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+#pragma unroll
+    for (int i = 0; i < NV / 2; ++i) { v[i] = hi4[i]; v[NV / 2 + i] = lo4[i]; }
+  }
+}
+
+// Stores a row prepared by split_row in LDS slot `slot`.
+template <typename T, int DH, int NV>
+__device__ __forceinline__ void stage_row(uint16_t* __restrict__ g_hi, uint16_t* __restrict__ g_lo,
+                                          int slot, const uint4 (&v)[NV]) {
+  constexpr int GS = GRow<DH>::kStride;
+  if constexpr (!mma_traits<T>::kSplit) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) reinterpret_cast<uint4*>(g_hi + slot * GS)[i] = v[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < NV / 2; ++i) {
+      reinterpret_cast<uint4*>(g_hi + slot * GS)[i] = v[i];
+      reinterpret_cast<uint4*>(g_lo + slot * GS)[i] = v[NV / 2 + i];
     }
   }
+}
+
+typedef short i16x4_t __attribute__((ext_vector_type(4)));
+// 8 rows (p, p + stride, ...) of the lane's column through two transposing reads of 4 rows each
+__device__ __forceinline__ uint4 tr16_frag(const uint16_t* p, int stride) {
+  typedef __attribute__((address_space(3))) i16x4_t lds_v4;
+  const i16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)p);
+  const i16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p + 4 * stride));
+  const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+  return make_uint4(ua.x, ua.y, ub.x, ub.y);
 }
 
 // The wave's pending operand tiles: up to 32 point slots filled densely by the owned points of
@@ -746,7 +779,8 @@ struct TileAcc {
   __device__ __forceinline__ void init(uint16_t* lds, int lane) {
     a_hi = lds; a_lo = lds + L::kA;
     g_hi = lds + (M::kSplit ? 2 : 1) * L::kA; g_lo = g_hi + L::kG;
-    for (int i = lane; i < L::kWords / 2; i += 64) reinterpret_cast<uint32_t*>(lds)[i] = 0u;
+    static_assert(L::kWords % 8 == 0, "16-byte vectors");
+    for (int i = lane; i < L::kWords / 8; i += 64) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -758,25 +792,19 @@ struct TileAcc {
   // program order, so the fragment reads see the producers' writes without a barrier.)
   __device__ __forceinline__ void flush(int lane) {
     const int n = lane & 31, kg = lane >> 5;
-    const int nn = (DH >= 32) ? n : (n % DH);            // Dh = 16: columns 16..31 are don't-care
+    // B fragment = 8 consecutive slots (K) of one channel: two transposing LDS reads (ds_read_b64_tr_b16: in a
+    // 16-lane group lane i addresses the 4-channel piece (row i / 4, quad i % 4) and receives channel i of the 4
+    // rows) instead of 8 u16 reads + packing.  Dh = 16: columns 16..31 are don't-care (re-read 0..15).
+    constexpr int GS = GRow<DH>::kStride;
+    const int tr = (kg * 8 + ((lane & 15) >> 2)) * GS + (DH >= 32 ? ((lane >> 4) & 1) * 16 : 0) + (lane & 3) * 4;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      uint16_t bh[8], bl[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        bh[j] = g_hi[(kb * 16 + kg * 8 + j) * GRow<DH>::kStride + nn];
-        if (M::kSplit) bl[j] = g_lo[(kb * 16 + kg * 8 + j) * GRow<DH>::kStride + nn];
-      }
-      uint4 b_hi, b_lo;
-      b_hi.x = bh[0] | ((uint32_t)bh[1] << 16); b_hi.y = bh[2] | ((uint32_t)bh[3] << 16);
-      b_hi.z = bh[4] | ((uint32_t)bh[5] << 16); b_hi.w = bh[6] | ((uint32_t)bh[7] << 16);
-      if (M::kSplit) {
-        b_lo.x = bl[0] | ((uint32_t)bl[1] << 16); b_lo.y = bl[2] | ((uint32_t)bl[3] << 16);
-        b_lo.z = bl[4] | ((uint32_t)bl[5] << 16); b_lo.w = bl[6] | ((uint32_t)bl[7] << 16);
-      }
+      const uint4 b_hi = tr16_frag(g_hi + kb * 16 * GS + tr, GS);
+      uint4 b_lo = make_uint4(0, 0, 0, 0);
+      if (M::kSplit) b_lo = tr16_frag(g_lo + kb * 16 * GS + tr, GS);
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
-        const int ao = (rb * 32 + n) * kAStride + kb * 16 + kg * 8;
+        const int ao = a_index(rb * 32 + n, kb * 16 + kg * 8);
         const uint4 f_hi = *reinterpret_cast<const uint4*>(a_hi + ao);
         acc[rb] = M::mma(f_hi, b_hi, acc[rb]);
         if (M::kSplit) {
@@ -791,18 +819,30 @@ struct TileAcc {
     fill = 0;
   }
 
-  // Adds the owned points of one batch (one point per lane).
-  // grad_out row of the lane's record: grow_base (wave-uniform: sample, head) + grow_off elements (query * row)
-  __device__ __forceinline__ void add(const int (&lp)[4], const float (&cwt)[4], bool any,
-                                      const T* __restrict__ grow_base, unsigned grow_off, int lane) {
+  static constexpr int kNV = DH * elem<T>::kBytes / 16;
+
+  // The lane's grad_out row: grow_base (wave-uniform: sample, head) + grow_off elements (query * row).
+  static __device__ __forceinline__ void gather(const T* __restrict__ grow_base, unsigned grow_off, bool want,
+                                                uint4 (&grow)[kNV]) {
+#pragma unroll
+    for (int i = 0; i < kNV; ++i)
+      grow[i] = want ? reinterpret_cast<const uint4*>(gather_ptr(grow_base, grow_off))[i] : make_uint4(0, 0, 0, 0);
+  }
+
+  // Adds the owned points of one batch (one point per lane) whose grad_out rows are already in registers.
+  // The operand conversions (row split, coefficient encoding) run once for the 64 lanes; only the LDS stores sit
+  // in the per-half loop (a half's instructions cost the same with 32 lanes masked off).
+  __device__ __forceinline__ void add_rows(const int (&lp)[4], const float (&cwt)[4], bool any,
+                                           uint4 (&grow)[kNV], int lane) {
     const unsigned long long m = __ballot(any);
     if (m == 0ull) return;
-    // issue the grad_out row loads first: a pending MFMA round (flush) below overlaps their latency
-    constexpr int NV = DH * elem<T>::kBytes / 16;
-    uint4 grow[NV];
+    split_row<T, kNV>(grow);
+    uint16_t chi[4], clo[4];
 #pragma unroll
-    for (int i = 0; i < NV; ++i)
-      grow[i] = any ? reinterpret_cast<const uint4*>(gather_ptr(grow_base, grow_off))[i] : make_uint4(0, 0, 0, 0);
+    for (int k = 0; k < 4; ++k) {
+      chi[k] = M::enc(cwt[k]);
+      clo[k] = M::kSplit ? M::enc(cwt[k] - M::dec(chi[k])) : (uint16_t)0;
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const unsigned int hm = (unsigned int)(m >> (32 * half));
@@ -811,18 +851,27 @@ struct TileAcc {
       if (fill + cnt > 32) flush(lane);
       if (any && (lane >> 5) == half) {
         const int slot = fill + __popc(hm & ((1u << (lane & 31)) - 1u));
-        stage_row<T, DH, NV>(g_hi, g_lo, slot, grow);
+        stage_row<T, DH, kNV>(g_hi, g_lo, slot, grow);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           if (lp[k] >= 0) {
-            const uint16_t hi = M::enc(cwt[k]);
-            a_hi[lp[k] * kAStride + slot] = hi;
-            if (M::kSplit) a_lo[lp[k] * kAStride + slot] = M::enc(cwt[k] - M::dec(hi));
+            const int ai = a_index(lp[k], slot);
+            a_hi[ai] = chi[k];
+            if (M::kSplit) a_lo[ai] = clo[k];
           }
         }
       }
       fill += cnt;
     }
+  }
+
+  // Same, fetching the rows here: the loads are issued first, a pending MFMA round (flush) overlaps their latency.
+  __device__ __forceinline__ void add(const int (&lp)[4], const float (&cwt)[4], bool any,
+                                      const T* __restrict__ grow_base, unsigned grow_off, int lane) {
+    if (__ballot(any) == 0ull) return;
+    uint4 grow[kNV];
+    gather(grow_base, grow_off, any, grow);
+    add_rows(lp, cwt, any, grow, lane);
   }
 };
 
@@ -833,7 +882,7 @@ struct TileAcc {
 // of the finished tile (rounded once for 16-bit outputs), so grad_value needs no zeroing; only a
 // tile whose bucket overflowed adds its sums to what lift_ovf_* scattered there.
 template <typename T, int DH, int P, int RB>
-__global__ __launch_bounds__(256, 3) void lift_bwd_value_kernel(const LiftArgs a, const TileArgs t) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 3)) void lift_bwd_value_kernel(const LiftArgs a, const TileArgs t) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds_all[];
   using L = TileLds<T, DH, RB>;
   TileGeom g;
@@ -850,18 +899,33 @@ __global__ __launch_bounds__(256, 3) void lift_bwd_value_kernel(const LiftArgs a
   const int cnt_raw = a.bin_cnt[bucket];
   const int n = min(cnt_raw, a.cap);
   const float4* __restrict__ bp = a.bins + bucket * a.cap;
-  const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  float4 nrec = (lane < n) ? bp[lane] : zero4;
+  // Two batches of records and one batch of grad_out rows in flight: a wave is a serial chain of dependent round
+  // trips (record -> row of its query -> LDS -> MFMA) and only 2-3 waves fit a SIMD, so the row gather of batch
+  // i + 1 is issued before batch i is processed (every record of the bucket has a corner in this tile: the
+  // gather is unconditional).
+  using TA = TileAcc<T, DH, RB>;
+  const T* __restrict__ gbase = gout + (long)g.b * a.Nq * row + g.h * DH;
+  // (loads are unconditional on clamped indices — lanes past the end re-read the last record and are masked by
+  //  `valid`: predicated vector loads made the compiler wait for each one where it was issued)
+  const int last = max(n - 1, 0);
+  float4 rec1 = bp[min(lane, last)];
+  float4 rec2 = bp[min(64 + lane, last)];
+  uint4 rows1[TA::kNV];
+  TA::gather(gbase, (unsigned)__float_as_int(rec1.w) * (unsigned)row, true, rows1);
   for (int e0 = 0; e0 < n; e0 += 64) {
-    const float4 rec = nrec;
+    const float4 rec = rec1;
+    uint4 rows[TA::kNV];
+#pragma unroll
+    for (int i = 0; i < TA::kNV; ++i) rows[i] = rows1[i];
     const bool valid = e0 + lane < n;
-    if (e0 + 64 < n) nrec = (e0 + 64 + lane < n) ? bp[e0 + 64 + lane] : zero4;
-    const int q = valid ? __float_as_int(rec.w) : 0;
+    rec1 = rec2;
+    TA::gather(gbase, (unsigned)__float_as_int(rec1.w) * (unsigned)row, true, rows1);
+    rec2 = bp[min(e0 + 128 + lane, last)];
     int lp[4];
     float cwt[4];
     const Footprint f = footprint_px(rec.x, rec.y, a.fh, a.fw);
     const bool any = tile_own(f, rec.z, valid, g, t.tile_w, lp, cwt);
-    ta.add(lp, cwt, any, gout + (long)g.b * a.Nq * row + g.h * DH, (unsigned)q * (unsigned)row, lane);
+    ta.add_rows(lp, cwt, any, rows, lane);
   }
   if (ta.fill > 0) ta.flush(lane);
   // ---- store the tile: D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5);
@@ -999,6 +1063,7 @@ __global__ __launch_bounds__(256) void lift_bwd_value_camera_kernel(const LiftAr
       q2 = fetch_q(c0 + 128, v2);
     }
     // grad_out rows of the 64 queries -> LDS, then this lane's B fragments for the 4 K-blocks
+    split_row<T, NV>(cur.grow);
     stage_row<T, DH, NV>(g_hi, g_lo, lane, cur.grow);
     uint4 b_hi[4], b_lo[4];
 #pragma unroll
@@ -1431,7 +1496,9 @@ static int plan_backward(const LiftArgs& a, int Dh, int P, int dtype, int ref_is
     t.tiles_y = (a.fh + 7) / 8;
     t.chunks = 1;
     t.chunk_q = 0;
-    t.waves = 4;
+    static const int grid_waves = getenv("UBV_GRID_WAVES") ? atoi(getenv("UBV_GRID_WAVES")) : 0;
+    // f32 tiles hold 13 KB of LDS per wave: blocks of 2 waves pack 12 waves on a CU (the register limit), blocks of 4 only 8
+    t.waves = grid_waves > 0 ? grid_waves : (dtype == UBV_F32 ? 2 : 4);
     // bucket capacity: twice the expected records per tile (P points per query-head, Nq/S queries
     // per pixel, 1.3 tiles per point); the overflow list takes whatever concentrates beyond that
     const double expect = 1.3 * P * 64.0 * (double)a.Nq / ((double)a.fh * a.fw);

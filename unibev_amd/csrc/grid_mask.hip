@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void grid_mask_kernel(const T* __restrict__ x,
 extern "C" int ubv_grid_mask(const void* x, void* y, int64_t planes, int h, int w, int d, int l, int st_h, int st_w,
                              int use_h, int use_w, int mode, int dtype, void* stream) {
   using namespace ubv;
-  UBV_CHECK_ARG(x && y && planes >= 0 && h > 0 && w > 0, "grid_mask: bad arguments");
+  UBV_CHECK_ARG(planes >= 0 && h > 0 && w > 0 && (planes == 0 || (x && y)), "grid_mask: bad arguments");
   UBV_CHECK_ARG(d >= 2 && l >= 1 && l < d && st_h >= 0 && st_h < d && st_w >= 0 && st_w < d,
                 "grid_mask: need d >= 2, 1 <= l < d, 0 <= st < d (got d=%d l=%d st_h=%d st_w=%d)", d, l, st_h, st_w);
   UBV_CHECK_ARG(dtype >= 0 && dtype <= 2, "grid_mask: unknown dtype %d", dtype);
