@@ -1180,6 +1180,7 @@ __global__ __launch_bounds__(256) void narrow_kernel(const float* __restrict__ s
 
 #include "bev_lift_cam.inl"
 #include "bev_lift_shared.inl"
+#include "bev_lift_win.inl"
 
 // ---- dispatch ----------------------------------------------------------------------------------------
 // Algorithmic (compulsory) bytes of each kernel: every operand read once, every result written
@@ -1260,6 +1261,19 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
       }
     }
     static const int shared_env = getenv("UBV_LIFT_SHARED") ? atoi(getenv("UBV_LIFT_SHARED")) : 1;
+    if (shared_env && win_ok<T, DH, P>(a)) {   // BEV-grid queries: corners served from an LDS window (bev_lift_win.inl)
+      constexpr int HG = 128 / (DH * (int)sizeof(T));
+      const int chunk = (int)(((long)a.total_tiles * (a.H / HG) + 7) / 8);
+      const dim3 grid(8 * chunk);
+      if (sizeof(T) == 2 && a.ol16) {
+        if (wide) hipLaunchKernelGGL((lift_fwd_win_kernel<T, DH, VECS, P, sizeof(T) == 2, HG>), grid, dim3(256), kWinLds, st, a, chunk);
+        else hipLaunchKernelGGL((lift_fwd_win_kernel<T, DH, VEC, P, sizeof(T) == 2, HG>), grid, dim3(256), kWinLds, st, a, chunk);
+      } else {
+        if (wide) hipLaunchKernelGGL((lift_fwd_win_kernel<T, DH, VECS, P, false, HG>), grid, dim3(256), kWinLds, st, a, chunk);
+        else hipLaunchKernelGGL((lift_fwd_win_kernel<T, DH, VEC, P, false, HG>), grid, dim3(256), kWinLds, st, a, chunk);
+      }
+      return;
+    }
     if (shared_env) {            // per-point arithmetic shared inside the lane group (bev_lift_shared.inl)
       if (sizeof(T) == 2 && a.ol16)
         {
@@ -1339,6 +1353,18 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     }
     {
       ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes);
+      if (win_ok<T, DH, P>(a)) {
+        constexpr int HG = 128 / (DH * (int)sizeof(T));
+        const int chunk = (int)(((long)a.total_tiles * (a.H / HG) + 7) / 8);
+        const dim3 grid(8 * chunk);
+        if (sizeof(T) == 2 && a.ol16) {
+          if (wide) hipLaunchKernelGGL((lift_bwd_query_win_kernel<T, DH, VECS, P, sizeof(T) == 2, HG>), grid, dim3(256), kWinLds, st, a, chunk);
+          else hipLaunchKernelGGL((lift_bwd_query_win_kernel<T, DH, VEC, P, sizeof(T) == 2, HG>), grid, dim3(256), kWinLds, st, a, chunk);
+        } else {
+          if (wide) hipLaunchKernelGGL((lift_bwd_query_win_kernel<T, DH, VECS, P, false, HG>), grid, dim3(256), kWinLds, st, a, chunk);
+          else hipLaunchKernelGGL((lift_bwd_query_win_kernel<T, DH, VEC, P, false, HG>), grid, dim3(256), kWinLds, st, a, chunk);
+        }
+      } else
       if (sizeof(T) == 2 && a.ol16)
         {
           if (wide) hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VECS, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
