@@ -279,9 +279,10 @@ def run_mode(args, name, head, world, rank, device, want_ops):
         launch_dt += time.perf_counter() - t1
     torch.cuda.synchronize()
     launch_dt /= min(args.steps, 10)
+    nsteps_run = args.warmup + 1 + args.steps + min(args.steps, 10)       # (profilers divide by this)
     rec = {'dtype': name, 'value': world * args.bs * args.steps / dt, 'ms_per_step': 1e3 * dt / args.steps,
            'host_enqueue_ms_per_step': 1e3 * launch_dt, 'host_loop_ms_per_step': 1e3 * host_dt / args.steps,
-           'hip_graphs': graphed,
+           'hip_graphs': graphed, 'steps_run': nsteps_run,
            'residual_stream': 'f32' if (args.fp32_stream or name == 'fp32') else name,
            'parity': PARITY_NOTE[name]}
     # ---- per-op roofline: the same step, eager, HIP events on the launch stream around every

@@ -1,0 +1,32 @@
+#!/bin/bash
+# On the GPU box: everything profiles/r0N_* is made from.  tools/profile_job.sh <name> -> gpurun_out/<name>/
+#   gpurun --timeout 2400 -- 'bash tools/profile_job.sh r2fin'
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/${1:-prof}
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+B="python $ROOT/bench.py"
+# 1. the judged tests
+(cd $ROOT && timeout 1500 python -m pytest tests -q -m gpu > $OUT/tests.txt 2>&1)
+# 2. bench lines: default (f32 headline + 16-bit sub-records + gemm / voxel records + CPU baseline), cat-128, one stream
+(cd $ROOT && $B > $OUT/bench.json 2> $OUT/bench.err)
+(cd $ROOT && $B --workload LC_cat128 --no-cpu-baseline --no-extras > $OUT/bench_cat128.json 2> $OUT/bench_cat128.err)
+(cd $ROOT && $B --single-stream --no-cpu-baseline --no-extras --no-kernel-timing > $OUT/bench_single_stream.json 2>/dev/null)
+# 3. rocprofv3 kernel summary of the default bench command (what roofline.achieved must agree with)
+rocprofv3 --kernel-trace -d /tmp/prof_cmd -o cmd -- $B --no-cpu-baseline > $OUT/bench_profiled.json 2>/dev/null
+python $ROOT/tools/db_table.py /tmp/prof_cmd/cmd_results.db 1 80 > $OUT/bench_command_kernel_totals.txt
+# 4. per-step kernel tables: eager launches, one stream, 10 + 3 steps
+for dt in fp32 bf16; do
+  rocprofv3 --kernel-trace -d /tmp/prof_$dt -o e -- $B --dtype $dt --no-graph --single-stream --no-extras \
+      --no-cpu-baseline --no-kernel-timing --steps 10 --warmup 3 > $OUT/bench_${dt}_eager.json 2>/dev/null
+  python $ROOT/tools/db_table.py /tmp/prof_$dt/e_results.db 24 60 > $OUT/${dt}_eager_kernel_table.txt
+done
+# 5. operator micro-benchmarks
+for dt in bf16 fp32; do
+  python $ROOT/tools/bench_lift.py --dtype $dt > $OUT/bench_lift_$dt.txt 2>&1
+  python $ROOT/tools/bench_lift.py --dtype $dt --img-hw 800 1440 --dh 16 > $OUT/bench_lift_cat128_$dt.txt 2>&1
+done
+python $ROOT/tools/bench_gemm.py > $OUT/bench_gemm.txt 2>&1
+# 6. HBM traffic per op (PMC passes)
+bash $ROOT/tools/collect_traffic.sh $OUT > $OUT/traffic.log 2>&1
+ls -la $OUT

@@ -1018,7 +1018,6 @@ __global__ __launch_bounds__(256) void lift_bwd_value_camera_kernel(const LiftAr
   const T* __restrict__ gout = (const T*)a.gout;
   const float fwf = (float)a.fw, fhf = (float)a.fh;
   const int n = lane & 31, kg = lane >> 5;
-  const int nn = (DH >= 32) ? n : (n % DH);               // Dh = 16: columns 16..31 are don't-care
   const float inv_fw = 1.0f / fwf, inv_fh = 1.0f / fhf;
 
   struct Raw {
@@ -1066,19 +1065,14 @@ __global__ __launch_bounds__(256) void lift_bwd_value_camera_kernel(const LiftAr
     split_row<T, NV>(cur.grow);
     stage_row<T, DH, NV>(g_hi, g_lo, lane, cur.grow);
     uint4 b_hi[4], b_lo[4];
+    {
+      constexpr int GS = GRow<DH>::kStride;                // two transposing reads per fragment (see TileAcc::flush)
+      const int tr = (kg * 8 + ((lane & 15) >> 2)) * GS + (DH >= 32 ? ((lane >> 4) & 1) * 16 : 0) + (lane & 3) * 4;
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      uint16_t bh[8], bl[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        bh[j] = g_hi[(kb * 16 + kg * 8 + j) * GRow<DH>::kStride + nn];
-        if (M::kSplit) bl[j] = g_lo[(kb * 16 + kg * 8 + j) * GRow<DH>::kStride + nn];
+      for (int kb = 0; kb < 4; ++kb) {
+        b_hi[kb] = tr16_frag(g_hi + kb * 16 * GS + tr, GS);
+        b_lo[kb] = M::kSplit ? tr16_frag(g_lo + kb * 16 * GS + tr, GS) : make_uint4(0, 0, 0, 0);
       }
-      b_hi[kb] = make_uint4(bh[0] | ((uint32_t)bh[1] << 16), bh[2] | ((uint32_t)bh[3] << 16),
-                            bh[4] | ((uint32_t)bh[5] << 16), bh[6] | ((uint32_t)bh[7] << 16));
-      if (M::kSplit)
-        b_lo[kb] = make_uint4(bl[0] | ((uint32_t)bl[1] << 16), bl[2] | ((uint32_t)bl[3] << 16),
-                              bl[4] | ((uint32_t)bl[5] << 16), bl[6] | ((uint32_t)bl[7] << 16));
     }
     float w[P];
     softmax_row<P>(cur.lg, w);
