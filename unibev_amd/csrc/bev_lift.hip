@@ -420,8 +420,12 @@ __global__ __launch_bounds__(256) void lift_bin_kernel(const LiftArgs a, int til
   float lg[P], w[P], off[2 * P];
   load_ol<T, P>(a.logits, bq * a.log_stride + h * P, a.ol16, lg);
   load_ol<T, 2 * P>(a.offsets, bq * a.off_stride + h * 2 * P, a.ol16, off);
-  softmax_row<P>(lg, w);
+  // 16-bit data: hardware exp / reciprocals like the other kernels of the path (the kernel is bound by its
+  // per-point arithmetic: one lane = one point, ~150 instructions each with IEEE divisions)
+  constexpr bool FAST = sizeof(T) == 2;
+  softmax_row<P, FAST>(lg, w);
   const float cnt = (a.count != nullptr) ? a.count[bq] : 1.0f;
+  const float inv_cnt = 1.0f / cnt, inv_fw = 1.0f / fwf, inv_fh = 1.0f / fhf;
   for (int cam = 0; cam < a.Nc; ++cam) {
   const bool vis = valid && (a.vis0 == nullptr || a.vis0[(long)cam * a.Nq + q] != 0);
   if (a.Nc > 1 && __ballot(vis) == 0ull) continue;    // wave-uniform
@@ -448,11 +452,11 @@ __global__ __launch_bounds__(256) void lift_bin_kernel(const LiftArgs a, int til
   for (int p = 0; p < P; ++p) {
     const float2 r = *reinterpret_cast<const float2*>(rp + zi * 2);
     zi = (zi + 1 == a.Z) ? 0 : zi + 1;
-    const float lx = r.x + off[2 * p] / fwf;
-    const float ly = r.y + off[2 * p + 1] / fhf;
+    const float lx = r.x + div_or_mul<FAST>(off[2 * p], fwf, inv_fw);
+    const float ly = r.y + div_or_mul<FAST>(off[2 * p + 1], fhf, inv_fh);
     const float xp = lx * fwf - 0.5f, yp = ly * fhf - 0.5f;
     const Footprint f = footprint_px(xp, yp, a.fh, a.fw);
-    const float wn = w[p] / cnt;
+    const float wn = div_or_mul<FAST>(w[p], cnt, inv_cnt);
     const float4 rec = make_float4(xp, yp, wn, __int_as_float(q));
     int tk[4], hs[4], rank[4];
     bool nz[4], lead[4], local[4];
