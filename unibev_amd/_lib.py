@@ -8,7 +8,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libunibev_hip.so')
+# UBV_LIB_PATH: load another build of the same library (kernel A/B studies); the default is the in-tree build
+LIB_PATH = os.environ.get('UBV_LIB_PATH') or os.path.join(_HERE, 'libunibev_hip.so')
 
 _lib = None
 
