@@ -459,6 +459,26 @@ int ubv_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, floa
 int ubv_grid_mask(const void* x, void* y, int64_t planes, int h, int w, int d, int l, int st_h, int st_w,
                   int use_h, int use_w, int mode, int dtype, void* stream);
 
+/* ---- Modulated deformable convolution, DCNv2 (ResNet-101 stages 3-4) -------------
+ * Reference: [ext] mmcv `modulated_deform_conv_forward / _backward` (ops/csrc/pytorch/modulated_deform_conv.cpp,
+ * kernels in common/cuda/modulated_deform_conv_cuda_kernel.cuh) under `ModulatedDeformConv2dPack`, selected by
+ * `dcn=dict(type='DCNv2', deform_groups=1)` at configs/unibev/unibev_nus_LC_cnw_256_modality_dropout.py:229-236.
+ * Layouts differ from mmcv's on purpose (channels-last, tap-major columns):
+ *   x        [N, H, W, C]                      channels-last feature map
+ *   offset   [N, dg*2*kh*kw, Ho, Wo]           as the offset convolution emits it: (dy, dx) pairs per tap
+ *   mask     [N, dg*kh*kw, Ho, Wo]             modulation (after the sigmoid)
+ *   columns  [N*Ho*Wo, kh*kw*C]                column k*C + c = mask * bilinear sample of channel c at tap k
+ * The convolution is then y[N*Ho*Wo, Cout] = columns . Wp^T with Wp = weight.permute(0,2,3,1) ([Cout, kh*kw*C],
+ * ubv_gemm_nt), born channels-last.  Backward: grad_columns = grad_y . Wp (ubv_gemm_nt), ubv_dcn_col2im scatters
+ * grad_x (f32, ZEROED by the caller, atomics) and writes grad_offset / grad_mask (f32, every element written),
+ * grad_weight = ubv_gemm_wgrad(grad_y, columns).  C / dg must be a multiple of 4 (f32) or 8 (16-bit). */
+int ubv_dcn_im2col(const void* x, const void* offset, const void* mask, void* columns, int N, int H, int W, int C,
+                   int Ho, int Wo, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                   int deform_groups, int dtype, void* stream);
+int ubv_dcn_col2im(const void* grad_columns, const void* x, const void* offset, const void* mask, float* grad_x,
+                   float* grad_offset, float* grad_mask, int N, int H, int W, int C, int Ho, int Wo, int kh, int kw,
+                   int sh, int sw, int ph, int pw, int dh, int dw, int deform_groups, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

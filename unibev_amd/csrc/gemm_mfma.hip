@@ -353,7 +353,10 @@ static int gemm_nt_launch(const void* X, long ldx, const void* Wh, const void* W
   if (nt == 0) return UBV_ERR_UNSUPPORTED;
   const long row_tiles = (M + kGemmBM - 1) / kGemmBM;
   const dim3 grid((unsigned)((row_tiles + 7) / 8 * 8 * (N / nt))), blk(256);
-  const size_t lds = (size_t)((SPLIT ? 2 : 1) * (kGemmBM + nt) * (kc + 8)) * sizeof(uint16_t);
+  // operand tiles, or the epilogue's staged half tile (64 rows of nt + 4 floats) where that is larger: 16-bit data
+  // with 32-deep chunks (K % 64 != 0)
+  size_t lds = (size_t)((SPLIT ? 2 : 1) * (kGemmBM + nt) * (kc + 8)) * sizeof(uint16_t);
+  if (nt <= 128 && lds < (size_t)64 * (nt + 4) * sizeof(float)) lds = (size_t)64 * (nt + 4) * sizeof(float);
 #define UBV_GEMM_NB(NBV)                                                                                     \
   case NBV:                                                                                                  \
     if constexpr (!SPLIT) {                                                                                  \

@@ -1023,3 +1023,79 @@ def grid_mask(x, d, length, st_h, st_w, use_h=True, use_w=True, mode=1):
         check(lib().ubv_grid_mask(_p(x), _p(y), x.numel() // (h * w), h, w, int(d), int(length), int(st_h), int(st_w),
                                   1 if use_h else 0, 1 if use_w else 0, int(mode), _dt(x), _stream()), 'grid_mask')
         return y
+
+
+# ----------------------------------------------------------------------------------------------- DCNv2
+def _dcn_out_size(size, k, s, p, d):
+    return (size + 2 * p - (d * (k - 1) + 1)) // s + 1
+
+
+def _dcn_gemm(a, w):
+    """a [M, K] @ w[N, K]^T on the matrix cores where the shape allows it (f32: split weights), else the library."""
+    if a.dtype == torch.float32:
+        wh, wl, _, _ = split_weight(w, transposed=False)
+        y = gemm_nt(a, wh, wl)
+    else:
+        y = gemm_nt(a, w.to(a.dtype).contiguous())
+    return y if y is not None else a @ w.to(a.dtype).t()
+
+
+class ModulatedDeformConv2dFunction(Function):
+    """Drop-in for [ext] mmcv ``ModulatedDeformConv2dFunction`` (same argument order; ``groups`` must be 1, the only
+    value the configs use).  x / the result are NCHW tensors as in mmcv; internally channels-last — pass
+    ``channels_last`` tensors to avoid the two layout copies."""
+
+    @staticmethod
+    def forward(ctx, x, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, deform_groups=1):
+        if groups != 1:
+            raise NotImplementedError('ModulatedDeformConv2d: groups != 1 is not built')
+        pair = lambda v: (v, v) if isinstance(v, int) else tuple(v)
+        (sh, sw), (ph, pw), (dh, dw) = pair(stride), pair(padding), pair(dilation)
+        N, C, H, W = x.shape
+        Cout, _, kh, kw = weight.shape
+        Ho, Wo = _dcn_out_size(H, kh, sh, ph, dh), _dcn_out_size(W, kw, sw, pw, dw)
+        with _need_cuda(x, offset, mask, weight, bias):
+            xn = x.detach().permute(0, 2, 3, 1).contiguous()
+            off = offset.detach().to(x.dtype).contiguous()
+            mk = mask.detach().to(x.dtype).contiguous()
+            geom = (N, H, W, C, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, int(deform_groups))
+            col = torch.empty(N * Ho * Wo, kh * kw * C, dtype=x.dtype, device=x.device)
+            check(lib().ubv_dcn_im2col(_p(xn), _p(off), _p(mk), _p(col), *geom, _dt(x), _stream()), 'dcn_im2col')
+            wp = weight.detach().permute(0, 2, 3, 1).reshape(Cout, kh * kw * C).contiguous()
+            y = _dcn_gemm(col, wp)
+            if bias is not None:
+                y = y + bias.detach().to(y.dtype)
+        ctx.save_for_backward(xn, off, mk, col, wp)
+        ctx.geom, ctx.has_bias, ctx.wshape = geom, bias is not None, weight.shape
+        ctx.dtypes = (offset.dtype, mask.dtype, weight.dtype)
+        return y.view(N, Ho, Wo, Cout).permute(0, 3, 1, 2)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        xn, off, mk, col, wp = ctx.saved_tensors
+        geom = ctx.geom
+        N, H, W, C, Ho, Wo, kh, kw = geom[:8]
+        Cout = ctx.wshape[0]
+        with _need_cuda(grad_out, xn):
+            go = grad_out.permute(0, 2, 3, 1).contiguous().view(N * Ho * Wo, Cout).to(xn.dtype)
+            gcol = _dcn_gemm(go, wp.t().contiguous())                       # [M, K] = dY . Wp
+            gx = torch.zeros(N, H, W, C, dtype=torch.float32, device=xn.device)
+            goff = torch.empty(off.shape, dtype=torch.float32, device=xn.device)
+            gmask = torch.empty(mk.shape, dtype=torch.float32, device=xn.device)
+            check(lib().ubv_dcn_col2im(_p(gcol.contiguous()), _p(xn), _p(off), _p(mk), _p(gx), _p(goff), _p(gmask),
+                                       *geom, _dt(xn), _stream()), 'dcn_col2im')
+            gw = gb = None
+            if ctx.needs_input_grad[3] or (ctx.has_bias and ctx.needs_input_grad[4]):
+                res = gemm_wgrad(go, col)
+                if res is not None:
+                    gwf, gb = res
+                else:
+                    gwf, gb = go.float().t() @ col.float(), go.float().sum(0)
+                gw = gwf.view(Cout, kh, kw, C).permute(0, 3, 1, 2).to(ctx.dtypes[2])
+                gb = gb.to(ctx.dtypes[2]) if ctx.has_bias else None
+        return (gx.permute(0, 3, 1, 2).to(xn.dtype), goff.to(ctx.dtypes[0]), gmask.to(ctx.dtypes[1]), gw, gb,
+                None, None, None, None, None)
+
+
+modulated_deform_conv2d = ModulatedDeformConv2dFunction.apply

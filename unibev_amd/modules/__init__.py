@@ -11,3 +11,5 @@ from .voxel import HardSimpleVFE, Voxelization, extract_pts_feat, sparse_to_dens
 from .sparse_encoder import (SparseBasicBlock, SparseConv3d, SparseConvTensor, SparseEncoder,  # noqa
                              SparseSequential, SubMConv3d, make_sparse_convmodule)
 from .grid_mask import GridMask  # noqa
+from .backbones import (FPN, SECOND, SECONDFPN, ModulatedDeformConv2dPack, ResNet,  # noqa
+                        extract_img_feat)

@@ -88,6 +88,8 @@ HEADS = Registry('head')
 DETECTORS = Registry('detector')
 VOXEL_ENCODERS = Registry('voxel_encoder')
 MIDDLE_ENCODERS = Registry('middle_encoder')
+BACKBONES = Registry('backbone')
+NECKS = Registry('neck')
 
 
 def build_attention(cfg, default_args=None):
