@@ -83,6 +83,12 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const T* __restrict__ x
 }
 
 // One wave per (m, k, group): d(input) by f32 atomics, d(offset) / d(mask) reduced over the group's channels.
+// 4 channels per lane for every data type (with 8, a 256-channel group kept half the wave idle and the 16-bit
+// launch took twice the f32 one).  The kernel is bound by its atomics — 36 per input element, neighbouring waves
+// on the same lines: 890 us at 12 x 256 x 16x44, against 44 us for the im2col.  Two LDS-window variants (8x8 output
+// tile x 64 channels, window flushed once) were measured and dropped: ds_add_f32 runs at ~190 clocks per wave
+// instruction (692 us), and wave-private channels with plain read-modify-writes need 16x more wave iterations
+// (instruction-bound, 1 100 us).
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void dcn_col2im_kernel(const T* __restrict__ gcol, const T* __restrict__ x,
                                                          const T* __restrict__ offset, const T* __restrict__ mask,
@@ -196,8 +202,8 @@ extern "C" int ubv_dcn_col2im(const void* grad_columns, const void* x, const voi
   hipStream_t st = as_stream(stream);
   switch (dtype) {
     case UBV_F32: hipLaunchKernelGGL((dcn_col2im_kernel<float, 4>), grid, blk, 0, st, (const float*)grad_columns, (const float*)x, (const float*)offset, (const float*)mask, grad_x, grad_offset, grad_mask, g); break;
-    case UBV_F16: hipLaunchKernelGGL((dcn_col2im_kernel<f16_t, 8>), grid, blk, 0, st, (const f16_t*)grad_columns, (const f16_t*)x, (const f16_t*)offset, (const f16_t*)mask, grad_x, grad_offset, grad_mask, g); break;
-    default: hipLaunchKernelGGL((dcn_col2im_kernel<bf16_t, 8>), grid, blk, 0, st, (const bf16_t*)grad_columns, (const bf16_t*)x, (const bf16_t*)offset, (const bf16_t*)mask, grad_x, grad_offset, grad_mask, g); break;
+    case UBV_F16: hipLaunchKernelGGL((dcn_col2im_kernel<f16_t, 4>), grid, blk, 0, st, (const f16_t*)grad_columns, (const f16_t*)x, (const f16_t*)offset, (const f16_t*)mask, grad_x, grad_offset, grad_mask, g); break;
+    default: hipLaunchKernelGGL((dcn_col2im_kernel<bf16_t, 4>), grid, blk, 0, st, (const bf16_t*)grad_columns, (const bf16_t*)x, (const bf16_t*)offset, (const bf16_t*)mask, grad_x, grad_offset, grad_mask, g); break;
   }
   UBV_CHECK_LAUNCH("dcn_col2im");
   return UBV_OK;
