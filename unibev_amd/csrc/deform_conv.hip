@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const T* __restrict__ x
 // on the same lines: 890 us at 12 x 256 x 16x44, against 44 us for the im2col.  Two LDS-window variants (8x8 output
 // tile x 64 channels, window flushed once) were measured and dropped: ds_add_f32 runs at ~190 clocks per wave
 // instruction (692 us), and wave-private channels with plain read-modify-writes need 16x more wave iterations
-// (instruction-bound, 1 100 us).
+// (instruction-bound, 1 100 us); walking the taps outermost so that concurrent waves hit different lines changed
+// nothing (1 166 vs 1 175 us forward + backward): it is the atomic RATE (~88 G/s), not contention.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void dcn_col2im_kernel(const T* __restrict__ gcol, const T* __restrict__ x,
                                                          const T* __restrict__ offset, const T* __restrict__ mask,
