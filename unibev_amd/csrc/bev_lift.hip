@@ -969,6 +969,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 3)) void lift_bwd_value_
 }
 
 #include "bev_lift_maps.inl"
+#include "dcn_owner.inl"
 
 // ------------------------------------------------------------------------------------------------
 // CAMERA owner tiles, one lane per QUERY: a round trip to memory fetches everything 64 queries need

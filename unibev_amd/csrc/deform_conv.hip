@@ -26,6 +26,7 @@ struct DcnTap {
   bool live;           // position inside (-1, H) x (-1, W)
   int h0, w0;          // floor of the position
   float lh, lw;        // fractional parts
+  float dy, dx;        // the raw offsets
 };
 
 template <typename T>
@@ -38,6 +39,7 @@ __device__ __forceinline__ DcnTap dcn_tap(const DcnGeom& g, const T* __restrict_
   const float hp = (float)(ho * g.sh - g.ph + i * g.dh) + dy;
   const float wp = (float)(wo * g.sw - g.pw + j * g.dw) + dx;
   DcnTap t;
+  t.dy = dy; t.dx = dx;
   t.live = hp > -1.0f && wp > -1.0f && hp < (float)g.H && wp < (float)g.W;
   const float hf = floorf(hp), wf = floorf(wp);
   t.h0 = t.live ? (int)hf : 0;
@@ -94,7 +96,7 @@ template <typename T, int VEC>
 __global__ __launch_bounds__(256) void dcn_col2im_kernel(const T* __restrict__ gcol, const T* __restrict__ x,
                                                          const T* __restrict__ offset, const T* __restrict__ mask,
                                                          float* __restrict__ gx, float* __restrict__ goff,
-                                                         float* __restrict__ gmask, const DcnGeom g) {
+                                                         float* __restrict__ gmask, const DcnGeom g, int reach) {
   const int K = g.kh * g.kw, Cg = g.C / g.dg, CV = Cg / VEC;
   const long waves = (long)g.N * g.Ho * g.Wo * K * g.dg;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -110,6 +112,9 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(const T* __restrict__ g
   const long mi = (((long)n * g.dg + grp) * K + k) * plane + pix;
   const long oi = (((long)n * g.dg + grp) * 2 * K + 2 * k) * plane + pix;
   float s_mask = 0.0f, s_h = 0.0f, s_w = 0.0f;
+  // reach >= 0: the owner-tile pass (dcn_owner.inl) took every sample with |dy|, |dx| <= reach; only the others
+  // are scattered here (same predicate on the same values)
+  const bool scatter = reach < 0 || !(fabsf(tp.dy) <= (float)reach && fabsf(tp.dx) <= (float)reach);
   if (tp.live) {                                                     // wave-uniform
     const float mk = elem<T>::to_float(mask[mi]);
     const float hh = 1.0f - tp.lh, hw = 1.0f - tp.lw;
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(const T* __restrict__ g
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           dot = fmaf(gc[e], v[e], dot);
-          atomic_add_f32(gx + xo + e, gc[e] * mk * wgt[q]);
+          if (scatter) atomic_add_f32(gx + xo + e, gc[e] * mk * wgt[q]);
         }
         s_mask = fmaf(dot, wgt[q], s_mask);
         s_h = fmaf(dot, dh[q] * mk, s_h);
@@ -201,10 +206,15 @@ extern "C" int ubv_dcn_col2im(const void* grad_columns, const void* x, const voi
   UBV_CHECK_ARG((waves + 3) / 4 < (1L << 31), "dcn_col2im: too many elements");
   const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
   hipStream_t st = as_stream(stream);
+  // d(input): owner tiles on the matrix cores for the samples within kDcnReach of their tap (plain stores, every
+  // pixel once), the rest — and everything, when the shape is outside that kernel's reach — by atomics below
+  const bool owned = dcn_owner_launch(grad_columns, offset, mask, grad_x, N, H, W, C, Ho, Wo, kh, kw, sh, sw, ph, pw,
+                                      dh, dw, deform_groups, dtype, st);
+  const int reach = owned ? 3 : -1;
   switch (dtype) {
-    case UBV_F32: hipLaunchKernelGGL((dcn_col2im_kernel<float, 4>), grid, blk, 0, st, (const float*)grad_columns, (const float*)x, (const float*)offset, (const float*)mask, grad_x, grad_offset, grad_mask, g); break;
-    case UBV_F16: hipLaunchKernelGGL((dcn_col2im_kernel<f16_t, 4>), grid, blk, 0, st, (const f16_t*)grad_columns, (const f16_t*)x, (const f16_t*)offset, (const f16_t*)mask, grad_x, grad_offset, grad_mask, g); break;
-    default: hipLaunchKernelGGL((dcn_col2im_kernel<bf16_t, 4>), grid, blk, 0, st, (const bf16_t*)grad_columns, (const bf16_t*)x, (const bf16_t*)offset, (const bf16_t*)mask, grad_x, grad_offset, grad_mask, g); break;
+    case UBV_F32: hipLaunchKernelGGL((dcn_col2im_kernel<float, 4>), grid, blk, 0, st, (const float*)grad_columns, (const float*)x, (const float*)offset, (const float*)mask, grad_x, grad_offset, grad_mask, g, reach); break;
+    case UBV_F16: hipLaunchKernelGGL((dcn_col2im_kernel<f16_t, 4>), grid, blk, 0, st, (const f16_t*)grad_columns, (const f16_t*)x, (const f16_t*)offset, (const f16_t*)mask, grad_x, grad_offset, grad_mask, g, reach); break;
+    default: hipLaunchKernelGGL((dcn_col2im_kernel<bf16_t, 4>), grid, blk, 0, st, (const bf16_t*)grad_columns, (const bf16_t*)x, (const bf16_t*)offset, (const bf16_t*)mask, grad_x, grad_offset, grad_mask, g, reach); break;
   }
   UBV_CHECK_LAUNCH("dcn_col2im");
   return UBV_OK;

@@ -201,6 +201,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int chunk) { return (bid & 7) 
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// DCNv2 d(input) by owner tiles (dcn_owner.inl, compiled with bev_lift.hip whose TileAcc it reuses); false when the
+// shape is outside its reach.  Samples with an offset component beyond kDcnReach are left to the caller.
+bool dcn_owner_launch(const void* gcol, const void* offset, const void* mask, float* gx, int N, int H, int W, int C,
+                      int Ho, int Wo, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int dg,
+                      int dtype, hipStream_t st);
+
 // RAII pair of HIP events around one kernel launch (a no-op unless ubv_profile_enable(1)).
 class ProfScope {
  public:
