@@ -469,8 +469,8 @@ int ubv_grid_mask(const void* x, void* y, int64_t planes, int h, int w, int d, i
  *   mask     [N, dg*kh*kw, Ho, Wo]             modulation (after the sigmoid)
  *   columns  [N*Ho*Wo, kh*kw*C]                column k*C + c = mask * bilinear sample of channel c at tap k
  * The convolution is then y[N*Ho*Wo, Cout] = columns . Wp^T with Wp = weight.permute(0,2,3,1) ([Cout, kh*kw*C],
- * ubv_gemm_nt), born channels-last.  Backward: grad_columns = grad_y . Wp (ubv_gemm_nt), ubv_dcn_col2im scatters
- * grad_x (f32, ZEROED by the caller, atomics) and writes grad_offset / grad_mask (f32, every element written),
+ * ubv_gemm_nt), born channels-last.  Backward: grad_columns = grad_y . Wp (ubv_gemm_nt), ubv_dcn_col2im produces
+ * grad_x (f32, ZEROED by the caller: owner tiles + atomics for far offsets) and grad_offset / grad_mask (f32),
  * grad_weight = ubv_gemm_wgrad(grad_y, columns).  C / dg must be a multiple of 4 (f32) or 8 (16-bit). */
 int ubv_dcn_im2col(const void* x, const void* offset, const void* mask, void* columns, int N, int H, int W, int C,
                    int Ho, int Wo, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,

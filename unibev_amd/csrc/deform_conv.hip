@@ -7,9 +7,10 @@
 // the feature map is channels-last and the column matrix is [N*Ho*Wo, kh*kw*C] with the TAP outermost, so a
 // lane is 16 bytes of consecutive channels of one (pixel, tap): every gather and every column store is a
 // coalesced row segment, the convolution itself is ubv_gemm_nt on the row-major columns (weights permuted once
-// to [Cout, kh*kw*C]) and the result is born channels-last.  Backward: dCol = dY . W (ubv_gemm_nt), then ONE
-// pass (col2im) scatters d(input) with f32 atomics and reduces d(offset) / d(mask) over the channels of the
-// deformable group inside the wave; dW is ubv_gemm_wgrad over (dY, columns).
+// to [Cout, kh*kw*C]) and the result is born channels-last.  Backward: dCol = dY . W (ubv_gemm_nt); d(input) on
+// owner tiles with MFMA (dcn_owner.inl) for the samples near their tap, f32 atomics here for the rest; d(offset) /
+// d(mask) reduced over the channels of the deformable group inside the wave; dW is ubv_gemm_wgrad over
+// (dY, columns).
 //
 // Sampling semantics (dmcn_im2col_bilinear): position p = (ho*s - pad + i*dil + dy, wo*s - pad + j*dil + dx);
 // a position with p <= -1 or p >= size contributes 0, otherwise the four corners with corners outside the map
