@@ -252,8 +252,8 @@ def run_mode(args, name, head, world, rank, device, want_ops):
     step = gs.step if graphed else gs.eager_step
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        from unibev_amd import dp as _dp
+        _dp.barrier(device)                        # (async all-reduce: see dp.all_reduce)
         torch.cuda.synchronize()
 
     step()
@@ -345,6 +345,8 @@ def gemm_record(device, bs):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
+        from unibev_amd import dp as _dp
+        _dp.drain_watchdog()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode='thread_local'):
             for _ in range(n):

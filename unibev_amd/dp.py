@@ -56,18 +56,44 @@ def wrap_ddp(module, device_ids=None, bucket_cap_mb=32):
         bucket_cap_mb=bucket_cap_mb)
 
 
+def all_reduce(t, op):
+    """``dist.all_reduce`` issued as an ASYNC op and waited for at once.  A synchronous RCCL collective runs on
+    the caller's current stream and records its completion events there; the process group's watchdog thread keeps
+    querying those events until it has retired the work (every ~100 ms), and HIP refuses ``hipEventQuery`` on an event
+    whose stream is capturing a graph (hipErrorCapturedEvent, which aborts the process from the watchdog).  The step
+    captures its HIP graphs on that same stream moments after the warm-up's last all-reduce — one run in six died
+    there.  Async ops run on the group's own stream, which never captures; ``wait()`` only makes the current stream
+    wait for it."""
+    dist.all_reduce(t, op=op, async_op=True).wait()
+    return t
+
+
+def drain_watchdog():
+    """Called before a graph capture: lets the watchdog retire the collectives that have finished (it polls every
+    100 ms), so that nothing it still holds refers to the stream about to capture."""
+    if dist.is_initialized() and dist.get_backend() == 'nccl':
+        torch.cuda.synchronize()
+        import time
+        time.sleep(0.35)
+
+
 def max_over_ranks(value, device='cpu'):
     """MAX of a python float over all ranks (bench.py times the slowest rank)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    all_reduce(t, dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def barrier():
+def barrier(device=None):
+    """All ranks reach this point (an all-reduce of one element; see ``all_reduce`` for why not ``dist.barrier``)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        dev = device if device is not None else ('cuda' if dist.get_backend() == 'nccl' else 'cpu')
+        t = torch.zeros(1, device=dev)
+        all_reduce(t, dist.ReduceOp.SUM)
+        if t.is_cuda:
+            torch.cuda.synchronize()
 
 
 class FlatGradients:
@@ -106,7 +132,7 @@ class FlatGradients:
         if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_ddp()):
             return
         if dist.get_backend() == 'nccl':
-            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
+            all_reduce(self.flat, dist.ReduceOp.AVG)
         else:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            all_reduce(self.flat, dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())

@@ -89,6 +89,8 @@ class GraphedStep:
                     self._clear_grads()
                     self._fwd_bwd()
         torch.cuda.synchronize()
+        from . import dp
+        dp.drain_watchdog()                              # RCCL's watchdog must hold nothing from this stream (dp.all_reduce)
         for combo in self._combos():
             self.tr.forced_flags = combo
             self._clear_grads()
