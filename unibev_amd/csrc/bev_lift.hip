@@ -405,7 +405,8 @@ struct TileArgs;
 template <typename T, int DH, int P, int MODE>
 __global__ __launch_bounds__(256) void lift_bin_kernel(const LiftArgs a, int tiles_x, int tiles) {
   // per wave: an 8x8 torus of tile slots — occupant tile, local count, global base
-  __shared__ int slot_tile[4][64], slot_cnt[4][64], slot_base[4][64];
+  __shared__ volatile int slot_tile[4][64];
+  __shared__ int slot_cnt[4][64], slot_base[4][64];
   const int wv = wave_in_block(), lane = threadIdx.x & 63;
   slot_tile[wv][lane] = -1;
   slot_cnt[wv][lane] = 0;
@@ -480,8 +481,12 @@ __global__ __launch_bounds__(256) void lift_bin_kernel(const LiftArgs a, int til
       local[k] = false;
       rank[k] = 0;
       if (lead[k]) {
-        const int prev = atomicCAS(&slot_tile[wv][hs[k]], -1, tk[k]);
-        local[k] = (prev == -1) || (prev == tk[k]);
+        // claim the slot with plain LDS accesses: the lanes that see it free all write their tile, one write wins,
+        // everybody re-reads (a wave's LDS operations execute in order; the slot arrays are per wave) — an atomicCAS
+        // here serialised the 64 lanes on one address a second time, next to the rank counter below
+        volatile int* st = &slot_tile[wv][hs[k]];
+        if (*st == -1) *st = tk[k];
+        local[k] = *st == tk[k];
         if (local[k]) rank[k] = atomicAdd(&slot_cnt[wv][hs[k]], 1);
         else {
           const int i = atomicAdd(cntp + tk[k], 1);
