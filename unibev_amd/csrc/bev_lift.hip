@@ -520,19 +520,20 @@ __global__ __launch_bounds__(256) void lift_bin_kernel(const LiftArgs a, int til
 // its bucket sums on top for exactly those tiles.  Both exit at once when nothing overflowed.
 __global__ __launch_bounds__(256) void lift_ovf_zero_kernel(const LiftArgs a, int tiles_x, int tiles,
                                                             int Dh) {
-  if (*a.ovf_n == 0) return;
-  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wave >= (long)a.B * a.H * tiles) return;
-  if (a.bin_cnt[wave] <= a.cap) return;
+  if (*a.ovf_n == 0) return;                         // (a small grid walks the tiles: the common case is this exit)
+  const long total = (long)a.B * a.H * tiles;
   const int lane = threadIdx.x & 63;
-  const int tl = (int)(wave % tiles), bh = (int)(wave / tiles);
-  const int h = bh % a.H, b = bh / a.H;
-  const int x0 = (tl % tiles_x) * 8, y0 = (tl / tiles_x) * 8;
-  const long row = (long)a.H * Dh;
-  float* gv = a.gvalue + (long)b * a.fh * a.fw * row + h * Dh;
-  const int py = lane >> 3, px = lane & 7;
-  if (y0 + py < a.fh && x0 + px < a.fw)
-    for (int c = 0; c < Dh; ++c) gv[((long)(y0 + py) * a.fw + (x0 + px)) * row + c] = 0.0f;
+  for (long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6); wave < total; wave += (long)gridDim.x * 4) {
+    if (a.bin_cnt[wave] <= a.cap) continue;
+    const int tl = (int)(wave % tiles), bh = (int)(wave / tiles);
+    const int h = bh % a.H, b = bh / a.H;
+    const int x0 = (tl % tiles_x) * 8, y0 = (tl / tiles_x) * 8;
+    const long row = (long)a.H * Dh;
+    float* gv = a.gvalue + (long)b * a.fh * a.fw * row + h * Dh;
+    const int py = lane >> 3, px = lane & 7;
+    if (y0 + py < a.fh && x0 + px < a.fw)
+      for (int c = 0; c < Dh; ++c) gv[((long)(y0 + py) * a.fw + (x0 + px)) * row + c] = 0.0f;
+  }
 }
 
 template <typename T, int DH>
@@ -1350,9 +1351,10 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     }
     {
       const long tw = (long)a.B * a.H * tiles;
-      hipLaunchKernelGGL(lift_ovf_zero_kernel, dim3((unsigned)((tw + 3) / 4)), dim3(256), 0, s2, a,
+      const long zb = (tw + 3) / 4;
+      hipLaunchKernelGGL(lift_ovf_zero_kernel, dim3((unsigned)(zb < 256 ? zb : 256)), dim3(256), 0, s2, a,
                          t.tiles_x, tiles, DH);
-      hipLaunchKernelGGL((lift_ovf_scatter_kernel<T, DH>), dim3(1024), dim3(256), 0, s2, a, t.tiles_x,
+      hipLaunchKernelGGL((lift_ovf_scatter_kernel<T, DH>), dim3(256), dim3(256), 0, s2, a, t.tiles_x,
                          tiles);
     }
     {
