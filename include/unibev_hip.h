@@ -319,6 +319,11 @@ int ubv_gemm_wgrad(const void* grad_out, const void* x, float* partials, float* 
  * [K, N] for the input-gradient GEMM.  One launch per Linear per step. */
 int ubv_split_weight(const float* w, int N, int K, void* w_hi, void* w_lo, void* wt_hi, void* wt_lo,
                      void* stream);
+/* The same for n parameters in one launch (the weights of every Linear of a pass).  Entry i is a parameter
+ * [rows, cols]; wh / wl point at its first row inside a (possibly concatenated) [N_total, cols] pair of halves, wth / wtl
+ * (both NULL or both set) at its first COLUMN inside the [cols, N_total] transposed halves with leading dimension ld_t. */
+int ubv_split_weights_batched(int n, const float* const* w, const int* rows, const int* cols, void* const* wh,
+                              void* const* wl, void* const* wth, void* const* wtl, const int* ld_t, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Reductions behind the gradients of the encoder's Linear layers (value_proj, sampling_offsets,

@@ -169,3 +169,35 @@ def test_flat_adamw_matches_torch_adamw_with_clipping(max_norm):
         for p, r in zip(mine, ref):
             torch.testing.assert_close(p.detach(), r.detach(), rtol=2e-6, atol=2e-7)
     assert all(p.data_ptr() >= opt.flat.data_ptr() for p in mine)      # parameters live in the flat buffer
+
+
+def test_split_weights_batched_matches_the_per_weight_kernel():
+    from unibev_amd import functional as UF
+    g = torch.Generator(device='cpu').manual_seed(5)
+    groups = [[torch.randn(256, 256, generator=g).to(DEV)],
+              [torch.randn(64, 256, generator=g).to(DEV), torch.randn(32, 256, generator=g).to(DEV)],      # concatenated
+              [torch.randn(512, 256, generator=g).to(DEV)], [torch.randn(100, 72, generator=g).to(DEV)]]
+    groups += [[torch.randn(40, 33, generator=g).to(DEV)] for _ in range(60)]                               # > one launch
+    got = UF.split_weights_batched(groups)
+    for grp, out in zip(groups, got):
+        want = UF.split_weight(torch.cat(grp, 0))
+        for a, b in zip(out, want):
+            assert a.shape == b.shape and torch.equal(a, b)
+
+
+def test_second_pass_takes_the_presplit_weights_and_follows_weight_updates():
+    import unibev_amd.linear as UL
+    lin = torch.nn.Linear(256, 96).to(DEV)
+    x = torch.randn(300, 256, device=DEV)
+    UL.clear_lowp_cache()
+    outs = []
+    for it in range(3):
+        with UL.lowp_step_cache():
+            if it > 0:
+                assert len(UL._SPLIT_PASS) == 1          # split on entry, before the layer asked for it
+            outs.append(UL.linear(x, lin.weight, lin.bias))
+        with torch.no_grad():
+            lin.weight.mul_(2.0)
+    assert torch.allclose(outs[1], 2 * outs[0] - lin.bias.detach(), rtol=1e-4, atol=1e-4)
+    ref = torch.nn.functional.linear(x, lin.weight / 2, lin.bias)
+    assert float((outs[2] - ref).detach().abs().max()) < 1e-3 * float(ref.detach().abs().max())

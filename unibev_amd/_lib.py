@@ -54,6 +54,7 @@ SIGNATURES = {
     'ubv_grid_mask': (c_int, [_P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'ubv_dcn_im2col': (c_int, [_P, _P, _P, _P] + [c_int] * 16 + [_P]),
     'ubv_dcn_col2im': (c_int, [_P] * 7 + [c_int] * 16 + [_P]),
+    'ubv_split_weights_batched': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'ubv_sumsq_workspace': (c_int64, []),
     'ubv_sumsq_f32': (c_int, [_P, c_int64, _P, _P, _P]),
     'ubv_adamw_flat': (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, _P, _P, c_float, _P]),

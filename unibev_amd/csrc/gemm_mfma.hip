@@ -338,6 +338,53 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
   }
 }
 
+// All the Linear weights of a pass in ONE launch (the per-weight kernel above is 46 launches of ~5 us per f32
+// step, each far too small to fill the chip).  An entry is one parameter [rows, cols]; several entries may be the
+// row blocks of one concatenated weight: wh / wl point at the entry's first row of the [N_total, cols] halves,
+// wth / wtl at column col_t of the [cols, N_total] transposed halves (leading dimension ld_t).
+constexpr int kSplitBatch = 48;
+struct SplitEntry {
+  const float* w;
+  uint16_t *wh, *wl, *wth, *wtl;
+  int rows, cols, ld_t, tile_end;                       // tile_end: exclusive prefix of 32 x 32 tiles
+};
+struct SplitBatch { SplitEntry e[kSplitBatch]; int n; };
+
+__global__ __launch_bounds__(256) void split_weights_batched_kernel(const SplitBatch b) {
+  __shared__ uint16_t th[32][33], tl[32][33];
+  int i = 0;
+  while (i + 1 < b.n && (int)blockIdx.x >= b.e[i].tile_end) ++i;
+  const SplitEntry& e = b.e[i];
+  const int t = blockIdx.x - (i ? b.e[i - 1].tile_end : 0);
+  const int tk = (e.cols + 31) / 32;
+  const int n0 = (t / tk) * 32, k0 = (t % tk) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = n0 + ty + 8 * r, k = k0 + tx;
+    uint16_t h = 0, l = 0;
+    if (n < e.rows && k < e.cols) {
+      const float v = e.w[(long)n * e.cols + k];
+      h = (uint16_t)float_to_bf16_bits(v);
+      l = (uint16_t)float_to_bf16_bits(v - bf16_bits_to_float(h));
+      e.wh[(long)n * e.cols + k] = h;
+      e.wl[(long)n * e.cols + k] = l;
+    }
+    th[ty + 8 * r][tx] = h;
+    tl[ty + 8 * r][tx] = l;
+  }
+  __syncthreads();
+  if (e.wth == nullptr) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int k = k0 + ty + 8 * r, n = n0 + tx;
+    if (n < e.rows && k < e.cols) {
+      e.wth[(long)k * e.ld_t + n] = th[tx][ty + 8 * r];
+      e.wtl[(long)k * e.ld_t + n] = tl[tx][ty + 8 * r];
+    }
+  }
+}
+
 template <bool SPLIT, bool F16, bool OUT16>
 static int gemm_nt_launch(const void* X, long ldx, const void* Wh, const void* Wl, long ldw, const float* bias,
                           const void* R, void* Y, long ldy, long M, int N, int K, const GemmAct& act, hipStream_t st) {
@@ -378,6 +425,29 @@ static int gemm_nt_launch(const void* X, long ldx, const void* Wh, const void* W
 }
 
 }  // namespace ubv
+
+extern "C" int ubv_split_weights_batched(int n, const float* const* w, const int* rows, const int* cols,
+                                         void* const* wh, void* const* wl, void* const* wth, void* const* wtl,
+                                         const int* ld_t, void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(n >= 0 && (n == 0 || (w && rows && cols && wh && wl && wth && wtl && ld_t)), "split_weights_batched: bad arguments");
+  for (int base = 0; base < n; base += kSplitBatch) {
+    SplitBatch b{};
+    b.n = n - base < kSplitBatch ? n - base : kSplitBatch;
+    int tiles = 0;
+    for (int i = 0; i < b.n; ++i) {
+      const int j = base + i;
+      UBV_CHECK_ARG(w[j] && wh[j] && wl[j] && rows[j] > 0 && cols[j] > 0 && (wth[j] == nullptr) == (wtl[j] == nullptr),
+                    "split_weights_batched: entry %d", j);
+      tiles += ((rows[j] + 31) / 32) * ((cols[j] + 31) / 32);
+      b.e[i] = SplitEntry{w[j], (uint16_t*)wh[j], (uint16_t*)wl[j], (uint16_t*)wth[j], (uint16_t*)wtl[j],
+                          rows[j], cols[j], ld_t[j], tiles};
+    }
+    hipLaunchKernelGGL(split_weights_batched_kernel, dim3((unsigned)tiles), dim3(256), 0, as_stream(stream), b);
+  }
+  UBV_CHECK_LAUNCH("split_weights_batched");
+  return UBV_OK;
+}
 
 extern "C" int ubv_split_weight(const float* w, int N, int K, void* wh, void* wl, void* wth, void* wtl,
                                 void* stream) {

@@ -634,6 +634,41 @@ def split_weight(w, transposed=True):
 
 
 @torch.no_grad()
+def split_weights_batched(groups):
+    """``split_weight`` for many weights in ONE launch (``ubv_split_weights_batched``).  ``groups``: list of lists of
+    f32 CUDA parameters [N_i, K] that are used concatenated along dim 0.  Returns one (w_hi, w_lo, wt_hi, wt_lo)
+    per group, carved from a single fresh bf16 buffer."""
+    if not groups:
+        return []
+    dev = groups[0][0].device
+    with _need_cuda(*[p for g in groups for p in g]):
+        total = sum(4 * sum(p.shape[0] for p in g) * g[0].shape[1] for g in groups)
+        buf = torch.empty(total, dtype=torch.bfloat16, device=dev)
+        outs, ent, o = [], [], 0
+        for g in groups:
+            K = g[0].shape[1]
+            N = sum(p.shape[0] for p in g)
+            wh, wl = buf[o:o + N * K].view(N, K), buf[o + N * K:o + 2 * N * K].view(N, K)
+            wth, wtl = buf[o + 2 * N * K:o + 3 * N * K].view(K, N), buf[o + 3 * N * K:o + 4 * N * K].view(K, N)
+            o += 4 * N * K
+            outs.append((wh, wl, wth, wtl))
+            r = 0
+            for p in g:
+                w = p.detach()
+                if w.dtype != torch.float32 or not w.is_contiguous() or w.shape[1] != K:
+                    raise ValueError('split_weights_batched: contiguous f32 [N, K] weights of one K per group')
+                ent.append((w.data_ptr(), p.shape[0], K, wh[r:].data_ptr(), wl[r:].data_ptr(),
+                            wth[:, r:].data_ptr(), wtl[:, r:].data_ptr(), N))
+                r += p.shape[0]
+        n = len(ent)
+        PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
+        col = lambda i: [e[i] for e in ent]
+        check(lib().ubv_split_weights_batched(n, PA(*col(0)), IA(*col(1)), IA(*col(2)), PA(*col(3)), PA(*col(4)),
+                                              PA(*col(5)), PA(*col(6)), IA(*col(7)), _stream()), 'split_weights_batched')
+        return outs
+
+
+@torch.no_grad()
 def gemm_nt(x, w_hi, w_lo=None, bias=None, residual=None, out=None):
     """y = x @ w^T (+ bias) (+ residual) on the matrix cores (``ubv_gemm_nt``).  f32 ``x`` takes the
     split weight (w_hi, w_lo); 16-bit ``x`` takes w_hi of its own type.  Returns None when the shape

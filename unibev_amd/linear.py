@@ -94,6 +94,7 @@ def lowp_step_cache():
     from . import functional as UF
     UF.new_step()                     # backward accumulators of this pass come from a fresh arena
     _SPLIT_PASS.clear()
+    _presplit()
     if _SHADOWS and _masters_changed():
         plan = _refresh_plan()
         with torch.no_grad():
@@ -109,6 +110,8 @@ def lowp_step_cache():
 
 
 def clear_lowp_cache():
+    _SPLIT_USED.clear()
+    _SPLIT_PREV.clear()
     _SHADOWS.clear()
     _PLAN.update(n=-1, groups=[], params=[], versions=None)
     _DIRTY[0] = True
@@ -135,6 +138,31 @@ _MFMA_WGRAD = os.environ.get('UBV_WGRAD', 'mfma') != 'library'
 _MFMA_16_MAXN = 192          # 16-bit data: the MFMA kernel wins for narrow outputs, the library for wide ones
 
 
+_SPLIT_USED = {}            # weight groups the CURRENT pass asked for: key -> parameters
+_SPLIT_PREV = {}            # ... the previous pass asked for: split together, in one launch, when the next pass starts
+
+
+def _presplit():
+    """On entry to a pass: the weight groups the previous pass used are split in ONE launch
+    (``split_weights_batched``: 46 launches of ~5 us each per f32 step otherwise).  A pass that asks for none (16-bit
+    autocast) makes the next one start empty again."""
+    global _SPLIT_USED, _SPLIT_PREV
+    _SPLIT_PREV, _SPLIT_USED = _SPLIT_USED, {}
+    if not _SPLIT_PREV or not _MFMA_F32:
+        return
+    groups = [g for g in _SPLIT_PREV.values()
+              if all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.dim() == 2 for p in g)]
+    if not groups:
+        return
+    from . import functional as UF
+    by_dev = {}
+    for g in groups:
+        by_dev.setdefault(g[0].device, []).append(g)
+    for gs in by_dev.values():
+        for g, out in zip(gs, UF.split_weights_batched(gs)):
+            _SPLIT_PASS[tuple(id(p) for p in g)] = out
+
+
 def _split_weights(weights):
     key = tuple(id(p) for p in weights)
     hit = _SPLIT_PASS.get(key) if _ACTIVE else None
@@ -144,6 +172,8 @@ def _split_weights(weights):
         hit = UF.split_weight(w)
         if _ACTIVE:
             _SPLIT_PASS[key] = hit
+    if _ACTIVE:
+        _SPLIT_USED[key] = list(weights)
     return hit
 
 
