@@ -1529,8 +1529,8 @@ static int plan_backward(const LiftArgs& a, int Dh, int P, int dtype, int ref_is
     t.chunks = 1;
     t.chunk_q = 0;
     static const int grid_waves = getenv("UBV_GRID_WAVES") ? atoi(getenv("UBV_GRID_WAVES")) : 0;
-    // f32 tiles hold 13 KB of LDS per wave: blocks of 2 waves pack 12 waves on a CU (the register limit), blocks of 4 only 8
-    t.waves = grid_waves > 0 ? grid_waves : (dtype == UBV_F32 ? 2 : 4);
+    // f32 tiles hold 13 KB of LDS per wave: blocks of 2 or 3 waves pack 12 waves on a CU (the register limit), blocks of 4 only 8
+    t.waves = grid_waves > 0 ? grid_waves : (dtype == UBV_F32 ? 3 : 4);   // (f32: 1 / 2 / 3 waves measured 112 / 114 / 109 us on the self-attention shape)
     // bucket capacity: twice the expected records per tile (P points per query-head, Nq/S queries
     // per pixel, 1.3 tiles per point); the overflow list takes whatever concentrates beyond that
     const double expect = 1.3 * P * 64.0 * (double)a.Nq / ((double)a.fh * a.fw);
