@@ -27,6 +27,7 @@ for dt in bf16 fp32; do
   python $ROOT/tools/bench_lift.py --dtype $dt --img-hw 800 1440 --dh 16 > $OUT/bench_lift_cat128_$dt.txt 2>&1
 done
 python $ROOT/tools/bench_gemm.py > $OUT/bench_gemm.txt 2>&1
+python $ROOT/tools/bench_backbone.py 2>&1 | grep -v '^/opt' > $OUT/bench_backbone.txt
 # 6. HBM traffic per op (PMC passes)
 bash $ROOT/tools/collect_traffic.sh $OUT > $OUT/traffic.log 2>&1
 ls -la $OUT
