@@ -69,6 +69,37 @@ def dynamic_scatter(feats, coors, reduce_type):
     return of[:m], oc[:m], mp, cnt[:m]
 
 
+def dynamic_scatter_backward(grad_voxel_feats, feats, voxel_feats, point2voxel_map, voxel_points_count, reduce_type):
+    """Sequential restatement of [ext] mmdet3d 0.18.1 ``dynamic_point_to_voxel_backward``
+    (ops/voxel/src/scatter_points_cuda.cu: ``add_reduce_traceback_grad_kernel`` for sum / mean,
+    ``max_reduce_traceback_scatter_idx_kernel`` + ``max_reduce_scatter_grad_kernel`` for max): the gradient of a
+    (voxel, channel) maximum goes to ONE point, the smallest point index whose feature equals the reduced value
+    (``atomicMin`` over point indices).  Source not vendored in /root/reference: parity unpinned, known-answer tested."""
+    g = np.asarray(grad_voxel_feats, np.float64)
+    f = np.asarray(feats, np.float32)
+    N, C = f.shape
+    out = np.zeros((N, C), np.float64)
+    if reduce_type in ('sum', 'mean'):
+        for i in range(N):
+            v = int(point2voxel_map[i])
+            if v >= 0:
+                out[i] = g[v] / (int(voxel_points_count[v]) if reduce_type == 'mean' else 1)
+        return out
+    arg = np.full((len(voxel_feats), C), N, np.int64)
+    for i in range(N):                       # ascending point index: the first hit is the minimum
+        v = int(point2voxel_map[i])
+        if v < 0:
+            continue
+        for ch in range(C):
+            if f[i, ch] == voxel_feats[v, ch] and arg[v, ch] == N:
+                arg[v, ch] = i
+    for v in range(len(voxel_feats)):
+        for ch in range(C):
+            if arg[v, ch] < N:
+                out[arg[v, ch], ch] = g[v, ch]
+    return out
+
+
 def voxel_mean(voxels, num_points):
     v = np.ascontiguousarray(voxels, np.float32)
     n = np.ascontiguousarray(num_points, np.int32)

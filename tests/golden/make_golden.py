@@ -465,7 +465,92 @@ def gen_grid_mask():
     save('grid_mask', **out)
 
 
+PIPELINE_VIEWS = (3, 30, 50, 7)        # views, h, w, seed: 30x50 pads to 32x64 under size_divisor=32
+
+
+def pipeline_views():
+    n, h, w, seed = PIPELINE_VIEWS
+    rs = np.random.RandomState(seed)
+    return [rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8) for _ in range(n)]
+
+
+def gen_pipelines():
+    """datasets/pipelines/transform_3d.py: ``PadMultiViewImage`` (:7-57), ``NormalizeMultiviewImage`` (:60-95) and
+    ``CustomCollect3D`` (:199-284) — the reference's own classes, imported from where they lie, run on seeded views
+    in the order of the shipped configs (normalize -> pad -> collect, configs/unibev/...cnw...:119-137).  mmcv's three
+    image helpers are stand-ins restating the published functions (mmcv/image/geometric.py ``impad`` /
+    ``impad_to_multiple``: constant border on the bottom / right; mmcv/image/photometric.py ``imnormalize``: f32 copy,
+    BGR->RGB when ``to_rgb``, subtract the mean, multiply by 1 / std computed in f64)."""
+    stub.install()
+    mmcv = sys.modules['mmcv']
+
+    def impad(img, *, shape=None, padding=None, pad_val=0, padding_mode='constant'):
+        assert shape is not None and padding is None and padding_mode == 'constant'
+        out = np.full((shape[0], shape[1]) + img.shape[2:], pad_val, dtype=img.dtype)
+        out[:img.shape[0], :img.shape[1]] = img
+        return out
+
+    def impad_to_multiple(img, divisor, pad_val=0):
+        h = int(np.ceil(img.shape[0] / divisor)) * divisor
+        w = int(np.ceil(img.shape[1] / divisor)) * divisor
+        return impad(img, shape=(h, w), pad_val=pad_val)
+
+    def imnormalize(img, mean, std, to_rgb=True):
+        img = img.copy().astype(np.float32)
+        mean = np.float64(mean.reshape(1, -1))
+        stdinv = 1 / np.float64(std.reshape(1, -1))
+        if to_rgb:
+            img = np.ascontiguousarray(img[..., ::-1])
+        img = img - mean.astype(np.float32)          # cv2.subtract / cv2.multiply work in the array's f32
+        return img * stdinv.astype(np.float32)
+
+    mmcv.impad, mmcv.impad_to_multiple, mmcv.imnormalize = impad, impad_to_multiple, imnormalize
+
+    class DataContainer:
+        def __init__(self, data, stack=False, padding_value=0, cpu_only=False, pad_dims=2):
+            self.data, self.cpu_only = data, cpu_only
+    par = stub._mod('mmcv.parallel', DataContainer=DataContainer)
+    mmcv.parallel = par
+    pipes = stub.Registry('pipeline')
+    for n in ('mmdet.datasets',):
+        stub._mod(n).__path__ = []
+    stub._mod('mmdet.datasets.builder', PIPELINES=pipes)
+    spec = importlib.util.spec_from_file_location(
+        'ref_transform_3d', os.path.join(REF_MODULES, '..', '..', 'datasets', 'pipelines', 'transform_3d.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    metas = syn.img_metas(1, PIPELINE_VIEWS[0], (PIPELINE_VIEWS[1], PIPELINE_VIEWS[2]))[0]
+    for tag, norm, pad in (('cfg', dict(mean=[103.530, 116.280, 123.675], std=[1.0, 1.0, 1.0], to_rgb=False),
+                            dict(size_divisor=32)),
+                           ('rgb', dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True),
+                            dict(size=(40, 56), pad_val=2))):
+        res = dict(img=pipeline_views(), lidar2img=metas['lidar2img'], sample_idx='tok', unrelated=1,
+                   points='PTS', pts_filename='a.bin', box_type_3d='LiDAR')
+        res = mod.NormalizeMultiviewImage(**norm)(res)
+        res = mod.PadMultiViewImage(**pad)(res)
+        data = mod.CustomCollect3D(keys=['points', 'img'])(res)
+        assert isinstance(data['img_metas'], DataContainer) and data['img_metas'].cpu_only
+        m = data['img_metas'].data
+        out[tag + '_img'] = np.stack(data['img'])
+        out[tag + '_data_keys'] = np.array(json.dumps(list(data)))
+        out[tag + '_meta_keys'] = np.array(json.dumps(list(m)))
+        for k in ('img_shape', 'pad_shape', 'ori_shape'):
+            out[f'{tag}_{k}'] = np.asarray(m[k])
+        out[tag + '_norm_mean'] = m['img_norm_cfg']['mean']
+        out[tag + '_norm_std'] = m['img_norm_cfg']['std']
+        out[tag + '_norm_to_rgb'] = np.array(int(m['img_norm_cfg']['to_rgb']))
+        out[tag + '_pad_fixed_size'] = np.asarray(res['pad_fixed_size'] if res['pad_fixed_size'] is not None else [-1])
+        out[tag + '_pad_size_divisor'] = np.asarray(res['pad_size_divisor'] if res['pad_size_divisor'] is not None else -1)
+        out[tag + '_repr'] = np.array(json.dumps([repr(mod.PadMultiViewImage(**pad)),
+                                                  repr(mod.CustomCollect3D(keys=['img']))]))
+    out['views_ck'] = checksum(np.stack(pipeline_views()))
+    save('pipelines', **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'pipelines':
+        return gen_pipelines()
     torch.manual_seed(0)
     torch.set_num_threads(8)
     mods = load_reference()
@@ -478,6 +563,7 @@ def main():
     gen_fullsize(mods)
     gen_head(mods)
     gen_grid_mask()
+    gen_pipelines()
 
 
 if __name__ == '__main__':

@@ -43,6 +43,48 @@ def test_bench_json_contract(force_ddp):
         assert d['gemm'] and d['voxel']['voxels'] > 10000 and d['voxel']['points_per_s'] > 0
 
 
+@pytest.mark.parametrize('workload,ops', [('C', {'self_attn', 'sca_img'}), ('L', {'self_attn', 'sca_pts'}),
+                                          ('LC_cat128', {'self_attn', 'sca_pts', 'sca_img'})])
+def test_bench_other_workloads(workload, ops):
+    """BASELINE.json configs[1] (camera-only), [2] (LiDAR-only) and [4] (cat-128, 25x45 camera maps) through the
+    same command: contract fields, the workload named in ``config``, a roofline entry per sampling op."""
+    d = _run({}, '--workload', workload, '--dtype', 'fp32', '--no-extras', '--no-parity')
+    assert d['value'] > 0 and d['dtype'] == 'fp32' and d['n_gpus'] == 1 and 'lowp' not in d
+    assert {'C': 'unibev_nus_C', 'L': 'unibev_nus_L', 'LC_cat128': 'unibev_nus_LC_cat_128'}[workload] in d['config']['workload']
+    assert {o['op'] for o in d['roofline_ops']} == ops
+    assert all(0 < o['frac'] < 1 and o['pass'] in ('fwd', 'bwd') for o in d['roofline_ops'])
+    assert d['roofline']['bound'] == 'hbm' and d['config']['step'].startswith('fwd + bwd (HIP graphs)')
+
+
+def test_bench_launches_its_own_ranks():
+    """``python bench.py --gpus N`` with no torchrun environment starts N ranks itself (torch.distributed.run on
+    127.0.0.1) and prints ONE line with rccl_ranks == N.  On a one-GPU box: N = 1 through the same launcher
+    (``--launcher spawn``), one rank WITH an RCCL process group — the flat-gradient all-reduce, the deterministic
+    watchdog drain before graph capture and the max-over-ranks timing all run."""
+    import torch
+    n = 2 if torch.cuda.device_count() >= 2 else 1
+    flags = ['--gpus', str(n), '--dtype', 'fp32', '--no-extras', '--no-parity', '--no-kernel-timing']
+    if n == 1:
+        flags += ['--launcher', 'spawn']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1',
+                          '--no-cpu-baseline', *flags], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == n and d['config']['rccl_ranks'] == n and d['config']['global_batch'] == 2 * n
+    assert d['config']['launcher'].startswith('self') and d['value'] > 0
+    assert d['config']['step'].startswith('fwd + bwd (HIP graphs)')
+
+
+def test_bench_refuses_a_mismatched_world_and_a_silent_eager_fallback():
+    env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29543')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1'],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode != 0 and 'WORLD_SIZE=1' in out.stderr
+
+
 def test_graph_replay_matches_eager_and_follows_the_modality_protocol():
     """GraphedStep: with dropout off the replayed gradients equal the eager ones (up to the order of
     f32 atomic adds); the per-step graph is chosen by the reference's

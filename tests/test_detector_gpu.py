@@ -1,0 +1,162 @@
+"""``UniBEV`` detector (registry key DETECTORS:'UniBEV', unibev_detector.py:17-175) end to end
+on the device: raw point clouds + camera images -> voxelize -> VFE -> SparseEncoder -> SECOND -> SECONDFPN, GridMask
+(off in eval) -> ResNet(DCNv2) -> FPN, -> BEV encoders + fusion -> ``fused_bev_embed``, against the CHAIN OF ORACLES
+(oracle/voxelize_ref.c, sparse_conv_ref.py, backbones_ref.py + dcn_ref.py, unibev_ref.py) on the same seeded state
+dict — a small instance of the shipped L+C CNW config's structure."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+PCR = [-8.0, -8.0, -5.0, 8.0, 8.0, 3.0]
+VOX = [0.25, 0.25, 0.2]
+C = 64
+BEV_H, BEV_W = 10, 12
+IMG_HW = (64, 96)
+NCAM = 2
+
+
+def _model_cfg(fusion='linear', feature_norm='ChannelNormWeights'):
+    from unibev_amd import configs
+    head = configs.head_cfg(embed_dims=C, bev_h=BEV_H, bev_w=BEV_W, num_query=20, num_layers=2, decoder_layers=1,
+                            num_cams=NCAM, fusion_method=fusion, feature_norm=feature_norm, drop_modality=0.5)
+    for enc in ('img_encoder', 'pts_encoder'):
+        head['transformer'][enc]['pc_range'] = PCR
+        head['transformer'][enc]['transformerlayers']['attn_cfgs'][1]['pc_range'] = PCR
+    head['bbox_coder']['pc_range'] = PCR
+    return dict(
+        type='UniBEV', use_grid_mask=True,
+        pts_voxel_layer=dict(max_num_points=10, voxel_size=VOX, point_cloud_range=PCR, max_voxels=(9000, 12000)),
+        pts_voxel_encoder=dict(type='HardSimpleVFE', num_features=5),
+        pts_middle_encoder=dict(type='SparseEncoder', in_channels=5, sparse_shape=[41, 64, 64], output_channels=32,
+                                order=('conv', 'norm', 'act'), base_channels=8,
+                                encoder_channels=((8, 8, 16), (16, 16, 32), (32, 32, 64), (64, 64)),
+                                encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)),
+                                block_type='basicblock'),
+        pts_backbone=dict(type='SECOND', in_channels=64, out_channels=[32, 64], layer_nums=[1, 2], layer_strides=[1, 2],
+                          norm_cfg=dict(type='BN', eps=1e-3, momentum=0.01), conv_cfg=dict(type='Conv2d', bias=False)),
+        pts_neck=dict(type='SECONDFPN', in_channels=[32, 64], upsample_strides=[1, 2], out_channels=[C // 2, C // 2],
+                      norm_cfg=dict(type='BN', eps=1e-3, momentum=0.01), upsample_cfg=dict(type='deconv', bias=False),
+                      use_conv_for_no_stride=True),
+        img_backbone=dict(type='ResNet', depth=50, num_stages=4, out_indices=(3,), frozen_stages=1,
+                          norm_cfg=dict(type='BN2d', requires_grad=False), norm_eval=True, style='caffe', with_cp=True,
+                          dcn=dict(type='DCNv2', deform_groups=1, fallback_on_stride=False),
+                          stage_with_dcn=(False, False, True, True)),
+        img_neck=dict(type='FPN', in_channels=[2048], out_channels=C, start_level=0, add_extra_convs='on_output',
+                      num_outs=1, relu_before_extra_convs=True),
+        pts_bbox_head=head,
+        train_cfg=dict(pts=dict(grid_size=[64, 64, 40], voxel_size=VOX, point_cloud_range=PCR)))
+
+
+def _clouds():
+    rs = np.random.RandomState(11)
+    out = []
+    for n in (6000, 4500):
+        p = np.stack([rs.uniform(-9, 9, n), rs.uniform(-9, 9, n), np.clip(rs.standard_normal(n) - 1, -5, 2.99),
+                      rs.uniform(0, 255, n), np.zeros(n)], 1).astype(np.float32)
+        out.append(p)
+    return out
+
+
+def _oracle_chain(det, clouds, imgs, metas, model_cfg):
+    """The same forward with the oracles, f32 torch on the CPU, from the detector's own state dict."""
+    from oracle import backbones_ref as B, c_ref, sparse_conv_ref as S, unibev_ref as R
+    sd = {k: v.detach().cpu() for k, v in det.state_dict().items()}
+    sub = lambda pre: {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    feats, coors = [], []
+    for b, p in enumerate(clouds):
+        v, c, n = c_ref.hard_voxelize(p, VOX, PCR, 10, 12000)              # eval mode: the test-time voxel cap
+        feats.append(torch.from_numpy(c_ref.voxel_mean(v, n)[:, :5]))
+        coors.append(torch.from_numpy(np.concatenate([np.full((len(c), 1), b, np.int32), c], 1)))
+    mcfg = model_cfg['pts_middle_encoder']
+    x = S.sparse_encoder(sub('pts_middle_encoder.'), mcfg, torch.cat(feats), torch.cat(coors), len(clouds))
+    x = B.second(sub('pts_backbone.'), x, [1, 2], [1, 2])
+    pts_feats = B.second_fpn(sub('pts_neck.'), x, [1, 2], True)
+    bs, n = imgs.shape[:2]
+    f = B.resnet(sub('img_backbone.'), imgs.reshape(bs * n, *imgs.shape[2:]), 50, out_indices=(3,), style='caffe')
+    f = B.fpn(sub('img_neck.'), f, 1, 0, 'on_output', True)
+    img_feats = [t.view(bs, n, *t.shape[1:]) for t in f]
+    head = sub('pts_bbox_head.')
+    bev_pos = R.learned_positional_encoding(head['positional_encoding.row_embed.weight'],
+                                            head['positional_encoding.col_embed.weight'], bs, BEV_H, BEV_W)
+    fused = R.transformer_encode_fuse(sub('pts_bbox_head.transformer.'), model_cfg['pts_bbox_head']['transformer'],
+                                      img_feats, pts_feats, head['bev_embedding.weight'], BEV_H, BEV_W, bev_pos, metas)
+    return fused, img_feats, pts_feats
+
+
+@pytest.mark.parametrize('fusion,norm', [('linear', 'ChannelNormWeights'), ('cat', None)])
+def test_detector_forward_bev_matches_the_oracle_chain(fusion, norm):
+    from test_backbones_parity import _randomize
+    from unibev_amd import registry as reg, synthetic as syn
+    cfg = _model_cfg(fusion, norm)
+    torch.manual_seed(0)
+    det = reg.DETECTORS.build(copy.deepcopy(cfg))
+    det.init_weights()
+    for m in (det.img_backbone, det.img_neck, det.pts_backbone, det.pts_neck):
+        _randomize(m, 21)
+    det = det.to(DEV).eval()
+    # batch statistics in the LiDAR branch (its oracles restate training-mode batch norm); everything else eval:
+    # dropout, modality dropout and GridMask off
+    for m in (det.pts_middle_encoder, det.pts_backbone, det.pts_neck):
+        m.train()
+    clouds = _clouds()
+    imgs = torch.randn(2, NCAM, 3, *IMG_HW, generator=torch.Generator().manual_seed(5))
+    metas = syn.img_metas(2, NCAM, IMG_HW, jitter_seed=3)
+    with torch.no_grad():
+        img_feats, pts_feats, _ = det.extract_feat(imgs.to(DEV), [torch.from_numpy(c).to(DEV) for c in clouds], None,
+                                                   metas)
+        fused = det.forward_bev(points=[torch.from_numpy(c).to(DEV) for c in clouds], img_metas=metas,
+                                img=imgs.to(DEV))
+        ref, ref_img, ref_pts = _oracle_chain(det, clouds, imgs, metas, cfg)
+    s = 2 if fusion == 'cat' else 1
+    assert fused.shape == (BEV_H * BEV_W, 2, C * s)
+    assert img_feats[0].shape == (2, NCAM, C, 2, 3) and pts_feats[0].shape == (2, C, 8, 8)
+    rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
+    assert rel(pts_feats[0], ref_pts[0]) < 2e-3, rel(pts_feats[0], ref_pts[0])
+    assert rel(img_feats[0], ref_img[0]) < 2e-3, rel(img_feats[0], ref_img[0])
+    assert rel(fused, ref) < 2e-3, rel(fused, ref)
+    assert float((fused.float().cpu() - ref).abs().max()) < 1e-2 * float(ref.abs().max())
+
+
+def test_detector_voxelize_and_outs_contract():
+    """``voxelize`` returns (voxels, num_points, coors [b, z, y, x]) bit-exact against the C oracle per sample;
+    ``forward_outs`` carries the head's dict; ``forward_train`` / ``simple_test`` stop at the out-of-scope loss /
+    decode with NotImplementedError after running the whole forward; gradients reach the backbones."""
+    from oracle import c_ref
+    from unibev_amd import registry as reg, synthetic as syn
+    cfg = _model_cfg()
+    torch.manual_seed(1)
+    det = reg.DETECTORS.build(copy.deepcopy(cfg)).to(DEV).train()
+    clouds = _clouds()
+    pts = [torch.from_numpy(c).to(DEV) for c in clouds]
+    voxels, num, coors = det.voxelize(pts)
+    off = 0
+    for b, p in enumerate(clouds):
+        v, c, n = c_ref.hard_voxelize(p, VOX, PCR, 10, 9000)               # train mode: max_voxels[0]
+        m = len(c)
+        assert np.array_equal(coors[off:off + m, 1:].cpu().numpy(), c) and (coors[off:off + m, 0] == b).all()
+        assert np.array_equal(num[off:off + m].cpu().numpy(), n)
+        assert np.array_equal(voxels[off:off + m].cpu().numpy(), v)
+        off += m
+    assert off == len(coors) and coors.dtype == torch.int32 and not voxels.requires_grad
+    imgs = torch.randn(2, NCAM, 3, *IMG_HW, device=DEV)
+    metas = syn.img_metas(2, NCAM, IMG_HW)
+    np.random.seed(0)
+    outs = det.forward_outs(points=pts, img_metas=metas, img=imgs)
+    assert outs['bev_embed'].shape == (BEV_H * BEV_W, 2, C)
+    assert outs['all_cls_scores'].shape == (1, 2, 20, 10) and outs['all_bbox_preds'].shape == (1, 2, 20, 10)
+    (outs['bev_embed'].square().mean() + outs['all_bbox_preds'].square().mean()).backward()
+    for name in ('img_backbone.layer3.0.conv2.conv_offset.weight', 'img_neck.fpn_convs.0.conv.weight',
+                 'pts_middle_encoder.conv_input.0.weight', 'pts_backbone.blocks.0.0.weight',
+                 'pts_neck.deblocks.1.0.weight', 'pts_bbox_head.bev_embedding.weight'):
+        g = dict(det.named_parameters())[name].grad
+        assert g is not None and torch.isfinite(g).all(), name
+    assert det.img_backbone.layer1[0].conv1.weight.grad is None                # frozen stage
+    with pytest.raises(NotImplementedError):
+        det(return_loss=True, points=pts, img_metas=metas, img=imgs, gt_bboxes_3d=None, gt_labels_3d=None)
+    det.eval()
+    with pytest.raises(NotImplementedError), torch.no_grad():
+        det(return_loss=False, points=[pts], img_metas=[metas], img=[imgs])

@@ -96,3 +96,17 @@ def test_dynamic_scatter_oracle_vs_numpy_unique():
     np.testing.assert_array_equal(mp, [2, 1, 2, -1, 1, 0])
     np.testing.assert_array_equal(cnt, [1, 2, 2])
     np.testing.assert_array_equal(vf, [[10, 11], [5, 6], [2, 3]])
+
+
+def test_dynamic_scatter_backward_oracle_known_answers():
+    """The max gradient goes to the FIRST point attaining the maximum (published op: atomicMin over point indices),
+    sum copies, mean divides by the count; invalid points get nothing."""
+    feats = np.array([[1, 0], [3, 0], [3, 0], [2, 0], [9, 9]], np.float32)
+    mp = np.array([0, 0, 0, 0, -1])
+    vf, cnt, g = np.array([[3, 0]], np.float32), np.array([4]), np.array([[5.0, 7.0]])
+    np.testing.assert_array_equal(c_ref.dynamic_scatter_backward(g, feats, vf, mp, cnt, 'max'),
+                                  [[0, 7], [5, 0], [0, 0], [0, 0], [0, 0]])
+    np.testing.assert_array_equal(c_ref.dynamic_scatter_backward(g, feats, vf, mp, cnt, 'sum'),
+                                  [[5, 7]] * 4 + [[0, 0]])
+    np.testing.assert_array_equal(c_ref.dynamic_scatter_backward(g, feats, vf, mp, cnt, 'mean'),
+                                  [[1.25, 1.75]] * 4 + [[0, 0]])

@@ -1,6 +1,7 @@
 """Host data contract: the pipeline stages that produce the two meta keys
 the encoder reads, and the one-upload-per-batch form of ``lidar2img``."""
 import numpy as np
+import pytest
 import torch
 
 from unibev_amd import synthetic as syn
@@ -54,3 +55,62 @@ def test_collect_and_device_metas():
     a = _lidar2img_tensor(metas, torch.device('cpu'))
     b = _lidar2img_tensor(dev, torch.device('cpu'))
     assert torch.equal(a, b) and _lidar2img_tensor(metas, torch.device('cpu')) is a      # cached upload
+
+
+def test_pipeline_stages_vs_reference_recorded_vectors():
+    """tests/golden/pipelines.npz: the reference's own ``NormalizeMultiviewImage`` -> ``PadMultiViewImage`` ->
+    ``CustomCollect3D`` (transform_3d.py:7-95, 199-284, imported by tests/golden/make_golden.py) on seeded views, in
+    the shipped configs' order and in an RGB / fixed-size variant: pixel values, every shape key, the collected key
+    sets and their order, the norm cfg and the reprs."""
+    import json
+    from _util import golden, checksum
+    import make_golden as mg
+    g = golden('pipelines')
+    views = mg.pipeline_views()
+    np.testing.assert_array_equal(checksum(np.stack(views)), g['views_ck'])
+    metas = syn.img_metas(1, mg.PIPELINE_VIEWS[0], mg.PIPELINE_VIEWS[1:3])[0]
+    for tag, norm, pad in (('cfg', dict(mean=[103.530, 116.280, 123.675], std=[1.0, 1.0, 1.0], to_rgb=False),
+                            dict(size_divisor=32)),
+                           ('rgb', dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True),
+                            dict(size=(40, 56), pad_val=2))):
+        res = dict(img=[v.copy() for v in views], lidar2img=metas['lidar2img'], sample_idx='tok', unrelated=1,
+                   points='PTS', pts_filename='a.bin', box_type_3d='LiDAR')
+        res = PIPELINES.build(dict(type='NormalizeMultiviewImage', **norm))(res)
+        res = PIPELINES.build(dict(type='PadMultiViewImage', **pad))(res)
+        data = PIPELINES.build(dict(type='CustomCollect3D', keys=['points', 'img']))(res)
+        assert list(data) == json.loads(str(g[tag + '_data_keys']))
+        m = data['img_metas']
+        assert list(m) == json.loads(str(g[tag + '_meta_keys']))
+        got = np.stack(data['img'])
+        assert got.dtype == g[tag + '_img'].dtype and got.shape == g[tag + '_img'].shape
+        np.testing.assert_array_equal(got, g[tag + '_img'])                 # bit-exact: same f32 operations
+        for k in ('img_shape', 'pad_shape', 'ori_shape'):
+            np.testing.assert_array_equal(np.asarray(m[k]), g[f'{tag}_{k}'])
+        np.testing.assert_array_equal(m['img_norm_cfg']['mean'], g[tag + '_norm_mean'])
+        np.testing.assert_array_equal(m['img_norm_cfg']['std'], g[tag + '_norm_std'])
+        assert int(m['img_norm_cfg']['to_rgb']) == int(g[tag + '_norm_to_rgb'])
+        fixed, div = g[tag + '_pad_fixed_size'], int(g[tag + '_pad_size_divisor'])
+        assert (res['pad_fixed_size'] is None and fixed.tolist() == [-1]) or list(res['pad_fixed_size']) == fixed.tolist()
+        assert (res['pad_size_divisor'] is None and div == -1) or res['pad_size_divisor'] == div
+        reprs = json.loads(str(g[tag + '_repr']))
+        assert repr(PadMultiViewImage(**pad)) == reprs[0]
+        assert repr(CustomCollect3D(keys=['img'])) == reprs[1]
+
+
+@pytest.mark.gpu
+def test_metas_to_device_feeds_point_sampling_on_the_gpu():
+    """One pinned upload per batch; the encoder projects from the device views and gets the visibility / camera
+    coordinates it gets from host arrays (reference: encoder_unibev_detr_img.py:115-124 rebuilds the tensor from numpy
+    on every forward)."""
+    from unibev_amd.modules.encoders import ImgEncoder
+    dev = torch.device('cuda')
+    metas = syn.img_metas(2, 6, (256, 704), jitter_seed=2)
+    on_dev = metas_to_device(metas, dev)
+    assert all(m['lidar2img'].is_cuda and m['lidar2img'].dtype == torch.float32 for m in on_dev)
+    assert on_dev[0]['lidar2img'].untyped_storage().data_ptr() == on_dev[1]['lidar2img'].untyped_storage().data_ptr()
+    ref3d = ImgEncoder.get_reference_points(50, 50, 8, 4, dim='3d', bs=2, device=dev)
+    enc = ImgEncoder.__new__(ImgEncoder)
+    pc = [-54, -54, -5, 54, 54, 3]
+    cam_a, mask_a = ImgEncoder.point_sampling(enc, ref3d, pc, metas)
+    cam_b, mask_b = ImgEncoder.point_sampling(enc, ref3d, pc, on_dev)
+    assert torch.equal(mask_a, mask_b) and torch.equal(cam_a, cam_b) and mask_a.any()

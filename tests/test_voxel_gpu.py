@@ -172,3 +172,31 @@ def test_dynamic_scatter_edge_cases_and_module():
     assert vfeat.tolist() == [[10.0, 11.0], [5.0, 6.0], [2.0, 3.0]]
     vfeat.sum().backward()
     assert feats.grad.tolist() == [[0.5, 0.5], [0.5, 0.5], [0.5, 0.5], [0.0, 0.0], [0.5, 0.5], [1.0, 1.0]]
+
+
+@pytest.mark.parametrize('reduce_type', ['sum', 'mean', 'max'])
+def test_dynamic_scatter_backward_with_ties_vs_sequential_oracle(reduce_type):
+    """LiDAR channels tie constantly (quantised intensity, all-zero time stamps): the max gradient must reach exactly
+    one point per (voxel, channel) — the smallest index attaining the maximum — as the published op traces it back."""
+    from unibev_amd.modules.voxel import dynamic_scatter as ds
+    rs = np.random.RandomState(5)
+    n = 4000
+    coors = rs.randint(0, 6, (n, 3)).astype(np.int32)
+    coors[rs.rand(n) < 0.05] = -1
+    feats = np.stack([rs.randint(0, 4, n), np.zeros(n), rs.standard_normal(n), rs.randint(0, 2, n)], 1).astype(np.float32)
+    fg = t(feats, device=DEV).requires_grad_()
+    vf, vc = ds(fg, t(coors, device=DEV), reduce_type)
+    cot = rs.standard_normal(tuple(vf.shape)).astype(np.float32)
+    (vf * t(cot, device=DEV)).sum().backward()
+    ef, ec, emp, ecnt = c_ref.dynamic_scatter(feats, coors, reduce_type)
+    np.testing.assert_array_equal(vf.detach().cpu().numpy(), ef)
+    want = c_ref.dynamic_scatter_backward(cot, feats, ef, emp, ecnt, reduce_type)
+    np.testing.assert_allclose(fg.grad.cpu().numpy(), want, rtol=1e-6, atol=0)
+    if reduce_type == 'max':                 # one receiver per (voxel, channel)
+        assert int((fg.grad != 0).sum()) <= ef.size and float(fg.grad[:, 1].abs().sum()) > 0
+    # no valid point at all: zero gradient, no error
+    fz = t(feats[:7], device=DEV).requires_grad_()
+    vz, _ = ds(fz, torch.full((7, 3), -1, dtype=torch.int32, device=DEV), reduce_type)
+    assert vz.shape[0] == 0
+    vz.sum().backward()
+    assert fz.grad is not None and float(fz.grad.abs().sum()) == 0

@@ -30,6 +30,8 @@ def study(fixture):
     scale = np.abs(sub).max()
     modes = [('fp32', torch.float32, False, {}), ('fp32/gemm-bf16x3', torch.float32, False, {'UBV_GEMM_EMU': 'bf16x3'}),
              ('fp32/gemm-bf16x3 except offsets+logits', torch.float32, False, {'UBV_GEMM_EMU': 'bf16x3-keep-offlog'})]
+    modes.append(('fp32/value-fp16', torch.float32, False, {'_value': torch.float16}))
+    modes.append(('fp32/value-bf16', torch.float32, False, {'_value': torch.bfloat16}))
     for dt, name in ((torch.float16, 'fp16'), (torch.bfloat16, 'bf16')):
         modes.append((name + '/stream16', dt, True, {}))
         modes.append((name + '/stream32', dt, False, {}))
@@ -38,6 +40,9 @@ def study(fixture):
     for name, dt, lowp, env in modes:
         for k in ('UBV_OFFLOG', 'UBV_GEMM_EMU'):
             os.environ.pop(k, None)
+        env = dict(env)
+        from unibev_amd.modules.deform_attn import set_value_storage
+        set_value_storage(env.pop('_value', None))
         os.environ.update(env)
         model.lowp_stream = lowp
         with torch.no_grad(), torch.autocast('cuda', dtype=dt, enabled=dt != torch.float32):

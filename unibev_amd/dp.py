@@ -68,13 +68,23 @@ def all_reduce(t, op):
     return t
 
 
-def drain_watchdog():
-    """Called before a graph capture: lets the watchdog retire the collectives that have finished (it polls every
-    100 ms), so that nothing it still holds refers to the stream about to capture."""
-    if dist.is_initialized() and dist.get_backend() == 'nccl':
-        torch.cuda.synchronize()
-        import time
-        time.sleep(0.35)
+def drain_watchdog(timeout_s=30.0):
+    """Called before a graph capture: returns once RCCL's watchdog thread holds NO work of this process any more, so
+    that it queries no event while a stream captures.  Deterministic, no timing assumption: every collective issued
+    so far has completed on the device (``synchronize``), and ``ProcessGroupNCCL::waitForPendingWorks`` blocks until
+    the watchdog has taken each of them off its work list (it re-checks the list under the watchdog's own lock; the
+    watchdog only ever queries the events of works still on that list).  Together with ``all_reduce`` above
+    (collectives run on the group's stream, never on the capturing one) nothing the watchdog can touch refers to the
+    capture.  Groups without that entry point (gloo, older torch) have no such watchdog."""
+    if not (dist.is_initialized() and dist.get_backend() == 'nccl'):
+        return
+    torch.cuda.synchronize()
+    pg = dist.distributed_c10d._get_default_group()
+    wait = getattr(pg, '_wait_for_pending_works', None)
+    if wait is None:                                  # pragma: no cover - torch without the binding
+        raise RuntimeError('drain_watchdog: this torch build has no ProcessGroup._wait_for_pending_works; '
+                           'cannot guarantee that RCCL\'s watchdog is idle before a HIP-graph capture')
+    wait()
 
 
 def max_over_ranks(value, device='cpu'):

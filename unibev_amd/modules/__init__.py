@@ -13,3 +13,4 @@ from .sparse_encoder import (SparseBasicBlock, SparseConv3d, SparseConvTensor, S
 from .grid_mask import GridMask  # noqa
 from .backbones import (FPN, SECOND, SECONDFPN, ModulatedDeformConv2dPack, ResNet,  # noqa
                         extract_img_feat)
+from .detector import UniBEV  # noqa

@@ -33,6 +33,28 @@ def _OFFLOG_F32():
     return os.environ.get('UBV_OFFLOG', '') == 'fp32'
 
 
+_VALUE_STORAGE = [{'fp16': torch.float16, 'bf16': torch.bfloat16}.get(os.environ.get('UBV_VALUE16', ''))]
+
+
+def set_value_storage(dtype):
+    """VALUE-ONLY 16-bit mode ("fp16/bf16 value for the build"): the residual stream,
+    every Linear (split-bf16 MFMA products), offsets, logits, softmax and sampling locations stay f32; only the
+    projected value maps the sampling kernels gather from — and with them the sampled output and, in backward,
+    ``grad_output`` / ``grad_value`` — are stored in ``dtype`` (torch.float16 / torch.bfloat16; None = off).  Halves
+    the gathered bytes.  Returns the previous setting."""
+    if dtype not in (None, torch.float16, torch.bfloat16):
+        raise ValueError('value storage must be None, torch.float16 or torch.bfloat16')
+    prev, _VALUE_STORAGE[0] = _VALUE_STORAGE[0], dtype
+    return prev
+
+
+def _store_value(value):
+    st = _VALUE_STORAGE[0]
+    if st is not None and value.is_cuda and value.dtype == torch.float32:
+        return value.to(st)
+    return value
+
+
 def static_hw(spatial_shapes):
     """Host copy [(h, w), ...] of a ``spatial_shapes`` tensor without a device sync when the
     producer attached one (``_ubv_hw``); otherwise one ``tolist()`` (sync) as in any eager use."""
@@ -150,11 +172,12 @@ class _DeformAttnBase(BaseModule):
     def project_value(self, value, key_padding_mask=None, passthru=False):
         if passthru:
             assert key_padding_mask is None
-            return linear_pass(value, self.value_proj.weight, self.value_proj.bias)
+            value, alias = linear_pass(value, self.value_proj.weight, self.value_proj.bias)
+            return _store_value(value), alias
         value = ubv_linear(value, self.value_proj.weight, self.value_proj.bias)
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
-        return value
+        return _store_value(value)
 
     def k1(self, value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
         bs, num_value = value.shape[:2]

@@ -29,8 +29,10 @@ class UniBEV_Head(BaseModule):
         self.num_query = num_query
         self.num_classes = num_classes
         # DETRHead: sigmoid classification (every shipped config: FocalLoss, use_sigmoid=True) has
-        # num_classes outputs, softmax one more for the background
-        self.use_sigmoid_cls = bool((loss_cls or {}).get('use_sigmoid', True))
+        # num_classes outputs, softmax one more for the background.  Defaults as in [ext] mmdet: DETRHead's default
+        # loss is CrossEntropyLoss (use_sigmoid=False); FocalLoss defaults to use_sigmoid=True, every other loss False
+        loss_cls = dict(loss_cls) if loss_cls else dict(type='CrossEntropyLoss', use_sigmoid=False)
+        self.use_sigmoid_cls = bool(loss_cls.get('use_sigmoid', loss_cls.get('type') == 'FocalLoss'))
         self.cls_out_channels = num_classes if self.use_sigmoid_cls else num_classes + 1
         self.with_box_refine = with_box_refine
         self.as_two_stage = as_two_stage
@@ -93,6 +95,16 @@ class UniBEV_Head(BaseModule):
             bias_init = float(-math.log((1 - 0.01) / 0.01))
             for m in self.cls_branches:
                 nn.init.constant_(m[-1].bias, bias_init)
+
+    def loss(self, *args, **kwargs):
+        """unibev_head.py:322-427 (Hungarian assignment + focal / L1 losses): out of scope, SURVEY.md section 2 #13."""
+        raise NotImplementedError('UniBEV_Head.loss: the Hungarian loss is outside the hot path (SURVEY.md section 2); '
+                                  'take the head outputs from forward() and apply your own criterion')
+
+    def get_bboxes(self, *args, **kwargs):
+        """unibev_head.py:429-456 (NMSFreeCoder decode): out of scope, SURVEY.md section 2 #16."""
+        raise NotImplementedError('UniBEV_Head.get_bboxes: NMS-free box decoding is outside the hot path '
+                                  '(SURVEY.md section 2); decode all_cls_scores / all_bbox_preds of forward()')
 
     def bev_inputs(self, bs, dtype, device):
         """(bev_queries, bev_pos) exactly as unibev_head.py:171-182 builds them."""

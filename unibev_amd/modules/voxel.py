@@ -91,15 +91,25 @@ class _DynamicScatterFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_vf, grad_vc=None):
+        """[ext] mmdet3d ``dynamic_point_to_voxel_backward``: sum copies the voxel's gradient to its points, mean
+        divides by the count, max routes each (voxel, channel) gradient to ONE point — the smallest point index whose
+        feature equals the maximum (the published op's ``atomicMin`` over point indices), never to every tied point."""
         feats, vf, mp, cnt = ctx.saved_tensors
+        n, c = feats.shape
+        if vf.shape[0] == 0 or n == 0:                   # no valid point: nothing receives a gradient
+            return torch.zeros_like(feats), None, None
         valid = mp >= 0
         idx = mp.clamp(min=0).long()
         g = grad_vf[idx]
         if ctx.reduce_type == 'mean':
             g = g / cnt[idx].to(g.dtype)[:, None]
         elif ctx.reduce_type == 'max':
-            g = g * (feats.float() == vf[idx]).to(g.dtype)
-        return g * valid[:, None].to(g.dtype), None, None
+            pidx = torch.arange(n, device=feats.device).view(n, 1).expand(n, c)
+            tied = (feats.float() == vf[idx]) & valid[:, None]
+            first = torch.full((vf.shape[0], c), n, dtype=torch.long, device=feats.device)
+            first.scatter_reduce_(0, idx.view(n, 1).expand(n, c), torch.where(tied, pidx, n), 'amin')
+            g = g * (first[idx] == pidx).to(g.dtype)
+        return (g * valid[:, None].to(g.dtype)).to(feats.dtype), None, None
 
 
 def dynamic_scatter(feats, coors, reduce_type='max'):
