@@ -32,8 +32,8 @@ def _model_cfg(fusion='linear', feature_norm='ChannelNormWeights'):
         pts_voxel_layer=dict(max_num_points=10, voxel_size=VOX, point_cloud_range=PCR, max_voxels=(9000, 12000)),
         pts_voxel_encoder=dict(type='HardSimpleVFE', num_features=5),
         pts_middle_encoder=dict(type='SparseEncoder', in_channels=5, sparse_shape=[41, 64, 64], output_channels=32,
-                                order=('conv', 'norm', 'act'), base_channels=8,
-                                encoder_channels=((8, 8, 16), (16, 16, 32), (32, 32, 64), (64, 64)),
+                                order=('conv', 'norm', 'act'),
+                                encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 64), (64, 64)),
                                 encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)),
                                 block_type='basicblock'),
         pts_backbone=dict(type='SECOND', in_channels=64, out_channels=[32, 64], layer_nums=[1, 2], layer_strides=[1, 2],

@@ -124,10 +124,16 @@ def _encoder_gradients_vs_oracle(name, R):
     (fused * t(cot, device=DEV)).sum().backward()
 
     def close(a, b, what):
+        # every Linear of the product path is a split-bf16 MFMA product (~2^-17 per product; since round 3 also the
+        # first layer's, whose batch-expanded input used to fall to the IEEE library GEMM): normwise 1e-3 like the
+        # bar on the BEV features, and 4e-3 on the single worst element (measured 2.8e-3 on an FFN weight gradient of
+        # this random-parameter fixture, which amplifies a unit round-off ~1000x)
         b = b.numpy()
+        a = a.cpu().numpy()
         s = max(np.abs(b).max(), 1e-6)
-        err = np.abs(a.cpu().numpy() - b).max() / s
-        assert err < 2e-3, (what, err)
+        err = np.abs(a - b).max() / s
+        nerr = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12)
+        assert err < 4e-3 and nerr < 1e-3, (what, err, nerr)
     close(gi[0].grad, oi[0].grad, 'img feats')
     close(gp[0].grad, op[0].grad, 'pts feats')
     close(gq.grad, oq.grad, 'bev queries')
@@ -208,34 +214,79 @@ def test_encoder_fullsize_vs_reference_statistics(fixture):
     np.testing.assert_allclose(checksum(pts_bev.cpu().numpy())[1], g['pts_bev_ck'][1], rtol=1e-4)
 
 
-# Full-size distance of the 16-bit autocast paths to the REFERENCE-recorded vectors (normwise, on the
-# recorded subsample), measured on MI355X and asserted with ~1.4x headroom (tools/precision_study.py):
-#   fixture            fp16 (16-bit stream)   bf16 (16-bit stream)   fp32
-#   fullsize_init      7.3e-4  < 1e-3 bar     5.8e-3                 7e-6    initial sampling parameters,
-#                                                                            spatially correlated maps
-#   fullsize           2.8e-2                 1.9e-1                 3.2e-4  i.i.d. maps, random offset
-#                                                                            weights: every rounding moves
-#                                                                            sampling points by O(1) values
-#   fullsize_cat128    6.1e-3                 4.7e-2                 6.5e-5  cfg5 (C = 128, 25x45 maps)
-# The adversarial fixtures amplify a unit round-off ~1000x (f32: 6e-8 -> 6e-5), so no 16-bit storage of
-# activations can hold 1e-3 there; on the operating point the bench runs at (and training starts
-# from) fp16 is inside the bar.
-LOWP_DISTANCE = {('fullsize_init', torch.float16): 1.0e-3, ('fullsize_init', torch.bfloat16): 8e-3,
-                 ('fullsize', torch.float16): 4e-2, ('fullsize', torch.bfloat16): 0.26,
-                 ('fullsize_cat128', torch.float16): 9e-3, ('fullsize_cat128', torch.bfloat16): 6.5e-2}
+# Full-size distance of the reduced-precision modes to the REFERENCE-recorded vectors (normwise, on the recorded
+# subsample) against BASELINE's bar of 1e-3.  Modes: 'fp16' / 'bf16' = autocast (16-bit GEMM operands, value maps and
+# residual stream); 'value-fp16' / 'value-bf16' = f32 everywhere (split-bf16 MFMA GEMMs, f32 stream, offsets, logits)
+# with ONLY the projected value maps / sampled outputs stored in 16 bits (deform_attn.set_value_storage).
+# Measured on MI355X (tools/precision_study.py, profiles/r03_precision_study.txt):
+#   fixture            fp32     value-fp16  fp16     value-bf16  bf16
+#   fullsize_init      7e-6     2.3e-4      7.2e-4   1.8e-3      5.8e-3   initial sampling parameters, correlated maps
+#   fullsize           3.2e-4   3.1e-3      2.8e-2   2.4e-2      1.9e-1   i.i.d. maps, random offset weights
+#   fullsize_cat128    6.5e-5   8.6e-4      6.1e-3   6.9e-3      4.7e-2   cfg5 (C = 128, 25x45 maps)
+# The adversarial fixture amplifies a unit round-off ~1000x (f32: 6e-8 -> 6e-5): every rounding of a sampled value
+# moves the next layers' sampling points, and on i.i.d. maps a moved point changes the sample by O(1).  Only f32
+# passes everywhere; value-fp16 passes at the operating point and on cfg5; nothing with bf16 storage passes.
+# Combinations that MISS the bar are listed with a ceiling (regression guard) and reported as xfail — strictly: a
+# listed combination that comes inside the bar fails the test until it is taken off the list.
+PARITY_BAR = 1e-3
+LOWP_MODES = {'fp16': (torch.float16, None), 'bf16': (torch.bfloat16, None),
+              'value-fp16': (torch.float32, torch.float16), 'value-bf16': (torch.float32, torch.bfloat16)}
+LOWP_MISSES = {('fullsize', 'fp16'): 4e-2, ('fullsize_cat128', 'fp16'): 9e-3,
+               ('fullsize_init', 'bf16'): 8e-3, ('fullsize', 'bf16'): 0.26, ('fullsize_cat128', 'bf16'): 6.5e-2,
+               ('fullsize', 'value-fp16'): 4.5e-3,
+               ('fullsize_init', 'value-bf16'): 2.6e-3, ('fullsize', 'value-bf16'): 3.5e-2,
+               ('fullsize_cat128', 'value-bf16'): 1e-2}
 
 
-@pytest.mark.parametrize('fixture,dtype', sorted(LOWP_DISTANCE, key=str))
-def test_fullsize_16bit_distance_to_reference_vectors(fixture, dtype):
+@pytest.mark.parametrize('mode', list(LOWP_MODES))
+@pytest.mark.parametrize('fixture', ['fullsize_init', 'fullsize', 'fullsize_cat128'])
+def test_fullsize_reduced_precision_distance_to_reference_vectors(fixture, mode):
+    from unibev_amd.modules.deform_attn import set_value_storage
     cfg, sd, inp, g = encoder_case(fixture)
     model = _build(cfg).to(DEV).eval()
     _load(model, sd)
-    with torch.no_grad(), torch.autocast('cuda', dtype=dtype):
-        fused, _, _ = _run(model, inp)
+    dtype, vstore = LOWP_MODES[mode]
+    prev = set_value_storage(vstore)
+    try:
+        with torch.no_grad(), torch.autocast('cuda', dtype=dtype, enabled=dtype != torch.float32):
+            fused, _, _ = _run(model, inp)
+    finally:
+        set_value_storage(prev)
     assert fused.dtype == dtype
     f = fused.float().cpu().numpy().reshape(-1)[g['fused_idx']]
     err = np.linalg.norm(f - g['fused_sub']) / np.linalg.norm(g['fused_sub'])
-    assert err < LOWP_DISTANCE[(fixture, dtype)], err
+    ceiling = LOWP_MISSES.get((fixture, mode))
+    if ceiling is None:
+        assert err < PARITY_BAR, err
+        return
+    assert err < ceiling, f'{err:.3e}: worse than the recorded miss'
+    assert err >= PARITY_BAR, f'{err:.3e} is now inside the bar: take ({fixture}, {mode}) off LOWP_MISSES'
+    pytest.xfail(f'{mode} on {fixture}: {err:.2e} misses the 1e-3 bar (expected, see the table above)')
+
+
+def test_value_storage_mode_gradients_match_f32():
+    """value-fp16 backward: grad_output / grad_value travel in fp16 through the sampling kernels, everything else in
+    f32 — parameter and input gradients stay within 8e-3 (normwise; measured 3.3e-3) of the all-f32 run on the small CNW case."""
+    from unibev_amd.modules.deform_attn import set_value_storage
+    cfg, sd, inp, g = encoder_case('cnw')
+    grads = {}
+    for tag, st in (('f32', None), ('v16', torch.float16)):
+        model = _build(cfg).to(DEV).eval()
+        _load(model, sd)
+        img = [t(x, device=DEV).requires_grad_() for x in inp['img']]
+        pts = [t(x, device=DEV).requires_grad_() for x in inp['pts']]
+        prev = set_value_storage(st)
+        try:
+            fused = model.encode(img, pts, t(inp['bev_q'], device=DEV), inp['bev_h'], inp['bev_w'],
+                                 bev_pos=t(inp['bev_pos'], device=DEV), img_metas=inp['metas'])
+            fused.square().mean().backward()
+        finally:
+            set_value_storage(prev)
+        assert fused.dtype == torch.float32
+        grads[tag] = [img[0].grad, pts[0].grad] + [p.grad for n, p in model.named_parameters()
+                                                  if p.grad is not None and 'value_proj.weight' in n]
+    for a, b in zip(grads['v16'], grads['f32']):
+        assert float((a - b).norm() / b.norm()) < 8e-3
 
 
 @pytest.mark.parametrize('lowp_stream', [True, False])

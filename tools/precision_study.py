@@ -28,8 +28,7 @@ def study(fixture):
     model.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
     idx, sub = g['fused_idx'], g['fused_sub']
     scale = np.abs(sub).max()
-    modes = [('fp32', torch.float32, False, {}), ('fp32/gemm-bf16x3', torch.float32, False, {'UBV_GEMM_EMU': 'bf16x3'}),
-             ('fp32/gemm-bf16x3 except offsets+logits', torch.float32, False, {'UBV_GEMM_EMU': 'bf16x3-keep-offlog'})]
+    modes = [('fp32', torch.float32, False, {})]
     modes.append(('fp32/value-fp16', torch.float32, False, {'_value': torch.float16}))
     modes.append(('fp32/value-bf16', torch.float32, False, {'_value': torch.bfloat16}))
     for dt, name in ((torch.float16, 'fp16'), (torch.bfloat16, 'bf16')):

@@ -22,7 +22,10 @@ class Mode(TorchDispatchMode):
         out = func(*args, **(kwargs or {}))
         name = str(func)
         big = [a for a in args if isinstance(a, torch.Tensor) and a.numel() >= 5_000_000]
-        if big and any(k in name for k in ('add', 'clone', 'copy', 'mul', 'sum', 'cat', 'contiguous')):
+        gemm = any(k in name for k in ('aten.mm', 'aten.addmm', 'aten.bmm', 'aten.linear', 'aten.matmul'))
+        if gemm:
+            big = [a for a in args if isinstance(a, torch.Tensor)]
+        if big and (gemm or any(k in name for k in ('add', 'clone', 'copy', 'mul', 'sum', 'cat', 'contiguous', 'div', 'to.', '_to_copy'))):
             st = traceback.extract_stack()
             site = [f'{os.path.basename(f.filename)}:{f.lineno}:{f.name}' for f in st if 'unibev_amd' in f.filename][-2:]
             log[(name, tuple(big[0].shape), tuple(big[0].stride()), ' <- '.join(reversed(site)) or 'autograd engine')] += 1

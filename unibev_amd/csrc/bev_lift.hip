@@ -1226,6 +1226,44 @@ static CamArgs cam_args(const LiftArgs& a, const void* vfrag) {
   return c;
 }
 
+// Heads per block of the shared-footprint kernels (bev_lift_shared.inl, shared_item): 0 = all heads in one block.
+// Single large maps (self-attention, SCA-pts, the decoder's cross-attention) are walked one head group at a time
+// so that an XCD's resident blocks gather from a slice of the map that fits its L2; the small per-camera maps stay in
+// L2 anyway.  UBV_LIFT_HB = 0 | 1 | 2 | 4 forces a value.
+static int shared_hb(const LiftArgs& a, int esize, int lp, bool bwd) {
+  static const int env = getenv("UBV_LIFT_HB") ? atoi(getenv("UBV_LIFT_HB")) : -1;
+  int hb = env;
+  if (hb < 0) {
+    // measured at bs = 2 on the 200x200 / 180x180 maps (profiles/r03_lift_hb_{fp32,bf16}.txt), us for HB = 0 / 1 / 2 / 4:
+    //   f32  self-attn forward 96 / 82 / 89 / 93, query gradient 108 / 112 / 109 / 106
+    //   bf16 self-attn forward 50 / - / 49 / 48, query gradient 52 / - / 44 / 43; SCA-pts 82 / - / 78 / 77, 94 / - / 81 / 78
+    const double map_bytes = (double)a.fh * a.fw * a.H * 32 * esize;        // one sample's map (Dh <= 32)
+    hb = (a.Nc == 1 && map_bytes > 8e6) ? ((esize == 4 && !bwd) ? 1 : 4) : 0;
+  }
+  if (hb <= 0 || hb >= a.H || a.H % hb != 0 || 64 % (hb * lp) != 0) return 0;
+  return hb;
+}
+
+template <typename T, int DH, int VEC, int P, bool OL16>
+static void launch_fwd_shared(const LiftArgs& a, hipStream_t st) {
+  const int hb = shared_hb(a, sizeof(T), DH / VEC, false);
+  const unsigned blocks = 8u * a.chunk * (hb ? a.H / hb : 1);
+  if (hb == 1) hipLaunchKernelGGL((lift_fwd_shared_kernel<T, DH, VEC, P, OL16, 1>), dim3(blocks), dim3(256), 0, st, a);
+  else if (hb == 2) hipLaunchKernelGGL((lift_fwd_shared_kernel<T, DH, VEC, P, OL16, 2>), dim3(blocks), dim3(256), 0, st, a);
+  else if (hb == 4) hipLaunchKernelGGL((lift_fwd_shared_kernel<T, DH, VEC, P, OL16, 4>), dim3(blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((lift_fwd_shared_kernel<T, DH, VEC, P, OL16, 0>), dim3(8u * a.chunk), dim3(256), 0, st, a);
+}
+
+template <typename T, int DH, int VEC, int P, bool OL16>
+static void launch_bwd_query_shared(const LiftArgs& a, hipStream_t st) {
+  const int hb = shared_hb(a, sizeof(T), DH / VEC, true);
+  const unsigned blocks = 8u * a.chunk * (hb ? a.H / hb : 1);
+  if (hb == 1) hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, OL16, 1>), dim3(blocks), dim3(256), 0, st, a);
+  else if (hb == 2) hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, OL16, 2>), dim3(blocks), dim3(256), 0, st, a);
+  else if (hb == 4) hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, OL16, 4>), dim3(blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, OL16, 0>), dim3(8u * a.chunk), dim3(256), 0, st, a);
+}
+
 template <typename T, int DH, int P>
 static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool cam_mfma, void* fwd_ws,
                         hipStream_t st) {
@@ -1282,13 +1320,13 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     if (shared_env) {            // per-point arithmetic shared inside the lane group (bev_lift_shared.inl)
       if (sizeof(T) == 2 && a.ol16)
         {
-          if (wide) hipLaunchKernelGGL((lift_fwd_shared_kernel<T, DH, VECS, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
-          else hipLaunchKernelGGL((lift_fwd_shared_kernel<T, DH, VEC, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+          if (wide) launch_fwd_shared<T, DH, VECS, P, sizeof(T) == 2>(a, st);
+          else launch_fwd_shared<T, DH, VEC, P, sizeof(T) == 2>(a, st);
         }
       else
         {
-          if (wide) hipLaunchKernelGGL((lift_fwd_shared_kernel<T, DH, VECS, P, false>), dim3(blocks), dim3(256), 0, st, a);
-          else hipLaunchKernelGGL((lift_fwd_shared_kernel<T, DH, VEC, P, false>), dim3(blocks), dim3(256), 0, st, a);
+          if (wide) launch_fwd_shared<T, DH, VECS, P, false>(a, st);
+          else launch_fwd_shared<T, DH, VEC, P, false>(a, st);
         }
       return;
     }
@@ -1373,13 +1411,13 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
       } else
       if (sizeof(T) == 2 && a.ol16)
         {
-          if (wide) hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VECS, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
-          else hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+          if (wide) launch_bwd_query_shared<T, DH, VECS, P, sizeof(T) == 2>(a, st);
+          else launch_bwd_query_shared<T, DH, VEC, P, sizeof(T) == 2>(a, st);
         }
       else
         {
-          if (wide) hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VECS, P, false>), dim3(blocks), dim3(256), 0, st, a);
-          else hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, false>), dim3(blocks), dim3(256), 0, st, a);
+          if (wide) launch_bwd_query_shared<T, DH, VECS, P, false>(a, st);
+          else launch_bwd_query_shared<T, DH, VEC, P, false>(a, st);
         }
     }
     constexpr int RB = 2;
@@ -1412,13 +1450,13 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
       ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes);
       if (sizeof(T) == 2 && a.ol16)
         {
-          if (wide) hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VECS, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
-          else hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+          if (wide) launch_bwd_query_shared<T, DH, VECS, P, sizeof(T) == 2>(a, st);
+          else launch_bwd_query_shared<T, DH, VEC, P, sizeof(T) == 2>(a, st);
         }
       else
         {
-          if (wide) hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VECS, P, false>), dim3(blocks), dim3(256), 0, st, a);
-          else hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, false>), dim3(blocks), dim3(256), 0, st, a);
+          if (wide) launch_bwd_query_shared<T, DH, VECS, P, false>(a, st);
+          else launch_bwd_query_shared<T, DH, VEC, P, false>(a, st);
         }
     }
     constexpr int RB = 2;
@@ -1482,13 +1520,13 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     }
     if (sizeof(T) == 2 && a.ol16)
       {
-        if (wide) hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VECS, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, sizeof(T) == 2>), dim3(blocks), dim3(256), 0, st, a);
+        if (wide) launch_bwd_query_shared<T, DH, VECS, P, sizeof(T) == 2>(a, st);
+        else launch_bwd_query_shared<T, DH, VEC, P, sizeof(T) == 2>(a, st);
       }
     else
       {
-        if (wide) hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VECS, P, false>), dim3(blocks), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, false>), dim3(blocks), dim3(256), 0, st, a);
+        if (wide) launch_bwd_query_shared<T, DH, VECS, P, false>(a, st);
+        else launch_bwd_query_shared<T, DH, VEC, P, false>(a, st);
       }
   }
 }

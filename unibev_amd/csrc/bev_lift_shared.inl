@@ -109,16 +109,37 @@ __device__ __forceinline__ void own_points(const LiftArgs& a, long bq, int h, in
   for (int s = 0; s < NOWN; ++s) w_own[s] = FAST ? w_own[s] * inv : w_own[s] / sum;
 }
 
-template <typename T, int DH, int VEC, int P, bool OL16>
+// Work item of a block: (8x8 query tile, group of HB heads).  HB = 0: all heads, items dealt to the XCDs in contiguous
+// bands (xcd_remap).  HB > 0: an XCD still owns a contiguous band of `chunk` tiles, but walks it once PER HEAD GROUP,
+// group slowest — the blocks resident on an XCD at any time then gather from 1/NG of the bytes of the band's value
+// rows (f32, HB = 1: 6-8 tile rows x 200 px x 128 B = 1.7 MB instead of 13 MB), which fits its 4 MiB L2.  With all
+// heads in one block the band's rows fell out of L2 between neighbouring tile rows and every corner was re-fetched
+// over the fabric (PMC: 463 MB fetched for 113 MB of operands, 5.8 TB/s — the kernel was bound by that).
+template <int HB>
+__device__ __forceinline__ bool shared_item(const LiftArgs& a, int& item, int& h0) {
+  if constexpr (HB == 0) {
+    item = xcd_remap(blockIdx.x, a.chunk);
+    h0 = 0;
+  } else {
+    const int v = (int)(blockIdx.x >> 3);
+    const int hg = v / a.chunk;
+    item = (int)(blockIdx.x & 7) * a.chunk + (v - hg * a.chunk);
+    h0 = hg * HB;
+  }
+  return item < a.total_tiles;
+}
+
+template <typename T, int DH, int VEC, int P, bool OL16, int HB = 0>
 __global__ __launch_bounds__(256) void lift_fwd_shared_kernel(const LiftArgs a) {
   constexpr int LP = DH / VEC;
   constexpr int NOWN = (P + LP - 1) / LP;
   constexpr bool FAST = sizeof(T) == 2;
-  const int item = xcd_remap(blockIdx.x, a.chunk);
-  if (item >= a.total_tiles) return;
-  const int LQ = a.H * LP, QW = kWave / LQ;
+  int item, h0;
+  if (!shared_item<HB>(a, item, h0)) return;
+  const int HL = HB == 0 ? a.H : HB;                // heads of this block
+  const int LQ = HL * LP, QW = kWave / LQ;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int cg = lane % LP, h = (lane / LP) % a.H, sub = lane / LQ;
+  const int cg = lane % LP, h = h0 + (lane / LP) % HL, sub = lane / LQ;
   const int S = a.fh * a.fw;
   const long row = (long)a.H * DH;
   const T* __restrict__ value = (const T*)a.value;
@@ -187,16 +208,17 @@ __global__ __launch_bounds__(256) void lift_fwd_shared_kernel(const LiftArgs a) 
   }
 }
 
-template <typename T, int DH, int VEC, int P, bool OL16>
+template <typename T, int DH, int VEC, int P, bool OL16, int HB = 0>
 __global__ __launch_bounds__(256) void lift_bwd_query_shared_kernel(const LiftArgs a) {
   constexpr int LP = DH / VEC;
   constexpr int NOWN = (P + LP - 1) / LP;
   constexpr bool FAST = sizeof(T) == 2;
-  const int item = xcd_remap(blockIdx.x, a.chunk);
-  if (item >= a.total_tiles) return;
-  const int LQ = a.H * LP, QW = kWave / LQ;
+  int item, h0;
+  if (!shared_item<HB>(a, item, h0)) return;
+  const int HL = HB == 0 ? a.H : HB;
+  const int LQ = HL * LP, QW = kWave / LQ;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int cg = lane % LP, h = (lane / LP) % a.H, sub = lane / LQ;
+  const int cg = lane % LP, h = h0 + (lane / LP) % HL, sub = lane / LQ;
   const int S = a.fh * a.fw;
   const long row = (long)a.H * DH;
   const T* __restrict__ value = (const T*)a.value;

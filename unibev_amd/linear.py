@@ -216,6 +216,11 @@ class _Linear(Function):
         w = _cached_lowp(weights, dtype)
         b = _cached_lowp(biases, dtype) if has_bias else None
         xc = x.to(dtype)
+        if xc.is_cuda and not xc.is_contiguous():
+            # e.g. the first layer's queries: the BEV embedding expanded over the batch (stride 0).  Materialised once here,
+            # the MFMA kernels below take it; left as it was, every GEMM of that layer fell to the library path
+            # (clone + sgemm + bias add: 116 us against 48 us at 80 000 x 256 x 256)
+            xc = xc.contiguous()
         ctx.meta = (x.dtype, n, has_bias, [p.shape[0] for p in weights], [p.dtype for p in params])
         y = None
         split = None
