@@ -111,6 +111,9 @@ def parse():
                     help="'auto': when --gpus N > 1 and no torchrun environment is present, re-exec under "
                          "torch.distributed.run with N ranks; 'spawn': always (also N = 1: one rank with a process "
                          "group, the multi-GPU code path on a one-GPU box); 'none': never")
+    ap.add_argument('--cpu-baseline-plan', action='store_true',
+                    help='BASELINE.md section 3 in full (forward of cfg1-cfg5, forward + backward of cfg2 / cfg3) through the '
+                         'oracle on this host, as `cpu_baseline_plan`; a few minutes of CPU time, not part of the default run')
     ap.add_argument('--allow-eager', action='store_true',
                     help='if HIP-graph capture fails, time eager launches instead of exiting non-zero')
     ap.add_argument('--no-parity', action='store_true',
@@ -426,6 +429,49 @@ def gemm_record(device, bs):
     return out
 
 
+def k1_record(device, bs):
+    """The deformable-sampling OPERATOR at the mmcv boundary (``MultiScaleDeformableAttnFunction``: explicit locations and
+    weights, what a maintainer binding at INTEGRATION.md level 2 calls) on the self-attention instance (S = Nq = 40 000,
+    H = 8, Dh = 32, P = 4, f32): forward, backward on the owner-tile plan, backward with grad_value atomics."""
+    from unibev_amd import functional as UF
+    from unibev_amd.modules.deform_attn import index_tensor, shapes_tensor
+    B, Hq, Wq, H, Dh, P = bs, 200, 200, 8, 32, 4
+    S = Nq = Hq * Wq
+    g = torch.Generator(device='cpu').manual_seed(3)
+    ys, xs = torch.meshgrid(torch.arange(Hq), torch.arange(Wq), indexing='ij')
+    ref = torch.stack(((xs + 0.5) / Wq, (ys + 0.5) / Hq), -1).view(1, Nq, 1, 1, 1, 2)
+    loc = (ref + 0.015 * torch.randn(B, Nq, H, 1, P, 2, generator=g)).to(device).requires_grad_()
+    aw = torch.softmax(torch.randn(B, Nq, H, 1, P, generator=g), -1).to(device).requires_grad_()
+    v = torch.randn(B, S, H, Dh, generator=g).to(device).requires_grad_()
+    go = torch.randn(B, Nq, H * Dh, generator=g).to(device)
+    ss, ls = shapes_tensor([(Hq, Wq)], device), index_tensor([0], device)
+    plain = torch.as_tensor([[Hq, Wq]], dtype=torch.long, device=device)      # no host copy attached: atomic kernel
+
+    def timed(fn, n=10):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return 1e3 * e0.elapsed_time(e1) / n
+
+    def fwd_bwd(shapes):
+        v.grad = loc.grad = aw.grad = None
+        UF.ms_deform_attn(v, shapes, ls, loc, aw).backward(go)
+
+    with torch.no_grad():
+        f_us = timed(lambda: UF.ms_deform_attn(v, ss, ls, loc, aw))
+    fb_planned, fb_atomic = timed(lambda: fwd_bwd(ss)), timed(lambda: fwd_bwd(plain))
+    fb, bb = k1_bytes(B, S, Nq, H * Dh, H, P, 4, False), k1_bytes(B, S, Nq, H * Dh, H, P, 4, True)
+    return {'shape': f'B={B} S=Nq={S} H={H} Dh={Dh} P={P} f32', 'fwd_us': f_us, 'fwd_frac': fb / f_us / 1e3 / HBM_PEAK_GBS,
+            'bwd_planned_us': fb_planned - f_us, 'bwd_planned_frac': bb / (fb_planned - f_us) / 1e3 / HBM_PEAK_GBS,
+            'bwd_atomic_us': fb_atomic - f_us, 'bwd_atomic_frac': bb / (fb_atomic - f_us) / 1e3 / HBM_PEAK_GBS,
+            'note': 'backward = (forward + backward) - forward, eager launches; bytes: SURVEY.md section 8(d) k1 formulas'}
+
+
 def voxel_record(device):
     """LiDAR front end at cfg3's size: hard voxelization (T = 10, 90 000 voxel budget) of a 30 000
     point cloud + VFE mean + the dense scatter of a SparseEncoder-sized output; nothing read back."""
@@ -591,9 +637,12 @@ def main():
         if world == 1 and not args.no_extras:
             out['gemm'] = gemm_record(device, args.bs)
             out['voxel'] = voxel_record(device)
+            out['k1_operator'] = k1_record(device, args.bs)
         # ---- CPU baseline: the oracle's forward on this host ------------------------------
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, tcfg, head)
+        if world == 1 and args.cpu_baseline_plan:
+            out['cpu_baseline_plan'] = cpu_baseline_plan()
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
@@ -641,6 +690,67 @@ def cpu_baseline(args, tcfg, head):
             'cpu': cpu, 'host_cores': os.cpu_count(),
             'sample': f'forward only, fp32, bs=1, eval: 3 warm-up + {len(times)} timed passes of the same '
                       f'workload, median {med:.2f} s, through oracle/unibev_ref.py (torch CPU)'}
+
+
+def cpu_baseline_plan(threads=16, max_seconds=40.0):
+    """the oracle's forward through ``fused_bev_embed`` for cfg1-cfg5 of BASELINE.json.configs
+    (bs = 1, fp32, eval) and forward + backward for cfg2 / cfg3; 1 warm-up + up to 5 timed passes per entry (median),
+    each entry bounded to ``max_seconds``.  ``threads`` torch CPU threads: all 256 hardware threads of the GPU host
+    oversubscribe torch's small kernels (78.9 s per pass measured against ~3 s with 16) — the count used is reported."""
+    import platform
+    from oracle import unibev_ref as R
+    from unibev_amd import configs as cfgs
+    from unibev_amd import synthetic as syn
+    torch.set_num_threads(min(os.cpu_count() or 1, threads))
+    plan = [('cfg1 unibev_nus_C 2 views (plumbing)', dict(embed_dims=256, feature_norm=None, drop_modality=None, modalities='C', num_cams=2), (256, 704), None, 2, False),
+            ('cfg2 unibev_nus_C 6x256x704', dict(embed_dims=256, feature_norm=None, drop_modality=None, modalities='C'), (256, 704), None, 6, True),
+            ('cfg3 unibev_nus_L', dict(embed_dims=256, feature_norm=None, drop_modality=None, modalities='L'), (256, 704), (180, 180), 6, True),
+            ('cfg4 unibev_nus_LC_cnw_256', dict(embed_dims=256, fusion_method='linear', feature_norm='ChannelNormWeights', drop_modality=0.5), (256, 704), (180, 180), 6, False),
+            ('cfg5 unibev_nus_LC_cat_128 6x800x1440', dict(embed_dims=128, fusion_method='cat', feature_norm=None, drop_modality=0.5), (800, 1440), (180, 180), 6, False)]
+    out = []
+    for name, kw, img_hw, pts_hw, ncam, with_bwd in plan:
+        C = kw['embed_dims']
+        tcfg = cfgs.transformer_cfg(decoder=None, **kw)
+        tcfg.pop('decoder')
+        from unibev_amd import build_transformer
+        torch.manual_seed(0)
+        model = build_transformer(json.loads(json.dumps(tcfg)))
+        model.init_weights()
+        sd = {k: v.detach().float() for k, v in model.state_dict().items()}
+        g = torch.Generator().manual_seed(1000)
+        mods = kw.get('modalities', 'LC')
+        img = [torch.randn(1, ncam, C, img_hw[0] // 32, img_hw[1] // 32, generator=g)] if 'C' in mods else None
+        pts = [torch.randn(1, C, *pts_hw, generator=g)] if 'L' in mods else None
+        metas = syn.img_metas(1, ncam, img_hw)
+        bev_q = torch.randn(200 * 200, C, generator=g) * 0.1
+        pos = torch.randn(1, C, 200, 200, generator=g) * 0.1
+        cfg = json.loads(json.dumps(tcfg))
+
+        def run(backward):
+            P = {k: (v.clone().requires_grad_() if backward else v) for k, v in sd.items()}
+            with torch.set_grad_enabled(backward):
+                fused = R.transformer_encode_fuse(P, cfg, img, pts, bev_q, 200, 200, pos, metas)
+                if backward:
+                    fused.square().mean().backward()
+            return fused
+        for backward in ((False, True) if with_bwd else (False,)):
+            run(backward)
+            times, spent = [], 0.0
+            while len(times) < 5 and spent < max_seconds:
+                t0 = time.perf_counter()
+                run(backward)
+                times.append(time.perf_counter() - t0)
+                spent += times[-1]
+            med = float(np.median(times))
+            out.append({'config': name, 'pass': 'fwd+bwd' if backward else 'fwd', 'seconds_per_sample': med,
+                        'samples_per_s': 1.0 / med, 'timed_passes': len(times)})
+    cpu = platform.processor() or ''
+    try:
+        cpu = [ln.split(':', 1)[1].strip() for ln in open('/proc/cpuinfo') if ln.startswith('model name')][0]
+    except Exception:
+        pass
+    return {'kind': 'port', 'cores': torch.get_num_threads(), 'host_cores': os.cpu_count(), 'cpu': cpu,
+            'protocol': 'oracle/unibev_ref.py (torch CPU), fp32, bs = 1, eval, 1 warm-up + <= 5 timed passes, median', 'entries': out}
 
 
 if __name__ == '__main__':

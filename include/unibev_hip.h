@@ -81,6 +81,22 @@ int ubv_ms_deform_attn_backward(const void* value, const int64_t* spatial_shapes
                                 int H, int Dh, int L, int Nq, int P, int dtype, int im2col_step,
                                 void* stream);
 
+/* The same backward for ONE level whose shape (fh, fw) the HOST knows (mmcv's signature hands spatial_shapes over as a
+ * device tensor; [ext] mmcv ms_deform_attn_cuda_backward reads it on the host, ops/csrc/pytorch/cuda/ms_deform_attn_cuda.cu).
+ * grad_value is computed by OWNER TILES — the sampling points are binned by the 8x8-pixel tile they touch and each tile
+ * accumulates its points on the matrix cores and stores its pixels once — instead of one f32 atomic per (corner,
+ * channel): grad_value is WRITTEN (no zeroing needed), bit-reproducible up to the arrival order inside a tile.
+ * grad_sampling_loc / grad_attn_weight as above.  Shapes: L == 1, fh * fw == S, Dh in {16, 32}, P in {4, 8}, H * Dh /
+ * (16 bytes of channels) dividing 64; anything else returns UBV_ERR_UNSUPPORTED (-3) and the caller keeps
+ * ubv_ms_deform_attn_backward.  `workspace`: ubv_ms_deform_attn_backward_workspace(...) bytes of device scratch (0: shape
+ * not covered). */
+int64_t ubv_ms_deform_attn_backward_workspace(int B, int fh, int fw, int H, int Dh, int Nq, int P, int dtype);
+int ubv_ms_deform_attn_backward_planned(const void* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                                        const float* sampling_loc, const float* attn_weight, const void* grad_out,
+                                        float* grad_value, float* grad_sampling_loc, float* grad_attn_weight, int B,
+                                        int S, int H, int Dh, int L, int Nq, int P, int dtype, int fh, int fw,
+                                        void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused BEV query lifting (one level): offsets -> locations, logits -> softmax, sampling,
  * per-camera accumulation and the camera mean, in one kernel; nothing but the GEMM outputs is
@@ -431,6 +447,16 @@ int64_t ubv_spconv_table_slots(int64_t n);
 int ubv_spconv_wgrad_splits(int64_t rows, int kvol);
 int ubv_spconv_wgrad(const void* grad_out, const void* feats, const int32_t* nbr, int64_t ld, int64_t rows,
                      float* partials, float* grad_w, int Cout, int Cin, int kvol, int splits, int dtype, void* stream);
+
+/* The same weight gradient over COMPACTED (output row, input row) pairs — spconv's rulebook form (spconv 1.x
+ * `indice_pairs` / `indice_pair_num`, built by get_indice_pairs; mmdet3d/ops/spconv/functional.py
+ * SparseConvFunction.backward -> indice_conv_backward multiplies only the pairs of each offset).  Per offset k the
+ * first counts[k] entries of out_rows[k][.] / in_rows[k][.] (leading dimension ld) name the rows of grad_out and
+ * feats to multiply; slabs past the count store zero tiles at once.  On LiDAR clouds ~70 % of the (row, offset)
+ * slots of a submanifold convolution have no neighbour: this form skips them (9.8 -> 3.x ms per encoder backward). */
+int ubv_spconv_wgrad_pairs(const void* grad_out, const void* feats, const int32_t* in_rows, const int32_t* out_rows,
+                           const int32_t* counts, int64_t ld, int64_t rows, float* partials, float* grad_w, int Cout,
+                           int Cin, int kvol, int splits, int dtype, void* stream);
 int ubv_spconv_hash_build(const int32_t* coors, int64_t n, int D, int H, int W, int64_t* table_keys,
                           int32_t* table_vals, int64_t slots, void* stream);
 int ubv_spconv_neighbors(const int32_t* coors, int64_t rows, int B, const int* row_dims, const int* target_dims,

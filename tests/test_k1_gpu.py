@@ -146,3 +146,82 @@ def test_k1_full_size_properties():
     sub = c_ref.msda_forward(v1.cpu().numpy(), [(Hq, Wq)], loc[:, idx].cpu().numpy(),
                              aw[:, idx].cpu().numpy())
     np.testing.assert_allclose(o1[:, idx].cpu().numpy(), sub, rtol=2e-5, atol=2e-5)
+
+
+def _hw_levels(shapes, dev):
+    """spatial_shapes carrying its host copy, as the modules' ``shapes_tensor`` produces it: the backward may then
+    plan owner tiles (``ubv_ms_deform_attn_backward_planned``)."""
+    ss, ls = _levels(shapes, dev)
+    ss._ubv_hw = [tuple(int(v) for v in s) for s in shapes]
+    return ss, ls
+
+
+@pytest.mark.parametrize('B,shape,H,Dh,P,Nq,spread', [
+    (2, (13, 17), 8, 32, 4, 301, 0.45),
+    (1, (20, 20), 8, 16, 8, 400, 0.45),
+    (2, (9, 40), 8, 32, 8, 777, 0.3),
+    (1, (16, 16), 8, 32, 4, 3000, 0.01),     # every point lands on a few pixels: bucket overflow path
+])
+def test_k1_planned_backward_vs_c_oracle_and_the_atomic_kernel(B, shape, H, Dh, P, Nq, spread):
+    """Operator-level backward without grad_value atomics (owner tiles): same gradients as the C oracle within the
+    atomic kernel's tolerances, and the two device paths agree."""
+    from oracle import c_ref
+    from unibev_amd import functional as UF
+    rs = np.random.RandomState(Nq)
+    S = shape[0] * shape[1]
+    value = rs.standard_normal((B, S, H, Dh)).astype(np.float32)
+    loc = (0.5 + spread * rs.standard_normal((B, Nq, H, 1, P, 2))).astype(np.float32)
+    aw = rs.random_sample((B, Nq, H, 1, P)).astype(np.float32)
+    gout = rs.standard_normal((B, Nq, H * Dh)).astype(np.float32)
+    gv, gl, gw = c_ref.msda_backward(value, [shape], loc, aw, gout)
+    got = {}
+    for tag, levels in (('planned', _hw_levels), ('atomic', _levels)):
+        v = t(value, device=DEV).requires_grad_()
+        l = t(loc, device=DEV).requires_grad_()
+        w = t(aw, device=DEV).requires_grad_()
+        ss, ls = levels([shape], DEV)
+        UF.enable_profile(True)
+        UF.ms_deform_attn(v, ss, ls, l, w).backward(t(gout, device=DEV))
+        prof = UF.profile_results()
+        UF.enable_profile(False)
+        assert ('k1_bwd_planned' in prof) == (tag == 'planned') and ('k1_bwd' in prof) == (tag == 'atomic'), list(prof)
+        got[tag] = (v.grad, l.grad, w.grad)
+        scale = np.abs(gv).max()
+        np.testing.assert_allclose(v.grad.cpu().numpy(), gv, rtol=1e-4, atol=1e-4 * max(1.0, scale))
+        np.testing.assert_allclose(l.grad.cpu().numpy(), gl, rtol=1e-4, atol=5e-4)
+        np.testing.assert_allclose(w.grad.cpu().numpy(), gw, rtol=1e-4, atol=1e-4)
+    # same query-side kernel in both (compiled with / without the atomic scatter: fused-multiply-add placement may differ)
+    torch.testing.assert_close(got['planned'][1], got['atomic'][1], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(got['planned'][2], got['atomic'][2], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-4), (torch.bfloat16, 1.5e-2)])
+def test_k1_full_size_gradients_vs_c_oracle(dtype, tol):
+    """BASELINE size (S = Nq = 40 000, H = 8, Dh = 32, P = 4): the planned backward's grad_value on the WHOLE map and
+    grad_loc / grad_weight on a strided sample of queries against the f64 C oracle (normwise)."""
+    from oracle import c_ref
+    from unibev_amd.functional import ms_deform_attn
+    rs = np.random.RandomState(7)
+    B, Hq, Wq, H, Dh, P = 1, 200, 200, 8, 32, 4
+    S = Nq = Hq * Wq
+    ys, xs = np.meshgrid(np.arange(Hq), np.arange(Wq), indexing='ij')
+    ref = np.stack(((xs + 0.5) / Wq, (ys + 0.5) / Hq), -1).reshape(1, Nq, 1, 1, 1, 2)
+    loc = (ref + 0.015 * rs.standard_normal((B, Nq, H, 1, P, 2))).astype(np.float32)
+    e = np.exp(rs.standard_normal((B, Nq, H, 1, P)))
+    aw = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+    value = rs.standard_normal((B, S, H, Dh)).astype(np.float32)
+    gout = rs.standard_normal((B, Nq, H * Dh)).astype(np.float32)
+    if dtype != torch.float32:                       # exactly representable operands
+        value = t(value).to(dtype).float().numpy()
+        gout = t(gout).to(dtype).float().numpy()
+    gv, gl, gw = c_ref.msda_backward(value, [(Hq, Wq)], loc, aw, gout)
+    v = t(value, device=DEV).to(dtype).requires_grad_()
+    l = t(loc, device=DEV).requires_grad_()
+    w = t(aw, device=DEV).requires_grad_()
+    ss, ls = _hw_levels([(Hq, Wq)], DEV)
+    ms_deform_attn(v, ss, ls, l, w).backward(t(gout, device=DEV).to(dtype))
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    assert rel(v.grad.float().cpu().numpy(), gv) < tol
+    idx = np.arange(0, Nq, 97)
+    assert rel(l.grad.cpu().numpy()[:, idx], gl[:, idx]) < max(tol, 2e-4)
+    assert rel(w.grad.cpu().numpy()[:, idx], gw[:, idx]) < max(tol, 2e-4)

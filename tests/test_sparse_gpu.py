@@ -185,3 +185,37 @@ def test_extract_pts_feat_connects_voxelization_vfe_and_middle_encoder():
     assert both.shape == (2, 256, 180, 180)
     for b in range(2):      # eval-mode BatchNorm: samples do not interact
         torch.testing.assert_close(both[b], singles[b][0], rtol=1e-5, atol=1e-6)
+
+
+def test_rulebooks_are_kept_while_the_same_coordinates_come_back():
+    """SparseEncoder keeps hash tables / neighbour maps / compacted pairs across calls for an unmodified coordinate
+    tensor (identity + version): same results bit for bit, no rebuild; an in-place edit or a new tensor rebuilds."""
+    from unibev_amd.registry import MIDDLE_ENCODERS, build_from_cfg
+    rs = np.random.RandomState(3)
+    cfg = dict(type='SparseEncoder', in_channels=5, sparse_shape=[41, 32, 32], output_channels=32,
+               encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 64), (64, 64)),
+               encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)), block_type='basicblock')
+    torch.manual_seed(0)
+    enc = build_from_cfg(cfg, MIDDLE_ENCODERS).to(DEV).train()
+    coors = _cloud(rs, 2, cfg['sparse_shape'], 2000).to(DEV)
+    feats = torch.from_numpy(rs.standard_normal((2000, 5)).astype(np.float32)).to(DEV).requires_grad_()
+    outs, grads = [], []
+    for _ in range(2):
+        for p in enc.parameters():
+            p.grad = None
+        y = enc(feats, coors, 2)
+        y.square().sum().backward()
+        outs.append(y.detach().clone())
+        grads.append(enc.conv_input[0].weight.grad.clone())
+    book = next(iter(enc._rulebooks.values()))[3]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(grads[0], grads[1])
+    assert 'subm1' in book and book['subm1'][4].get('pairs') is not None       # compacted pairs built by the backward
+    same = enc._rulebooks[id(coors)][3]
+    enc(feats, coors, 2)
+    assert enc._rulebooks[id(coors)][3] is same                                # reused
+    coors[0, 3] = (coors[0, 3] + 1) % 32                                       # in-place edit: version moves
+    enc(feats, coors, 2)
+    assert enc._rulebooks[id(coors)][3] is not same
+    fresh = build_from_cfg(cfg, MIDDLE_ENCODERS).to(DEV).train()
+    fresh.load_state_dict(enc.state_dict())
+    torch.testing.assert_close(enc(feats, coors, 2), fresh(feats, coors.clone(), 2), rtol=0, atol=0)

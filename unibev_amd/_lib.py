@@ -25,6 +25,8 @@ SIGNATURES = {
     'ubv_profile_read': (c_int64, [c_char_p, c_int64]),
     'ubv_ms_deform_attn_forward': (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 9 + [_P]),
     'ubv_ms_deform_attn_backward': (c_int, [_P] * 9 + [c_int] * 9 + [_P]),
+    'ubv_ms_deform_attn_backward_workspace': (c_int64, [c_int] * 8),
+    'ubv_ms_deform_attn_backward_planned': (c_int, [_P] * 9 + [c_int] * 10 + [_P, c_int64, _P]),
     'ubv_bev_lift_forward_workspace': (c_int64, [c_int] * 8),
     'ubv_bev_lift_forward': (c_int, [_P, _P, c_int64, _P, c_int64, c_int, _P, _P, _P, _P]
                              + [c_int] * 12 + [_P, c_int64, _P]),
@@ -61,6 +63,7 @@ SIGNATURES = {
     'ubv_spconv_table_slots': (c_int64, [c_int64]),
     'ubv_spconv_wgrad_splits': (c_int, [c_int64, c_int]),
     'ubv_spconv_wgrad': (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'ubv_spconv_wgrad_pairs': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ubv_spconv_hash_build': (c_int, [_P, c_int64, c_int, c_int, c_int, _P, _P, c_int64, _P]),
     'ubv_spconv_neighbors': (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, c_int64, _P, c_int64, _P]),
     'ubv_spconv_candidates': (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P]),

@@ -402,7 +402,9 @@ struct TileArgs;
 // bin_start[bucket] + cursor) — per-camera maps, where the load per tile varies 100:1 (the rows at the
 // horizon receive 85 % of the projected pillars) and no fixed capacity fits.  The cameras are walked in
 // the wave; one that none of the wave's 64 queries sees costs a ballot.
-template <typename T, int DH, int P, int MODE>
+// K1: the operator-level backward (ubv_ms_deform_attn_backward_planned): a.offsets holds explicit sampling LOCATIONS
+// [B, Nq, H, P, 2] (normalised x, y), a.logits the attention WEIGHTS [B, Nq, H, P] — no reference points, no softmax.
+template <typename T, int DH, int P, int MODE, bool K1 = false>
 __global__ __launch_bounds__(256) void lift_bin_kernel(const LiftArgs a, int tiles_x, int tiles) {
   // per wave: an 8x8 torus of tile slots — occupant tile, local count, global base
   __shared__ volatile int slot_tile[4][64];
@@ -419,18 +421,23 @@ __global__ __launch_bounds__(256) void lift_bin_kernel(const LiftArgs a, int til
   const long bq = (long)b * a.Nq + q;
   const float fwf = (float)a.fw, fhf = (float)a.fh;
   float lg[P], w[P], off[2 * P];
-  load_ol<T, P>(a.logits, bq * a.log_stride + h * P, a.ol16, lg);
-  load_ol<T, 2 * P>(a.offsets, bq * a.off_stride + h * 2 * P, a.ol16, off);
+  load_ol<T, P>(a.logits, bq * a.log_stride + h * P, K1 ? 0 : a.ol16, lg);
+  load_ol<T, 2 * P>(a.offsets, bq * a.off_stride + h * 2 * P, K1 ? 0 : a.ol16, off);
   // 16-bit data: hardware exp / reciprocals like the other kernels of the path (the kernel is bound by its
   // per-point arithmetic: one lane = one point, ~150 instructions each with IEEE divisions)
-  constexpr bool FAST = sizeof(T) == 2;
-  softmax_row<P, FAST>(lg, w);
+  constexpr bool FAST = sizeof(T) == 2 && !K1;
+  if constexpr (K1) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) w[i] = lg[i];
+  } else {
+    softmax_row<P, FAST>(lg, w);
+  }
   const float cnt = (a.count != nullptr) ? a.count[bq] : 1.0f;
   const float inv_cnt = 1.0f / cnt, inv_fw = 1.0f / fwf, inv_fh = 1.0f / fhf;
   for (int cam = 0; cam < a.Nc; ++cam) {
   const bool vis = valid && (a.vis0 == nullptr || a.vis0[(long)cam * a.Nq + q] != 0);
   if (a.Nc > 1 && __ballot(vis) == 0ull) continue;    // wave-uniform
-  const float* rp = a.ref + (((long)cam * a.B + b) * a.Nq + q) * a.Z * 2;
+  const float* rp = K1 ? nullptr : a.ref + (((long)cam * a.B + b) * a.Nq + q) * a.Z * 2;
   const int tile_base = ((b * a.Nc + cam) * a.H + h) * tiles;     // first bucket of this (map, head)
   int* __restrict__ cntp = (MODE == 2 ? a.bin_cur : a.bin_cnt) + tile_base;
   float4* __restrict__ binp = MODE == 0 ? a.bins + (long)tile_base * a.cap : a.bins;
@@ -451,10 +458,15 @@ __global__ __launch_bounds__(256) void lift_bin_kernel(const LiftArgs a, int til
   int zi = 0;
 #pragma unroll
   for (int p = 0; p < P; ++p) {
-    const float2 r = *reinterpret_cast<const float2*>(rp + zi * 2);
-    zi = (zi + 1 == a.Z) ? 0 : zi + 1;
-    const float lx = r.x + div_or_mul<FAST>(off[2 * p], fwf, inv_fw);
-    const float ly = r.y + div_or_mul<FAST>(off[2 * p + 1], fhf, inv_fh);
+    float lx, ly;
+    if constexpr (K1) {
+      lx = off[2 * p]; ly = off[2 * p + 1];
+    } else {
+      const float2 r = *reinterpret_cast<const float2*>(rp + zi * 2);
+      zi = (zi + 1 == a.Z) ? 0 : zi + 1;
+      lx = r.x + div_or_mul<FAST>(off[2 * p], fwf, inv_fw);
+      ly = r.y + div_or_mul<FAST>(off[2 * p + 1], fhf, inv_fh);
+    }
     const float xp = lx * fwf - 0.5f, yp = ly * fhf - 0.5f;
     const Footprint f = footprint_px(xp, yp, a.fh, a.fw);
     const float wn = div_or_mul<FAST>(w[p], cnt, inv_cnt);
@@ -1559,7 +1571,7 @@ static int plan_backward(const LiftArgs& a, int Dh, int P, int dtype, int ref_is
   // laid out, clustered queries simply spill into the (exact) overflow list.
   const int cband = a.fw <= 192 ? 192 / a.fw : 0;            // rows per CAMERA band
   const bool cam_fits = cband >= 1 && (a.fh + cband - 1) / cband <= 8;
-  if (a.Nc == 1 && ((ref_is_grid && a.qw > 0) || !cam_fits)) {
+  if (a.Nc == 1 && ((ref_is_grid && a.qw > 0) || !cam_fits || ref_is_grid == 2)) {     // (2: the k1 operator asks for GRID)
     t.mode = 1;
     t.tile_w = t.tile_h = 8;                 // 64 pixels = 2 MFMA row blocks
     t.tiles_x = (a.fw + 7) / 8;
@@ -1778,6 +1790,65 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_g
   }
   if (!ok) { set_error("bev_lift: dispatch failed"); return UBV_ERR_UNSUPPORTED; }
   UBV_CHECK_LAUNCH(bwd ? "bev_lift_backward" : "bev_lift_forward");
+  return UBV_OK;
+}
+
+// ---- grad_value of the k1 OPERATOR (msda_k1.hip) on the GRID owner-tile plan: explicit locations / weights are binned
+// by owner tile (lift_bin_kernel<..., K1>) and the owner tiles store every pixel once — no f32 atomics on grad_value.
+// One level, the shapes bev_lift covers; anything else keeps the atomic kernel.
+bool k1_grid_ok(int H, int Dh, int P, int dtype, int fh, int fw) {
+  return lift_shape_ok(H, Dh, P, dtype) && fh >= 1 && fw >= 1;
+}
+static void k1_grid_args(LiftArgs& a, TileArgs& t, int B, int fh, int fw, int H, int Dh, int Nq, int P, int dtype) {
+  a = LiftArgs{};
+  a.B = B; a.Nc = 1; a.fh = fh; a.fw = fw; a.H = H; a.Nq = Nq; a.Z = 1;
+  a.tiles_per_sample = (Nq + 63) / 64;
+  a.total_tiles = B * a.tiles_per_sample;
+  a.chunk = (a.total_tiles + 7) / 8;
+  (void)plan_backward(a, Dh, P, dtype, 2, t);
+}
+int64_t k1_grid_workspace(int B, int fh, int fw, int H, int Dh, int Nq, int P, int dtype) {
+  LiftArgs a; TileArgs t;
+  k1_grid_args(a, t, B, fh, fw, H, Dh, Nq, P, dtype);
+  return (int64_t)grid_ws(a, t, P).total;
+}
+template <typename T, int DH, int P>
+static void k1_grid_launch(const LiftArgs& a, const TileArgs& t, hipStream_t st) {
+  const int tiles = t.tiles_x * t.tiles_y;
+  const long waves = (long)a.total_tiles * a.H;
+  hipLaunchKernelGGL((lift_bin_kernel<T, DH, P, 0, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a,
+                     t.tiles_x, tiles);
+  const long tw = (long)a.B * a.H * tiles, zb = (tw + 3) / 4;
+  hipLaunchKernelGGL(lift_ovf_zero_kernel, dim3((unsigned)(zb < 256 ? zb : 256)), dim3(256), 0, st, a, t.tiles_x, tiles, DH);
+  hipLaunchKernelGGL((lift_ovf_scatter_kernel<T, DH>), dim3(256), dim3(256), 0, st, a, t.tiles_x, tiles);
+  constexpr int RB = 2;
+  const size_t lds = (size_t)t.waves * TileLds<T, DH, RB>::kWords * sizeof(uint16_t);
+  hipLaunchKernelGGL((lift_bwd_value_kernel<T, DH, P, RB>), dim3(8 * t.chunk), dim3(64 * t.waves), lds, st, a, t);
+}
+int k1_grid_value(const float* loc, const float* aw, const void* gout, float* gvalue, int B, int fh, int fw, int H,
+                  int Dh, int Nq, int P, int dtype, void* ws, int64_t ws_bytes, hipStream_t st) {
+  LiftArgs a; TileArgs t;
+  k1_grid_args(a, t, B, fh, fw, H, Dh, Nq, P, dtype);
+  const GridWs w = grid_ws(a, t, P);
+  if (ws == nullptr || ws_bytes < (int64_t)w.total) {
+    set_error("ms_deform_attn_backward_planned: workspace of %lld bytes needed, got %lld", (long long)w.total, (long long)ws_bytes);
+    return UBV_ERR_INVALID;
+  }
+  a.offsets = loc; a.off_stride = (long)H * P * 2; a.logits = aw; a.log_stride = (long)H * P;
+  a.gout = gout; a.gvalue = gvalue;
+  a.bin_cnt = (int*)ws;
+  a.ovf_n = a.bin_cnt + (size_t)B * H * t.tiles_x * t.tiles_y;
+  a.bins = (float4*)((char*)ws + w.bins_off);
+  a.ovf_rec = (float4*)((char*)ws + w.ovf_rec_off);
+  a.ovf_tile = (int*)((char*)ws + w.ovf_tile_off);
+  a.cap = t.cap;
+  a.ovf_cap = (int)min(w.ovf_cap, (long)INT_MAX);
+  if (hipMemsetAsync(ws, 0, w.cnt_bytes, st) != hipSuccess) { set_error("ms_deform_attn_backward_planned: memset failed"); return UBV_ERR_LAUNCH; }
+#define UBV_K1G(TT) do { \
+    if (Dh == 32 && P == 8) k1_grid_launch<TT, 32, 8>(a, t, st); else if (Dh == 32 && P == 4) k1_grid_launch<TT, 32, 4>(a, t, st); \
+    else if (Dh == 16 && P == 8) k1_grid_launch<TT, 16, 8>(a, t, st); else k1_grid_launch<TT, 16, 4>(a, t, st); } while (0)
+  if (dtype == UBV_F32) UBV_K1G(float); else if (dtype == UBV_F16) UBV_K1G(f16_t); else UBV_K1G(bf16_t);
+#undef UBV_K1G
   return UBV_OK;
 }
 

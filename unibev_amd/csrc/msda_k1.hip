@@ -79,7 +79,8 @@ __global__ __launch_bounds__(256) void k1_fwd_kernel(
   vec_io<T, VEC>::store(out + bq * H * DH + h * DH + cg * VEC, acc);
 }
 
-template <typename T, int DH, int VEC>
+// GV = false: grad_loc / grad_weight only (grad_value comes from the owner tiles, ubv_ms_deform_attn_backward_planned)
+template <typename T, int DH, int VEC, bool GV = true>
 __global__ __launch_bounds__(256) void k1_bwd_kernel(
     const T* __restrict__ value, const int64_t* __restrict__ ss, const int64_t* __restrict__ ls,
     const float* __restrict__ loc, const float* __restrict__ aw, const T* __restrict__ gout,
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void k1_bwd_kernel(
         for (int i = 0; i < VEC; ++i) d = fmaf(go[i], v[i], d);
         dot[k] = d * f.m[k];                       // corners outside the map read as zero
         const float c = a * f.w[k];
-        if (active && c != 0.0f) {
+        if (GV && active && c != 0.0f) {
 #pragma unroll
           for (int i = 0; i < VEC; ++i) atomic_add_f32(gvalue + o + i, c * go[i]);
         }
@@ -285,7 +286,51 @@ static int k1_dispatch(const K1Args& a, int dtype, bool bwd, void* stream) {
   return UBV_OK;
 }
 
+template <typename T, int DH>
+static void launch_query_only(const K1Args& a, hipStream_t st) {
+  constexpr int VEC = 16 / elem<T>::kBytes, LP = DH / VEC;
+  const int QW = kWave / (a.H * LP);
+  const long waves = ((long)a.B * a.Nq + QW - 1) / QW;
+  hipLaunchKernelGGL((k1_bwd_kernel<T, DH, VEC, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
+                     (const T*)a.value, a.ss, a.ls, a.loc, a.aw, (const T*)a.gout, a.gvalue, a.gloc, a.gaw, a.B, a.S,
+                     a.H, a.L, a.Nq, a.P);
+}
+
 }  // namespace ubv
+
+extern "C" int64_t ubv_ms_deform_attn_backward_workspace(int B, int fh, int fw, int H, int Dh, int Nq, int P,
+                                                         int dtype) {
+  if (B <= 0 || Nq <= 0 || !ubv::k1_grid_ok(H, Dh, P, dtype, fh, fw)) return 0;
+  return ubv::k1_grid_workspace(B, fh, fw, H, Dh, Nq, P, dtype);
+}
+
+extern "C" int ubv_ms_deform_attn_backward_planned(const void* value, const int64_t* spatial_shapes,
+                                                   const int64_t* level_start, const float* sampling_loc,
+                                                   const float* attn_weight, const void* grad_out, float* grad_value,
+                                                   float* grad_sampling_loc, float* grad_attn_weight, int B, int S,
+                                                   int H, int Dh, int L, int Nq, int P, int dtype, int fh, int fw,
+                                                   void* workspace, int64_t workspace_bytes, void* stream) {
+  using namespace ubv;
+  if (L != 1 || (long)fh * fw != S || !k1_grid_ok(H, Dh, P, dtype, fh, fw)) {
+    set_error("ms_deform_attn_backward_planned: one level of fh x fw = S pixels, Dh in {16, 32}, P in {4, 8} "
+              "(got L=%d S=%d %dx%d Dh=%d P=%d)", L, S, fh, fw, Dh, P);
+    return UBV_ERR_UNSUPPORTED;
+  }
+  if (Nq == 0) return UBV_OK;
+  UBV_CHECK_ARG(value && spatial_shapes && level_start && sampling_loc && attn_weight && grad_out && grad_value &&
+                    grad_sampling_loc && grad_attn_weight, "ms_deform_attn_backward_planned: null pointer");
+  K1Args a{value, spatial_shapes, level_start, sampling_loc, attn_weight, nullptr, grad_out, grad_value,
+           grad_sampling_loc, grad_attn_weight, B, S, H, Dh, L, Nq, P};
+  hipStream_t st = as_stream(stream);
+#define UBV_K1Q(TT) do { if (Dh == 32) launch_query_only<TT, 32>(a, st); else launch_query_only<TT, 16>(a, st); } while (0)
+  if (dtype == UBV_F32) UBV_K1Q(float); else if (dtype == UBV_F16) UBV_K1Q(f16_t); else UBV_K1Q(bf16_t);
+#undef UBV_K1Q
+  const int rc = k1_grid_value(sampling_loc, attn_weight, grad_out, grad_value, B, fh, fw, H, Dh, Nq, P, dtype,
+                               workspace, workspace_bytes, st);
+  if (rc != UBV_OK) return rc;
+  UBV_CHECK_LAUNCH("ms_deform_attn_backward_planned");
+  return UBV_OK;
+}
 
 extern "C" int ubv_ms_deform_attn_forward(const void* value, const int64_t* spatial_shapes,
                                           const int64_t* level_start, const float* sampling_loc,

@@ -207,6 +207,12 @@ bool dcn_owner_launch(const void* gcol, const void* offset, const void* mask, fl
                       int Ho, int Wo, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int dg,
                       int dtype, hipStream_t st);
 
+// grad_value of the k1 operator on the GRID owner-tile plan (bev_lift.hip), called from msda_k1.hip
+bool k1_grid_ok(int H, int Dh, int P, int dtype, int fh, int fw);
+int64_t k1_grid_workspace(int B, int fh, int fw, int H, int Dh, int Nq, int P, int dtype);
+int k1_grid_value(const float* loc, const float* aw, const void* gout, float* gvalue, int B, int fh, int fw, int H,
+                  int Dh, int Nq, int P, int dtype, void* ws, int64_t ws_bytes, hipStream_t st);
+
 // RAII pair of HIP events around one kernel launch (a no-op unless ubv_profile_enable(1)).
 class ProfScope {
  public:

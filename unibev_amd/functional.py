@@ -5,6 +5,7 @@ These are the operator-level drop-ins for the reference's un-vendored extension 
 requires CUDA(HIP) tensors; there is no CPU path (``UniBEVHipError`` / ``RuntimeError``).
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -126,6 +127,9 @@ def _stream():
 
 
 # ----------------------------------------------------------------------------------------------- k1
+_K1_PLAN = [os.environ.get('UBV_K1_PLAN', '1') != '0']        # 0: keep the atomic grad_value kernel everywhere
+
+
 class MultiScaleDeformableAttnFunction(Function):
     """Drop-in for [ext] mmcv ``MultiScaleDeformableAttnFunction`` (call sites
     spatial_cross_attention_img.py:433-435, spatial_cross_attention_pts.py:440-442,
@@ -156,6 +160,9 @@ class MultiScaleDeformableAttnFunction(Function):
                                                        int(im2col_step), _stream()),
                       'ms_deform_attn_forward')
             ctx.save_for_backward(value, ss, ls, loc, aw)
+            # host copy of the shapes when the producer attached one (deform_attn.shapes_tensor): lets the backward
+            # plan owner tiles without reading the device tensor back
+            ctx.hw = getattr(value_spatial_shapes, '_ubv_hw', None)
             ctx.im2col_step = int(im2col_step)
             ctx.in_dtypes = (sampling_locations.dtype, attention_weights.dtype)
             return out
@@ -168,9 +175,24 @@ class MultiScaleDeformableAttnFunction(Function):
             B, S, H, Dh = value.shape
             _, Nq, _, L, P, _ = loc.shape
             go = grad_output.to(value.dtype).contiguous()
-            gv = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
             gloc = torch.empty_like(loc)
             gaw = torch.empty_like(aw)
+            # one level with host-known shape: grad_value on the GRID owner-tile plan — sampling points binned by
+            # owner tile, every pixel stored once, no f32 atomics (ubv_ms_deform_attn_backward_planned)
+            if L == 1 and ctx.hw is not None and len(ctx.hw) == 1 and _K1_PLAN[0]:
+                fh, fw = ctx.hw[0]
+                nws = int(lib().ubv_ms_deform_attn_backward_workspace(B, fh, fw, H, Dh, Nq, P, _dt(value)))
+                if nws > 0 and fh * fw == S:
+                    gv = torch.empty(value.shape, dtype=torch.float32, device=value.device)
+                    ws = _workspace(nws, value.device)
+                    with _timed('k1_bwd_planned'):
+                        check(lib().ubv_ms_deform_attn_backward_planned(
+                            _p(value), _p(ss), _p(ls), _p(loc), _p(aw), _p(go), _p(gv), _p(gloc), _p(gaw), B, S, H, Dh,
+                            L, Nq, P, _dt(value), int(fh), int(fw), _p(ws), nws, _stream()),
+                            'ms_deform_attn_backward_planned')
+                    return (gv.to(value.dtype), None, None, gloc.to(ctx.in_dtypes[0]),
+                            gaw.to(ctx.in_dtypes[1]), None)
+            gv = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
             with _timed('k1_bwd'):
                 check(lib().ubv_ms_deform_attn_backward(_p(value), _p(ss), _p(ls), _p(loc), _p(aw),
                                                         _p(go), _p(gv), _p(gloc), _p(gaw), B, S, H, Dh,
@@ -1026,9 +1048,20 @@ def spconv_gather_mma(feats, nbr, w_hi, w_lo, cout):
 
 
 @torch.no_grad()
-def spconv_wgrad(grad_out, feats, nbr):
-    """[kvol, Cin, Cout] f32 weight gradient of a sparse convolution (``ubv_spconv_wgrad``), or None when
-    the channel counts are outside the kernel's reach."""
+def spconv_pairs(nbr):
+    """Compacted rulebook of a neighbour map [kvol, rows]: per offset the rows that HAVE a neighbour first, in row
+    order (stable) -> (out_rows, in_rows, counts) int32.  Deterministic, nothing read back; built once per indice key."""
+    valid = nbr >= 0
+    order = torch.argsort((~valid).to(torch.uint8), dim=1, stable=True).to(torch.int32)
+    in_rows = torch.gather(nbr, 1, order.long())
+    return order.contiguous(), in_rows.contiguous(), valid.sum(1, dtype=torch.int32).contiguous()
+
+
+@torch.no_grad()
+def spconv_wgrad(grad_out, feats, nbr, pairs=None):
+    """[kvol, Cin, Cout] f32 weight gradient of a sparse convolution (``ubv_spconv_wgrad``; with ``pairs`` =
+    ``spconv_pairs(nbr)`` the compacted form ``ubv_spconv_wgrad_pairs``), or None when the channel counts are
+    outside the kernel's reach."""
     with _need_cuda(grad_out, feats, nbr):
         kvol, rows = nbr.shape
         cout, cin = grad_out.shape[1], feats.shape[1]
@@ -1039,8 +1072,14 @@ def spconv_wgrad(grad_out, feats, nbr):
         blk = cout * cin + cout
         part = _workspace(4 * S * kvol * blk, feats.device)
         out = torch.empty(kvol, blk, dtype=torch.float32, device=feats.device)
-        rc = lib().ubv_spconv_wgrad(_p(grad_out.contiguous()), _p(feats.contiguous()), _p(nbr), rows, rows, _p(part),
-                                    _p(out), cout, cin, kvol, S, _dt(feats), _stream())
+        if pairs is not None:
+            out_rows, in_rows, counts = pairs
+            rc = lib().ubv_spconv_wgrad_pairs(_p(grad_out.contiguous()), _p(feats.contiguous()), _p(in_rows), _p(out_rows),
+                                              _p(counts), rows, rows, _p(part), _p(out), cout, cin, kvol, S, _dt(feats),
+                                              _stream())
+        else:
+            rc = lib().ubv_spconv_wgrad(_p(grad_out.contiguous()), _p(feats.contiguous()), _p(nbr), rows, rows, _p(part),
+                                        _p(out), cout, cin, kvol, S, _dt(feats), _stream())
         if rc == -3:
             return None
         check(rc, 'spconv_wgrad')

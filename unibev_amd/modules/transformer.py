@@ -108,22 +108,24 @@ class UniBEVTransformer(BaseModule):
         """Parameter names follow transformer_fusion.py:130-182 (they are checkpoint keys)."""
         if self.feature_norm == 'ChannelNormWeights':
             self.feature_norm_layer = nn.Softmax(dim=0)
-            self.pts_channel_weights = nn.Parameter(torch.Tensor(self.embed_dims))
-            self.img_channel_weights = nn.Parameter(torch.Tensor(self.embed_dims))
+            # (the reference allocates these with torch.Tensor(n) — uninitialised memory until init_weights(); zeros here:
+            #  no RNG consumed, and a model used before init_weights() / load_state_dict() is finite instead of garbage)
+            self.pts_channel_weights = nn.Parameter(torch.zeros(self.embed_dims))
+            self.img_channel_weights = nn.Parameter(torch.zeros(self.embed_dims))
         elif self.feature_norm in _UNSUPPORTED_NORMS:
             raise NotImplementedError(
                 f'feature_norm={self.feature_norm!r}: experimental variant of the reference '
                 f'(transformer_fusion.py:136-155) that no shipped config selects')
         if self.spatial_norm == 'SpatialNormWeights':
             self.spatial_norm_layer = nn.Softmax(dim=0)
-            self.pts_spatial_weights = nn.Parameter(torch.Tensor(self.bev_h * self.bev_w))
-            self.img_spatial_weights = nn.Parameter(torch.Tensor(self.bev_h * self.bev_w))
+            self.pts_spatial_weights = nn.Parameter(torch.zeros(self.bev_h * self.bev_w))
+            self.img_spatial_weights = nn.Parameter(torch.zeros(self.bev_h * self.bev_w))
         if self.with_img_bev_encoder:
-            self.img_level_embeds = nn.Parameter(torch.Tensor(self.num_feature_levels,
+            self.img_level_embeds = nn.Parameter(torch.zeros(self.num_feature_levels,
                                                               self.embed_dims))
-            self.cams_embeds = nn.Parameter(torch.Tensor(self.num_cams, self.embed_dims))
+            self.cams_embeds = nn.Parameter(torch.zeros(self.num_cams, self.embed_dims))
         if self.with_pts_bev_encoder:
-            self.pts_level_embeds = nn.Parameter(torch.Tensor(self.num_feature_levels,
+            self.pts_level_embeds = nn.Parameter(torch.zeros(self.num_feature_levels,
                                                               self.embed_dims))
         if self.use_modal_embeds is not None:
             raise NotImplementedError('use_modal_embeds: unused by every shipped config '
