@@ -495,9 +495,27 @@ def voxel_record(device):
     us = 1e3 * e0.elapsed_time(e1) / 20
     m = int(vnum.item())
     nbytes = N * F * 4 + N * 3 * 4 + m * (F + 3 + 1) * 4
+    # a batch of clouds in ONE launch chain (ubv_hard_voxelize_batch, what UniBEV.voxelize runs): per-cloud time at
+    # the per-GPU batch of the reference's configs (1, shipped) and of BASELINE's cfg4 (2), and at 8
+    batch = {}
+    for nb in (2, 8):
+        clouds = [torch.from_numpy(syn.lidar_points(30000, seed=s)).to(device) for s in range(nb)]
+
+        def front_b():
+            v, c, n, m_ = UF.hard_voxelize_batch(clouds, syn.VOXEL_SIZE, syn.PC_RANGE, 10, 90000)
+            return UF.voxel_mean(v.view(-1, 10, F), n.view(-1))
+        for _ in range(3):
+            front_b()
+        e0.record()
+        for _ in range(10):
+            front_b()
+        e1.record()
+        torch.cuda.synchronize()
+        batch[f'us_per_cloud_batch{nb}'] = 1e3 * e0.elapsed_time(e1) / 10 / nb
     rec = {'points': N, 'voxels': m, 'us_per_cloud': us, 'points_per_s': N / us * 1e6,
-           'algorithmic_bytes': nbytes, 'GBps': nbytes / us / 1e3,
-           'note': 'hard voxelize + VFE mean, 7 launches: latency-bound, not bandwidth-bound'}
+           'algorithmic_bytes': nbytes, 'GBps': nbytes / us / 1e3, **batch,
+           'note': 'hard voxelize + VFE mean; one cloud per chain (us_per_cloud) is latency-bound: 8 launches + 2 '
+                   'fills; a batch shares the chain (us_per_cloud_batchN)'}
     rec['middle_encoder'] = middle_encoder_record(device, mean[:m], coors[:m])
     return rec
 

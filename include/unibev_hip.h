@@ -380,6 +380,17 @@ int ubv_hard_voxelize(const float* points, float* voxels, int32_t* coors, int32_
                       const float* voxel_size_host, const float* range_host, int max_points,
                       int max_voxels, void* stream);
 
+/* A BATCH of clouds in one launch chain ([ext] mmdet3d runs Voxelization once per sample from a Python loop,
+ * models/detectors/unibev_detector.py:163-167): cloud b = points_host[b] [n_host[b], F] (host arrays of device pointers
+ * / counts, B <= 16).  Every sample is voxelized exactly as by ubv_hard_voxelize (same numbering, same caps, bit for
+ * bit); outputs are per-sample slabs voxels [B, max_voxels, max_points, F], coors [B, max_voxels, 3], num_points
+ * [B, max_voxels], voxel_num [B] (device).  workspace: ubv_hard_voxelize_batch_workspace(B, max_b n, ...) bytes. */
+int64_t ubv_hard_voxelize_batch_workspace(int B, int n_max, int max_points, int max_voxels);
+int ubv_hard_voxelize_batch(const float* const* points_host, const int* n_host, int B, float* voxels, int32_t* coors,
+                            int32_t* num_points, int32_t* voxel_num, void* workspace, int64_t workspace_bytes, int F,
+                            const float* voxel_size_host, const float* range_host, int max_points, int max_voxels,
+                            void* stream);
+
 /* [ext] mmdet3d dynamic_voxelize: coors [N, 3] int32 (z, y, x), or (-1,-1,-1) when outside. */
 int ubv_dynamic_voxelize(const float* points, int32_t* coors, int N, int F,
                          const float* voxel_size_host, const float* range_host, void* stream);
@@ -457,6 +468,21 @@ int ubv_spconv_wgrad(const void* grad_out, const void* feats, const int32_t* nbr
 int ubv_spconv_wgrad_pairs(const void* grad_out, const void* feats, const int32_t* in_rows, const int32_t* out_rows,
                            const int32_t* counts, int64_t ld, int64_t rows, float* partials, float* grad_w, int Cout,
                            int Cin, int kvol, int splits, int dtype, void* stream);
+
+/* BatchNorm1d (+ ReLU) over the rows of a sparse feature matrix x [N, C] — the norm / activation between the sparse
+ * convolutions ([ext] mmdet3d make_sparse_convmodule / SparseBasicBlock: BatchNorm1d(eps 1e-3, momentum 0.01), ReLU;
+ * torch.nn.functional.batch_norm semantics: biased variance for the normalisation, unbiased for running_var).
+ * training != 0: batch statistics (mean / rstd [C] are WRITTEN, running_* updated when given); else mean / rstd are
+ * INPUTS (the caller derives them from the running statistics).  y = relu?(gamma * (x - mean) * rstd + beta).
+ * partial: ubv_rows_bn_partial_elems(C) floats of scratch.  Deterministic (fixed-order two-level sums).
+ * backward: grad_x, grad_gamma [C], grad_beta [C] written; relu != 0 masks grad_y where the forward output was 0. */
+int64_t ubv_rows_bn_partial_elems(int C);
+int ubv_rows_bn_forward(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                        float* mean, float* rstd, float* partial, void* y, int64_t N, int C, float eps, float momentum,
+                        int relu, int training, int dtype, void* stream);
+int ubv_rows_bn_backward(const void* x, const void* grad_y, const float* gamma, const float* beta, const float* mean,
+                         const float* rstd, float* partial, float* grad_gamma, float* grad_beta, void* grad_x, int64_t N,
+                         int C, int relu, int dtype, void* stream);
 int ubv_spconv_hash_build(const int32_t* coors, int64_t n, int D, int H, int W, int64_t* table_keys,
                           int32_t* table_vals, int64_t slots, void* stream);
 int ubv_spconv_neighbors(const int32_t* coors, int64_t rows, int B, const int* row_dims, const int* target_dims,

@@ -219,3 +219,41 @@ def test_rulebooks_are_kept_while_the_same_coordinates_come_back():
     fresh = build_from_cfg(cfg, MIDDLE_ENCODERS).to(DEV).train()
     fresh.load_state_dict(enc.state_dict())
     torch.testing.assert_close(enc(feats, coors, 2), fresh(feats, coors.clone(), 2), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('C,relu', [(16, True), (32, False), (64, True), (128, True)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_rows_batch_norm_vs_torch(C, relu, dtype):
+    """Fused BatchNorm1d (+ ReLU) over sparse feature rows: output, running statistics, and the gradients of x / gamma /
+    beta equal torch.nn.BatchNorm1d (+ ReLU) in f64 on the same values — training and eval mode."""
+    from unibev_amd.functional import rows_batch_norm
+    rs = np.random.RandomState(C)
+    N = 5000 + C
+    x = torch.from_numpy(rs.standard_normal((N, C)).astype(np.float32) * 2 + 0.5).to(dtype)
+    cot = torch.from_numpy(rs.standard_normal((N, C)).astype(np.float32)).to(dtype)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for training in (True, False):
+        bn = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).to(DEV).train(training)
+        ref = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).double().train(training)
+        with torch.no_grad():
+            for m in (bn, ref):
+                m.weight.copy_(torch.from_numpy(rs.uniform(0.5, 1.5, C)))
+                m.bias.copy_(torch.from_numpy(rs.standard_normal(C) * 0.3))
+                m.running_mean.copy_(torch.from_numpy(rs.standard_normal(C) * 0.2))
+                m.running_var.copy_(torch.from_numpy(rs.uniform(0.5, 2.0, C)))
+            ref.weight.copy_(bn.weight.double().cpu()); ref.bias.copy_(bn.bias.double().cpu())
+            ref.running_mean.copy_(bn.running_mean.double().cpu()); ref.running_var.copy_(bn.running_var.double().cpu())
+        xg = x.to(DEV).requires_grad_()
+        y = rows_batch_norm(xg, bn, relu=relu)
+        assert y is not None and y.dtype == dtype
+        x64 = x.double().requires_grad_()
+        r = ref(x64)
+        r = torch.relu(r) if relu else r
+        (y.float() * cot.to(DEV).float()).sum().backward()
+        (r * cot.double()).sum().backward()
+        rel = lambda a, b: float((a.double().cpu() - b).norm() / b.norm().clamp_min(1e-30))
+        assert rel(y, r.detach()) < tol
+        assert rel(xg.grad, x64.grad) < (tol if dtype == torch.float32 else 4e-2)
+        assert rel(bn.weight.grad, ref.weight.grad) < tol and rel(bn.bias.grad, ref.bias.grad) < tol
+        assert rel(bn.running_mean, ref.running_mean) < 1e-5 and rel(bn.running_var, ref.running_var) < 1e-5
+        assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)

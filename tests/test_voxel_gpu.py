@@ -200,3 +200,33 @@ def test_dynamic_scatter_backward_with_ties_vs_sequential_oracle(reduce_type):
     assert vz.shape[0] == 0
     vz.sum().backward()
     assert fz.grad is not None and float(fz.grad.abs().sum()) == 0
+
+
+def test_hard_voxelize_batch_is_bit_identical_to_per_sample_calls():
+    """One launch chain for a list of clouds (``ubv_hard_voxelize_batch``): every sample equals its own
+    ``ubv_hard_voxelize`` call and the C oracle bit for bit — clouds of different sizes, an empty one, a voxel cap that
+    bites; ``voxelize_cat`` gives the reference's concatenated (voxels, num_points, coors [b, z, y, x])."""
+    from unibev_amd.functional import hard_voxelize, hard_voxelize_batch
+    from unibev_amd.modules.voxel import Voxelization, voxelize_cat
+    clouds = [syn.lidar_points(30000, seed=3), syn.lidar_points(7000, seed=4), np.zeros((0, 5), np.float32),
+              syn.lidar_points(19000, seed=5)]
+    dev = [t(c, device=DEV) for c in clouds]
+    for cap in (90000, 5000):
+        v, c, n, m = hard_voxelize_batch(dev, syn.VOXEL_SIZE, syn.PC_RANGE, 10, cap)
+        assert v.shape == (4, cap, 10, 5) and m.shape == (4,)
+        for b, cloud in enumerate(clouds):
+            ev, ec, en = c_ref.hard_voxelize(cloud, syn.VOXEL_SIZE, syn.PC_RANGE, 10, cap)
+            k = int(m[b])
+            assert k == len(ec)
+            np.testing.assert_array_equal(c[b, :k].cpu().numpy(), ec)
+            np.testing.assert_array_equal(n[b, :k].cpu().numpy(), en)
+            np.testing.assert_array_equal(v[b, :k].cpu().numpy(), ev)
+            if len(cloud):
+                sv, sc, sn, sm = hard_voxelize(dev[b], syn.VOXEL_SIZE, syn.PC_RANGE, 10, cap)
+                assert int(sm) == k and torch.equal(sv[:k], v[b, :k]) and torch.equal(sc[:k], c[b, :k])
+    layer = Voxelization(syn.VOXEL_SIZE, syn.PC_RANGE, 10, (90000, 120000)).eval()
+    voxels, num, coors = voxelize_cat(layer, dev)
+    per = [layer(p) for p in dev]
+    assert torch.equal(voxels, torch.cat([p[0] for p in per])) and torch.equal(num, torch.cat([p[2] for p in per]))
+    assert torch.equal(coors[:, 1:], torch.cat([p[1] for p in per]))
+    assert coors[:, 0].tolist() == sum(([b] * len(p[1]) for b, p in enumerate(per)), [])

@@ -9,8 +9,9 @@ B="python $ROOT/bench.py"
 # 1. the judged tests
 (cd $ROOT && timeout 1500 python -m pytest tests -q -m gpu > $OUT/tests.txt 2>&1)
 # 2. bench lines: default (f32 headline + 16-bit sub-records + gemm / voxel records + CPU baseline), cat-128, one stream
-(cd $ROOT && $B > $OUT/bench.json 2> $OUT/bench.err)
+(cd $ROOT && $B --cpu-baseline-plan > $OUT/bench.json 2> $OUT/bench.err)
 (cd $ROOT && $B --workload LC_cat128 --no-cpu-baseline --no-extras > $OUT/bench_cat128.json 2> $OUT/bench_cat128.err)
+for w in C L; do (cd $ROOT && $B --workload $w --no-cpu-baseline --no-extras > $OUT/bench_$w.json 2> $OUT/bench_$w.err); done
 (cd $ROOT && $B --single-stream --no-cpu-baseline --no-extras --no-kernel-timing > $OUT/bench_single_stream.json 2>/dev/null)
 # 3. rocprofv3 kernel summary of the default bench command (what roofline.achieved must agree with)
 rocprofv3 --kernel-trace -d /tmp/prof_cmd -o cmd -- $B --no-cpu-baseline > $OUT/bench_profiled.json 2>/dev/null
@@ -29,5 +30,5 @@ done
 python $ROOT/tools/bench_gemm.py > $OUT/bench_gemm.txt 2>&1
 python $ROOT/tools/bench_backbone.py 2>&1 | grep -v '^/opt' > $OUT/bench_backbone.txt
 # 6. HBM traffic per op (PMC passes)
-bash $ROOT/tools/collect_traffic.sh $OUT > $OUT/traffic.log 2>&1
+UBV_COMMIT=${UBV_COMMIT:-unrecorded} bash $ROOT/tools/collect_traffic.sh $OUT > $OUT/traffic.log 2>&1
 ls -la $OUT

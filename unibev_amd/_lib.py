@@ -63,6 +63,9 @@ SIGNATURES = {
     'ubv_spconv_table_slots': (c_int64, [c_int64]),
     'ubv_spconv_wgrad_splits': (c_int, [c_int64, c_int]),
     'ubv_spconv_wgrad': (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'ubv_rows_bn_partial_elems': (c_int64, [c_int]),
+    'ubv_rows_bn_forward': (c_int, [_P] * 9 + [c_int64, c_int, c_float, c_float, c_int, c_int, c_int, _P]),
+    'ubv_rows_bn_backward': (c_int, [_P] * 10 + [c_int64, c_int, c_int, c_int, _P]),
     'ubv_spconv_wgrad_pairs': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ubv_spconv_hash_build': (c_int, [_P, c_int64, c_int, c_int, c_int, _P, _P, c_int64, _P]),
     'ubv_spconv_neighbors': (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, c_int64, _P, c_int64, _P]),
@@ -74,6 +77,9 @@ SIGNATURES = {
     'ubv_split_weight': (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P]),
     'ubv_linear_grad_reduce': (c_int, [_P, c_int64, c_int, _P, _P, c_int, c_int64, _P, c_int, _P]),
     'ubv_hard_voxelize_workspace': (c_int64, [c_int, c_int, c_int]),
+    'ubv_hard_voxelize_batch_workspace': (c_int64, [c_int, c_int, c_int, c_int]),
+    'ubv_hard_voxelize_batch': (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, c_int64, c_int, ctypes.POINTER(c_float),
+                                        ctypes.POINTER(c_float), c_int, c_int, _P]),
     'ubv_hard_voxelize': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int,
                                   ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_int,
                                   _P]),

@@ -154,19 +154,25 @@ template <> struct spc_mma<f16_t> {
 };
 template <> struct spc_mma<float> : spc_mma<bf16_t> {};
 
-// RB: 32-row blocks per wave.  Every B fragment (a slice of W_k, fetched from L2 by every wave that needs it)
-// then feeds RB MFMA groups: with one row block per wave the weight traffic — 1.8 MB of W per 32 output rows at
-// 128 x 128 channels — was the bound (9.6 TB/s of L2 reads measured).
+// RB: 32-row blocks per wave.  The weight block W_k of an offset is staged ONCE PER BLOCK in LDS (80 - 272-byte rows:
+// conflict-free 16-byte fragment reads) and feeds the 4 waves x RB row blocks of the block.  Before, every wave
+// fetched its B fragments from L2 itself: 1.8 MB of W per 64 output rows at 128 x 128 channels — 578 us per
+// convolution of the 128-channel stage, bound by those reads (round 2: one row block per wave, 9.6 TB/s of L2 reads).
 template <typename T, int NB, int RB>
 __global__ __launch_bounds__(256) void spconv_gather_mma_kernel(const T* __restrict__ feats, const int32_t* __restrict__ nbr,
                                                                 long ld, long rows, const uint16_t* __restrict__ w_hi,
                                                                 const uint16_t* __restrict__ w_lo, T* __restrict__ out,
                                                                 int Cin, int Cout, int kvol) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t wlds[];
   constexpr bool SPLIT = sizeof(T) == 4;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long row0 = ((long)blockIdx.x * 4 + wv) * (32 * RB);
-  if (row0 >= rows) return;
+  const bool wave_live = row0 < rows;                     // (idle waves of the last block still take the barriers)
   const int m = lane & 31, kg = lane >> 5;
+  const int LD = Cin + 8;                                 // halves per staged row
+  uint16_t* __restrict__ s_hi = wlds;
+  uint16_t* __restrict__ s_lo = wlds + NB * 32 * LD;
+  const int cpr = Cin / 8, pieces = NB * 32 * cpr;        // 16-byte pieces per row / per plane
   sf32x16_t acc[RB][NB];
 #pragma unroll
   for (int i = 0; i < RB; ++i)
@@ -181,41 +187,67 @@ __global__ __launch_bounds__(256) void spconv_gather_mma_kernel(const T* __restr
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const long row = row0 + i * 32 + m;
-      idx[i] = row < rows ? nbr[(long)k * ld + row] : -1;
+      idx[i] = (wave_live && row < rows) ? nbr[(long)k * ld + row] : -1;
       any = any || idx[i] >= 0;
     }
+    // ---- W_k -> LDS, by the whole block
+    __syncthreads();                                      // the previous offset's fragments are consumed
+    {
+      const uint16_t* gh = w_hi + (long)k * NB * 32 * Cin;
+      const uint16_t* gl = SPLIT ? w_lo + (long)k * NB * 32 * Cin : nullptr;
+      for (int p = threadIdx.x; p < pieces; p += 256) {
+        const int r = p / cpr, c8 = (p - r * cpr) * 8;
+        *reinterpret_cast<uint4*>(s_hi + r * LD + c8) = *reinterpret_cast<const uint4*>(gh + (long)r * Cin + c8);
+        if constexpr (SPLIT)
+          *reinterpret_cast<uint4*>(s_lo + r * LD + c8) = *reinterpret_cast<const uint4*>(gl + (long)r * Cin + c8);
+      }
+    }
+    __syncthreads();
     if (__ballot(any) == 0ull) continue;                  // no row of this wave has a neighbour at offset k
-    const uint16_t* wk_hi = w_hi + ((long)k * NB * 32 + m) * Cin + kg * 8;
-    const uint16_t* wk_lo = SPLIT ? w_lo + ((long)k * NB * 32 + m) * Cin + kg * 8 : nullptr;
+    const uint16_t* wk_hi = s_hi + m * LD + kg * 8;
+    const uint16_t* wk_lo = SPLIT ? s_lo + m * LD + kg * 8 : nullptr;
+    // A fragments straight from the gathered rows, the NEXT 16-channel step's loads issued before this step's MFMAs
+    // (the loop is a chain of dependent gathers otherwise: index -> row -> convert -> MFMA)
+    constexpr int NV = SPLIT ? 2 : 1;                      // 16-byte loads per row and step
+    uint4 raw[RB][NV], nxt[RB][NV];
+    auto load_a = [&](int c0, uint4 (&dst)[RB][NV]) {
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const T* frow = feats + (long)(idx[i] >= 0 ? idx[i] : 0) * Cin + kg * 8 + c0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          dst[i][v] = reinterpret_cast<const uint4*>(frow)[v];
+          if (idx[i] < 0) dst[i][v] = make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
+    };
+    load_a(0, raw);
     for (int c0 = 0; c0 < Cin; c0 += 16) {
+      if (c0 + 16 < Cin) load_a(c0 + 16, nxt);
       uint4 a_hi[RB], a_lo[RB];
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
-        a_hi[i] = make_uint4(0u, 0u, 0u, 0u);
-        a_lo[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (idx[i] >= 0) {
-          const T* frow = feats + (long)idx[i] * Cin + kg * 8 + c0;
-          if constexpr (SPLIT) {
-            const float4 v0 = *reinterpret_cast<const float4*>(frow);
-            const float4 v1 = *reinterpret_cast<const float4*>(frow + 4);
-            uint4 h, l;
-            h.x = cvt_pk_bf16(v0.x, v0.y); h.y = cvt_pk_bf16(v0.z, v0.w);
-            h.z = cvt_pk_bf16(v1.x, v1.y); h.w = cvt_pk_bf16(v1.z, v1.w);
-            l.x = cvt_pk_bf16(v0.x - __uint_as_float(h.x << 16), v0.y - __uint_as_float(h.x & 0xffff0000u));
-            l.y = cvt_pk_bf16(v0.z - __uint_as_float(h.y << 16), v0.w - __uint_as_float(h.y & 0xffff0000u));
-            l.z = cvt_pk_bf16(v1.x - __uint_as_float(h.z << 16), v1.y - __uint_as_float(h.z & 0xffff0000u));
-            l.w = cvt_pk_bf16(v1.z - __uint_as_float(h.w << 16), v1.w - __uint_as_float(h.w & 0xffff0000u));
-            a_hi[i] = h; a_lo[i] = l;
-          } else {
-            a_hi[i] = *reinterpret_cast<const uint4*>(frow);
-          }
+        if constexpr (SPLIT) {
+          const float4 v0 = __builtin_bit_cast(float4, raw[i][0]);
+          const float4 v1 = __builtin_bit_cast(float4, raw[i][1]);
+          uint4 h, l;
+          h.x = cvt_pk_bf16(v0.x, v0.y); h.y = cvt_pk_bf16(v0.z, v0.w);
+          h.z = cvt_pk_bf16(v1.x, v1.y); h.w = cvt_pk_bf16(v1.z, v1.w);
+          l.x = cvt_pk_bf16(v0.x - __uint_as_float(h.x << 16), v0.y - __uint_as_float(h.x & 0xffff0000u));
+          l.y = cvt_pk_bf16(v0.z - __uint_as_float(h.y << 16), v0.w - __uint_as_float(h.y & 0xffff0000u));
+          l.z = cvt_pk_bf16(v1.x - __uint_as_float(h.z << 16), v1.y - __uint_as_float(h.z & 0xffff0000u));
+          l.w = cvt_pk_bf16(v1.z - __uint_as_float(h.w << 16), v1.w - __uint_as_float(h.w & 0xffff0000u));
+          a_hi[i] = h; a_lo[i] = l;
+        } else {
+          a_hi[i] = raw[i][0];
+          a_lo[i] = make_uint4(0u, 0u, 0u, 0u);
         }
       }
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        const uint4 b_hi = *reinterpret_cast<const uint4*>(wk_hi + (long)j * 32 * Cin + c0);
+        const uint4 b_hi = *reinterpret_cast<const uint4*>(wk_hi + j * 32 * LD + c0);
         uint4 b_lo = make_uint4(0u, 0u, 0u, 0u);
-        if constexpr (SPLIT) b_lo = *reinterpret_cast<const uint4*>(wk_lo + (long)j * 32 * Cin + c0);
+        if constexpr (SPLIT) b_lo = *reinterpret_cast<const uint4*>(wk_lo + j * 32 * LD + c0);
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
           acc[i][j] = spc_mma<T>::run(a_hi[i], b_hi, acc[i][j]);
@@ -225,9 +257,14 @@ __global__ __launch_bounds__(256) void spconv_gather_mma_kernel(const T* __restr
           }
         }
       }
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) raw[i][v] = nxt[i][v];
     }
   }
   // D[i][n]: this lane holds column n = lane & 31 (output channel within block j), rows (r & 3) + 8 (r >> 2) + 4 kg
+  if (!wave_live) return;
 #pragma unroll
   for (int i = 0; i < RB; ++i)
 #pragma unroll
@@ -248,9 +285,14 @@ static int spconv_launch(const void* feats, const int32_t* nbr, long ld, long ro
   const int nb = (Cout + 31) / 32;
   constexpr int RB = 2;
   const dim3 grid((unsigned)((rows + 128 * RB - 1) / (128 * RB))), blk(256);
+  const size_t lds = (size_t)(sizeof(T) == 4 ? 2 : 1) * nb * 32 * (Cin + 8) * sizeof(uint16_t);
+  // (more than 64 KB of dynamic LDS at 128 x 128 f32 channels: ask for it explicitly)
 #define UBV_SPC(NBV)                                                                                            \
   case NBV:                                                                                                     \
-    hipLaunchKernelGGL((spconv_gather_mma_kernel<T, NBV, RB>), grid, blk, 0, st, (const T*)feats, nbr, ld, rows, \
+    if (lds > 64 * 1024)                                                                                        \
+      (void)hipFuncSetAttribute((const void*)spconv_gather_mma_kernel<T, NBV, RB>,                              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
+    hipLaunchKernelGGL((spconv_gather_mma_kernel<T, NBV, RB>), grid, blk, lds, st, (const T*)feats, nbr, ld, rows, \
                        (const uint16_t*)w_hi, (const uint16_t*)w_lo, (T*)out, Cin, Cout, kvol);                 \
     break;
   switch (nb) {

@@ -50,10 +50,10 @@ __device__ __forceinline__ bool point_coord(const float* __restrict__ p, const V
   return ok;
 }
 
-__global__ __launch_bounds__(256) void vox_key_insert_kernel(
+__device__ __forceinline__ void vox_key_insert_body(const int bid, 
     const float* __restrict__ points, int N, int F, VoxGeom g, uint32_t* __restrict__ keys,
     unsigned long long* __restrict__ table, uint32_t mask) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = bid * blockDim.x + threadIdx.x;
   if (i >= N) return;
   int c[3];
   const bool ok = point_coord(points + (long)i * F, g, c);
@@ -74,10 +74,10 @@ __global__ __launch_bounds__(256) void vox_key_insert_kernel(
 }
 
 // head[i] = 1 iff point i is the first point of its voxel; first[i] = first point of i's voxel.
-__global__ __launch_bounds__(256) void vox_head_kernel(
+__device__ __forceinline__ void vox_head_body(const int bid, 
     const uint32_t* __restrict__ keys, int N, const unsigned long long* __restrict__ table,
     uint32_t mask, int* __restrict__ first, int* __restrict__ head) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = bid * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const uint32_t key = keys[i];
   int f = -1;
@@ -96,11 +96,11 @@ __global__ __launch_bounds__(256) void vox_head_kernel(
 // ---- exclusive scan over int32 (3 kernels: per-block, block sums, add) ------------------------------
 constexpr int kScanBlock = 1024;
 
-__global__ __launch_bounds__(256) void scan_block_kernel(const int* __restrict__ in,
+__device__ __forceinline__ void scan_block_body(const int bid, const int* __restrict__ in,
                                                          int* __restrict__ out,
                                                          int* __restrict__ sums, int N) {
   __shared__ int wave_tot[4];
-  const int base = blockIdx.x * kScanBlock + threadIdx.x * 4;
+  const int base = bid * kScanBlock + threadIdx.x * 4;
   int v[4], s = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) { v[k] = (base + k < N) ? in[base + k] : 0; s += v[k]; }
@@ -121,10 +121,10 @@ __global__ __launch_bounds__(256) void scan_block_kernel(const int* __restrict__
     if (base + k < N) out[base + k] = run;
     run += v[k];
   }
-  if (threadIdx.x == 255) sums[blockIdx.x] = off + incl;
+  if (threadIdx.x == 255) sums[bid] = off + incl;
 }
 
-__global__ void scan_sums_kernel(int* __restrict__ sums, int nblocks, int* __restrict__ total,
+__device__ __forceinline__ void scan_sums_body(int* __restrict__ sums, int nblocks, int* __restrict__ total,
                                  int clamp) {
   // one wave, sequential over chunks of 64 block sums
   const int lane = threadIdx.x;
@@ -144,11 +144,11 @@ __global__ void scan_sums_kernel(int* __restrict__ sums, int nblocks, int* __res
 }
 
 // Adds the block offsets and, per point, pushes it into its voxel's slot chain.
-__global__ __launch_bounds__(256) void vox_assign_kernel(
+__device__ __forceinline__ void vox_assign_body(const int bid, 
     const uint32_t* __restrict__ keys, const int* __restrict__ first,
     const int* __restrict__ scan, const int* __restrict__ sums, int N, VoxGeom g, int max_points,
     int max_voxels, int* __restrict__ slots, int32_t* __restrict__ coors) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = bid * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int f = first[i];
   if (f < 0) return;
@@ -170,12 +170,12 @@ __global__ __launch_bounds__(256) void vox_assign_kernel(
   }
 }
 
-__global__ __launch_bounds__(256) void vox_gather_kernel(
+__device__ __forceinline__ void vox_gather_body(const int bid, 
     const float* __restrict__ points, int F, const int* __restrict__ slots,
     const int* __restrict__ voxel_num, int max_points, float* __restrict__ voxels,
     int32_t* __restrict__ num_points, int max_voxels) {
   // one thread per (voxel, slot, feature)
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long t = (long)bid * blockDim.x + threadIdx.x;
   const long per_v = (long)max_points * F;
   if (t >= (long)max_voxels * per_v) return;
   const int v = (int)(t / per_v);
@@ -191,6 +191,80 @@ __global__ __launch_bounds__(256) void vox_gather_kernel(
     num_points[v] = n;
   }
 }
+
+
+// ---- kernels: one sample (blockIdx.x walks the sample) and a batch (blockIdx.y = sample; every per-sample array at
+// a fixed stride, point counts and cloud pointers in VoxBatch) — a batch is ONE launch chain instead of one per cloud
+constexpr int kVoxMaxBatch = 16;
+struct VoxBatch {
+  const float* points[kVoxMaxBatch];
+  int n[kVoxMaxBatch];
+  long ws_stride;                 // bytes of workspace per sample
+  long key_off, first_off, head_off, scan_off, sums_off, table_off, slots_off;   // offsets inside a sample's workspace
+  uint32_t mask;                  // table capacity - 1 (sized for the largest cloud)
+};
+
+__global__ __launch_bounds__(256) void vox_key_insert_kernel(const float* __restrict__ points, int N, int F, VoxGeom g,
+                                                             uint32_t* __restrict__ keys,
+                                                             unsigned long long* __restrict__ table, uint32_t mask) {
+  vox_key_insert_body(blockIdx.x, points, N, F, g, keys, table, mask);
+}
+__global__ __launch_bounds__(256) void vox_head_kernel(const uint32_t* __restrict__ keys, int N,
+                                                       const unsigned long long* __restrict__ table, uint32_t mask,
+                                                       int* __restrict__ first, int* __restrict__ head) {
+  vox_head_body(blockIdx.x, keys, N, table, mask, first, head);
+}
+__global__ __launch_bounds__(256) void scan_block_kernel(const int* __restrict__ in, int* __restrict__ out,
+                                                         int* __restrict__ sums, int N) {
+  scan_block_body(blockIdx.x, in, out, sums, N);
+}
+__global__ void scan_sums_kernel(int* __restrict__ sums, int nblocks, int* __restrict__ total, int clamp) {
+  scan_sums_body(sums, nblocks, total, clamp);
+}
+__global__ __launch_bounds__(256) void vox_assign_kernel(const uint32_t* __restrict__ keys, const int* __restrict__ first,
+                                                         const int* __restrict__ scan, const int* __restrict__ sums, int N,
+                                                         VoxGeom g, int max_points, int max_voxels, int* __restrict__ slots,
+                                                         int32_t* __restrict__ coors) {
+  vox_assign_body(blockIdx.x, keys, first, scan, sums, N, g, max_points, max_voxels, slots, coors);
+}
+__global__ __launch_bounds__(256) void vox_gather_kernel(const float* __restrict__ points, int F, const int* __restrict__ slots,
+                                                         const int* __restrict__ voxel_num, int max_points,
+                                                         float* __restrict__ voxels, int32_t* __restrict__ num_points,
+                                                         int max_voxels) {
+  vox_gather_body(blockIdx.x, points, F, slots, voxel_num, max_points, voxels, num_points, max_voxels);
+}
+
+#define UBV_VOX_WS(type, off) ((type*)(ws + (long)blockIdx.y * vb.ws_stride + vb.off))
+__global__ __launch_bounds__(256) void vox_key_insert_batch_kernel(VoxBatch vb, char* ws, int F, VoxGeom g) {
+  vox_key_insert_body(blockIdx.x, vb.points[blockIdx.y], vb.n[blockIdx.y], F, g, UBV_VOX_WS(uint32_t, key_off),
+                      UBV_VOX_WS(unsigned long long, table_off), vb.mask);
+}
+__global__ __launch_bounds__(256) void vox_head_batch_kernel(VoxBatch vb, char* ws) {
+  vox_head_body(blockIdx.x, UBV_VOX_WS(uint32_t, key_off), vb.n[blockIdx.y], UBV_VOX_WS(unsigned long long, table_off),
+                vb.mask, UBV_VOX_WS(int, first_off), UBV_VOX_WS(int, head_off));
+}
+__global__ __launch_bounds__(256) void scan_block_batch_kernel(VoxBatch vb, char* ws) {
+  scan_block_body(blockIdx.x, UBV_VOX_WS(int, head_off), UBV_VOX_WS(int, scan_off), UBV_VOX_WS(int, sums_off),
+                  vb.n[blockIdx.y]);
+}
+__global__ void scan_sums_batch_kernel(VoxBatch vb, char* ws, int* __restrict__ voxel_num, int clamp) {
+  const int n = vb.n[blockIdx.y];
+  scan_sums_body(UBV_VOX_WS(int, sums_off), (n + kScanBlock - 1) / kScanBlock, voxel_num + blockIdx.y, clamp);
+}
+__global__ __launch_bounds__(256) void vox_assign_batch_kernel(VoxBatch vb, char* ws, VoxGeom g, int max_points,
+                                                               int max_voxels, int32_t* __restrict__ coors) {
+  vox_assign_body(blockIdx.x, UBV_VOX_WS(uint32_t, key_off), UBV_VOX_WS(int, first_off), UBV_VOX_WS(int, scan_off),
+                  UBV_VOX_WS(int, sums_off), vb.n[blockIdx.y], g, max_points, max_voxels, UBV_VOX_WS(int, slots_off),
+                  coors + (long)blockIdx.y * max_voxels * 3);
+}
+__global__ __launch_bounds__(256) void vox_gather_batch_kernel(VoxBatch vb, char* ws, int F, const int* __restrict__ voxel_num,
+                                                               int max_points, float* __restrict__ voxels,
+                                                               int32_t* __restrict__ num_points, int max_voxels) {
+  vox_gather_body(blockIdx.x, vb.points[blockIdx.y], F, UBV_VOX_WS(int, slots_off), voxel_num + blockIdx.y, max_points,
+                  voxels + (long)blockIdx.y * max_voxels * max_points * F, num_points + (long)blockIdx.y * max_voxels,
+                  max_voxels);
+}
+#undef UBV_VOX_WS
 
 __global__ __launch_bounds__(256) void dynamic_voxelize_kernel(const float* __restrict__ points,
                                                                int N, int F, VoxGeom g,
@@ -215,7 +289,8 @@ __global__ __launch_bounds__(256) void voxel_mean_kernel(const float* __restrict
   if (voxel_num != nullptr && v >= *voxel_num) return;
   float s = 0.0f;
   for (int k = 0; k < T; ++k) s += voxels[((long)v * T + k) * F + f];
-  mean[t] = s / (float)num_points[v];
+  const int np_ = num_points[v];
+  mean[t] = np_ > 0 ? s / (float)np_ : 0.0f;      // (rows past the voxel count of a padded batch hold no points)
 }
 
 __global__ __launch_bounds__(256) void sparse_to_dense_kernel(
@@ -324,6 +399,66 @@ extern "C" int ubv_hard_voxelize(const float* points, float* voxels, int32_t* co
   hipLaunchKernelGGL(vox_gather_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, points,
                      F, slots, voxel_num, max_points, voxels, num_points, max_voxels);
   UBV_CHECK_LAUNCH("hard_voxelize");
+  return UBV_OK;
+}
+
+
+extern "C" int64_t ubv_hard_voxelize_batch_workspace(int B, int n_max, int max_points, int max_voxels) {
+  if (B <= 0 || B > ubv::kVoxMaxBatch || n_max < 0 || max_points <= 0 || max_voxels <= 0) return -1;
+  return (int64_t)B * (int64_t)ubv::vox_layout(n_max, max_points, max_voxels).total;
+}
+
+extern "C" int ubv_hard_voxelize_batch(const float* const* points_host, const int* n_host, int B, float* voxels,
+                                       int32_t* coors, int32_t* num_points, int32_t* voxel_num, void* workspace,
+                                       int64_t workspace_bytes, int F, const float* voxel_size_host,
+                                       const float* range_host, int max_points, int max_voxels, void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(points_host && n_host && voxels && coors && num_points && voxel_num && workspace && voxel_size_host &&
+                    range_host, "hard_voxelize_batch: null pointer");
+  UBV_CHECK_ARG(B > 0 && B <= kVoxMaxBatch, "hard_voxelize_batch: 1 .. %d clouds per call (got %d)", kVoxMaxBatch, B);
+  UBV_CHECK_ARG(F >= 3 && max_points > 0 && max_voxels > 0, "hard_voxelize_batch: bad dimension (F=%d T=%d M=%d)", F,
+                max_points, max_voxels);
+  VoxGeom g;
+  UBV_CHECK_ARG(make_geom(voxel_size_host, range_host, g), "hard_voxelize_batch: bad voxel grid");
+  int n_max = 0;
+  VoxBatch vb{};
+  for (int b = 0; b < B; ++b) {
+    UBV_CHECK_ARG(n_host[b] >= 0 && (n_host[b] == 0 || points_host[b] != nullptr), "hard_voxelize_batch: cloud %d", b);
+    vb.points[b] = points_host[b];
+    vb.n[b] = n_host[b];
+    n_max = n_host[b] > n_max ? n_host[b] : n_max;
+  }
+  const VoxWs w = vox_layout(n_max, max_points, max_voxels);
+  UBV_CHECK_ARG(workspace_bytes >= (int64_t)B * (int64_t)w.total, "hard_voxelize_batch: workspace %lld < %lld bytes",
+                (long long)workspace_bytes, (long long)B * (long long)w.total);
+  vb.ws_stride = (long)w.total;
+  vb.key_off = (long)w.keys; vb.first_off = (long)w.first; vb.head_off = (long)w.head; vb.scan_off = (long)w.scan;
+  vb.sums_off = (long)w.sums; vb.table_off = (long)w.table; vb.slots_off = (long)w.slots;
+  const uint32_t cap = table_capacity(n_max);
+  vb.mask = cap - 1;
+  hipStream_t st = as_stream(stream);
+  char* ws = (char*)workspace;
+  // tables (0xFF) and slot chains (0x7f7f7f7f) of every sample: their regions sit at fixed offsets of each stride
+  for (int b = 0; b < B; ++b) {
+    if (hipMemsetAsync(ws + (size_t)b * w.total + w.table, 0xFF, (size_t)cap * 8, st) != hipSuccess ||
+        hipMemsetAsync(ws + (size_t)b * w.total + w.slots, 0x7f, (size_t)max_voxels * max_points * 4, st) != hipSuccess) {
+      set_error("hard_voxelize_batch: memset failed");
+      return UBV_ERR_LAUNCH;
+    }
+  }
+  const int nb = (n_max + 255) / 256, sb = (n_max + kScanBlock - 1) / kScanBlock;
+  if (n_max > 0) {
+    hipLaunchKernelGGL(vox_key_insert_batch_kernel, dim3(nb, B), dim3(256), 0, st, vb, ws, F, g);
+    hipLaunchKernelGGL(vox_head_batch_kernel, dim3(nb, B), dim3(256), 0, st, vb, ws);
+    hipLaunchKernelGGL(scan_block_batch_kernel, dim3(sb, B), dim3(256), 0, st, vb, ws);
+  }
+  hipLaunchKernelGGL(scan_sums_batch_kernel, dim3(1, B), dim3(64), 0, st, vb, ws, voxel_num, max_voxels);
+  if (n_max > 0)
+    hipLaunchKernelGGL(vox_assign_batch_kernel, dim3(nb, B), dim3(256), 0, st, vb, ws, g, max_points, max_voxels, coors);
+  const long nt = (long)max_voxels * max_points * F;
+  hipLaunchKernelGGL(vox_gather_batch_kernel, dim3((unsigned)((nt + 255) / 256), B), dim3(256), 0, st, vb, ws, F, voxel_num,
+                     max_points, voxels, num_points, max_voxels);
+  UBV_CHECK_LAUNCH("hard_voxelize_batch");
   return UBV_OK;
 }
 

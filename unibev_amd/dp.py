@@ -121,6 +121,7 @@ class FlatGradients:
         self.params = [p for p in params]
         dev = self.params[0].device
         self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dtype, device=dev)
+        self.missing = []
         self.views, o = [], 0
         for p in self.params:
             self.views.append(self.flat[o:o + p.numel()].view_as(p))
@@ -128,6 +129,10 @@ class FlatGradients:
 
     def collect(self):
         """Copy every parameter's current ``.grad`` into its view (one multi-tensor copy)."""
+        # parameters without a gradient in this pass are zero-filled here; ``missing`` names them so that an
+        # optimizer with torch semantics (AdamW SKIPS a parameter whose grad is None: no decay, no moment update) can
+        # refuse instead of silently decaying them (optim.FlatAdamW.step)
+        self.missing = [i for i, p in enumerate(self.params) if p.grad is None]
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
         torch._foreach_copy_(self.views, grads)
 

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 from ..registry import BACKBONES, DETECTORS, HEADS, MIDDLE_ENCODERS, NECKS, VOXEL_ENCODERS
 from .grid_mask import GridMask
-from .voxel import Voxelization
+from .voxel import Voxelization, voxelize_cat
 
 
 def _build(cfg, registry):
@@ -143,13 +143,9 @@ class UniBEV(nn.Module):
 
     @staticmethod
     def _voxelize(layer, points):
-        voxels, coors, num_points = [], [], []
-        for i, res in enumerate(points):
-            v, c, n = layer(res)
-            voxels.append(v)
-            coors.append(F.pad(c, (1, 0), mode='constant', value=i))
-            num_points.append(n)
-        return torch.cat(voxels, dim=0), torch.cat(num_points, dim=0), torch.cat(coors, dim=0)
+        # the reference loops over the samples (one Voxelization call and one host read each); here the batch is one
+        # launch chain and one read of the B voxel counts (modules/voxel.py::voxelize_cat), same result bit for bit
+        return voxelize_cat(layer, points)
 
     @torch.no_grad()
     def voxelize(self, points):

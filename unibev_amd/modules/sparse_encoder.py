@@ -194,11 +194,24 @@ class SparseSequential(nn.Sequential):
     """spconv.SparseSequential: sparse layers take the tensor object, dense ones its feature matrix."""
 
     def forward(self, x):
-        for m in self:
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
             if isinstance(m, (_SparseConvBase, SparseBasicBlock, SparseSequential)):
                 x = m(x)
+            elif isinstance(m, nn.BatchNorm1d):
+                # BatchNorm1d (+ the ReLU behind it) over the active rows as one fused pass each way
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                y = UF.rows_batch_norm(x.features, m, relu=relu)
+                if y is None:
+                    x = x.replace(m(x.features))
+                else:
+                    x = x.replace(y)
+                    i += 1 if relu else 0
             else:
                 x = x.replace(m(x.features))
+            i += 1
         return x
 
 
@@ -246,9 +259,12 @@ class SparseBasicBlock(nn.Module):
     def forward(self, x):
         identity = x.features
         out = self.conv1(x)
-        out = out.replace(self.relu(self.bn1(out.features)))
+        y = UF.rows_batch_norm(out.features, self.bn1, relu=True)
+        out = out.replace(y if y is not None else self.relu(self.bn1(out.features)))
         out = self.conv2(out)
-        f = self.bn2(out.features)
+        f = UF.rows_batch_norm(out.features, self.bn2, relu=False)
+        if f is None:
+            f = self.bn2(out.features)
         if self.downsample is not None:
             identity = self.downsample(x).features
         return out.replace(self.relu(f + identity.to(f.dtype)))

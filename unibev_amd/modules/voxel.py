@@ -82,7 +82,15 @@ class _DynamicScatterFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, coors, reduce_type):
         vf, vc, mp, cnt, vnum = UF.dynamic_scatter(feats, coors, reduce_type)
-        m = int(vnum[0].item())          # the published op returns exact shapes: one read of M
+        # the kernel packs each coordinate into 63 // D (at most 21) bits of a sort key: a larger coordinate cannot be
+        # told from an invalid (negative) one there, so it is rejected HERE instead of being dropped silently — in the
+        # same host read that fetches M (the published op returns exact shapes)
+        bits = min(21, 63 // max(int(coors.shape[1]), 1))
+        too_big = (coors >= (1 << bits)).any().to(vnum.dtype).view(1) if coors.numel() else vnum.new_zeros(1)
+        m, _, bad = torch.cat((vnum, too_big)).tolist()
+        if bad:
+            raise ValueError(f'dynamic_scatter: voxel coordinates must be below 2^{bits} = {1 << bits} '
+                             f'(got max {int(coors.max())})')
         vf, vc, cnt = vf[:m], vc[:m], cnt[:m]
         ctx.reduce_type = reduce_type
         ctx.save_for_backward(feats, vf, mp, cnt)
@@ -152,20 +160,33 @@ class DynamicScatter(nn.Module):
 def voxelize_batch_padded(voxel_layer, points):
     """Sync-free ``UniBEV.voxelize``: per-sample full-capacity buffers and device-side voxel counts;
     nothing is sliced, so no voxel count is read back.  Returns lists of (voxels, coors, num, vnum)
-    per sample (``HardSimpleVFE.forward_padded`` / ``sparse_to_dense`` take the device counts)."""
-    return [voxel_layer.forward_padded(res) for res in points]
+    per sample (``HardSimpleVFE.forward_padded`` / ``sparse_to_dense`` take the device counts).  The whole batch is
+    ONE launch chain (``ubv_hard_voxelize_batch``)."""
+    v, c, n, m = UF.hard_voxelize_batch(list(points), voxel_layer.voxel_size, voxel_layer.point_cloud_range,
+                                        voxel_layer.max_num_points, voxel_layer._limit())
+    return [(v[b], c[b], n[b], m[b:b + 1]) for b in range(len(points))]
 
 
 def voxelize_batch(voxel_layer, points):
     """``UniBEV.voxelize`` (unibev_detector.py:151-175): per-sample voxelization, concatenation and
     the batch index prepended to coors -> (voxels, num_points, coors_batch (sum M, 4))."""
-    voxels, coors, num_points = [], [], []
-    for i, res in enumerate(points):
-        v, c, n = voxel_layer(res)
-        voxels.append(v)
-        coors.append(F.pad(c, (1, 0), mode='constant', value=i))
-        num_points.append(n)
-    return torch.cat(voxels, 0), torch.cat(num_points, 0), torch.cat(coors, 0)
+    return voxelize_cat(voxel_layer, points)
+
+
+def voxelize_cat(voxel_layer, points):
+    """Hard voxelization of a list of clouds in one launch chain, then the reference's concatenated form (one read of
+    the B voxel counts instead of one per sample).  Dynamic voxelization keeps the per-sample calls."""
+    if voxel_layer.max_num_points == -1 or voxel_layer._limit() == -1 or len(points) == 0:
+        out = [voxel_layer(res) for res in points]
+        coors = [F.pad(c, (1, 0), mode='constant', value=i) for i, (_, c, _) in enumerate(out)]
+        return torch.cat([o[0] for o in out], 0), torch.cat([o[2] for o in out], 0), torch.cat(coors, 0)
+    v, c, n, m = UF.hard_voxelize_batch(list(points), voxel_layer.voxel_size, voxel_layer.point_cloud_range,
+                                        voxel_layer.max_num_points, voxel_layer._limit())
+    counts = m.tolist()
+    voxels = torch.cat([v[b, :k] for b, k in enumerate(counts)], 0)
+    num_points = torch.cat([n[b, :k] for b, k in enumerate(counts)], 0)
+    coors = torch.cat([F.pad(c[b, :k], (1, 0), mode='constant', value=b) for b, k in enumerate(counts)], 0)
+    return voxels, num_points, coors
 
 
 def sparse_to_dense(features, coors, batch_size, spatial_shape):

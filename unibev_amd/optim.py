@@ -6,8 +6,14 @@ followed by ``torch.optim.AdamW`` (projects/UniBEV/configs/unibev/unibev_nus_LC_
 multi-tensor launches over ~200 tensors (0.4 ms per step at the encoder's 13.9 M parameters).
 
 The parameters are re-pointed at views of the flat buffer (``p.data``); the gradients come from a
-``dp.FlatGradients`` (the buffer the gradient all-reduce already uses).  One parameter group (one lr / weight
-decay): what the encoder-side parameters of the shipped configs share.
+``dp.FlatGradients`` (the buffer the gradient all-reduce already uses).
+
+Restrictions, enforced loudly: ONE parameter group (one lr / weight decay — what the encoder-side parameters of the
+shipped configs share; the configs' ``paramwise_cfg`` lr_mult = 0.1 applies to ``img_backbone`` only, which is outside
+this optimizer's parameter list), and EVERY parameter must receive a gradient in every step: ``torch.optim.AdamW`` skips
+a parameter whose grad is None (no decay, no moment update), a flat pass cannot, so ``step`` raises when the gradient
+collection reports parameters without a gradient (freeze them with ``requires_grad_(False)`` and leave them out, or
+use the torch optimizer: ``bench.py --torch-optimizer``).
 """
 import torch
 
@@ -44,6 +50,11 @@ class FlatAdamW:
     def step(self):
         """One update from ``grads.flat`` (the parameters' ``.grad`` views).  Nothing is read back."""
         g = self.grads.flat
+        if self.grads.missing:
+            names = ', '.join(str(tuple(self.params[i].shape)) for i in self.grads.missing[:4])
+            raise RuntimeError(f'FlatAdamW: {len(self.grads.missing)} parameter(s) received no gradient in this step '
+                               f'(shapes {names} ...): torch.optim.AdamW would skip them, the flat pass would decay '
+                               f'them.  Exclude them (requires_grad_(False)) or use the torch optimizer.')
         with UF._need_cuda(self.flat, g):
             st = UF._stream()
             sq = None
