@@ -201,3 +201,24 @@ def test_second_pass_takes_the_presplit_weights_and_follows_weight_updates():
     assert torch.allclose(outs[1], 2 * outs[0] - lin.bias.detach(), rtol=1e-4, atol=1e-4)
     ref = torch.nn.functional.linear(x, lin.weight / 2, lin.bias)
     assert float((outs[2] - ref).detach().abs().max()) < 1e-3 * float(ref.detach().abs().max())
+
+
+def test_fused_ffn_activation_refuses_a_second_consumer():
+    """``linear_relu_dropout`` -> ``linear_after_relu_dropout`` folds the activation's derivative into the second
+    Linear's input gradient.  If the activation also feeds something else, autograd sums a folded and a raw gradient:
+    the backward must fail loudly instead of applying the derivative to the sum."""
+    from unibev_amd.linear import linear_after_relu_dropout, linear_relu_dropout
+    torch.manual_seed(0)
+    x = torch.randn(300, 64, device=DEV, requires_grad=True)
+    w1 = torch.randn(128, 64, device=DEV, requires_grad=True)
+    w2 = torch.randn(64, 128, device=DEV, requires_grad=True)
+    a = linear_relu_dropout(x, w1, None, 0.1, True)
+    y = linear_after_relu_dropout(a, w2, None, 0.1, True)
+    (y.sum() + a.sum()).backward.__self__       # (build the graph with two consumers of `a`)
+    with pytest.raises(RuntimeError, match='besides'):
+        (y.sum() + a.sum()).backward()
+    # the sanctioned use works, and so does the activation without a folding consumer
+    a = linear_relu_dropout(x, w1, None, 0.0, True)
+    linear_after_relu_dropout(a, w2, None, 0.0, True).sum().backward()
+    a = linear_relu_dropout(x.detach().requires_grad_(), w1, None, 0.0, True)
+    a.sum().backward()

@@ -285,6 +285,13 @@ class _Linear(Function):
         if act is not None and act[0] == 'relu_drop' and UF.grad_tag_stale(grad_out, '_ubv_masked'):
             raise RuntimeError('linear_relu_dropout: the activation fed something besides '
                                'linear_after_relu_dropout (its gradient arrived partly pre-multiplied)')
+        if act is not None and act[0] == 'relu_drop' and getattr(ctx, 'ubv_folded', False) and \
+                not UF.grad_tag(grad_out, '_ubv_masked'):
+            # a linear_after_relu_dropout consumed this activation (it folds the derivative into its input gradient and
+            # tags the result) yet the gradient arriving here is untagged: autograd summed it with another consumer's
+            # gradient into a fresh tensor.  Applying the derivative to the sum would scale the folded part twice.
+            raise RuntimeError('linear_relu_dropout: the activation was also used by something besides '
+                               'linear_after_relu_dropout; its gradient arrived as a sum of pre-multiplied and raw parts')
         if act is not None and act[0] == 'relu_drop' and not UF.grad_tag(grad_out, '_ubv_masked'):
             # the consumer did not fold the activation's derivative into its input gradient
             a_out = ctx.saved_tensors[2 + ctx.n_wt]
@@ -426,7 +433,14 @@ def linear_relu_dropout(x, weight, bias=None, p=0.0, training=False, passthru=Fa
 
 
 def linear_after_relu_dropout(a, weight, bias=None, p=0.0, training=False):
-    """``F.linear(a, weight, bias)`` for ``a = linear_relu_dropout(...)`` (the second half of an FFN)."""
+    """``F.linear(a, weight, bias)`` for ``a = linear_relu_dropout(...)`` (the second half of an FFN).  Marks the
+    producer's autograd node: its backward then insists on receiving exactly this Linear's (tagged) input gradient."""
+    fn = getattr(a, 'grad_fn', None)
+    if fn is not None:
+        try:
+            fn.ubv_folded = True
+        except AttributeError:
+            pass
     return _run(a, [weight], [bias], act=('masked_in', float(p) if training else 0.0))
 
 
