@@ -372,6 +372,56 @@ def test_lift_camera_matrix_core_plan(case, dtype, ftol, tiled):
     assert bad.sum() <= 1e-5 * bad.size + 1, int(bad.sum())       # pixel-boundary discontinuities
 
 
+@pytest.mark.parametrize('case', [
+    # B, Nc, fh, fw, H, Dh, qh, qw, P, Z
+    (2, 6, 8, 22, 8, 32, 30, 33, 8, 4),      # the BASELINE camera maps (176 pixels, 14 K-blocks)
+    (1, 3, 4, 6, 8, 32, 7, 9, 8, 4),         # 24 pixels
+    (2, 2, 12, 16, 8, 32, 17, 20, 8, 2),     # 192 pixels: 15 K-blocks, 8 row blocks, every backward pass
+    (1, 1, 6, 9, 4, 32, 11, 13, 8, 8),       # one camera, 4 heads, Z = 8
+])
+@pytest.mark.parametrize('tiled', [True, False])
+def test_lift_camera_matrix_core_plan_fp32(case, tiled):
+    """f32 data on the matrix-core CAMERA plan (bev_lift_cam32.inl): both MFMA operands split into bf16 hi + lo
+    halves, three products per K-block (the two backward kernels by default, the forward one too under
+    UBV_CAM_MFMA32=2).  Held to the f32 bars of test_lift_fp32_forward_backward against the fp64
+    oracle — the split must not be visible."""
+    from unibev_amd.functional import bev_lift
+    B, Nc, fh, fw, H, Dh, qh, qw, P, Z = case
+    value, offlog, ref, vis0, count, gout = make_case(case, 23, Nc > 1)
+    v64, ol64 = t(value).requires_grad_(), t(offlog).requires_grad_()
+    o_ref = oracle_lift(v64, ol64, t(ref), None if vis0 is None else t(vis0),
+                        None if count is None else t(count).double(), Nc, fh, fw, H, P)
+    o_ref.backward(t(gout))
+    v = t(value, torch.float32, DEV).requires_grad_()
+    ol = t(offlog, torch.float32, DEV).requires_grad_()
+    out = bev_lift(v, ol, t(ref, torch.float32, DEV), Nc, (fh, fw), H, P,
+                   vis0=None if vis0 is None else t(vis0, device=DEV),
+                   count=None if count is None else t(count, device=DEV),
+                   query_grid=(qh, qw) if tiled else None)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), o_ref.detach().numpy(), rtol=3e-5, atol=3e-5)
+    out.backward(t(gout, torch.float32, DEV))
+    np.testing.assert_allclose(v.grad.cpu().numpy(), v64.grad.numpy(), rtol=2e-4, atol=2e-4)
+    bad = ~np.isclose(ol.grad.cpu().numpy(), ol64.grad.numpy(), rtol=2e-4, atol=5e-4)
+    assert bad.sum() <= 1e-5 * bad.size + 1, int(bad.sum())       # pixel-boundary discontinuities
+
+
+def test_lift_camera_matrix_core_plan_fp32_forward_kernel():
+    """The f32 matrix-core FORWARD kernel is off by default (slower than the gather kernel); it stays in the library
+    behind UBV_CAM_MFMA32=2, read once per process — so the parity cases above are re-run in a child process."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get('UBV_CAM_MFMA32') == '2':
+        pytest.skip('already the child run')
+    env = dict(os.environ, UBV_CAM_MFMA32='2')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_lift_gpu.py'), '-q', '-x',
+                        '-k', 'test_lift_camera_matrix_core_plan_fp32 and not forward_kernel'],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert '8 passed' in r.stdout, r.stdout[-500:]
+
+
 @pytest.mark.parametrize('plan', ['grid', 'camera'])
 def test_lift_backward_repeatable_and_independent_of_kernel_concurrency(plan):
     """Round 1 saw lift_bwd_query_kernel return a handful of different values in 1-2 % of launches when

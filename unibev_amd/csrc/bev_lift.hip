@@ -44,6 +44,7 @@ struct LiftArgs {
   int* cam_list; int* cam_n;                     // per-camera compacted visible queries or null
   int ext_list;                                  // lists supplied by the caller (ubv_compact_visible)
   float* slab;                                   // CAMERA: per-chunk partial maps or null
+  const void* vnat_hi; const void* vnat_lo;      // f32 matrix-core CAMERA plan: bf16 hi / lo copies of value (its layout)
   // MAPS backward (large per-camera maps): exact CSR buckets + work items (bev_lift_maps.inl)
   int* bin_cur;                                  // fill cursors per bucket
   int* bin_start;                                // [buckets + 1] first record of each bucket
@@ -1196,6 +1197,7 @@ __global__ __launch_bounds__(256) void narrow_kernel(const float* __restrict__ s
 }
 
 #include "bev_lift_cam.inl"
+#include "bev_lift_cam32.inl"
 #include "bev_lift_shared.inl"
 #include "bev_lift_win.inl"
 
@@ -1218,19 +1220,31 @@ static LiftBytes lift_bytes(const LiftArgs& a, int Dh, int P, int esize) {
   return b;
 }
 
-// CAMERA plan on the matrix cores (bev_lift_cam.inl): 16-bit data, Dh = 32, P = 8, maps of <= 192 pixels
-static bool cam_mfma_ok(const LiftArgs& a, int Dh, int P, int dtype) {
+// CAMERA plan on the matrix cores (bev_lift_cam.inl; f32 data with split operands: bev_lift_cam32.inl): Dh = 32,
+// P = 8, maps of <= 192 pixels.  UBV_CAM_MFMA=0 switches it off.  f32 data (UBV_CAM_MFMA32, default 1): the two
+// backward kernels take the plan — measured at 6 x 8x22, bs = 2: query gradient 167 -> 144 us, value gradient
+// 279 -> 172 us — the forward kernel does not (190 us against the shared-footprint gather kernel's 148: hi + lo
+// fragments are 30 KB per (wave, camera) and its 31 KB coefficient matrix leaves one wave per SIMD);
+// UBV_CAM_MFMA32=2 runs it anyway, 0 switches the f32 plan off.
+static bool cam_mfma_ok(const LiftArgs& a, int Dh, int P, int dtype, bool fwd = false) {
   static const int env = getenv("UBV_CAM_MFMA") ? atoi(getenv("UBV_CAM_MFMA")) : 1;
-  return env != 0 && dtype != UBV_F32 && Dh == 32 && P == 8 && a.fh >= 1 && a.fw >= 1 && a.fh <= 13 &&
-         cam_kpad(a.fh, a.fw) <= 16 * kCamKbMax;
+  static const int env32 = getenv("UBV_CAM_MFMA32") ? atoi(getenv("UBV_CAM_MFMA32")) : 1;
+  return env != 0 && (dtype != UBV_F32 || env32 >= (fwd ? 2 : 1)) && Dh == 32 && P == 8 && a.fh >= 1 && a.fw >= 1 &&
+         a.fh <= 13 && cam_kpad(a.fh, a.fw) <= 16 * kCamKbMax;
 }
-static size_t cam_vfrag_bytes(const LiftArgs& a) {
+// fragment-ordered copy of value: one buffer of 16-bit fragments, two (hi, lo) for f32 data
+static size_t cam_vfrag_bytes(const LiftArgs& a, int dtype = UBV_BF16) {
   const size_t KB = cam_kpad(a.fh, a.fw) <= 14 * 16 ? 14 : 15;
-  return (size_t)a.B * a.Nc * a.H * KB * 64 * 16;
+  return (size_t)a.B * a.Nc * a.H * KB * 64 * 16 * (dtype == UBV_F32 ? 2 : 1);
 }
-static CamArgs cam_args(const LiftArgs& a, const void* vfrag) {
+// f32 backward: bf16 hi + lo copies of value in its own layout
+static size_t cam_vnat_bytes(const LiftArgs& a, int Dh) {
+  return (((size_t)a.B * a.Nc * a.fh * a.fw * a.H * Dh * 2) + 255) & ~(size_t)255;
+}
+static CamArgs cam_args(const LiftArgs& a, const void* vfrag, int dtype = UBV_BF16) {
   CamArgs c{};
   c.vfrag = vfrag;
+  if (vfrag != nullptr && dtype == UBV_F32) c.vfrag_lo = (const char*)vfrag + cam_vfrag_bytes(a);
   c.KB = cam_kpad(a.fh, a.fw) <= 14 * 16 ? 14 : 15;       // 14 covers the 8x22 maps
   c.witems = a.total_tiles * 2 * a.H;                      // a wave is half a tile for one head
   c.chunk = (c.witems + 7) / 8;
@@ -1312,6 +1326,20 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
           if (a.ol16) hipLaunchKernelGGL((lift_cam_fwd_kernel<T, 8, true, 15>), grid, blk, lds, st, a, c);
           else hipLaunchKernelGGL((lift_cam_fwd_kernel<T, 8, false, 15>), grid, blk, lds, st, a, c);
         }
+        return;
+      }
+    }
+    if constexpr (DH == 32 && P == 8 && sizeof(T) == 4) {
+      if (cam_mfma) {                            // f32 data: split operands (bev_lift_cam32.inl)
+        const CamArgs c = cam_args(a, fwd_ws, UBV_F32);
+        const long nthreads = (long)a.B * a.Nc * a.H * c.KB * 64;
+        hipLaunchKernelGGL(value_frags32_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st,
+                           (const float*)a.value, (uint16_t*)c.vfrag, (uint16_t*)c.vfrag_lo, a.B * a.Nc, a.fh * a.fw,
+                           a.H, a.fh, a.fw, c.KB);
+        const size_t lds = (size_t)32 * (c.KB * 16 + 4) * sizeof(uint32_t);
+        const dim3 grid(8 * c.chunk), blk(64);
+        if (c.KB == 14) hipLaunchKernelGGL((lift_cam32_fwd_kernel<8, 14>), grid, blk, lds, st, a, c);
+        else hipLaunchKernelGGL((lift_cam32_fwd_kernel<8, 15>), grid, blk, lds, st, a, c);
         return;
       }
     }
@@ -1504,6 +1532,18 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
           done = true;
         }
       }
+      if constexpr (DH == 32 && P == 8 && sizeof(T) == 4) {
+        if (cam_mfma && t.tiles_y == 1) {          // f32 data: 32 queries per batch, packed hi | lo coefficients
+          const CamArgs c = cam_args(a, nullptr);
+          const int mbt = (c.KB + 1) / 2;
+          const size_t l2 = (size_t)t.waves * (mbt * 32 * kCam32VStride + 32 * 32) * sizeof(uint32_t);
+          if (mbt == 7)
+            hipLaunchKernelGGL((lift_cam32_bwd_value_kernel<8, 7>), dim3(8 * t.chunk), dim3(64 * t.waves), l2, st, a, t, c);
+          else
+            hipLaunchKernelGGL((lift_cam32_bwd_value_kernel<8, 8>), dim3(8 * t.chunk), dim3(64 * t.waves), l2, st, a, t, c);
+          done = true;
+        }
+      }
       if (!done) {
         if (rb3)
           hipLaunchKernelGGL((lift_bwd_value_camera_kernel<T, DH, P, 3>), dim3(8 * t.chunk),
@@ -1527,6 +1567,17 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
           hipLaunchKernelGGL((lift_cam_bwd_query_kernel<T, 8, true>), dim3(8 * c.chunk), dim3(64), lds, st, a, c);
         else
           hipLaunchKernelGGL((lift_cam_bwd_query_kernel<T, 8, false>), dim3(8 * c.chunk), dim3(64), lds, st, a, c);
+        return;
+      }
+    }
+    if constexpr (DH == 32 && P == 8 && sizeof(T) == 4) {
+      if (cam_mfma && a.vnat_hi != nullptr) {
+        const CamArgs c = cam_args(a, nullptr);
+        const long n8 = (long)a.B * a.Nc * a.fh * a.fw * a.H * DH / 8;
+        hipLaunchKernelGGL(value_split32_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st,
+                           (const float*)a.value, (uint16_t*)a.vnat_hi, (uint16_t*)a.vnat_lo, n8);
+        const size_t lds = (size_t)32 * kCamDStr * sizeof(float);
+        hipLaunchKernelGGL((lift_cam32_bwd_query_kernel<8>), dim3(8 * c.chunk), dim3(64), lds, st, a, c);
         return;
       }
     }
@@ -1613,7 +1664,8 @@ static int plan_backward(const LiftArgs& a, int Dh, int P, int dtype, int ref_is
     // is cut into two bands of 3 row blocks when it fits — half the LDS per wave, four waves per CU; each band
     // re-walks the visible list (UBV_CAM_F32_BANDS=1 keeps one band)
     static const int f32_bands = getenv("UBV_CAM_F32_BANDS") ? atoi(getenv("UBV_CAM_F32_BANDS")) : 2;
-    if (dtype == UBV_F32 && bands == 1 && f32_bands == 2) {        // (four quarter bands: 756 us)
+    const bool cam32 = dtype == UBV_F32 && bands == 1 && cam_mfma_ok(a, Dh, P, dtype);   // whole padded map per wave (bev_lift_cam32.inl)
+    if (dtype == UBV_F32 && bands == 1 && f32_bands == 2 && !cam32) {        // (four quarter bands: 756 us)
       const int half = (a.fh + 1) / 2;
       if (half * a.fw <= 96) { t.tile_h = half; t.tiles_y = 2; }
     }
@@ -1623,7 +1675,7 @@ static int plan_backward(const LiftArgs& a, int Dh, int P, int dtype, int ref_is
     static const int split_env = getenv("UBV_CAM_SPLIT") ? atoi(getenv("UBV_CAM_SPLIT")) : 0;
     // (one block per CU: its LDS holds 4 waves' operand tiles, or 2 with f32 data's hi + lo tiles;
     // one block too many would cost a whole second round, so round down)
-    t.waves = (dtype == UBV_F32 && t.tile_h * a.fw > 96) ? 2 : 4;
+    t.waves = (dtype == UBV_F32 && t.tile_h * a.fw > 96 && !cam32) ? 2 : 4;
     const int combos = a.B * a.Nc * t.tiles_y * a.H;
     int split = split_env > 0 ? split_env : (256 * t.waves) / combos;
     split = max(1, min(split, (a.Nq + 63) / 64));
@@ -1672,12 +1724,15 @@ static MapsWs maps_ws(const LiftArgs& a, const TileArgs& t, int Dh, int P) {
   w.total = w.slab_off + al((size_t)w.max_items * 64 * Dh * sizeof(float));
   return w;
 }
-static size_t lift_ws_bytes(int mode, const LiftArgs& a, const TileArgs& t, int Dh, int P) {
+static size_t cam_slab_bytes(const LiftArgs& a, const TileArgs& t, int Dh) {
+  return (((size_t)a.B * a.Nc * a.H * t.chunks * a.fh * a.fw * Dh * sizeof(float)) + 255) & ~(size_t)255;
+}
+static size_t lift_ws_bytes(int mode, const LiftArgs& a, const TileArgs& t, int Dh, int P, int dtype) {
   if (mode == kPlanGrid) return grid_ws(a, t, P).total;
   if (mode == kPlanMaps) return maps_ws(a, t, Dh, P).total;
-  if (mode == kAtomNone)     // visible-query lists + one partial map per (b, cam, head, chunk)
-    return lift_list_bytes(a) +
-           (size_t)a.B * a.Nc * a.H * t.chunks * a.fh * a.fw * Dh * sizeof(float);
+  if (mode == kAtomNone)     // visible-query lists + one partial map per (b, cam, head, chunk) (+ f32 matrix-core plan: hi / lo copies of value)
+    return lift_list_bytes(a) + cam_slab_bytes(a, t, Dh) +
+           ((dtype == UBV_F32 && cam_mfma_ok(a, Dh, P, dtype)) ? 2 * cam_vnat_bytes(a, Dh) : 0);
   return 0;
 }
 
@@ -1725,7 +1780,7 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_g
   int mode = -1;
   if (bwd) {
     mode = plan_backward(a, Dh, P, dtype, ref_is_grid, t);
-    const size_t need = lift_ws_bytes(mode, a, t, Dh, P);
+    const size_t need = lift_ws_bytes(mode, a, t, Dh, P, dtype);
     UBV_CHECK_ARG(need == 0 || (ws != nullptr && ws_bytes >= (int64_t)need),
                   "bev_lift_backward: workspace of %lld bytes needed, got %lld", (long long)need,
                   (long long)ws_bytes);
@@ -1766,6 +1821,10 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_g
         a.cam_n = (int*)ws + (size_t)a.Nc * a.Nq;
       }
       a.slab = (float*)((char*)ws + lift_list_bytes(a));
+      if (dtype == UBV_F32 && cam_mfma_ok(a, Dh, P, dtype)) {
+        a.vnat_hi = (char*)ws + lift_list_bytes(a) + cam_slab_bytes(a, t, Dh);
+        a.vnat_lo = (const char*)a.vnat_hi + cam_vnat_bytes(a, Dh);
+      }
     }
     if (mode == kAtomAll) {    // the owner-tile plans write every element of grad_value exactly once
       const size_t bytes = (size_t)a.B * a.Nc * a.fh * a.fw * a.H * Dh * sizeof(float);
@@ -1776,10 +1835,10 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_g
     }
   }
   // small per-camera maps: gather / dot products on the matrix cores (bev_lift_cam.inl)
-  bool cam_mfma = cam_mfma_ok(a, Dh, P, dtype) && (!bwd || mode == kAtomNone);
+  bool cam_mfma = cam_mfma_ok(a, Dh, P, dtype, !bwd) && (!bwd || mode == kAtomNone);
   void* fwd_ws = nullptr;
   if (cam_mfma && !bwd) {
-    if (ws != nullptr && ws_bytes >= (int64_t)cam_vfrag_bytes(a)) fwd_ws = ws;
+    if (ws != nullptr && ws_bytes >= (int64_t)cam_vfrag_bytes(a, dtype)) fwd_ws = ws;
     else cam_mfma = false;                       // no scratch given: the gather kernel needs none
   }
   bool ok = false;
@@ -1866,7 +1925,7 @@ extern "C" int64_t ubv_bev_lift_backward_workspace(int B, int Nc, int fh, int fw
   for (int dt : {UBV_BF16, UBV_F32}) {
     ubv::TileArgs t{};
     const int mode = ubv::plan_backward(a, Dh, P, dt, ref_is_grid, t);
-    const size_t b = ubv::lift_ws_bytes(mode, a, t, Dh, P);
+    const size_t b = ubv::lift_ws_bytes(mode, a, t, Dh, P, dt);
     need = b > need ? b : need;
   }
   return (int64_t)need;
@@ -1886,7 +1945,7 @@ extern "C" int64_t ubv_bev_lift_forward_workspace(int B, int Nc, int fh, int fw,
                                                   int dtype) {
   ubv::LiftArgs a{};
   a.B = B; a.Nc = Nc; a.fh = fh; a.fw = fw; a.H = H;
-  return ubv::cam_mfma_ok(a, Dh, P, dtype) ? (int64_t)ubv::cam_vfrag_bytes(a) : 0;
+  return ubv::cam_mfma_ok(a, Dh, P, dtype, true) ? (int64_t)ubv::cam_vfrag_bytes(a, dtype) : 0;
 }
 
 extern "C" int ubv_bev_lift_supported(int H, int Dh, int P, int dtype) {

@@ -28,7 +28,8 @@
 constexpr int kCamKbMax = 15;        // K-blocks of 16 padded pixels: (fw + 2) * (fh + 1) + 1 <= 240
 
 struct CamArgs {
-  const void* vfrag;    // [B*Nc][H][KB][64 lanes][8] value fragments
+  const void* vfrag;    // [B*Nc][H][KB][64 lanes][8] value fragments (f32 data: the bf16 hi halves)
+  const void* vfrag_lo; // f32 data: the bf16 lo halves, same layout
   int KB;               // K-blocks of the fragment buffer (14 or 15)
   int witems;           // (sample, tile, head) wave items
   int chunk;            // blocks per XCD
