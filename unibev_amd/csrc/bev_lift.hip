@@ -41,6 +41,8 @@ struct LiftArgs {
   float4* bins;                                  // [B,H,tiles,cap] (x_pix, y_pix, w/count, query index)
   int cap;                                       // bucket capacity
   int* ovf_n; float4* ovf_rec; int* ovf_tile; int ovf_cap;   // the appends that did not fit
+  int cnt_words;                                 // > 0: the query-gradient kernel (first of the op) zeroes bin_cnt[0 .. cnt_words)
+  int ovf_after;                                 // the overflow list is scattered AFTER the owner tiles stored (f32 grad_value)
   int* cam_list; int* cam_n;                     // per-camera compacted visible queries or null
   int ext_list;                                  // lists supplied by the caller (ubv_compact_visible)
   float* slab;                                   // CAMERA: per-chunk partial maps or null
@@ -70,6 +72,13 @@ template <typename T> __device__ __forceinline__ const T* gather_ptr(const T* ba
 // passes 0 otherwise): an integer division is ~40 instructions, this is one.
 __device__ __forceinline__ int div_mg(int n, int d, unsigned mg) {
   return mg != 0u ? (int)__umulhi((unsigned)n, mg) : n / d;
+}
+
+// GRID backward, first kernel of the op: zero the tile counters + the overflow counter the bin kernel (next launch on
+// the stream) appends through — a memset node less per op; every block takes a slice BEFORE any early exit.
+__device__ __forceinline__ void lift_zero_counters(const LiftArgs& a) {
+  if (a.cnt_words > 0)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.cnt_words; i += gridDim.x * blockDim.x) a.bin_cnt[i] = 0;
 }
 
 __device__ __forceinline__ bool lift_query(const LiftArgs& a, int item, int li, int& b, int& q) {
@@ -528,9 +537,11 @@ __global__ __launch_bounds__(256) void lift_bin_kernel(const LiftArgs a, int til
   }
 }
 
-// Overflow handling (rare: a tile received more than `cap` points).  Step A zeroes the f32 map of
-// the overflowed tiles, step B scatters the overflow list atomically into it; the owner kernel adds
-// its bucket sums on top for exactly those tiles.  Both exit at once when nothing overflowed.
+// Overflow handling (rare: a tile received more than `cap` points).  f32 grad_value (a.ovf_after): the owner tiles
+// store first, then lift_ovf_scatter_kernel adds the overflow list atomically on top — one launch that exits at once
+// when nothing overflowed.  16-bit grad_value (and the two-stream diagnostic mode) cannot add into the rounded output:
+// step A zeroes the f32 scratch map of the overflowed tiles, step B scatters into it BEFORE the owner kernel, which
+// adds its bucket sums on top for exactly those tiles and rounds once.
 __global__ __launch_bounds__(256) void lift_ovf_zero_kernel(const LiftArgs a, int tiles_x, int tiles,
                                                             int Dh) {
   if (*a.ovf_n == 0) return;                         // (a small grid walks the tiles: the common case is this exit)
@@ -953,7 +964,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 3)) void lift_bwd_value_
   if (ta.fill > 0) ta.flush(lane);
   // ---- store the tile: D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5);
   // tiles are 8 pixels wide, so the tile-local pixel index splits with a shift
-  const bool rmw = cnt_raw > a.cap;                    // lift_ovf_* scattered part of this tile
+  const bool rmw = cnt_raw > a.cap && !a.ovf_after;    // lift_ovf_* scattered part of this tile before this kernel
   // pixel (lx, ly) of accumulator element (rb, r): lx = (r & 3) + 4 (lane >> 5), ly = 4 rb + (r >> 2) — the lane
   // part (column, its half's 4-pixel shift) is one 32-bit offset, the (rb, r) part is wave-uniform: scalar
   // address arithmetic instead of a 64-bit multiply-add chain per element (it was a third of a self-attention
@@ -1395,9 +1406,9 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
                          a.gvalue, (T*)a.gvalue_lp, n);
     }
   } else if (bwd_mode == kPlanGrid) {
-    // bin the sampling points by owner tile (counters zeroed by the caller), scatter whatever
-    // overflowed a bucket (normally nothing: both kernels exit at once), then the query gradients
-    // and the owner tiles, each of which stores its finished pixels exactly once
+    // query gradients (the kernel also zeroes the tile counters), sampling points binned by owner tile, the owner
+    // tiles — each stores its finished pixels exactly once — and whatever overflowed a bucket added on top
+    // (normally nothing: that kernel exits at once).  4 launches; 16-bit grad_value keeps the older order, below.
     const int tiles = t.tiles_x * t.tiles_y;
     // Diagnostic only (UBV_LIFT_TWO_STREAM=1): the grad_value chain (bins -> overflow -> owner tiles)
     // on a side stream next to the query-gradient kernel, forked and joined with events inside this
@@ -1421,13 +1432,50 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
       (void)hipEventRecord(side_fork[dev], st);
       (void)hipStreamWaitEvent(s2, side_fork[dev], 0);
     }
+    // a.ovf_after: the query-gradient kernel runs FIRST and zeroes the counters (a.cnt_words) the bin kernel appends
+    // through — except the LDS-window kernel (SCA-pts, f32), which keeps a memset and bins -> query: with the zeroing
+    // loop in front of it that kernel measured 177 us instead of 157 (same registers, same occupancy, either launch
+    // order: the scheduler's placement of the window fill changed), the gather kernel does not care.  Without
+    // ovf_after the caller's memset zeroed the counters and the order is bins -> overflow -> query -> owner tiles.
+    const bool qfirst = a.ovf_after && !win_ok<T, DH, P>(a);
+    if (a.ovf_after && !qfirst) (void)hipMemsetAsync(a.bin_cnt, 0, (size_t)a.cnt_words * sizeof(int), st);
+    LiftArgs aq = a;
+    if (!qfirst) aq.cnt_words = 0;
+    auto run_query = [&]() {
+      {
+        ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes);
+        if (win_ok<T, DH, P>(a)) {
+          constexpr int HG = 128 / (DH * (int)sizeof(T));
+          const int chunk = (int)(((long)a.total_tiles * (a.H / HG) + 7) / 8);
+          const dim3 grid(8 * chunk);
+          if (sizeof(T) == 2 && a.ol16) {
+            if (wide) hipLaunchKernelGGL((lift_bwd_query_win_kernel<T, DH, VECS, P, sizeof(T) == 2, HG>), grid, dim3(256), kWinLds, st, aq, chunk);
+            else hipLaunchKernelGGL((lift_bwd_query_win_kernel<T, DH, VEC, P, sizeof(T) == 2, HG>), grid, dim3(256), kWinLds, st, aq, chunk);
+          } else {
+            if (wide) hipLaunchKernelGGL((lift_bwd_query_win_kernel<T, DH, VECS, P, false, HG>), grid, dim3(256), kWinLds, st, aq, chunk);
+            else hipLaunchKernelGGL((lift_bwd_query_win_kernel<T, DH, VEC, P, false, HG>), grid, dim3(256), kWinLds, st, aq, chunk);
+          }
+        } else
+        if (sizeof(T) == 2 && a.ol16)
+          {
+            if (wide) launch_bwd_query_shared<T, DH, VECS, P, sizeof(T) == 2>(aq, st);
+            else launch_bwd_query_shared<T, DH, VEC, P, sizeof(T) == 2>(aq, st);
+          }
+        else
+          {
+            if (wide) launch_bwd_query_shared<T, DH, VECS, P, false>(aq, st);
+            else launch_bwd_query_shared<T, DH, VEC, P, false>(aq, st);
+          }
+      }
+    };
+    if (qfirst) run_query();
     {
       const long waves = (long)a.total_tiles * a.H;
       ProfScope ps(name("bev_lift_bwd_bins"), s2, nb.offlog + nb.ref + nb.rec);
       hipLaunchKernelGGL((lift_bin_kernel<T, DH, P, 0>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
                          s2, a, t.tiles_x, tiles);
     }
-    {
+    if (!a.ovf_after) {
       const long tw = (long)a.B * a.H * tiles;
       const long zb = (tw + 3) / 4;
       hipLaunchKernelGGL(lift_ovf_zero_kernel, dim3((unsigned)(zb < 256 ? zb : 256)), dim3(256), 0, s2, a,
@@ -1435,31 +1483,7 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
       hipLaunchKernelGGL((lift_ovf_scatter_kernel<T, DH>), dim3(256), dim3(256), 0, s2, a, t.tiles_x,
                          tiles);
     }
-    {
-      ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes);
-      if (win_ok<T, DH, P>(a)) {
-        constexpr int HG = 128 / (DH * (int)sizeof(T));
-        const int chunk = (int)(((long)a.total_tiles * (a.H / HG) + 7) / 8);
-        const dim3 grid(8 * chunk);
-        if (sizeof(T) == 2 && a.ol16) {
-          if (wide) hipLaunchKernelGGL((lift_bwd_query_win_kernel<T, DH, VECS, P, sizeof(T) == 2, HG>), grid, dim3(256), kWinLds, st, a, chunk);
-          else hipLaunchKernelGGL((lift_bwd_query_win_kernel<T, DH, VEC, P, sizeof(T) == 2, HG>), grid, dim3(256), kWinLds, st, a, chunk);
-        } else {
-          if (wide) hipLaunchKernelGGL((lift_bwd_query_win_kernel<T, DH, VECS, P, false, HG>), grid, dim3(256), kWinLds, st, a, chunk);
-          else hipLaunchKernelGGL((lift_bwd_query_win_kernel<T, DH, VEC, P, false, HG>), grid, dim3(256), kWinLds, st, a, chunk);
-        }
-      } else
-      if (sizeof(T) == 2 && a.ol16)
-        {
-          if (wide) launch_bwd_query_shared<T, DH, VECS, P, sizeof(T) == 2>(a, st);
-          else launch_bwd_query_shared<T, DH, VEC, P, sizeof(T) == 2>(a, st);
-        }
-      else
-        {
-          if (wide) launch_bwd_query_shared<T, DH, VECS, P, false>(a, st);
-          else launch_bwd_query_shared<T, DH, VEC, P, false>(a, st);
-        }
-    }
+    if (!qfirst) run_query();
     constexpr int RB = 2;
     const size_t lds = (size_t)t.waves * TileLds<T, DH, RB>::kWords * sizeof(uint16_t);
     {
@@ -1468,6 +1492,8 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
       hipLaunchKernelGGL((lift_bwd_value_kernel<T, DH, P, RB>), dim3(8 * t.chunk), dim3(64 * t.waves),
                          lds, s2, a, t);
     }
+    if (a.ovf_after)
+      hipLaunchKernelGGL((lift_ovf_scatter_kernel<T, DH>), dim3(256), dim3(256), 0, s2, a, t.tiles_x, tiles);
     if (two) {
       (void)hipEventRecord(side_join[dev], s2);
       (void)hipStreamWaitEvent(st, side_join[dev], 0);
@@ -1793,7 +1819,10 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_g
       a.ovf_tile = (int*)((char*)ws + w.ovf_tile_off);
       a.cap = t.cap;
       a.ovf_cap = (int)min(w.ovf_cap, (long)INT_MAX);
-      if (hipMemsetAsync(ws, 0, w.cnt_bytes, st) != hipSuccess) {
+      static const bool two_env = getenv("UBV_LIFT_TWO_STREAM") != nullptr && atoi(getenv("UBV_LIFT_TWO_STREAM")) != 0;
+      a.ovf_after = (a.gvalue_lp == nullptr && !two_env) ? 1 : 0;
+      if (a.ovf_after) a.cnt_words = (int)(w.cnt_bytes / sizeof(int));      // zeroed by the query-gradient kernel
+      else if (hipMemsetAsync(ws, 0, w.cnt_bytes, st) != hipSuccess) {
         set_error("bev_lift_backward: memset failed");
         return UBV_ERR_LAUNCH;
       }

@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256) void lift_fwd_shared_kernel(const LiftArgs a) 
 
 template <typename T, int DH, int VEC, int P, bool OL16, int HB = 0>
 __global__ __launch_bounds__(256) void lift_bwd_query_shared_kernel(const LiftArgs a) {
+  lift_zero_counters(a);
   constexpr int LP = DH / VEC;
   constexpr int NOWN = (P + LP - 1) / LP;
   constexpr bool FAST = sizeof(T) == 2;
