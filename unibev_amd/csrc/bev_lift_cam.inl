@@ -411,9 +411,20 @@ __global__ __launch_bounds__(256) void lift_cam_bwd_value_kernel(const LiftArgs 
   TileGeom g;
   if (!tile_decode(a, t, g)) return;
   const int lane = threadIdx.x & 63;
-  const int cq = cam_chunk_len(a.cam_n[g.cam], t.chunks);
-  const int l0 = g.ck * cq;
-  const int ncand = min(cq, a.cam_n[g.cam] - l0);
+  int l0, ncand;
+  long slab_idx;
+  if (t.balanced) {
+    const int W = a.Nc * t.chunks, k = g.cam * t.chunks + g.ck;
+    CamShare sh;
+    if (!cam_share(a, W, k, sh)) return;
+    g.cam = sh.cam; l0 = sh.l0; ncand = sh.ncand;
+    slab_idx = ((long)g.b * a.H + g.h) * W + k;
+  } else {
+    const int cq = cam_chunk_len(a.cam_n[g.cam], t.chunks);
+    l0 = g.ck * cq;
+    ncand = min(cq, a.cam_n[g.cam] - l0);
+    slab_idx = (((long)g.b * a.Nc + g.cam) * a.H + g.h) * t.chunks + g.ck;
+  }
   if (ncand <= 0) return;
   uint16_t* A = lds_all + (threadIdx.x >> 6) * (kA + kG);
   uint16_t* G = A + kA;
@@ -529,8 +540,7 @@ __global__ __launch_bounds__(256) void lift_cam_bwd_value_kernel(const LiftArgs 
   }
   // ---- this share's partial map -> its slab ([b][cam][h][chunk][S][Dh], plain stores).  D: column =
   // channel lane & 31, row = padded slot (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of block mb
-  float* __restrict__ slab = a.slab + ((((long)g.b * a.Nc + g.cam) * a.H + g.h) * t.chunks + g.ck) *
-                                          ((long)a.fh * a.fw * DH);
+  float* __restrict__ slab = a.slab + slab_idx * ((long)a.fh * a.fw * DH);
 #pragma unroll
   for (int mb = 0; mb < MBT; ++mb) {
 #pragma unroll

@@ -18,7 +18,9 @@
 //    kernel batches 32 queries (lanes l / l + 32 share a query, as in the forward) so that its A^T stays at
 //    the 16-bit kernel's 36 KB per wave.
 //  * V fragments come from pre-split copies written once per call: fragment-ordered (forward), natural
-//    layout (query gradient).  Softmax and the divisions are the IEEE ones, like every other f32 kernel here.
+//    layout (query gradient).  The forward keeps IEEE softmax / divisions like every other f32 kernel here; the two
+//    backward kernels recompute the weights and locations with v_exp / v_rcp (~2 ulp: 1e-7 of a gradient, three
+//    orders below its test bar) — exp and the divisions were a fifth of their VALU instructions.
 
 // 8 f32 -> 4 dwords of bf16 hi pairs + 4 dwords of bf16 lo pairs
 __device__ __forceinline__ void split8(const float (&f)[8], uint4& hi, uint4& lo) {
@@ -246,13 +248,16 @@ __global__ __launch_bounds__(64) void lift_cam32_bwd_query_kernel(const LiftArgs
       split8(f, gfh[kb], gfl[kb]);
     }
   }
-  softmax_row<P, false>(lg, w);
+  softmax_row<P, true>(lg, w);                  // (backward: hardware exp / reciprocal, see the header)
   float wg[PG];
 #pragma unroll
   for (int i = 0; i < PG; ++i) wg[i] = g ? w[PG + i] : w[i];
   const float fwf = (float)a.fw, fhf = (float)a.fh;
+  {
+    const float inv_fw = __builtin_amdgcn_rcpf(fwf), inv_fh = __builtin_amdgcn_rcpf(fhf);
 #pragma unroll
-  for (int i = 0; i < PG; ++i) { off[2 * i] /= fwf; off[2 * i + 1] /= fhf; }
+    for (int i = 0; i < PG; ++i) { off[2 * i] *= inv_fw; off[2 * i + 1] *= inv_fh; }
+  }
   float gw[PG], gx[PG], gy[PG];
 #pragma unroll
   for (int i = 0; i < PG; ++i) { gw[i] = 0.0f; gx[i] = 0.0f; gy[i] = 0.0f; }
@@ -332,10 +337,10 @@ __global__ __launch_bounds__(64) void lift_cam32_bwd_query_kernel(const LiftArgs
       __builtin_amdgcn_wave_barrier();
     }
   }
-  const float cnt = (a.count != nullptr) ? a.count[bq] : 1.0f;
+  const float inv_cnt = (a.count != nullptr) ? __builtin_amdgcn_rcpf(a.count[bq]) : 1.0f;
   float sp = 0.0f;
 #pragma unroll
-  for (int i = 0; i < PG; ++i) { gw[i] /= cnt; sp = fmaf(wg[i], gw[i], sp); }
+  for (int i = 0; i < PG; ++i) { gw[i] *= inv_cnt; sp = fmaf(wg[i], gw[i], sp); }
   const float s = sp + __shfl_xor(sp, 32, 64);
   if (valid) {
     float gl[PG], gofs[2 * PG];
@@ -343,8 +348,8 @@ __global__ __launch_bounds__(64) void lift_cam32_bwd_query_kernel(const LiftArgs
     for (int i = 0; i < PG; ++i) {
       gl[i] = wg[i] * (gw[i] - s);
       // d(loc) -> d(offset): loc = ref + off / (fw, fh) and x = loc * fw - 0.5: the map sizes cancel
-      gofs[2 * i] = wg[i] * gx[i] / cnt;
-      gofs[2 * i + 1] = wg[i] * gy[i] / cnt;
+      gofs[2 * i] = wg[i] * gx[i] * inv_cnt;
+      gofs[2 * i + 1] = wg[i] * gy[i] * inv_cnt;
     }
     store_ol<float, PG>(a.glog, bq * a.glog_stride + h * P + g * PG, false, gl);
     store_ol<float, 2 * PG>(a.goff, bq * a.goff_stride + h * 2 * P + g * 2 * PG, false, gofs);
@@ -368,9 +373,20 @@ __global__ __launch_bounds__(256) void lift_cam32_bwd_value_kernel(const LiftArg
   TileGeom g;
   if (!tile_decode(a, t, g)) return;
   const int lane = threadIdx.x & 63;
-  const int cq = cam_chunk_len(a.cam_n[g.cam], t.chunks);
-  const int l0 = g.ck * cq;
-  const int ncand = min(cq, a.cam_n[g.cam] - l0);
+  int l0, ncand;
+  long slab_idx;
+  if (t.balanced) {
+    const int W = a.Nc * t.chunks, k = g.cam * t.chunks + g.ck;
+    CamShare sh;
+    if (!cam_share(a, W, k, sh)) return;
+    g.cam = sh.cam; l0 = sh.l0; ncand = sh.ncand;
+    slab_idx = ((long)g.b * a.H + g.h) * W + k;
+  } else {
+    const int cq = cam_chunk_len(a.cam_n[g.cam], t.chunks);
+    l0 = g.ck * cq;
+    ncand = min(cq, a.cam_n[g.cam] - l0);
+    slab_idx = (((long)g.b * a.Nc + g.cam) * a.H + g.h) * t.chunks + g.ck;
+  }
   if (ncand <= 0) return;
   uint32_t* A = lds32 + (threadIdx.x >> 6) * (kA + kG);
   float* G = reinterpret_cast<float*>(A + kA);
@@ -383,6 +399,7 @@ __global__ __launch_bounds__(256) void lift_cam32_bwd_value_kernel(const LiftArg
   const long row = (long)a.H * DH;
   const float* __restrict__ gout = (const float*)a.gout;
   const float fwf = (float)a.fw, fhf = (float)a.fh;
+  const float inv_fw = __builtin_amdgcn_rcpf(fwf), inv_fh = __builtin_amdgcn_rcpf(fhf);
   const int n = lane & 31, kg = lane >> 5;
   const int fh1 = c.fh1;
   uint32_t* acol = A + n;
@@ -440,14 +457,14 @@ __global__ __launch_bounds__(256) void lift_cam32_bwd_value_kernel(const LiftArg
       split8(f, bh[kb], bl[kb]);
     }
     float w[P];
-    softmax_row<P, false>(cur.lg, w);
-    const float sc = cur.valid ? 1.0f / cur.cnt : 0.0f;           // 1 / count, 0 for the list's tail
+    softmax_row<P, true>(cur.lg, w);
+    const float sc = cur.valid ? __builtin_amdgcn_rcpf(cur.cnt) : 0.0f;           // 1 / count, 0 for the list's tail
     unsigned mbmask = 0u;
     int k0s[PG];
     float cf[PG][4];
 #pragma unroll
     for (int i = 0; i < PG; ++i) {
-      const PadFoot f = pad_foot(cur.ref[i].x + cur.off[2 * i] / fwf, cur.ref[i].y + cur.off[2 * i + 1] / fhf,
+      const PadFoot f = pad_foot(cur.ref[i].x + cur.off[2 * i] * inv_fw, cur.ref[i].y + cur.off[2 * i + 1] * inv_fh,
                                  fwf, fhf, a.fw, a.fh, fh1);
       const float wp = (kg ? w[PG + i] : w[i]) * sc;
       const float wl = wp * f.lx, wh = wp - wl;
@@ -494,8 +511,7 @@ __global__ __launch_bounds__(256) void lift_cam32_bwd_value_kernel(const LiftArg
     }
     __builtin_amdgcn_wave_barrier();
   }
-  float* __restrict__ slab = a.slab + ((((long)g.b * a.Nc + g.cam) * a.H + g.h) * t.chunks + g.ck) *
-                                          ((long)a.fh * a.fw * DH);
+  float* __restrict__ slab = a.slab + slab_idx * ((long)a.fh * a.fw * DH);
 #pragma unroll
   for (int mb = 0; mb < MBT; ++mb) {
 #pragma unroll
