@@ -1305,6 +1305,7 @@ static CamArgs cam_args(const LiftArgs& a, const void* vfrag, int dtype = UBV_BF
   c.witems = a.total_tiles * 2 * a.H;                      // a wave is half a tile for one head
   c.chunk = (c.witems + 7) / 8;
   c.fh1 = a.fh + 1;
+  c.mg = (65536u + (unsigned)c.fh1 - 1u) / (unsigned)c.fh1;
   return c;
 }
 

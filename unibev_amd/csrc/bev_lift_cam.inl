@@ -34,6 +34,7 @@ struct CamArgs {
   int witems;           // (sample, tile, head) wave items
   int chunk;            // blocks per XCD
   int fh1;              // fh + 1: column stride of the padded map
+  unsigned mg;          // ceil(2^16 / fh1): kk / fh1 == (kk * mg) >> 16 for kk < 256, fh1 <= 14 (cam_pixel_mg)
 };
 
 __host__ __device__ inline int cam_kpad(int fh, int fw) { return (fw + 2) * (fh + 1) + 1; }
@@ -41,6 +42,15 @@ __host__ __device__ inline int cam_kpad(int fh, int fw) { return (fw + 2) * (fh 
 // padded K index -> pixel of the map, or false on the border
 __device__ __forceinline__ bool cam_pixel(int kk, int fh, int fw, int& pix) {
   const int c = kk / (fh + 1), r = kk - c * (fh + 1);
+  pix = (r - 1) * fw + (c - 1);
+  return r >= 1 && c >= 1 && c <= fw;
+}
+
+// the same with the division by a host-made reciprocal (kk < 256, fh + 1 <= 14: exact): the integer division was
+// ~25 instructions per call, 112 calls in the epilogue of the value-gradient kernels and 4 per pass of the
+// query-gradient kernels
+__device__ __forceinline__ bool cam_pixel_mg(int kk, int fh1, unsigned mg, int fw, int& pix) {
+  const int c = (int)(((unsigned)kk * mg) >> 16), r = kk - c * fh1;
   pix = (r - 1) * fw + (c - 1);
   return r >= 1 && c >= 1 && c <= fw;
 }
@@ -333,7 +343,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
       for (int jb = 0; jb < 4; ++jb) {
         const int mb = s * 3 + jb;
         int pix;
-        const bool in = cam_pixel(mb * 32 + n, a.fh, a.fw, pix) && mb < MB;
+        const bool in = cam_pixel_mg(mb * 32 + n, fh1, c.mg, a.fw, pix) && mb < MB;
         const T* vp = vb + (long)(in ? pix : 0) * row;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -546,7 +556,7 @@ __global__ __launch_bounds__(256) void lift_cam_bwd_value_kernel(const LiftArgs 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int pix;
-      if (cam_pixel(mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg, a.fh, a.fw, pix)) slab[(long)pix * DH + n] = acc[mb][r];
+      if (cam_pixel_mg(mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg, fh1, c.mg, a.fw, pix)) slab[(long)pix * DH + n] = acc[mb][r];
     }
   }
 }

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64) void lift_cam32_bwd_query_kernel(const LiftArgs
       for (int jb = 0; jb < 4; ++jb) {
         const int mb = s * 3 + jb;
         int pix;
-        const bool in = cam_pixel(mb * 32 + n, a.fh, a.fw, pix) && mb < MB;
+        const bool in = cam_pixel_mg(mb * 32 + n, fh1, c.mg, a.fw, pix) && mb < MB;
         const long po = vo + (long)(in ? pix : 0) * row;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void lift_cam32_bwd_value_kernel(const LiftArg
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int pix;
-      if (cam_pixel(mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg, a.fh, a.fw, pix)) slab[(long)pix * DH + n] = acc[mb][r];
+      if (cam_pixel_mg(mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg, fh1, c.mg, a.fw, pix)) slab[(long)pix * DH + n] = acc[mb][r];
     }
   }
 }
