@@ -214,13 +214,16 @@ def sampling_ops(workload, bs, esize, visible_pairs):
     return ops
 
 
-def op_roofline(prof, ops):
+def op_roofline(prof, ops, prof_ops=None):
     """Per sampling op and direction: duration = the library's op-level HIP-event scope, achieved =
-    compulsory bytes / duration; plus the kernels the op consists of."""
+    compulsory bytes / duration; plus the kernels the op consists of.  ``prof_ops``: a pass recorded with the
+    op-level scopes ALONE (no event records between an op's launches) — the durations come from it, the
+    per-kernel times from ``prof``."""
     out = []
+    prof_ops = prof_ops or prof
     for op, (tag, fb, bb) in ops.items():
         for direction, scope, nbytes in (('fwd', 'bev_lift_fwd<', fb), ('bwd', 'bev_lift_bwd_op<', bb)):
-            hit = [(k, r) for k, r in prof.items() if k.startswith(scope) and tag in k]
+            hit = [(k, r) for k, r in prof_ops.items() if k.startswith(scope) and tag in k]
             if not hit:
                 continue
             us = sum(r['avg_us'] for _, r in hit)
@@ -340,7 +343,13 @@ def run_mode(args, name, head, world, rank, device, want_ops):
         two = _tr._TWO_STREAMS[0]
         _tr.set_two_streams(False)
         UF.set_seed_base(None)
-        UF.kernel_profile(True)
+        UF.kernel_profile(True, ops_only=True)          # pass 1: whole operators (their durations)
+        for _ in range(min(args.steps, 10)):
+            gs.eager_step()
+        torch.cuda.synchronize()
+        prof_ops = UF.kernel_profile()
+        UF.kernel_profile(False)
+        UF.kernel_profile(True)                         # pass 2: every kernel inside them
         for _ in range(min(args.steps, 10)):
             gs.eager_step()
         torch.cuda.synchronize()
@@ -355,7 +364,7 @@ def run_mode(args, name, head, world, rank, device, want_ops):
                                               head.transformer.img_bev_encoder.pc_range,
                                               WORKLOADS[args.workload][1])
             pairs = args.bs * int(vis0.sum().item())         # rows of sample 0's visibility (quirk q1) per sample
-        ops = op_roofline(prof, sampling_ops(args.workload, args.bs, 4 if name == 'fp32' else 2, pairs))
+        ops = op_roofline(prof, sampling_ops(args.workload, args.bs, 4 if name == 'fp32' else 2, pairs), prof_ops)
         for o in ops:
             o['traffic'] = traffic_of(o, name, args.workload, args.bs)
         rec['roofline_ops'] = ops

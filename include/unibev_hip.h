@@ -43,7 +43,9 @@ const char* ubv_arch(void);
 /* Optional per-kernel timing: while enabled, every kernel of the sampling family is bracketed by
  * HIP events on its launch stream.  ubv_profile_read() synchronises on them and writes one line per
  * kernel name: "name<TAB>launches<TAB>total_ms<TAB>algorithmic_bytes_per_launch\n"; returns the
- * number of bytes the full text needs.  ubv_profile_enable(0|1) also clears the records. */
+ * number of bytes the full text needs.  ubv_profile_enable(0|1|2) also clears the records; 2 = the scopes around
+ * whole operators only ("bev_lift_fwd<…", "…_op<…"): the per-kernel scopes record their events between an
+ * operator's launches, so an operator's own duration is read from a level-2 pass. */
 int ubv_profile_enable(int on);
 int64_t ubv_profile_read(char* out, int64_t capacity);
 

@@ -27,10 +27,13 @@ struct ProfRec { char name[96]; double bytes; hipEvent_t e0, e1; };
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;
 bool g_prof_on = false;
+bool g_prof_ops_only = false;   // level 2: whole operators only — the scopes of the kernels inside an op put their own
+                                // event records between its launches and lengthen what the op-level scope measures
 }  // namespace
 
 ProfScope::ProfScope(const char* name, hipStream_t st, double bytes) : idx_(-1), st_(st) {
   if (!g_prof_on) return;
+  if (g_prof_ops_only && strncmp(name, "bev_lift_fwd<", 13) != 0 && strstr(name, "_op<") == nullptr) return;
   ProfRec r;
   snprintf(r.name, sizeof(r.name), "%s", name);
   r.bytes = bytes;
@@ -53,6 +56,7 @@ extern "C" int ubv_profile_enable(int on) {
   for (auto& r : ubv::g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   ubv::g_prof.clear();
   ubv::g_prof_on = on != 0;
+  ubv::g_prof_ops_only = on == 2;
   return UBV_OK;
 }
 

@@ -55,13 +55,15 @@ class _timed:
             _PROFILE.setdefault(self.name, []).append((self.s, self.e, self.meta))
 
 
-def kernel_profile(enable=None):
+def kernel_profile(enable=None, ops_only=False):
     """Per-kernel HIP-event timing inside the library (``ubv_profile_enable`` /
     ``ubv_profile_read``).  ``kernel_profile(True)`` starts, ``kernel_profile(False)`` stops;
     ``kernel_profile()`` returns {kernel name: dict(launches, total_ms, avg_us, bytes_per_launch)}
     (synchronises on the recorded events)."""
     if enable is not None:
-        check(lib().ubv_profile_enable(1 if enable else 0), 'profile_enable')
+        # ops_only: scopes around whole operators only (the per-kernel scopes record events between an op's
+        # launches, which the op-level scope then includes)
+        check(lib().ubv_profile_enable((2 if ops_only else 1) if enable else 0), 'profile_enable')
         return None
     n = lib().ubv_profile_read(None, 0)
     buf = ctypes.create_string_buffer(int(n) + 16)
