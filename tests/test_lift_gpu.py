@@ -382,8 +382,7 @@ def test_lift_camera_matrix_core_plan(case, dtype, ftol, tiled):
 @pytest.mark.parametrize('tiled', [True, False])
 def test_lift_camera_matrix_core_plan_fp32(case, tiled):
     """f32 data on the matrix-core CAMERA plan (bev_lift_cam32.inl): both MFMA operands split into bf16 hi + lo
-    halves, three products per K-block (the two backward kernels by default, the forward one too under
-    UBV_CAM_MFMA32=2).  Held to the f32 bars of test_lift_fp32_forward_backward against the fp64
+    halves, three products per K-block, forward and both backward kernels.  Held to the f32 bars of test_lift_fp32_forward_backward against the fp64
     oracle — the split must not be visible."""
     from unibev_amd.functional import bev_lift
     B, Nc, fh, fw, H, Dh, qh, qw, P, Z = case
@@ -405,9 +404,9 @@ def test_lift_camera_matrix_core_plan_fp32(case, tiled):
     assert bad.sum() <= 1e-5 * bad.size + 1, int(bad.sum())       # pixel-boundary discontinuities
 
 
-def test_lift_camera_matrix_core_plan_fp32_forward_kernel():
-    """The f32 matrix-core FORWARD kernel is off by default (slower than the gather kernel); it stays in the library
-    behind UBV_CAM_MFMA32=2, read once per process — so the parity cases above are re-run in a child process."""
+def test_lift_camera_matrix_core_plan_fp32_backward_only_mode():
+    """UBV_CAM_MFMA32=2 keeps the f32 forward on the gather kernel and only the two backward kernels on the matrix
+    cores (an A/B knob, read once per process) — the parity cases above are re-run that way in a child process."""
     import os
     import subprocess
     import sys
@@ -416,7 +415,7 @@ def test_lift_camera_matrix_core_plan_fp32_forward_kernel():
     env = dict(os.environ, UBV_CAM_MFMA32='2')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_lift_gpu.py'), '-q', '-x',
-                        '-k', 'test_lift_camera_matrix_core_plan_fp32 and not forward_kernel'],
+                        '-k', 'test_lift_camera_matrix_core_plan_fp32 and not backward_only'],
                        env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert '8 passed' in r.stdout, r.stdout[-500:]

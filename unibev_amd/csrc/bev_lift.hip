@@ -1277,15 +1277,13 @@ static LiftBytes lift_bytes(const LiftArgs& a, int Dh, int P, int esize) {
 }
 
 // CAMERA plan on the matrix cores (bev_lift_cam.inl; f32 data with split operands: bev_lift_cam32.inl): Dh = 32,
-// P = 8, maps of <= 192 pixels.  UBV_CAM_MFMA=0 switches it off.  f32 data (UBV_CAM_MFMA32, default 1): the two
-// backward kernels take the plan — measured at 6 x 8x22, bs = 2: query gradient 167 -> 144 us, value gradient
-// 279 -> 172 us — the forward kernel does not (190 us against the shared-footprint gather kernel's 148: hi + lo
-// fragments are 30 KB per (wave, camera) and its 31 KB coefficient matrix leaves one wave per SIMD);
-// UBV_CAM_MFMA32=2 runs it anyway, 0 switches the f32 plan off.
+// P = 8, maps of <= 192 pixels.  UBV_CAM_MFMA=0 switches it off.  f32 data (UBV_CAM_MFMA32: 1 = default, 0 = off,
+// 2 = backward kernels only), measured at 6 x 8x22, bs = 2 against the kernels it replaces: query gradient 167 -> 140 us,
+// value gradient 279 -> 156 us, forward 150 -> 123 us (its first version, whole map per wave: 190 us).
 static bool cam_mfma_ok(const LiftArgs& a, int Dh, int P, int dtype, bool fwd = false) {
   static const int env = getenv("UBV_CAM_MFMA") ? atoi(getenv("UBV_CAM_MFMA")) : 1;
   static const int env32 = getenv("UBV_CAM_MFMA32") ? atoi(getenv("UBV_CAM_MFMA32")) : 1;
-  return env != 0 && (dtype != UBV_F32 || env32 >= (fwd ? 2 : 1)) && Dh == 32 && P == 8 && a.fh >= 1 && a.fw >= 1 &&
+  return env != 0 && (dtype != UBV_F32 || (env32 != 0 && !(fwd && env32 == 2))) && Dh == 32 && P == 8 && a.fh >= 1 && a.fw >= 1 &&
          a.fh <= 13 && cam_kpad(a.fh, a.fw) <= 16 * kCamKbMax;
 }
 // fragment-ordered copy of value: one buffer of 16-bit fragments, two (hi, lo) for f32 data
@@ -1393,7 +1391,7 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
         hipLaunchKernelGGL(value_frags32_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st,
                            (const float*)a.value, (uint16_t*)c.vfrag, (uint16_t*)c.vfrag_lo, a.B * a.Nc, a.fh * a.fw,
                            a.H, a.fh, a.fw, c.KB);
-        const size_t lds = (size_t)32 * (c.KB * 16 + 4) * sizeof(uint32_t);
+        const size_t lds = (size_t)32 * kCam32AStr * sizeof(uint32_t);
         const dim3 grid(8 * c.chunk), blk(64);
         if (c.KB == 14) hipLaunchKernelGGL((lift_cam32_fwd_kernel<8, 14>), grid, blk, lds, st, a, c);
         else hipLaunchKernelGGL((lift_cam32_fwd_kernel<8, 15>), grid, blk, lds, st, a, c);

@@ -14,7 +14,7 @@
 //    halves, add, re-split: 9 VALU per corner).  Keeping plain f32 in LDS and splitting at fragment-read time
 //    would cost 24 VALU per 8-slot fragment, 15 fragments per camera pass against 16 corners.
 //  * the MFMA operand fragments de-interleave 8 consecutive dwords into 4 dwords of hi pairs + 4 of lo pairs.
-//  * a 32-query coefficient matrix is 31 KB (forward) — 5 waves per CU instead of 10 — and the value-gradient
+//  * the forward walks the padded map in 128-slot passes (a 17 KB coefficient window per wave) and the value-gradient
 //    kernel batches 32 queries (lanes l / l + 32 share a query, as in the forward) so that its A^T stays at
 //    the 16-bit kernel's 36 KB per wave.
 //  * V fragments come from pre-split copies written once per call: fragment-ordered (forward), natural
@@ -92,15 +92,23 @@ __global__ __launch_bounds__(256) void value_split32_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// Forward.  Same work decomposition as lift_cam_fwd_kernel: a wave is half an 8x8 query tile for one
-// head, lanes l and l + 32 share a query and split its 8 points.
+// Forward.  Same work decomposition as lift_cam_fwd_kernel — a wave is half an 8x8 query tile for one head, lanes
+// l and l + 32 share a query and split its 8 points — but the padded map is walked in PASSES of 128 slots that start
+// every 96 (as the query-gradient kernels do): a point belongs to the pass its first corner lies in, its last corner
+// (<= fh + 2 <= 15 slots further) is still inside it.  The coefficient window is then 32 x 132 dwords = 17 KB instead
+// of 31 (9 waves per CU instead of 5), a pass holds 8 hi + 8 lo V fragments instead of 30 in registers, and a half
+// tile of BEV queries — a few image columns wide — usually touches one or two of the three passes.
+constexpr int kCam32Win = 128;                 // slots per pass
+constexpr int kCam32AStr = kCam32Win + 4;      // dwords per row; / 4 is odd: conflict-free 16-byte reads
+
 template <int P, int KBT>
 __global__ __launch_bounds__(64) void lift_cam32_fwd_kernel(const LiftArgs a, const CamArgs c) {
   static_assert(P == 8, "two groups of 4 points");
   extern __shared__ __attribute__((aligned(16))) uint32_t lds32[];
   using M = mma_traits<bf16_t>;
-  constexpr int ASTR = KBT * 16 + 4;           // dwords per row; ASTR / 4 is odd: conflict-free 16-byte reads
+  constexpr int ASTR = kCam32AStr;
   constexpr int PG = P / 2;
+  constexpr int NPASS = (KBT * 16 + 95) / 96;
   const int lane = threadIdx.x, g = lane >> 5;
   const int witem = xcd_remap(blockIdx.x, c.chunk);
   if (witem >= c.witems) return;
@@ -141,12 +149,10 @@ __global__ __launch_bounds__(64) void lift_cam32_fwd_kernel(const LiftArgs a, co
     const bool v = (vismask >> cam) & 1u;
     if (__ballot(v) == 0ull) continue;
     const long fo = ((((long)b * a.Nc + cam) * a.H + h) * KBT) * 64 + lane;
-    uint4 avh[KBT], avl[KBT];
-#pragma unroll
-    for (int kb = 0; kb < KBT; ++kb) { avh[kb] = vfh[fo + (long)kb * 64]; avl[kb] = vfl[fo + (long)kb * 64]; }
     const float* __restrict__ rp = a.ref + (((long)cam * a.B + b) * a.Nq + q) * a.Z * 2;
-    int k0s[PG];
+    int k0s[PG], ps[PG];
     float cf[PG][4];
+    unsigned pmask = 0u;
 #pragma unroll
     for (int i = 0; i < PG; ++i) {
       const float2 r = *reinterpret_cast<const float2*>(rp + za[i] * 2);
@@ -155,38 +161,57 @@ __global__ __launch_bounds__(64) void lift_cam32_fwd_kernel(const LiftArgs a, co
       const float wl = wp * f.lx, wh = wp - wl;
       cf[i][3] = wl * f.ly; cf[i][2] = wl - cf[i][3];
       cf[i][1] = wh * f.ly; cf[i][0] = wh - cf[i][1];
-      k0s[i] = f.k0;
+      ps[i] = v ? (f.k0 >= 96) + (f.k0 >= 192) : -1;      // invisible here: in no pass
+      k0s[i] = f.k0 - 96 * (ps[i] < 0 ? 0 : ps[i]);        // window-local slot
+      if (v) pmask |= 1u << ps[i];
     }
 #pragma unroll
-    for (int ph = 0; ph < 2; ++ph) {
-      if (g == ph) {
+    for (int s = 0; s < NPASS; ++s) {
+      if (__ballot((pmask >> s) & 1u) == 0ull) continue;     // wave-uniform
+      constexpr int kFull = 8;
+      const int nkb = KBT - 6 * s < kFull ? KBT - 6 * s : kFull;       // K-blocks of this pass (compile time per s)
+      uint4 avh[kFull], avl[kFull];
 #pragma unroll
-        for (int i = 0; i < PG; ++i) {
+      for (int kb = 0; kb < kFull; ++kb)
+        if (kb < nkb) { avh[kb] = vfh[fo + (long)(6 * s + kb) * 64]; avl[kb] = vfl[fo + (long)(6 * s + kb) * 64]; }
+      // the two point groups of a query share its row: one group at a time
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        if (g == ph) {
+#pragma unroll
+          for (int i = 0; i < PG; ++i) {
+            if (ps[i] == s) {
+              uint32_t* e = arow + k0s[i];
+              const uint32_t u00 = e[0], u10 = e[1], u01 = e[fh1], u11 = e[fh1 + 1];
+              e[0] = coef_add(u00, cf[i][0]);
+              e[1] = coef_add(u10, cf[i][1]);
+              e[fh1] = coef_add(u01, cf[i][2]);
+              e[fh1 + 1] = coef_add(u11, cf[i][3]);
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int kb = 0; kb < kFull; ++kb) {
+        if (kb < nkb) {
+          uint4 bh, bl;
+          coef_frag(brow + kb * 16, bh, bl);
+          acc0 = M::mma(avh[kb], bh, acc0);
+          acc1 = M::mma(avl[kb], bh, acc1);
+          acc2 = M::mma(avh[kb], bl, acc2);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < PG; ++i) {
+        if (ps[i] == s) {
           uint32_t* e = arow + k0s[i];
-          const uint32_t u00 = e[0], u10 = e[1], u01 = e[fh1], u11 = e[fh1 + 1];
-          e[0] = coef_add(u00, cf[i][0]);
-          e[1] = coef_add(u10, cf[i][1]);
-          e[fh1] = coef_add(u01, cf[i][2]);
-          e[fh1 + 1] = coef_add(u11, cf[i][3]);
+          e[0] = 0u; e[1] = 0u; e[fh1] = 0u; e[fh1 + 1] = 0u;
         }
       }
       __builtin_amdgcn_wave_barrier();
     }
-#pragma unroll
-    for (int kb = 0; kb < KBT; ++kb) {
-      uint4 bh, bl;
-      coef_frag(brow + kb * 16, bh, bl);
-      acc0 = M::mma(avh[kb], bh, acc0);
-      acc1 = M::mma(avl[kb], bh, acc1);
-      acc2 = M::mma(avh[kb], bl, acc2);
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int i = 0; i < PG; ++i) {
-      uint32_t* e = arow + k0s[i];
-      e[0] = 0u; e[1] = 0u; e[fh1] = 0u; e[fh1 + 1] = 0u;
-    }
-    __builtin_amdgcn_wave_barrier();
   }
   // D^T: row = channel (r & 3) + 8 (r >> 2) + 4 g, column = this lane's query
   if (valid) {
