@@ -1606,7 +1606,7 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
         if (cam_mfma && t.tiles_y == 1) {          // f32 data: 32 queries per batch, packed hi | lo coefficients
           const CamArgs c = cam_args(a, nullptr);
           const int mbt = (c.KB + 1) / 2;
-          const size_t l2 = (size_t)t.waves * (mbt * 32 * kCam32VStride + 32 * 32) * sizeof(uint32_t);
+          const size_t l2 = (size_t)t.waves * (kCam32Win * kCam32VStride + 32 * 32) * sizeof(uint32_t);
           if (mbt == 7)
             hipLaunchKernelGGL((lift_cam32_bwd_value_kernel<8, 7>), dim3(8 * t.chunk), dim3(64 * t.waves), l2, st, a, t, c);
           else
@@ -1748,6 +1748,15 @@ static int plan_backward(const LiftArgs& a, int Dh, int P, int dtype, int ref_is
     t.waves = (dtype == UBV_F32 && t.tile_h * a.fw > 96 && !cam32) ? 2 : 4;
     const int combos = a.B * a.Nc * t.tiles_y * a.H;
     int split = split_env > 0 ? split_env : (256 * t.waves) / combos;
+    if (cam32) {
+      // f32 matrix-core value gradient (bev_lift_cam32.inl): 22.5 KB of LDS per wave -> one-wave blocks, 7 resident per
+      // CU, and list shares sized for exactly that one round.  Measured at 6 x 8x22, bs = 2 (value-gradient kernel, us)
+      // for 4 / 5 / 6 / 7 / 8 / 10 / 14 waves per CU: 218 / 183 / 154 / 141 / 186 / 175 / 161; four-wave blocks: 210.
+      static const int w32 = getenv("UBV_CAM32_WAVES") ? atoi(getenv("UBV_CAM32_WAVES")) : 1;
+      static const int per_cu = getenv("UBV_CAM32_PER_CU") ? atoi(getenv("UBV_CAM32_PER_CU")) : 7;
+      t.waves = w32 > 0 ? w32 : 1;
+      if (split_env <= 0) split = (256 * per_cu) / combos;
+    }
     split = max(1, min(split, (a.Nq + 63) / 64));
     t.chunk_q = 0;
     t.chunks = split;

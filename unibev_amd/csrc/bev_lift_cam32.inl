@@ -385,7 +385,10 @@ __global__ __launch_bounds__(64) void lift_cam32_bwd_query_kernel(const LiftArgs
 // Backward, value side: grad_value[pix, :] = sum_q A[q][pix] G[q, :] over a camera's visible queries, 32 per batch.
 // Lanes l and l + 32 share query l of the batch: each builds the footprints of 4 of its 8 points and loads half of
 // its grad_out row; A^T[slot][query] holds packed (hi | lo << 16) coefficients, G sits in LDS as f32 and is split
-// when the B fragments are read.
+// when the B fragments are read.  Like the forward, the padded map is walked in passes of 128 slots that start every
+// 96 (row blocks 3s .. 3s + 3 of the accumulators): A^T is a 128-row window, 18 KB + 4 KB of grad_out rows per wave
+// instead of 37 + 4, so seven one-wave blocks fit a CU where one four-wave block did — the kernel spent 43 % of its
+// cycles waiting with one wave per SIMD (profiles/r03_pmc_sca_img_fp32_sq.txt).
 constexpr int kCam32VStride = 36;    // dwords per A^T row: 32 query columns + 4 (144 B: conflict-free 16-byte reads)
 
 template <int P, int MBT>
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(256) void lift_cam32_bwd_value_kernel(const LiftArg
   extern __shared__ __attribute__((aligned(16))) uint32_t lds32[];
   using M = mma_traits<bf16_t>;
   constexpr int DH = 32, PG = P / 2;
-  constexpr int kA = MBT * 32 * kCam32VStride, kG = 32 * DH;     // dwords
+  constexpr int kA = kCam32Win * kCam32VStride, kG = 32 * DH;    // dwords: one pass window of A^T, grad_out rows
   TileGeom g;
   if (!tile_decode(a, t, g)) return;
   const int lane = threadIdx.x & 63;
@@ -484,8 +487,8 @@ __global__ __launch_bounds__(256) void lift_cam32_bwd_value_kernel(const LiftArg
     float w[P];
     softmax_row<P, true>(cur.lg, w);
     const float sc = cur.valid ? __builtin_amdgcn_rcpf(cur.cnt) : 0.0f;           // 1 / count, 0 for the list's tail
-    unsigned mbmask = 0u;
-    int k0s[PG];
+    unsigned pmask = 0u;
+    int k0s[PG], ps[PG];
     float cf[PG][4];
 #pragma unroll
     for (int i = 0; i < PG; ++i) {
@@ -495,46 +498,58 @@ __global__ __launch_bounds__(256) void lift_cam32_bwd_value_kernel(const LiftArg
       const float wl = wp * f.lx, wh = wp - wl;
       cf[i][3] = wl * f.ly; cf[i][2] = wl - cf[i][3];
       cf[i][1] = wh * f.ly; cf[i][0] = wh - cf[i][1];
-      k0s[i] = f.k0;
-      mbmask |= (1u << (f.k0 >> 5)) | (1u << ((f.k0 + fh1 + 1) >> 5));
+      ps[i] = (f.k0 >= 96) + (f.k0 >= 192);
+      k0s[i] = f.k0 - 96 * ps[i];                          // window-local slot
+      pmask |= 1u << ps[i];
     }
-    // the two point groups of a query share its column: one group at a time
-#pragma unroll
-    for (int ph = 0; ph < 2; ++ph) {
-      if (kg == ph) {
-#pragma unroll
-        for (int i = 0; i < PG; ++i) {
-          uint32_t* e = acol + k0s[i] * kCam32VStride;
-          const uint32_t u00 = e[0], u10 = e[kCam32VStride], u01 = e[fh1 * kCam32VStride], u11 = e[(fh1 + 1) * kCam32VStride];
-          e[0] = coef_add(u00, cf[i][0]);
-          e[kCam32VStride] = coef_add(u10, cf[i][1]);
-          e[fh1 * kCam32VStride] = coef_add(u01, cf[i][2]);
-          e[(fh1 + 1) * kCam32VStride] = coef_add(u11, cf[i][3]);
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-#define UBV_CAM32_MB_STEP(mb)                                                                             \
-    if ((mb) < MBT && __ballot((mbmask >> (mb)) & 1u) != 0ull) {                                          \
+    // one pass: the points whose first corner lies in slots [96 s, 96 s + 96) -> coefficients (the two point groups
+    // of a query share its column: one group at a time) -> the touched row blocks 3 s + jb -> clear
+#define UBV_CAM32_MB_STEP(s, jb)                                                                          \
+    if (3 * (s) + (jb) < MBT && __ballot((mbm >> (jb)) & 1u) != 0ull) {                                   \
+      constexpr int mbi = 3 * (s) + (jb) < MBT ? 3 * (s) + (jb) : 0;                                      \
       _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                  \
         uint4 ah, al;                                                                                     \
-        coef_frag(A + ((mb) * 32 + n) * kCam32VStride + kb * 16 + kg * 8, ah, al);                         \
-        acc[(mb) < MBT ? (mb) : 0] = M::mma(ah, bh[kb], acc[(mb) < MBT ? (mb) : 0]);                      \
-        acc[(mb) < MBT ? (mb) : 0] = M::mma(al, bh[kb], acc[(mb) < MBT ? (mb) : 0]);                      \
-        acc[(mb) < MBT ? (mb) : 0] = M::mma(ah, bl[kb], acc[(mb) < MBT ? (mb) : 0]);                      \
+        coef_frag(A + ((jb) * 32 + n) * kCam32VStride + kb * 16 + kg * 8, ah, al);                         \
+        acc[mbi] = M::mma(ah, bh[kb], acc[mbi]);                                                          \
+        acc[mbi] = M::mma(al, bh[kb], acc[mbi]);                                                          \
+        acc[mbi] = M::mma(ah, bl[kb], acc[mbi]);                                                          \
       }                                                                                                   \
     }
-    UBV_CAM32_MB_STEP(0) UBV_CAM32_MB_STEP(1) UBV_CAM32_MB_STEP(2) UBV_CAM32_MB_STEP(3)
-    UBV_CAM32_MB_STEP(4) UBV_CAM32_MB_STEP(5) UBV_CAM32_MB_STEP(6) UBV_CAM32_MB_STEP(7)
-#undef UBV_CAM32_MB_STEP
-    static_assert(MBT <= 8, "row-block steps are written out for 8 blocks");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int i = 0; i < PG; ++i) {
-      uint32_t* e = acol + k0s[i] * kCam32VStride;
-      e[0] = 0u; e[kCam32VStride] = 0u; e[fh1 * kCam32VStride] = 0u; e[(fh1 + 1) * kCam32VStride] = 0u;
+#define UBV_CAM32_PASS(s)                                                                                 \
+    if (3 * (s) < MBT && __ballot((pmask >> (s)) & 1u) != 0ull) {                                         \
+      unsigned mbm = 0u;                                                                                  \
+      _Pragma("unroll") for (int ph = 0; ph < 2; ++ph) {                                                  \
+        if (kg == ph) {                                                                                   \
+          _Pragma("unroll") for (int i = 0; i < PG; ++i) {                                                \
+            if (ps[i] == (s)) {                                                                           \
+              uint32_t* e = acol + k0s[i] * kCam32VStride;                                                \
+              const uint32_t u00 = e[0], u10 = e[kCam32VStride], u01 = e[fh1 * kCam32VStride],            \
+                             u11 = e[(fh1 + 1) * kCam32VStride];                                          \
+              e[0] = coef_add(u00, cf[i][0]);                                                             \
+              e[kCam32VStride] = coef_add(u10, cf[i][1]);                                                 \
+              e[fh1 * kCam32VStride] = coef_add(u01, cf[i][2]);                                           \
+              e[(fh1 + 1) * kCam32VStride] = coef_add(u11, cf[i][3]);                                     \
+            }                                                                                             \
+          }                                                                                               \
+        }                                                                                                 \
+        __builtin_amdgcn_wave_barrier();                                                                  \
+      }                                                                                                   \
+      _Pragma("unroll") for (int i = 0; i < PG; ++i)                                                      \
+        if (ps[i] == (s)) mbm |= (1u << (k0s[i] >> 5)) | (1u << ((k0s[i] + fh1 + 1) >> 5));               \
+      UBV_CAM32_MB_STEP(s, 0) UBV_CAM32_MB_STEP(s, 1) UBV_CAM32_MB_STEP(s, 2) UBV_CAM32_MB_STEP(s, 3)     \
+      __builtin_amdgcn_wave_barrier();                                                                    \
+      _Pragma("unroll") for (int i = 0; i < PG; ++i) {                                                    \
+        if (ps[i] == (s)) {                                                                               \
+          uint32_t* e = acol + k0s[i] * kCam32VStride;                                                    \
+          e[0] = 0u; e[kCam32VStride] = 0u; e[fh1 * kCam32VStride] = 0u; e[(fh1 + 1) * kCam32VStride] = 0u; \
+        }                                                                                                 \
+      }                                                                                                   \
+      __builtin_amdgcn_wave_barrier();                                                                    \
     }
-    __builtin_amdgcn_wave_barrier();
+    UBV_CAM32_PASS(0) UBV_CAM32_PASS(1) UBV_CAM32_PASS(2)
+#undef UBV_CAM32_PASS
+#undef UBV_CAM32_MB_STEP
+    static_assert(MBT <= 8, "three passes cover row blocks 0 .. 8");
   }
   float* __restrict__ slab = a.slab + slab_idx * ((long)a.fh * a.fw * DH);
 #pragma unroll
