@@ -310,6 +310,16 @@ int ubv_linear_forward(const void* x, const void* w, const void* bias, void* y, 
 int ubv_gemm_nt(const void* x, int64_t ldx, const void* w_hi, const void* w_lo, int64_t ldw,
                 const float* bias, const void* residual, void* y, int64_t ldy, int64_t M, int N, int K,
                 int dtype, void* stream);
+/* ubv_gemm_nt with a ROW-PERIODIC additive term: Y[m, :] = X[m, :] . W^T + bias + row_bias[m % row_period, :]
+ * (row_bias [row_period, N] in Y's type, leading dimension row_ld).  Replaces `query + query_pos` in front of the
+ * sampling_offsets / attention_weights Linears of the BEV self-attention ([ext] mmcv MultiScaleDeformableAttention
+ * .forward: `query = query + query_pos`, vendored copy P/models/modules/decoder.py:283-284): query_pos is the same
+ * for every sample of the batch, so (query + pos) . W^T = query . W^T + (pos . W^T)[q] with the second term computed
+ * once per step for all layers. */
+int ubv_gemm_nt_rowbias(const void* x, int64_t ldx, const void* w_hi, const void* w_lo, int64_t ldw,
+                        const float* bias, const void* row_bias, int64_t row_period, int64_t row_ld, void* y,
+                        int64_t ldy, int64_t M, int N, int K, int dtype, void* stream);
+
 /* The two GEMMs around the FFN activation ([ext] mmcv FFN: Sequential(Linear, ReLU, Dropout) -> Linear,
  * mmcv/cnn/bricks/transformer.py; configured at projects/UniBEV/configs/unibev/
  * unibev_nus_LC_cnw_256_modality_dropout.py:281-291, ffn_dropout 0.1) with the activation in the epilogue:

@@ -222,3 +222,41 @@ def test_fused_ffn_activation_refuses_a_second_consumer():
     linear_after_relu_dropout(a, w2, None, 0.0, True).sum().backward()
     a = linear_relu_dropout(x.detach().requires_grad_(), w1, None, 0.0, True)
     a.sum().backward()
+
+
+@pytest.mark.parametrize('view', [False, True])
+def test_gemm_nt_row_periodic_bias_and_linear_row_bias(view):
+    """ubv_gemm_nt_rowbias: + row_bias[m % R] in the epilogue (the positional term of the BEV self-attention's
+    offset / logit Linears), through the operator and through linear_cat_pass with its gradients."""
+    from unibev_amd import functional as UF
+    from unibev_amd.linear import linear_cat_pass
+    torch.manual_seed(3)
+    B, R, K, N = 3, 520, 256, 96
+    x = torch.randn(B, R, K, device='cuda')
+    w = torch.randn(N, K, device='cuda') / K ** 0.5
+    b = torch.randn(N, device='cuda')
+    table = torch.randn(R, 3 * N, device='cuda')
+    rb = table[:, N:2 * N] if view else table[:, :N].contiguous()
+    wh, wl, _, _ = UF.split_weight(w)
+    y = UF.gemm_nt(x, wh, wl, bias=b, row_bias=rb)
+    ref = (x.double() @ w.double().t() + b.double() + rb.double()[None]).float()
+    assert y is not None
+    torch.testing.assert_close(y, ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
+    # autograd: two weights sharing the input, pass-through alias, row_bias gradient = sum over the batch
+    w1 = torch.nn.Parameter(w[:64].clone()); w2 = torch.nn.Parameter(w[64:].clone())
+    b1 = torch.nn.Parameter(b[:64].clone()); b2 = torch.nn.Parameter(b[64:].clone())
+    xg = x.clone().requires_grad_()
+    rbg = rb.detach().clone().requires_grad_()
+    out, alias = linear_cat_pass(xg, (w1, w2), (b1, b2), row_bias=rbg)
+    cot, cot2 = torch.randn_like(out), torch.randn_like(xg)
+    ((out * cot).sum() + (alias * cot2).sum()).backward()
+    xr = x.double().requires_grad_()
+    wr = w.double().requires_grad_(); br = b.double().requires_grad_(); rr = rb.double().detach().clone().requires_grad_()
+    outr = xr @ wr.t() + br + rr[None]
+    ((outr * cot.double()).sum() + (xr * cot2.double()).sum()).backward()
+    torch.testing.assert_close(out.detach(), outr.detach().float(), rtol=2e-5, atol=2e-5 * float(outr.detach().abs().max()))
+    tol = lambda t: dict(rtol=2e-4, atol=2e-4 * float(t.abs().max()))       # noqa: E731
+    torch.testing.assert_close(xg.grad, xr.grad.float(), **tol(xr.grad))
+    torch.testing.assert_close(rbg.grad, rr.grad.float(), **tol(rr.grad))
+    torch.testing.assert_close(torch.cat((w1.grad, w2.grad)), wr.grad.float(), **tol(wr.grad))
+    torch.testing.assert_close(torch.cat((b1.grad, b2.grad)), br.grad.float(), **tol(br.grad))

@@ -76,3 +76,52 @@ def test_head_backward_reaches_decoder_and_encoder():
             assert sd[n].grad is not None and torch.isfinite(sd[n].grad).all() and sd[n].grad.abs().sum() > 0, n
         grads.append(sd['transformer.decoder.layers.0.attentions.1.value_proj.weight'].grad.clone())
     assert torch.equal(grads[0], grads[1])
+
+
+def test_positional_term_folded_into_offset_gemm_matches_unfolded():
+    """The BEV self-attentions add ``bev_pos`` as a per-query bias of their offset / logit GEMM (one table GEMM per
+    encoder, encoders._EncoderBase._fold_pos_terms) instead of forming ``query + query_pos``: same outputs and the
+    same gradients — queries, positional embeddings, layer weights — as the unfolded path (train mode off: no
+    dropout, so the two passes are comparable)."""
+    from unibev_amd.modules import encoders as E
+    head, g, img, pts, metas = build_case('cnw')
+    assert E._FOLD_POS
+    names = ['bev_embedding.weight', 'positional_encoding.row_embed.weight', 'positional_encoding.col_embed.weight',
+             'transformer.img_bev_encoder.layers.0.attentions.0.sampling_offsets.weight',
+             'transformer.img_bev_encoder.layers.0.attentions.0.attention_weights.bias',
+             'transformer.pts_bev_encoder.layers.0.attentions.0.attention_weights.weight',
+             'transformer.pts_bev_encoder.layers.0.attentions.0.value_proj.weight',
+             'transformer.img_bev_encoder.layers.0.attentions.0.output_proj.weight']
+    names = [n for n in names if n in dict(head.named_parameters())] + \
+        [n for n, _ in head.named_parameters() if n.endswith('layers.1.attentions.0.sampling_offsets.weight')]
+    params = dict(head.named_parameters())
+    # count which way the self-attentions went: the folded path hands a row_bias to offsets_and_logits
+    from unibev_amd.modules.deform_attn import MultiScaleDeformableAttention as MSDA
+    calls = {'fold': 0, 'plain': 0, 'layers': 0}
+    calls['layers'] = sum(len(enc.layers) for enc in (head.transformer.img_bev_encoder, head.transformer.pts_bev_encoder))
+    orig = MSDA.offsets_and_logits
+
+    def counted(self, query, passthru=False, row_bias=None):
+        if query.shape[1] == head.bev_h * head.bev_w:           # the encoders' self-attentions, not the decoder's
+            calls['fold' if row_bias is not None else 'plain'] += 1
+        return orig(self, query, passthru=passthru, row_bias=row_bias)
+    MSDA.offsets_and_logits = counted
+    res = []
+    for fold in (True, False):
+        E._FOLD_POS = fold
+        try:
+            head.zero_grad(set_to_none=True)
+            outs = head([t(x, device=DEV) for x in img], [t(x, device=DEV) for x in pts], metas)
+            loss = outs['bev_embed'].square().mean() + outs['all_bbox_preds'].square().mean()
+            loss.backward()
+            res.append((outs['bev_embed'].detach().clone(), {n: params[n].grad.clone() for n in names}))
+        finally:
+            E._FOLD_POS = True
+    MSDA.offsets_and_logits = orig
+    assert calls['fold'] == calls['layers'] > 0 and calls['plain'] == calls['layers'], calls    # one pass each way
+    (a, ga), (b, gb) = res
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+    for n in names:
+        scale = float(gb[n].abs().max())
+        assert scale > 0, n
+        torch.testing.assert_close(ga[n], gb[n], rtol=2e-3, atol=2e-3 * scale, msg=lambda m, n=n: f'{n}: {m}')

@@ -51,6 +51,8 @@ SIGNATURES = {
     'ubv_linear_workspace': (c_int64, []),
     'ubv_linear_forward': (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, c_int64, _P]),
     'ubv_gemm_nt': (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_int, _P]),
+    'ubv_gemm_nt_rowbias': (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, c_int,
+                                    c_int, c_int, _P]),
     'ubv_gemm_nt_act': (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, c_int64, c_int64, c_int, c_int, c_int,
                                 c_int, _P, c_float, c_uint64, _P, _P]),
     'ubv_grid_mask': (c_int, [_P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

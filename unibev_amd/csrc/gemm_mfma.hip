@@ -37,7 +37,8 @@ typedef __attribute__((ext_vector_type(4))) float gf32x4_t;      // uint4 / floa
 // keep mask of ubv_relu_dropout_forward (hash of seed and the element's index in the [M, N] output);
 // mode 2 y = acc * scale where mask[m][n] != 0, else 0 — the backward of that activation applied to the
 // input gradient of the NEXT Linear (mask = the activation's saved output).
-struct GemmAct { int mode; const void* mask; uint32_t thresh; float scale; uint64_t seed; const uint64_t* seed_dev; };
+struct GemmAct { int mode; const void* mask; uint32_t thresh; float scale; uint64_t seed; const uint64_t* seed_dev;
+                 long res_period, res_ld; };   // res_period > 0: R is a ROW-PERIODIC term, R[(m % res_period) * res_ld + n]
 
 constexpr int kGemmBM = 128;
 // K is walked in chunks of KC = 32 (f32 data: the hi + lo images double the LDS) or 64 (16-bit data, where
@@ -269,7 +270,8 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 3 : 2)) void gemm_nt_kernel(const v
             }
             if (Rv != nullptr) {
               float r4[4];
-              vec_io<TO, 4>::load((const TO*)Rv + m * ldy + n, r4);
+              const long ro = act.res_period > 0 ? (m % act.res_period) * act.res_ld + n : m * ldy + n;
+              vec_io<TO, 4>::load((const TO*)Rv + ro, r4);
               v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
             }
             vec_io<TO, 4>::store((TO*)Yv + m * ldy + n, v);
@@ -295,7 +297,8 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 3 : 2)) void gemm_nt_kernel(const v
         }
         if (Rv != nullptr) {
           float r4[4];
-          vec_io<TO, 4>::load((const TO*)Rv + o, r4);
+          const long ro = act.res_period > 0 ? (long)((unsigned)m % (unsigned)act.res_period) * act.res_ld + n0 + c4 : o;
+          vec_io<TO, 4>::load((const TO*)Rv + ro, r4);
           v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
         }
         vec_io<TO, 4>::store((TO*)Yv + o, v);
@@ -491,6 +494,18 @@ extern "C" int ubv_gemm_nt(const void* x, int64_t ldx, const void* w_hi, const v
                            const float* bias, const void* residual, void* y, int64_t ldy, int64_t M, int N,
                            int K, int dtype, void* stream) {
   return gemm_nt_run(x, ldx, w_hi, w_lo, ldw, bias, residual, y, ldy, M, N, K, dtype, ubv::GemmAct{}, stream, "gemm_nt");
+}
+
+extern "C" int ubv_gemm_nt_rowbias(const void* x, int64_t ldx, const void* w_hi, const void* w_lo, int64_t ldw,
+                                   const float* bias, const void* row_bias, int64_t row_period, int64_t row_ld, void* y,
+                                   int64_t ldy, int64_t M, int N, int K, int dtype, void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(row_bias != nullptr && row_period > 0 && row_period < (1LL << 31) && M < (1LL << 31) && row_ld >= N &&
+                    row_ld % 4 == 0 && ((uintptr_t)row_bias % 16) == 0,
+                "gemm_nt_rowbias: row_bias [row_period, N] with a 16-byte aligned leading dimension >= N");
+  GemmAct a{};
+  a.res_period = row_period; a.res_ld = row_ld;
+  return gemm_nt_run(x, ldx, w_hi, w_lo, ldw, bias, row_bias, y, ldy, M, N, K, dtype, a, stream, "gemm_nt_rowbias");
 }
 
 extern "C" int ubv_gemm_nt_act(const void* x, int64_t ldx, const void* w_hi, const void* w_lo, int64_t ldw,

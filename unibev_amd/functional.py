@@ -693,11 +693,12 @@ def split_weights_batched(groups):
 
 
 @torch.no_grad()
-def gemm_nt(x, w_hi, w_lo=None, bias=None, residual=None, out=None):
+def gemm_nt(x, w_hi, w_lo=None, bias=None, residual=None, out=None, row_bias=None):
     """y = x @ w^T (+ bias) (+ residual) on the matrix cores (``ubv_gemm_nt``).  f32 ``x`` takes the
     split weight (w_hi, w_lo); 16-bit ``x`` takes w_hi of its own type.  Returns None when the shape
-    is outside the kernel's reach (K % 32, N % 32)."""
-    with _need_cuda(x, w_hi, w_lo, bias, residual, out):
+    is outside the kernel's reach (K % 32, N % 32).  ``row_bias`` [R, N] (a view with a 16-byte aligned row stride is
+    fine): + row_bias[m % R] on row m (``ubv_gemm_nt_rowbias``), instead of ``residual``."""
+    with _need_cuda(x, w_hi, w_lo, bias, residual, out, row_bias):
         K = x.shape[-1]
         M = x.numel() // K
         N = w_hi.shape[0]
@@ -705,6 +706,17 @@ def gemm_nt(x, w_hi, w_lo=None, bias=None, residual=None, out=None):
             return None
         y = out if out is not None else torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
         b = None if bias is None else bias.float().contiguous()
+        if row_bias is not None:
+            assert residual is None and row_bias.dim() == 2 and row_bias.shape[1] == N and row_bias.dtype == x.dtype
+            R, ld = row_bias.shape[0], row_bias.stride(0)
+            if row_bias.stride(1) != 1 or M % R != 0 or ld % 4 != 0 or row_bias.data_ptr() % 16 != 0:
+                return None
+            rc = lib().ubv_gemm_nt_rowbias(_p(x), K, _p(w_hi), _p(w_lo), K, _p(b), _p(row_bias), R, ld, _p(y), N, M, N,
+                                           K, _dt(x), _stream())
+            if rc == -3:
+                return None
+            check(rc, 'gemm_nt_rowbias')
+            return y
         rc = lib().ubv_gemm_nt(_p(x), K, _p(w_hi), _p(w_lo), K, _p(b), _p(residual), _p(y), N, M, N, K,
                                _dt(x), _stream())
         if rc == -3:

@@ -210,9 +210,12 @@ class _Linear(Function):
     (``addmm``: D = grad_alias + grad_out @ W in the GEMM epilogue)."""
 
     @staticmethod
-    def forward(ctx, x, dtype, n, has_bias, passthru, act, *params):
+    def forward(ctx, x, dtype, n, has_bias, passthru, act, row_bias, *params):
+        # row_bias [R, N] (or None): + row_bias[m % R] on row m of the (M, N) output — a term that is the same for
+        # every sample of the batch (the Linear of ``query + query_pos`` split into query . W^T + (pos . W^T)[q])
         weights, biases = params[:n], params[n:]
         ctx.act = act
+        ctx.rb_rows = None if row_bias is None else row_bias.shape[0]
         w = _cached_lowp(weights, dtype)
         b = _cached_lowp(biases, dtype) if has_bias else None
         xc = x.to(dtype)
@@ -240,6 +243,10 @@ class _Linear(Function):
             if fuse:
                 y = UF.gemm_nt_act(xc, split[0], split[1], bias=b, act=1, p=act[1], seed=seed)
                 fused = y is not None
+            if y is None and row_bias is not None and row_bias.dtype == torch.float32:
+                y = UF.gemm_nt(xc, split[0], split[1], bias=b, row_bias=row_bias)
+                if y is not None:
+                    row_bias = None                        # added in the epilogue
             if y is None:
                 y = UF.gemm_nt(xc, split[0], split[1], bias=b)
         elif ok and dtype != torch.float32 and w.dtype == dtype and w.is_contiguous() and \
@@ -267,6 +274,9 @@ class _Linear(Function):
             xh, xl = split_(xc)
             wh, wl = split_(w)
             y = F.linear(xh, wh, b) + F.linear(xh, wl) + F.linear(xl, wh)
+        if row_bias is not None:                           # paths without the epilogue term
+            R = row_bias.shape[0]
+            y = (y.reshape(-1, R, y.shape[-1]) + row_bias.to(y.dtype)).reshape(y.shape)
         if fuse and not fused:
             y = UF.relu_dropout_raw(y, act[1], seed) if y.is_cuda else \
                 F.dropout(torch.relu(y), act[1], training=act[1] > 0)
@@ -300,6 +310,14 @@ class _Linear(Function):
             else:
                 grad_out = grad_out * (a_out != 0).to(grad_out.dtype) / (1.0 - act[1])
         go2 = grad_out.reshape(-1, grad_out.shape[-1])
+        grb = None
+        if ctx.rb_rows is not None and ctx.needs_input_grad[6]:
+            # d(row_bias) = sum over the batch of grad_out's row blocks (plain adds: the framework's outer-dimension
+            # reduction is slow on this shape, see bricks._ExpandBatch)
+            g3 = go2.reshape(-1, ctx.rb_rows, go2.shape[-1])
+            grb = g3[0] if g3.shape[0] == 1 else g3[0] + g3[1]
+            for i in range(2, g3.shape[0]):
+                grb = grb + g3[i]
         gx = None
         if act is not None and act[0] == 'masked_in' and ctx.needs_input_grad[0]:
             assert grad_alias is None, 'linear_after_relu_dropout has no pass-through output'
@@ -350,8 +368,8 @@ class _Linear(Function):
         x2 = xc.reshape(-1, xc.shape[-1])
         rows = x2.shape[0]
         gw = gb = None
-        need_w = any(ctx.needs_input_grad[6:6 + n])
-        need_b = has_bias and any(ctx.needs_input_grad[6 + n:])
+        need_w = any(ctx.needs_input_grad[7:7 + n])
+        need_b = has_bias and any(ctx.needs_input_grad[7 + n:])
         part = None
         if (need_w or need_b) and go2.is_cuda and _MFMA_WGRAD and go2.dtype == x2.dtype and \
                 go2.is_contiguous() and x2.is_contiguous():
@@ -364,13 +382,13 @@ class _Linear(Function):
                 grads = []
                 off = 0
                 for i in range(n):
-                    grads.append(gw[off:off + outs[i]].to(pdt[i]) if ctx.needs_input_grad[6 + i] else None)
+                    grads.append(gw[off:off + outs[i]].to(pdt[i]) if ctx.needs_input_grad[7 + i] else None)
                     off += outs[i]
                 off = 0
                 for i in range(n if has_bias else 0):
                     grads.append(gb[off:off + outs[i]].to(pdt[n + i]))
                     off += outs[i]
-                return (gx, None, None, None, None, None, *grads)
+                return (gx, None, None, None, None, None, grb, *grads)
         if need_w:
             s = _splits(rows)
             if s > 1:
@@ -403,10 +421,10 @@ class _Linear(Function):
         for i in range(n if has_bias else 0):
             grads.append(None if gb is None else gb[off:off + outs[i]].to(pdt[n + i]))
             off += outs[i]
-        return (gx, None, None, None, None, None, *grads)
+        return (gx, None, None, None, None, None, grb, *grads)
 
 
-def _run(x, weights, biases, passthru=False, act=None):
+def _run(x, weights, biases, passthru=False, act=None, row_bias=None):
     has_bias = biases[0] is not None
     params = list(weights) + (list(biases) if has_bias else [])
     if x.is_cuda and torch.is_autocast_enabled('cuda'):
@@ -414,9 +432,9 @@ def _run(x, weights, biases, passthru=False, act=None):
         # autocast dtype, so the ambient policy has nothing to cast (and the context manager costs
         # ~1 us x 3 per call on a host-bound forward)
         return _Linear.apply(x, torch.get_autocast_dtype('cuda'), len(weights), has_bias, passthru, act,
-                             *params)
+                             row_bias, *params)
     return _Linear.apply(x, x.dtype if x.dtype == weights[0].dtype else weights[0].dtype,
-                         len(weights), has_bias, passthru, act, *params)
+                         len(weights), has_bias, passthru, act, row_bias, *params)
 
 
 def linear(x, weight, bias=None):
@@ -455,6 +473,7 @@ def linear_pass(x, weight, bias=None):
     return _run(x, [weight], [bias], passthru=True)
 
 
-def linear_cat_pass(x, weights, biases):
-    """``linear_cat`` with the pass-through alias of ``linear_pass``."""
-    return _run(x, list(weights), list(biases), passthru=True)
+def linear_cat_pass(x, weights, biases, row_bias=None):
+    """``linear_cat`` with the pass-through alias of ``linear_pass``; ``row_bias`` [R, N]: + row_bias[m % R] on output
+    row m (a term shared by the samples of the batch, see ``_Linear``)."""
+    return _run(x, list(weights), list(biases), passthru=True, row_bias=row_bias)

@@ -367,7 +367,12 @@ class LearnedPositionalEncoding(BaseModule):
         y_embed = self.row_embed.weight[:h]
         pos = torch.cat((x_embed.unsqueeze(0).expand(h, w, -1),
                          y_embed.unsqueeze(1).expand(h, w, -1)), dim=-1)      # (h, w, 2F)
-        return pos.permute(2, 0, 1).unsqueeze(0).expand(bs, -1, -1, -1)
+        out = pos.permute(2, 0, 1).unsqueeze(0).expand(bs, -1, -1, -1)
+        # the un-expanded (h, w, C) table: UniBEVTransformer folds `query + query_pos` of the BEV self-attentions into a
+        # per-query bias of their offset / logit Linears (encoders._EncoderBase._fold_pos_terms), which needs the
+        # positional term once, not once per sample
+        out._ubv_pos_hw = pos
+        return out
 
 
 class _ExpandBatch(torch.autograd.Function):
@@ -393,9 +398,14 @@ def cast_keep_expand(t, dtype):
     materialising bs copies (and their transposed strides) as a plain ``.to`` would."""
     if t is None:
         return t
+    base = getattr(t, '_ubv_pos_hw', None)                  # LearnedPositionalEncoding's un-expanded table rides along
     if t.dim() > 1 and t.stride(0) == 0 and t.shape[0] > 1:
-        return _ExpandBatch.apply(t[:1].to(dtype), t.shape[0])
-    return t.to(dtype)
+        out = _ExpandBatch.apply(t[:1].to(dtype), t.shape[0])
+    else:
+        out = t.to(dtype)
+    if base is not None and out is not t and base.dtype == dtype:
+        out._ubv_pos_hw = base
+    return out
 
 
 __all__ = ['BaseModule', 'FFN', 'MultiheadAttention', 'BaseTransformerLayer',

@@ -148,10 +148,15 @@ class _DeformAttnBase(BaseModule):
     init_weight = init_weights
 
     # -- pieces --------------------------------------------------------------------------------
-    def offsets_and_logits(self, query, passthru=False):
+    def offsets_and_logits(self, query, passthru=False, row_bias=None):
         """One GEMM for both query Linears: rows [H*L*P*2 offsets | H*L*P logits].
         ``passthru``: also return the alias of ``query`` for the caller's residual branch
-        (``linear.linear_pass``)."""
+        (``linear.linear_pass``).  ``row_bias`` (Nq, H*L*P*3): the positional term of these Linears, the same for
+        every sample, added in the GEMM epilogue (``encoders._EncoderBase._fold_pos_terms``)."""
+        if row_bias is not None:
+            assert passthru
+            return linear_cat_pass(query, (self.sampling_offsets.weight, self.attention_weights.weight),
+                                   (self.sampling_offsets.bias, self.attention_weights.bias), row_bias=row_bias)
         if _OFFLOG_F32() and query.is_cuda and torch.is_autocast_enabled('cuda'):
             # offsets / logits computed and kept in f32 under autocast (precision knob: a 16-bit
             # pixel offset of 8 px carries 4e-3 px of rounding)
@@ -206,6 +211,30 @@ class MultiScaleDeformableAttention(_DeformAttnBase):
             value = query
         if identity is None:
             identity = query
+        pos_term = kwargs.pop('pos_term', None)
+        if pos_term is not None and kwargs.get('return_parts') and self.batch_first and value is query and \
+                identity is query and key_padding_mask is None and query.is_cuda and reference_points is not None and \
+                reference_points.shape[-1] == 2 and reference_points.shape[2] == 1 and \
+                pos_term.shape[0] == query.shape[1] and \
+                UF.bev_lift_supported(self.num_heads, self.embed_dims // self.num_heads, self.num_points, query.dtype):
+            # BEV self-attention with the positional term folded into the offset / logit GEMM (no `query + query_pos`):
+            # query -> value_proj -> alias -> offsets | logits -> alias = the residual, so the residual's gradient
+            # passes through both input-gradient GEMMs' epilogues and nothing is summed at the fan-out.  The first
+            # layer's batch-expanded queries are materialised once, for both GEMMs and the residual.
+            x = query if query.is_contiguous() else query.contiguous()
+            bs, num_query, _ = x.shape
+            hw = static_hw(spatial_shapes)
+            assert sum(h * w for h, w in hw) == num_query
+            v, alias = self.project_value(x, passthru=True)
+            offlog, identity = self.offsets_and_logits(alias, passthru=True, row_bias=pos_term)
+            grid = kwargs.get('bev_h'), kwargs.get('bev_w')
+            qgrid = grid if (grid[0] and grid[1] and grid[0] * grid[1] == num_query) else None
+            output = UF.bev_lift(v, offlog, reference_points.reshape(1, bs, num_query, 1, 2), 1, hw[0],
+                                 self.num_heads, self.num_points, query_grid=qgrid,
+                                 ref_is_grid=bool(kwargs.get('ref_is_grid')) and qgrid is not None,
+                                 slot_center=self.sampling_offsets.bias)
+            output = ubv_linear(output, self.output_proj.weight, self.output_proj.bias)
+            return output, identity, self.dropout.p
         if query_pos is not None:
             query = query + query_pos
         if not self.batch_first:

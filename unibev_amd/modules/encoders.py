@@ -18,6 +18,9 @@ from ..registry import TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE
 from .bricks import BaseTransformerLayer, TransformerLayerSequence
 from .deform_attn import shapes_tensor
 
+import os
+_FOLD_POS = os.environ.get('UBV_FOLD_POS', '1') != '0'
+
 
 def pillar_axes(H, W, Z, num_points_in_pillar, device, dtype=torch.float32):
     """Normalised 1-D pillar coordinates (xs[W], ys[H], zs[D]) with the reference's arithmetic
@@ -74,10 +77,37 @@ class _EncoderBase(TransformerLayerSequence):
             self._ref_cache[key] = v
         return v
 
+    def _fold_pos_terms(self, base, bev_query):
+        """``bev_pos`` is the same for every sample, so ``(query + bev_pos) . W^T`` of each layer's
+        sampling_offsets | attention_weights Linear is ``query . W^T + (bev_pos . W^T)[q]``: ONE GEMM over the (Nq, C)
+        table for all layers of this encoder gives the second terms, which the layers' GEMMs add in their epilogue
+        (``ubv_gemm_nt_rowbias``).  Per layer this removes the ``query + query_pos`` pass (and the saved sum), lets the
+        residual's gradient ride through both input-gradient GEMMs of the self-attention (no gradient sum at the
+        fan-out), and shrinks the positional gradient from (bs, Nq, C) accumulations to one (Nq, .) GEMM.
+        Returns the per-layer (Nq, H*P*3) views, or None when a layer is not shaped for it.  UBV_FOLD_POS=0: off."""
+        if base is None or not _FOLD_POS or not bev_query.is_cuda or bev_query.dtype != torch.float32:
+            return None
+        from .deform_attn import MultiScaleDeformableAttention
+        ws, sizes = [], []
+        for layer in self.layers:
+            att = layer.attentions[0] if len(getattr(layer, 'attentions', ())) else None
+            if not isinstance(att, MultiScaleDeformableAttention) or layer.operation_order[0] != 'self_attn' or \
+                    layer.pre_norm or not att.batch_first or att.num_levels != 1 or \
+                    att.sampling_offsets.weight.shape[1] != base.shape[1]:
+                return None
+            ws += [att.sampling_offsets.weight, att.attention_weights.weight]
+            sizes.append(att.sampling_offsets.weight.shape[0] + att.attention_weights.weight.shape[0])
+        from ..linear import linear_cat
+        terms = linear_cat(base, ws, [None] * len(ws))               # (Nq, sum of sizes), no bias: the layers add theirs
+        return list(torch.split(terms, sizes, dim=1))
+
     def _run_layers(self, bev_query, key, value, args, layer_kwargs):
         intermediate = []
         output = bev_query
-        for layer in self.layers:
+        pos_terms = self._fold_pos_terms(layer_kwargs.pop('bev_pos_base', None), bev_query)
+        for li, layer in enumerate(self.layers):
+            if pos_terms is not None:
+                layer_kwargs['pos_term'] = pos_terms[li]
             output = layer(bev_query, key, value, *args, **layer_kwargs)
             bev_query = output
             if self.return_intermediate:
@@ -245,7 +275,7 @@ class _BevLayer(BaseTransformerLayer):
     def forward(self, query, key=None, value=None, bev_pos=None, query_pos=None, key_pos=None,
                 attn_masks=None, query_key_padding_mask=None, key_padding_mask=None, ref_2d=None,
                 ref_3d=None, bev_h=None, bev_w=None, mask=None, spatial_shapes=None,
-                level_start_index=None, **kwargs):
+                level_start_index=None, pos_term=None, **kwargs):
         norm_index = attn_index = ffn_index = 0
         identity = query
         if attn_masks is None:
@@ -271,7 +301,7 @@ class _BevLayer(BaseTransformerLayer):
                     key_pos=bev_pos, attn_mask=attn_masks[attn_index],
                     key_padding_mask=query_key_padding_mask, reference_points=ref_2d,
                     spatial_shapes=ss, level_start_index=lsi, bev_h=bev_h, bev_w=bev_w,
-                    return_parts=parts, **kwargs)
+                    return_parts=parts, pos_term=pos_term, **kwargs)
                 attn_index += 1
                 fuse_next = parts and isinstance(query, tuple)
                 if not fuse_next:

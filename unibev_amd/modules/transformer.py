@@ -271,7 +271,12 @@ class UniBEVTransformer(BaseModule):
     def _encode(self, img_mlvl_feats, pts_mlvl_feats, bev_queries, bev_h, bev_w, bev_pos,
                 return_parts, **kwargs):
         bs = self._draw_modality_flags(img_mlvl_feats, pts_mlvl_feats)
+        pos_base = None
         if bev_pos is not None:
+            base = getattr(bev_pos, '_ubv_pos_hw', None)            # (h, w, C) table behind the batch-expanded bev_pos
+            if base is not None and base.is_cuda and base.dtype == torch.float32 and \
+                    not torch.is_autocast_enabled('cuda') and base.shape[0] * base.shape[1] == bev_h * bev_w:
+                pos_base = base.reshape(bev_h * bev_w, -1)
             bev_pos = bev_pos.flatten(2).permute(2, 0, 1)
         if torch.is_autocast_enabled('cuda') and \
                 (bev_queries[0] if isinstance(bev_queries, list) else bev_queries).is_cuda:
@@ -297,12 +302,12 @@ class UniBEVTransformer(BaseModule):
         def run_img():
             flat, ss, lsi = self._pre_process_img_feats(img_mlvl_feats, q_img)
             return self.img_bev_encoder(q_img, flat, flat, bev_h=bev_h, bev_w=bev_w, bev_pos=bev_pos,
-                                        spatial_shapes=ss, level_start_index=lsi, **kwargs)
+                                        spatial_shapes=ss, level_start_index=lsi, bev_pos_base=pos_base, **kwargs)
 
         def run_pts():
             flat, ss, lsi = self._pre_process_pts_feats(pts_mlvl_feats, q_pts)
             return self.pts_bev_encoder(q_pts, flat, flat, bev_h=bev_h, bev_w=bev_w, bev_pos=bev_pos,
-                                        spatial_shapes=ss, level_start_index=lsi, **kwargs)
+                                        spatial_shapes=ss, level_start_index=lsi, bev_pos_base=pos_base, **kwargs)
 
         ref_q = q_img if img_mlvl_feats is not None else q_pts
         if img_mlvl_feats is not None and pts_mlvl_feats is not None and ref_q.is_cuda and _TWO_STREAMS[0]:
