@@ -310,6 +310,20 @@ int ubv_linear_forward(const void* x, const void* w, const void* bias, void* y, 
 int ubv_gemm_nt(const void* x, int64_t ldx, const void* w_hi, const void* w_lo, int64_t ldw,
                 const float* bias, const void* residual, void* y, int64_t ldy, int64_t M, int N, int K,
                 int dtype, void* stream);
+/* The fused value_proj | sampling_offsets | attention_weights GEMM of the BEV self-attention ([ext] mmcv
+ * MultiScaleDeformableAttention.forward, vendored copy P/models/modules/decoder.py:283-312: three Linears on the same
+ * query) and its backward, f32 data.  ubv_gemm_nt_dual is ubv_gemm_nt with optional extras: columns k >= k_split of X
+ * come from x2 [M, K - k_split] (the input gradient of the concatenated weight from the two output gradients), columns
+ * n >= n_split of Y go to y2 [M, N - n_split] (value to one tensor, offsets | logits to another; n_split a multiple of
+ * 128, N need not fill the last column tile) and the row-periodic term of ubv_gemm_nt_rowbias then applies to y2 only.
+ * ubv_gemm_wgrad_dual is ubv_gemm_wgrad with grad_out given as [M, n_split] + [M, N - n_split]. */
+int ubv_gemm_nt_dual(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int k_split, const void* w_hi,
+                     const void* w_lo, int64_t ldw, const float* bias, const void* residual, const void* row_bias,
+                     int64_t row_period, int64_t row_ld, void* y, int64_t ldy, void* y2, int64_t ldy2, int n_split,
+                     int64_t M, int N, int K, void* stream);
+int ubv_gemm_wgrad_dual(const void* grad_out, const void* grad_out2, int n_split, const void* x, float* partials,
+                        float* grad_wb, int64_t M, int N, int K, int splits, void* stream);
+
 /* ubv_gemm_nt with a ROW-PERIODIC additive term: Y[m, :] = X[m, :] . W^T + bias + row_bias[m % row_period, :]
  * (row_bias [row_period, N] in Y's type, leading dimension row_ld).  Replaces `query + query_pos` in front of the
  * sampling_offsets / attention_weights Linears of the BEV self-attention ([ext] mmcv MultiScaleDeformableAttention

@@ -22,3 +22,15 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _seed_every_test():
+    """Every test starts from the same generator state (torch CPU + device, numpy): a test that draws inputs without
+    seeding them itself — and holds a tolerance that is a statement about round-off, ReLU flips or pixel-boundary
+    points — must not pass or fail by the draw."""
+    import numpy as np
+    import torch
+    torch.manual_seed(20240917)
+    np.random.seed(20240917 % (2 ** 32))
+    yield

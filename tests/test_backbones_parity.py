@@ -147,6 +147,7 @@ def test_resnet_dcn_stages_on_the_device_match_the_oracle():
                norm_eval=True, style='caffe', with_cp=True, dcn=dict(type='DCNv2', deform_groups=1, fallback_on_stride=False),
                stage_with_dcn=(False, False, True, True))
     m = ResNet(**cfg).train()
+    torch.manual_seed(11)          # (a fixed input: the gradient bound above is a statement about ReLU flips, which differ per input)
     x = torch.randn(2, 3, 96, 160)
     _compare(m, lambda P, x: R.resnet(P, x, 50, out_indices=(2, 3), style='caffe'), x, 2e-4, 8e-2, dev='cuda',
              grad_names=('layer3.1.conv2.weight', 'layer3.1.conv2.conv_offset.weight', 'layer4.0.conv2.conv_offset.bias',
@@ -159,6 +160,7 @@ def test_necks_and_lidar_backbone_on_the_device_match_the_oracle():
     from unibev_amd.registry import BACKBONES, NECKS, build_from_cfg
     neck = build_from_cfg(IMG_NECK, NECKS)
     P = _randomize(neck, 7)
+    torch.manual_seed(12)
     x = torch.randn(4, 2048, 8, 22)
     out = neck.cuda()([x.cuda()])
     ref = R.fpn(P, [x.double()], 1, 0, 'on_output', True)

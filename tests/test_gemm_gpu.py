@@ -260,3 +260,36 @@ def test_gemm_nt_row_periodic_bias_and_linear_row_bias(view):
     torch.testing.assert_close(rbg.grad, rr.grad.float(), **tol(rr.grad))
     torch.testing.assert_close(torch.cat((w1.grad, w2.grad)), wr.grad.float(), **tol(wr.grad))
     torch.testing.assert_close(torch.cat((b1.grad, b2.grad)), br.grad.float(), **tol(br.grad))
+
+
+def test_self_attn_in_fused_gemm_matches_separate_linears():
+    """ubv_gemm_nt_dual / ubv_gemm_wgrad_dual through linear.self_attn_in: value_proj | offsets | logits in one GEMM with
+    two outputs and the row-periodic positional term on the second, one input-gradient GEMM over both output gradients
+    with the residual's gradient in its epilogue, one weight-gradient pass — against fp64 torch."""
+    from unibev_amd.linear import self_attn_in, self_attn_in_supported
+    torch.manual_seed(5)
+    B, R, C, NV, NO, NA = 2, 700, 256, 256, 64, 32
+    x = torch.randn(B, R, C, device='cuda')
+    mk = lambda n: torch.nn.Parameter(torch.randn(n, C, device='cuda') / C ** 0.5)      # noqa: E731
+    wv, wo, wa = mk(NV), mk(NO), mk(NA)
+    bv, bo, ba = (torch.nn.Parameter(torch.randn(n, device='cuda')) for n in (NV, NO, NA))
+    table = torch.randn(R, 2 * (NO + NA), device='cuda')
+    rb = table[:, NO + NA:].detach().requires_grad_()           # a view with a row stride, as the encoders pass it
+    xg = x.clone().requires_grad_()
+    assert self_attn_in_supported(xg, rb, wv, wo, wa)
+    v, ol, alias = self_attn_in(xg, rb, wv, bv, wo, bo, wa, ba)
+    cv, co, ca = torch.randn_like(v), torch.randn_like(ol), torch.randn_like(alias)
+    ((v * cv).sum() + (ol * co).sum() + (alias * ca).sum()).backward()
+    d = lambda t: t.detach().double().requires_grad_()          # noqa: E731
+    xr, rr = d(x), d(rb)
+    pr = [d(p) for p in (wv, bv, wo, bo, wa, ba)]
+    vr = xr @ pr[0].t() + pr[1]
+    olr = xr @ torch.cat((pr[2], pr[4])).t() + torch.cat((pr[3], pr[5])) + rr[None]
+    ((vr * cv.double()).sum() + (olr * co.double()).sum() + (xr * ca.double()).sum()).backward()
+    tol = lambda t, r=2e-5: dict(rtol=r, atol=r * float(t.detach().abs().max()))       # noqa: E731
+    torch.testing.assert_close(v.detach(), vr.detach().float(), **tol(vr))
+    torch.testing.assert_close(ol.detach(), olr.detach().float(), **tol(olr))
+    torch.testing.assert_close(xg.grad, xr.grad.float(), **tol(xr.grad, 2e-4))
+    torch.testing.assert_close(rb.grad, rr.grad.float(), **tol(rr.grad, 2e-4))
+    for got, ref in zip((wv, bv, wo, bo, wa, ba), pr):
+        torch.testing.assert_close(got.grad, ref.grad.float(), **tol(ref.grad, 2e-4))

@@ -106,6 +106,14 @@ def test_positional_term_folded_into_offset_gemm_matches_unfolded():
             calls['fold' if row_bias is not None else 'plain'] += 1
         return orig(self, query, passthru=passthru, row_bias=row_bias)
     MSDA.offsets_and_logits = counted
+    # ... or goes straight to the fused value | offsets | logits GEMM
+    from unibev_amd.modules import deform_attn as DA
+    fused = DA.self_attn_in
+
+    def counted_fused(x, row_bias, *a, **k):
+        calls['fold'] += 1
+        return fused(x, row_bias, *a, **k)
+    DA.self_attn_in = counted_fused
     res = []
     for fold in (True, False):
         E._FOLD_POS = fold
@@ -118,6 +126,7 @@ def test_positional_term_folded_into_offset_gemm_matches_unfolded():
         finally:
             E._FOLD_POS = True
     MSDA.offsets_and_logits = orig
+    DA.self_attn_in = fused
     assert calls['fold'] == calls['layers'] > 0 and calls['plain'] == calls['layers'], calls    # one pass each way
     (a, ga), (b, gb) = res
     torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))

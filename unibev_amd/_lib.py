@@ -51,6 +51,9 @@ SIGNATURES = {
     'ubv_linear_workspace': (c_int64, []),
     'ubv_linear_forward': (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, c_int64, _P]),
     'ubv_gemm_nt': (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_int, _P]),
+    'ubv_gemm_nt_dual': (c_int, [_P, c_int64, _P, c_int64, c_int, _P, _P, c_int64, _P, _P, _P, c_int64, c_int64, _P, c_int64,
+                                 _P, c_int64, c_int, c_int64, c_int, c_int, _P]),
+    'ubv_gemm_wgrad_dual': (c_int, [_P, _P, c_int, _P, _P, _P, c_int64, c_int, c_int, c_int, _P]),
     'ubv_gemm_nt_rowbias': (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, c_int,
                                     c_int, c_int, _P]),
     'ubv_gemm_nt_act': (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, c_int64, c_int64, c_int, c_int, c_int,

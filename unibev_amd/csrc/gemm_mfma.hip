@@ -38,7 +38,12 @@ typedef __attribute__((ext_vector_type(4))) float gf32x4_t;      // uint4 / floa
 // mode 2 y = acc * scale where mask[m][n] != 0, else 0 — the backward of that activation applied to the
 // input gradient of the NEXT Linear (mask = the activation's saved output).
 struct GemmAct { int mode; const void* mask; uint32_t thresh; float scale; uint64_t seed; const uint64_t* seed_dev;
-                 long res_period, res_ld; };   // res_period > 0: R is a ROW-PERIODIC term, R[(m % res_period) * res_ld + n]
+                 long res_period, res_ld;      // res_period > 0: R is a ROW-PERIODIC term, R[(m % res_period) * res_ld + n]
+                 // "dual" form (ubv_gemm_nt_dual; the fused value_proj | offsets | logits GEMM of the BEV self-attention
+                 // and its input gradient): X's columns k >= k_split come from a second matrix, Y's columns n >= n_split
+                 // go to a second matrix (the row-periodic term then applies to those only); N need not fill the last
+                 // column tile
+                 const void* x2; long ldx2; int k_split; void* y2; long ldy2; int n_split; };
 
 constexpr int kGemmBM = 128;
 // K is walked in chunks of KC = 32 (f32 data: the hi + lo images double the LDS) or 64 (16-bit data, where
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 3 : 2)) void gemm_nt_kernel(const v
   const int wm = TWO_D ? (wv >> 1) : wv, wn = TWO_D ? (wv & 1) : 0;
   // 1-D grid, XCD-aware: block ids go round-robin over the 8 XCDs, so the column tiles of one row tile
   // are given consecutive slots of ONE XCD — they run together and share the X rows through its L2
-  const int ny = N / NT, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int ny = (N + NT - 1) / NT, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const long m0 = ((long)(slot / ny) * 8 + xcd) * kGemmBM;
   const int n0 = (slot % ny) * NT;
   if (m0 >= M) return;
@@ -106,18 +111,30 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 3 : 2)) void gemm_nt_kernel(const v
     const long r = m0 + xr + XSTEP * i;
     xrow[i] = (r < M ? r : M - 1) * ldx + xc;
   }
+  long xrow2[SPLIT ? XI : 1];
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const long r = m0 + xr + XSTEP * i;
+      xrow2[i] = (r < M ? r : M - 1) * act.ldx2 + xc;
+    }
+  }
   long wrow[WI];
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
     const int r = wr + WSTEP * i;
-    wrow[i] = (long)(n0 + (r < NT ? r : NT - 1)) * ldw + wc;          // N % NT == 0 (host)
+    const int n = n0 + (r < NT ? r : NT - 1);
+    wrow[i] = (long)(n < N ? n : N - 1) * ldw + wc;                   // (a ragged last tile re-reads row N - 1: never stored)
   }
   auto load_x = [&](int k0, auto setc) {
     constexpr int set = decltype(setc)::value;
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      if constexpr (SPLIT) xf[set][i] = *reinterpret_cast<const gf32x4_t*>((const float*)Xv + xrow[i] + k0);
-      else xq[set][i] = *reinterpret_cast<const gu32x4_t*>((const uint16_t*)Xv + xrow[i] + k0);
+      if constexpr (SPLIT) {
+        const bool second = act.x2 != nullptr && k0 >= act.k_split;          // chunk-uniform (k_split % KC == 0)
+        const float* xb = second ? (const float*)act.x2 : (const float*)Xv;
+        xf[set][i] = *reinterpret_cast<const gf32x4_t*>(xb + (second ? xrow2[i] + (k0 - act.k_split) : xrow[i] + k0));
+      } else xq[set][i] = *reinterpret_cast<const gu32x4_t*>((const uint16_t*)Xv + xrow[i] + k0);
     }
   };
   auto load_w = [&](int k0) {
@@ -245,7 +262,7 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 3 : 2)) void gemm_nt_kernel(const v
         for (int g = 0; g < 4; ++g) {
           const int nl = (wn * WNB + j) * 32 + 8 * g + 4 * half, n = n0 + nl;
           float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          if (bias != nullptr) {
+          if (bias != nullptr && n < N) {
             const float4 b = *reinterpret_cast<const float4*>(bias + n);
             v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
           }
@@ -261,7 +278,7 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 3 : 2)) void gemm_nt_kernel(const v
           if constexpr (STAGE) {
             *reinterpret_cast<float4*>(tile + (mrow & 63) * TLD + nl) = make_float4(v[0], v[1], v[2], v[3]);
           } else {
-            if (m >= M) continue;
+            if (m >= M || n >= N) continue;
             if (act.mode == 2) {
               float k4[4];
               vec_io<TO, 4>::load((const TO*)act.mask + m * ldy + n, k4);
@@ -282,26 +299,31 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 3 : 2)) void gemm_nt_kernel(const v
     if constexpr (STAGE) {
       __syncthreads();
       constexpr int CPR = NT / 4;                          // 16-byte chunks per row
+      const bool second = act.n_split > 0 && n0 >= act.n_split;           // (block-uniform) this tile belongs to Y2
+      TO* const Yo = second ? (TO*)act.y2 : (TO*)Yv;
+      const long ldo = second ? act.ldy2 : ldy;
+      const int nb = second ? n0 - act.n_split : n0;
+      const bool with_r = Rv != nullptr && (act.n_split == 0 || second);
       for (int e = tid; e < 64 * CPR; e += 256) {
         const int rl = e / CPR, c4 = (e - rl * CPR) * 4;
         const long m = m0 + hh * 64 + rl;
-        if (m >= M) continue;
+        if (m >= M || n0 + c4 >= N) continue;
         const float4 t4 = *reinterpret_cast<const float4*>(tile + rl * TLD + c4);
         float v[4] = {t4.x, t4.y, t4.z, t4.w};
-        const long o = m * ldy + n0 + c4;
+        const long o = m * ldo + nb + c4;
         if (act.mode == 2) {
           float k4[4];
           vec_io<TO, 4>::load((const TO*)act.mask + o, k4);
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = (k4[q] != 0.0f) ? v[q] * act.scale : 0.0f;
         }
-        if (Rv != nullptr) {
+        if (with_r) {
           float r4[4];
-          const long ro = act.res_period > 0 ? (long)((unsigned)m % (unsigned)act.res_period) * act.res_ld + n0 + c4 : o;
+          const long ro = act.res_period > 0 ? (long)((unsigned)m % (unsigned)act.res_period) * act.res_ld + nb + c4 : o;
           vec_io<TO, 4>::load((const TO*)Rv + ro, r4);
           v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
         }
-        vec_io<TO, 4>::store((TO*)Yv + o, v);
+        vec_io<TO, 4>::store(Yo + o, v);
       }
     }
   }
@@ -400,9 +422,10 @@ static int gemm_nt_launch(const void* X, long ldx, const void* Wh, const void* W
   int nt = 0;
   for (int c : {256, 192, 128, 96, 64, 32})
     if (c <= nt_cap && N % c == 0) { nt = c; break; }
+  if (act.n_split > 0) nt = 128;                           // dual outputs: 128-column tiles, the last one may be ragged
   if (nt == 0) return UBV_ERR_UNSUPPORTED;
   const long row_tiles = (M + kGemmBM - 1) / kGemmBM;
-  const dim3 grid((unsigned)((row_tiles + 7) / 8 * 8 * (N / nt))), blk(256);
+  const dim3 grid((unsigned)((row_tiles + 7) / 8 * 8 * ((N + nt - 1) / nt))), blk(256);
   // operand tiles, or the epilogue's staged half tile (64 rows of nt + 4 floats) where that is larger: 16-bit data
   // with 32-deep chunks (K % 64 != 0)
   size_t lds = (size_t)((SPLIT ? 2 : 1) * (kGemmBM + nt) * (kc + 8)) * sizeof(uint16_t);
@@ -508,6 +531,27 @@ extern "C" int ubv_gemm_nt_rowbias(const void* x, int64_t ldx, const void* w_hi,
   return gemm_nt_run(x, ldx, w_hi, w_lo, ldw, bias, row_bias, y, ldy, M, N, K, dtype, a, stream, "gemm_nt_rowbias");
 }
 
+extern "C" int ubv_gemm_nt_dual(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int k_split, const void* w_hi,
+                                const void* w_lo, int64_t ldw, const float* bias, const void* residual,
+                                const void* row_bias, int64_t row_period, int64_t row_ld, void* y, int64_t ldy, void* y2,
+                                int64_t ldy2, int n_split, int64_t M, int N, int K, void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG((x2 == nullptr) == (k_split == 0) && (y2 == nullptr) == (n_split == 0), "gemm_nt_dual: x2 / k_split and y2 / n_split come in pairs");
+  UBV_CHECK_ARG(x2 == nullptr || (k_split > 0 && k_split < K && k_split % 32 == 0 && ldx2 % 4 == 0 && ((uintptr_t)x2 % 16) == 0),
+                "gemm_nt_dual: k_split must be a multiple of 32 inside K, x2 16-byte aligned rows");
+  UBV_CHECK_ARG(y2 == nullptr || (n_split > 0 && n_split < N && n_split % 128 == 0 && ldy2 % 4 == 0 && ((uintptr_t)y2 % 16) == 0),
+                "gemm_nt_dual: n_split must be a multiple of 128 inside N, y2 16-byte aligned rows");
+  UBV_CHECK_ARG(residual == nullptr || row_bias == nullptr, "gemm_nt_dual: residual or row_bias, not both");
+  UBV_CHECK_ARG(row_bias == nullptr || (row_period > 0 && row_period < (1LL << 31) && M < (1LL << 31) && row_ld % 4 == 0 &&
+                                        ((uintptr_t)row_bias % 16) == 0), "gemm_nt_dual: bad row_bias");
+  UBV_CHECK_ARG(residual == nullptr || y2 == nullptr, "gemm_nt_dual: a full residual needs a single output");
+  GemmAct a{};
+  a.x2 = x2; a.ldx2 = ldx2; a.k_split = k_split; a.y2 = y2; a.ldy2 = ldy2; a.n_split = n_split;
+  if (row_bias != nullptr) { a.res_period = row_period; a.res_ld = row_ld; }
+  return gemm_nt_run(x, ldx, w_hi, w_lo, ldw, bias, row_bias != nullptr ? row_bias : residual, y, ldy, M, N, K, UBV_F32,
+                     a, stream, "gemm_nt_dual");
+}
+
 extern "C" int ubv_gemm_nt_act(const void* x, int64_t ldx, const void* w_hi, const void* w_lo, int64_t ldw,
                                const float* bias, void* y, int64_t ldy, int64_t M, int N, int K, int dtype,
                                int act, const void* mask, float p, uint64_t seed, const uint64_t* seed_dev,
@@ -570,7 +614,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
                                                             int tiles_k, int tiles, int splits, int rows_per_split,
                                                             const int32_t* __restrict__ xidx, long xld,
                                                             const int32_t* __restrict__ yidx,
-                                                            const int32_t* __restrict__ cnt) {
+                                                            const int32_t* __restrict__ cnt,
+                                                            const void* __restrict__ dY2v, int n_split) {
+  // dY2v / n_split (f32 only, ubv_gemm_wgrad_dual): columns n >= n_split of dY live in a second matrix [M, N - n_split]
+  // and the first one is [M, n_split] — the fused value_proj | offsets | logits weight gradient of the BEV self-attention
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   uint16_t* ty_h = lds;
   uint16_t* tx_h = ty_h + kWgPlane;
@@ -633,6 +680,11 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
         if (yidx != nullptr) { const int ry = yidx[mm]; ym = ry >= 0 ? ry : 0; }
       }
       if constexpr (SPLIT) {
+        if (n_split > 0) {
+          const bool second = n0 >= n_split;               // block-uniform (n_split % 128 == 0)
+          const float* yb = second ? (const float*)dY2v : (const float*)dYv;
+          fy[i] = *reinterpret_cast<const gf32x4_t*>(yb + ym * (long)(second ? N - n_split : n_split) + ((second && yok) ? ycol - n_split : ycol));
+        } else
         fy[i] = *reinterpret_cast<const gf32x4_t*>((const float*)dYv + ym * N + ycol);
         fx[i] = *reinterpret_cast<const gf32x4_t*>((const float*)Xv + xm * K + xcol);
         if (!(m < mend && yok)) fy[i] = gf32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -778,8 +830,24 @@ extern "C" int ubv_gemm_wgrad_splits(int64_t M, int N, int K) {
   return (int)s;
 }
 
+static int gemm_wgrad_run(const void* grad_out, const void* grad_out2, int n_split, const void* x, float* partials,
+                          float* grad_wb, int64_t M, int N, int K, int splits, int dtype, void* stream);
+
 extern "C" int ubv_gemm_wgrad(const void* grad_out, const void* x, float* partials, float* grad_wb, int64_t M,
                               int N, int K, int splits, int dtype, void* stream) {
+  return gemm_wgrad_run(grad_out, nullptr, 0, x, partials, grad_wb, M, N, K, splits, dtype, stream);
+}
+
+extern "C" int ubv_gemm_wgrad_dual(const void* grad_out, const void* grad_out2, int n_split, const void* x,
+                                   float* partials, float* grad_wb, int64_t M, int N, int K, int splits, void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(grad_out2 != nullptr && n_split > 0 && n_split < N && n_split % 128 == 0 && (N - n_split) % 4 == 0 &&
+                    ((uintptr_t)grad_out2 % 16) == 0, "gemm_wgrad_dual: n_split must be a multiple of 128 inside N");
+  return gemm_wgrad_run(grad_out, grad_out2, n_split, x, partials, grad_wb, M, N, K, splits, UBV_F32, stream);
+}
+
+static int gemm_wgrad_run(const void* grad_out, const void* grad_out2, int n_split, const void* x, float* partials,
+                          float* grad_wb, int64_t M, int N, int K, int splits, int dtype, void* stream) {
   using namespace ubv;
   UBV_CHECK_ARG(grad_out && x && partials && grad_wb && M > 0 && N > 0 && K > 0 && splits > 0,
                 "gemm_wgrad: bad arguments");
@@ -798,11 +866,11 @@ extern "C" int ubv_gemm_wgrad(const void* grad_out, const void* x, float* partia
   const size_t lds = (size_t)(dtype == UBV_F32 ? 4 : 2) * kWgPlane * sizeof(uint16_t);
   hipStream_t st = as_stream(stream);
   if (dtype == UBV_F32)
-    hipLaunchKernelGGL((gemm_wgrad_kernel<true, false, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps, (const int32_t*)nullptr, 0L, (const int32_t*)nullptr, (const int32_t*)nullptr);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<true, false, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps, (const int32_t*)nullptr, 0L, (const int32_t*)nullptr, (const int32_t*)nullptr, grad_out2, n_split);
   else if (dtype == UBV_F16)
-    hipLaunchKernelGGL((gemm_wgrad_kernel<false, true, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps, (const int32_t*)nullptr, 0L, (const int32_t*)nullptr, (const int32_t*)nullptr);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<false, true, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps, (const int32_t*)nullptr, 0L, (const int32_t*)nullptr, (const int32_t*)nullptr, grad_out2, n_split);
   else
-    hipLaunchKernelGGL((gemm_wgrad_kernel<false, false, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps, (const int32_t*)nullptr, 0L, (const int32_t*)nullptr, (const int32_t*)nullptr);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<false, false, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps, (const int32_t*)nullptr, 0L, (const int32_t*)nullptr, (const int32_t*)nullptr, grad_out2, n_split);
   const long len = (long)N * K + N;
   hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((len / 4 + 31) / 32)), dim3(256), 0, st, partials, splits, len,
                      grad_wb);
@@ -862,11 +930,11 @@ static int spconv_wgrad_run(const void* grad_out, const void* feats, const int32
   const size_t lds = (size_t)(dtype == UBV_F32 ? 4 : 2) * kWgPlane * sizeof(uint16_t);
   hipStream_t st = as_stream(stream);
   if (dtype == UBV_F32)
-    hipLaunchKernelGGL((gemm_wgrad_kernel<true, false, true>), grid, blk, lds, st, grad_out, feats, partials, (long)rows, Cout, Cin, 1, kvol, splits, (int)rps, nbr, (long)ld, out_rows, counts);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<true, false, true>), grid, blk, lds, st, grad_out, feats, partials, (long)rows, Cout, Cin, 1, kvol, splits, (int)rps, nbr, (long)ld, out_rows, counts, (const void*)nullptr, 0);
   else if (dtype == UBV_F16)
-    hipLaunchKernelGGL((gemm_wgrad_kernel<false, true, true>), grid, blk, lds, st, grad_out, feats, partials, (long)rows, Cout, Cin, 1, kvol, splits, (int)rps, nbr, (long)ld, out_rows, counts);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<false, true, true>), grid, blk, lds, st, grad_out, feats, partials, (long)rows, Cout, Cin, 1, kvol, splits, (int)rps, nbr, (long)ld, out_rows, counts, (const void*)nullptr, 0);
   else
-    hipLaunchKernelGGL((gemm_wgrad_kernel<false, false, true>), grid, blk, lds, st, grad_out, feats, partials, (long)rows, Cout, Cin, 1, kvol, splits, (int)rps, nbr, (long)ld, out_rows, counts);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<false, false, true>), grid, blk, lds, st, grad_out, feats, partials, (long)rows, Cout, Cin, 1, kvol, splits, (int)rps, nbr, (long)ld, out_rows, counts, (const void*)nullptr, 0);
   const long len = (long)kvol * ((long)Cout * Cin + Cout);
   hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((len / 4 + 31) / 32)), dim3(256), 0, st, partials, splits, len, grad_w);
   UBV_CHECK_LAUNCH("spconv_wgrad");

@@ -725,6 +725,61 @@ def gemm_nt(x, w_hi, w_lo=None, bias=None, residual=None, out=None, row_bias=Non
         return y
 
 
+def gemm_nt_dual(x, w_hi, w_lo, bias=None, x2=None, residual=None, out=None, y2_cols=0, row_bias=None):
+    """``ubv_gemm_nt_dual`` (f32): y = [x | x2] @ w^T (+ bias) (+ residual), or — ``y2_cols`` > 0 — the last ``y2_cols``
+    output columns returned as a second tensor with ``row_bias[m % R]`` added to them: (y, y2).  None when the shape is
+    outside the kernel's reach."""
+    with _need_cuda(x, w_hi, w_lo, bias, x2, residual, out, row_bias):
+        K1 = x.shape[-1]
+        M = x.numel() // K1
+        K = K1 + (x2.shape[-1] if x2 is not None else 0)
+        N = w_hi.shape[0]
+        ok = x.dtype == torch.float32 and x.is_contiguous() and (x2 is None or (x2.is_contiguous() and x2.dtype == x.dtype)) \
+            and K % 32 == 0 and K1 % 32 == 0 and N % 32 == 0 and w_hi.shape[1] == K
+        n1 = N - y2_cols
+        if not ok or (y2_cols and (n1 <= 0 or n1 % 128 != 0 or y2_cols % 4 != 0)):
+            return None
+        b = None if bias is None else bias.float().contiguous()
+        y = out if out is not None else torch.empty(*x.shape[:-1], n1, dtype=x.dtype, device=x.device)
+        y2 = torch.empty(*x.shape[:-1], y2_cols, dtype=x.dtype, device=x.device) if y2_cols else None
+        R = ld = 0
+        if row_bias is not None:
+            assert y2 is not None and row_bias.shape[1] == y2_cols and row_bias.dtype == x.dtype
+            R, ld = row_bias.shape[0], row_bias.stride(0)
+            if row_bias.stride(1) != 1 or M % R != 0 or ld % 4 != 0 or row_bias.data_ptr() % 16 != 0:
+                return None
+        rc = lib().ubv_gemm_nt_dual(_p(x), K1, _p(x2), 0 if x2 is None else x2.shape[-1], K1 if x2 is not None else 0,
+                                    _p(w_hi), _p(w_lo), K, _p(b), _p(residual), _p(row_bias), R, ld, _p(y), n1,
+                                    _p(y2), y2_cols, n1 if y2_cols else 0, M, N, K, _stream())
+        if rc == -3:
+            return None
+        check(rc, 'gemm_nt_dual')
+        return (y, y2) if y2_cols else y
+
+
+@torch.no_grad()
+def gemm_wgrad_dual(grad_out, grad_out2, x):
+    """``gemm_wgrad`` with grad_out given as two matrices [M, N1] | [M, N2] (N1 a multiple of 128): (grad_weight
+    [N1 + N2, K], grad_bias [N1 + N2]) in one pass over ``x`` (``ubv_gemm_wgrad_dual``, f32).  None when out of reach."""
+    with _need_cuda(grad_out, grad_out2, x):
+        M, N1 = grad_out.shape
+        N2 = grad_out2.shape[1]
+        K = x.shape[1]
+        N = N1 + N2
+        if N1 % 128 != 0 or N2 % 4 != 0 or K % 4 != 0 or M == 0 or grad_out2.shape[0] != M or \
+                not (grad_out.dtype == grad_out2.dtype == x.dtype == torch.float32) or \
+                not (grad_out.is_contiguous() and grad_out2.is_contiguous() and x.is_contiguous()):
+            return None
+        S = int(lib().ubv_gemm_wgrad_splits(M, N, K))
+        part = _workspace(4 * S * (N * K + N), x.device)
+        out = torch.empty(N * K + N, dtype=torch.float32, device=x.device)
+        rc = lib().ubv_gemm_wgrad_dual(_p(grad_out), _p(grad_out2), N1, _p(x), _p(part), _p(out), M, N, K, S, _stream())
+        if rc == -3:
+            return None
+        check(rc, 'gemm_wgrad_dual')
+        return out[:N * K].view(N, K), out[N * K:]
+
+
 def gemm_nt_act(x, w_hi, w_lo=None, bias=None, act=1, mask=None, p=0.0, seed=0):
     """``ubv_gemm_nt_act``: act 1 -> dropout(relu(x @ w^T + bias), p) with the keep mask of
     ``relu_dropout`` for ``seed``; act 2 -> (x @ w^T) / (1 - p) where ``mask`` != 0, else 0.  None when the

@@ -424,6 +424,98 @@ class _Linear(Function):
         return (gx, None, None, None, None, None, grb, *grads)
 
 
+class _SelfAttnIn(Function):
+    """The three Linears on the query of a BEV self-attention as ONE GEMM: ``value = x . Wv^T + bv`` and ``offsets |
+    logits = x . [Wo; Wa]^T + [bo; ba] + row_bias[q]`` (``ubv_gemm_nt_dual``: x is read once, the two results leave as two
+    tensors), plus the pass-through alias of ``x`` for the residual branch.  Backward: ONE input-gradient GEMM over
+    [d value | d offsets,logits] with the alias' gradient in its epilogue (in place when that tensor was made for this
+    edge), ONE weight-gradient pass over x (``ubv_gemm_wgrad_dual``), and d(row_bias) = the batch sum of d(offsets |
+    logits).  f32 CUDA tensors only; ``self_attn_in`` falls back to the separate Linears otherwise."""
+
+    @staticmethod
+    def forward(ctx, x, row_bias, wv, bv, wo, bo, wa, ba):
+        from . import functional as UF
+        split = _split_weights((wv, wo, wa))
+        bias = torch.cat((bv.detach(), bo.detach(), ba.detach())).float()
+        n2 = wo.shape[0] + wa.shape[0]
+        res = UF.gemm_nt_dual(x, split[0], split[1], bias=bias, y2_cols=n2, row_bias=row_bias)
+        if res is None:
+            raise RuntimeError('self_attn_in: shape outside ubv_gemm_nt_dual (checked by self_attn_in_supported)')
+        ctx.save_for_backward(x, split[2], split[3])
+        ctx.rows = row_bias.shape[0]
+        ctx.outs = (wv.shape[0], wo.shape[0], wa.shape[0])
+        return res[0], res[1], x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gv, gol, galias):
+        from . import functional as UF
+        x, wth, wtl = ctx.saved_tensors
+        C = x.shape[-1]
+        gv2 = gv.reshape(-1, gv.shape[-1])
+        gol2 = gol.reshape(-1, gol.shape[-1])
+        gv2 = gv2 if gv2.is_contiguous() else gv2.contiguous()
+        gol2 = gol2 if gol2.is_contiguous() else gol2.contiguous()
+        gx = None
+        if ctx.needs_input_grad[0]:
+            ga = None
+            if galias is not None:
+                ga = galias.reshape(-1, C)
+                ga = ga if ga.is_contiguous() else ga.contiguous()
+            own = ga is not None and UF.grad_tag(galias, '_ubv_owned') and ga.data_ptr() == galias.data_ptr()
+            gx = UF.gemm_nt_dual(gv2, wth, wtl, x2=gol2, residual=ga, out=ga if own else None)
+            if gx is None:
+                raise RuntimeError('self_attn_in: input gradient outside ubv_gemm_nt_dual')
+            gx = gx.view(x.shape)
+        grb = None
+        if ctx.needs_input_grad[1]:
+            g3 = gol2.view(-1, ctx.rows, gol2.shape[-1])
+            grb = g3[0] if g3.shape[0] == 1 else g3[0] + g3[1]
+            for i in range(2, g3.shape[0]):
+                grb = grb + g3[i]
+        # weight gradients: two passes over x measured FASTER than the fused ubv_gemm_wgrad_dual (90 vs 113 us back to
+        # back at M = 80 000: the kernel is bound by its tiles' MFMA / LDS work, which is the same either way, and
+        # the 352-row product takes 85 slabs of 6 tiles where the two take 128 x 4 and 256 x 2); UBV_SELF_IN_WGRAD=dual
+        # keeps the fused form for A/B runs
+        x2d = x.reshape(-1, C)
+        if _SELF_IN_WGRAD_DUAL:
+            res = UF.gemm_wgrad_dual(gv2, gol2, x2d)
+            if res is None:
+                raise RuntimeError('self_attn_in: weight gradient outside ubv_gemm_wgrad_dual')
+            gw, gb = res
+        else:
+            r1, r2 = UF.gemm_wgrad(gv2, x2d), UF.gemm_wgrad(gol2, x2d)
+            if r1 is None or r2 is None:
+                raise RuntimeError('self_attn_in: weight gradient outside ubv_gemm_wgrad')
+            gw = gb = None
+        nv, no, na = ctx.outs
+        if gw is not None:
+            r1, r2 = (gw[:nv], gb[:nv]), (gw[nv:], gb[nv:])
+        need = ctx.needs_input_grad
+        return (gx, grb,
+                r1[0] if need[2] else None, r1[1] if need[3] else None,
+                r2[0][:no] if need[4] else None, r2[1][:no] if need[5] else None,
+                r2[0][no:] if need[6] else None, r2[1][no:] if need[7] else None)
+
+
+def self_attn_in_supported(x, row_bias, wv, wo, wa):
+    """The fused GEMM takes f32 CUDA tensors, a contiguous query, a value width that is a multiple of 128 (its column
+    tiles) and the split-bf16 MFMA path switched on."""
+    ws = (wv, wo, wa)
+    return _MFMA_F32 and _FUSE_SELF_IN and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and \
+        not torch.is_autocast_enabled('cuda') and row_bias is not None and row_bias.dtype == torch.float32 and \
+        all(w.dtype == torch.float32 and w.is_contiguous() and w.shape[1] == x.shape[-1] for w in ws) and \
+        x.shape[-1] % 32 == 0 and wv.shape[0] % 128 == 0 and (wo.shape[0] + wa.shape[0]) % 32 == 0
+
+
+_FUSE_SELF_IN = os.environ.get('UBV_FUSE_SELF_IN', '1') != '0'
+_SELF_IN_WGRAD_DUAL = os.environ.get('UBV_SELF_IN_WGRAD', '') == 'dual'
+
+
+def self_attn_in(x, row_bias, wv, bv, wo, bo, wa, ba):
+    """(value, offsets | logits, alias of x) — see ``_SelfAttnIn``; check ``self_attn_in_supported`` first."""
+    return _SelfAttnIn.apply(x, row_bias, wv, bv, wo, bo, wa, ba)
+
+
 def _run(x, weights, biases, passthru=False, act=None, row_bias=None):
     has_bias = biases[0] is not None
     params = list(weights) + (list(biases) if has_bias else [])

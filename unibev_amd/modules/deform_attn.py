@@ -24,7 +24,7 @@ import torch.nn.functional as F
 
 from .. import functional as UF
 from ..linear import linear as ubv_linear
-from ..linear import linear_cat, linear_cat_pass, linear_pass
+from ..linear import linear_cat, linear_cat_pass, linear_pass, self_attn_in, self_attn_in_supported
 from ..registry import ATTENTION
 from .bricks import BaseModule, constant_init, xavier_init
 
@@ -225,8 +225,18 @@ class MultiScaleDeformableAttention(_DeformAttnBase):
             bs, num_query, _ = x.shape
             hw = static_hw(spatial_shapes)
             assert sum(h * w for h, w in hw) == num_query
-            v, alias = self.project_value(x, passthru=True)
-            offlog, identity = self.offsets_and_logits(alias, passthru=True, row_bias=pos_term)
+            if self.value_proj.bias is not None and self.sampling_offsets.bias is not None and \
+                    self_attn_in_supported(x, pos_term, self.value_proj.weight, self.sampling_offsets.weight,
+                                           self.attention_weights.weight):
+                # value_proj | sampling_offsets | attention_weights in one GEMM (x read once), their input and
+                # weight gradients in one GEMM each
+                v, offlog, identity = self_attn_in(x, pos_term, self.value_proj.weight, self.value_proj.bias,
+                                                   self.sampling_offsets.weight, self.sampling_offsets.bias,
+                                                   self.attention_weights.weight, self.attention_weights.bias)
+                v = _store_value(v)
+            else:
+                v, alias = self.project_value(x, passthru=True)
+                offlog, identity = self.offsets_and_logits(alias, passthru=True, row_bias=pos_term)
             grid = kwargs.get('bev_h'), kwargs.get('bev_w')
             qgrid = grid if (grid[0] and grid[1] and grid[0] * grid[1] == num_query) else None
             output = UF.bev_lift(v, offlog, reference_points.reshape(1, bs, num_query, 1, 2), 1, hw[0],
