@@ -281,8 +281,24 @@ def pre_process_pts_feats(P, mlvl_pts_feats):
     return torch.cat(flat, 2).permute(1, 0, 2), shapes                # (hw, bs, C)
 
 
+_MLP_NORM_ACT = {
+    'MLP_ChannelNormWeights': torch.relu,
+    'Leaky_ReLU_MLP_ChannelNormWeights': lambda v: F.leaky_relu(v, 0.01),
+    'ELU_MLP_ChannelNormWeights': F.elu,
+    'Sigmoid_MLP_ChannelNormWeights': torch.sigmoid,
+}
+
+
+def modality_projection(P, prefix, x):
+    """ModalityProjectionModule.forward (transformer_fusion.py:26-47): x + LayerNorm(relu(Linear(x)))."""
+    h = torch.relu(F.linear(x, P[prefix + 'net.0.weight'], P[prefix + 'net.0.bias']))
+    h = F.layer_norm(h, (h.shape[-1],), P[prefix + 'net.2.weight'], P[prefix + 'net.2.bias'])
+    return x + h
+
+
 def channel_feature_norm(P, img, pts, feature_norm, c_flag, l_flag):
-    """transformer_fusion.py:316-384, ChannelNormWeights branch (:323-337)."""
+    """transformer_fusion.py:316-384: ChannelNormWeights (:323-337), the learned per-sample variants
+    (:345-361) and the modality projection (:369-374)."""
     if img is None:
         img = torch.zeros_like(pts)
     elif pts is None:
@@ -297,6 +313,24 @@ def channel_feature_norm(P, img, pts, feature_norm, c_flag, l_flag):
             pw = fw[1:2].softmax(0)[0]
         img = img * iw
         pts = pts * pw
+    elif feature_norm in _MLP_NORM_ACT:
+        # one 2-way score per (sample, channel) from ALL tokens of both modalities: Linear over the token axis
+        tokens = torch.cat([img, pts], 1).transpose(1, 2)                      # (bs, C, 2 Nq)
+        score = _MLP_NORM_ACT[feature_norm](F.linear(tokens, P['channel_weights_proj.0.weight'],
+                                                     P['channel_weights_proj.0.bias']))   # (bs, C, 2)
+        if c_flag == 1 and l_flag == 1:
+            n = score.softmax(-1)
+            iw, pw = n[..., 0], n[..., 1]
+        else:
+            iw = score[..., :1].softmax(-1)[..., 0]                            # softmax of one entry: ones
+            pw = score[..., 1:].softmax(-1)[..., 0]
+        img = img * iw[:, None, :]
+        pts = pts * pw[:, None, :]
+    elif feature_norm == 'ModalityProjection':
+        pseudo_pts = modality_projection(P, 'l_modal_proj.', img)
+        pseudo_img = modality_projection(P, 'c_modal_proj.', pts)
+        img = torch.cat([img, pseudo_pts], -1)
+        pts = torch.cat([pseudo_img, pts], -1)
     elif feature_norm is not None:
         raise NotImplementedError(feature_norm)
     return img, pts
@@ -317,15 +351,33 @@ def spatial_feature_norm(P, img, pts, spatial_norm, c_flag, l_flag):
     return img, pts
 
 
-def multi_modal_fusion(img, pts, fusion_method, c_flag, l_flag):
-    """transformer_fusion.py:280-314 (linear / avg / cat; no modal embeddings)."""
+def multi_modal_fusion(img, pts, fusion_method, c_flag, l_flag, feature_norm=None, P=None,
+                       use_modal_embeds=None):
+    """transformer_fusion.py:280-314: linear / avg / cat, the flag vectors of the modality projection
+    (:287-300) and the modal embeddings (:304-310)."""
     if fusion_method == 'linear':
-        return c_flag * img + l_flag * pts
-    if fusion_method == 'avg':
-        return img * c_flag / (c_flag + l_flag) + pts * l_flag / (c_flag + l_flag)
-    if fusion_method == 'cat':
-        return torch.cat((img * c_flag, pts * l_flag), -1)
-    raise ValueError('Unrecognizable fusion method:{}'.format(fusion_method))
+        fused = c_flag * img + l_flag * pts
+    elif fusion_method == 'avg':
+        fused = img * c_flag / (c_flag + l_flag) + pts * l_flag / (c_flag + l_flag)
+    elif fusion_method == 'cat':
+        if feature_norm == 'ModalityProjection':
+            # img = [img | pseudo pts], pts = [pseudo img | pts]: a half is the real feature when its
+            # modality is present and the projection of the other modality when it is not
+            C = img.shape[-1] // 2
+            img_flags = torch.cat([torch.full((C,), float(c_flag)), torch.full((C,), float(1 - l_flag))]).to(img)
+            pts_flags = torch.cat([torch.full((C,), float(1 - c_flag)), torch.full((C,), float(l_flag))]).to(img)
+            fused = img * img_flags + pts * pts_flags
+        else:
+            fused = torch.cat((img * c_flag, pts * l_flag), -1)
+    else:
+        raise ValueError('Unrecognizable fusion method:{}'.format(fusion_method))
+    if use_modal_embeds == 'MLP':
+        status = torch.tensor([float(c_flag), float(l_flag)]).to(fused)
+        h = torch.relu(F.linear(status, P['modal_embbeding_mlp.0.weight'], P['modal_embbeding_mlp.0.bias']))
+        fused = fused + torch.relu(F.linear(h, P['modal_embbeding_mlp.2.weight'], P['modal_embbeding_mlp.2.bias']))
+    elif use_modal_embeds == 'Fixed':
+        fused = fused + (c_flag * P['modal_embbeding_C'] + l_flag * P['modal_embbeding_L'])
+    return fused
 
 
 def transformer_encode_fuse(P, cfg, img_mlvl_feats, pts_mlvl_feats, bev_queries, bev_h, bev_w,
@@ -367,7 +419,8 @@ def transformer_encode_fuse(P, cfg, img_mlvl_feats, pts_mlvl_feats, bev_queries,
     parts = (img_bev, pts_bev)
     img_n, pts_n = channel_feature_norm(P, img_bev, pts_bev, cfg.get('feature_norm'), c_flag, l_flag)
     img_n, pts_n = spatial_feature_norm(P, img_n, pts_n, cfg.get('spatial_norm'), c_flag, l_flag)
-    fused = multi_modal_fusion(img_n, pts_n, cfg.get('fusion_method', 'linear'), c_flag, l_flag)
+    fused = multi_modal_fusion(img_n, pts_n, cfg.get('fusion_method', 'linear'), c_flag, l_flag,
+                               cfg.get('feature_norm'), P, cfg.get('use_modal_embeds'))
     fused = fused.permute(1, 0, 2)
     return (fused, parts) if return_parts else fused
 

@@ -66,3 +66,21 @@ def encoder_case(name):
     inputs = dict(img=img, pts=pts, bev_q=bev_q, bev_pos=bev_pos, metas=metas, bev_h=bev_h,
                   bev_w=bev_w, bs=bs)
     return cfg, sd, inputs, g
+
+
+def variant_case(name):
+    """Seeded inputs / parameters of a ``variant_<name>`` fixture (the fusion variants no shipped config
+    selects): (cfg, state_dict(np), inputs dict, fixture with ``fused_<c><l>`` per modality-flag state)."""
+    import make_golden as mg
+    g = golden('variant_' + name)
+    cfg = json.loads(str(g['cfg_json']))
+    case = mg.VARIANT_CASES[name]
+    kw, bev_h, bev_w, bs, img_hw_f, pts_hw_f, img_hw, seed = case
+    img, pts, bev_q, bev_pos, oq, metas = mg.encoder_inputs(name, *case)
+    named = [(n, tuple(json.loads(s))) for n, s in zip(g['param_names'], g['param_shapes'])]
+    sd = syn.seeded_state_dict(named, seed)
+    np.testing.assert_array_equal(checksum(img[0]), g['img_ck'])
+    np.testing.assert_array_equal(checksum(pts[0]), g['pts_ck'])
+    np.testing.assert_array_equal(checksum(bev_q), g['bev_q_ck'])
+    inputs = dict(img=img, pts=pts, bev_q=bev_q, bev_pos=bev_pos, metas=metas, bev_h=bev_h, bev_w=bev_w, bs=bs)
+    return cfg, sd, inputs, g

@@ -350,6 +350,73 @@ def gen_modality_dropout(mods):
     save('modality_dropout', **out)
 
 
+# --------------------------------------------------------------------------- fusion variants no shipped config selects
+VARIANT_CASES = {
+    # name: (cfg kwargs, bev_h, bev_w, bs, img feat hw, pts feat hw, img_hw, seed)
+    # transformer_fusion.py:136-155 (learned per-sample channel weights), :152-155 + 287-300 (modality
+    # projection under cat fusion), :172-180 + 304-310 (modal embeddings)
+    'mlp_cnw': (dict(embed_dims=128, num_layers=1, num_cams=2, feature_norm='MLP_ChannelNormWeights',
+                     bev_h=6, bev_w=8), 6, 8, 2, (4, 6), (9, 11), (64, 96), 41),
+    'leaky_cnw': (dict(embed_dims=128, num_layers=1, num_cams=2, feature_norm='Leaky_ReLU_MLP_ChannelNormWeights',
+                       bev_h=6, bev_w=8), 6, 8, 2, (4, 6), (9, 11), (64, 96), 42),
+    'elu_cnw': (dict(embed_dims=128, num_layers=1, num_cams=2, feature_norm='ELU_MLP_ChannelNormWeights',
+                     bev_h=6, bev_w=8), 6, 8, 2, (4, 6), (9, 11), (64, 96), 43),
+    'sigmoid_cnw': (dict(embed_dims=128, num_layers=1, num_cams=2, feature_norm='Sigmoid_MLP_ChannelNormWeights',
+                         fusion_method='avg', bev_h=6, bev_w=8), 6, 8, 2, (4, 6), (9, 11), (64, 96), 44),
+    'modproj': (dict(embed_dims=128, num_layers=1, num_cams=2, feature_norm='ModalityProjection',
+                     fusion_method='cat', bev_h=6, bev_w=8), 6, 8, 2, (4, 6), (9, 11), (64, 96), 45),
+    'modproj_spatial': (dict(embed_dims=128, num_layers=1, num_cams=2, feature_norm='ModalityProjection',
+                             fusion_method='cat', spatial_norm='SpatialNormWeights', bev_h=6, bev_w=8),
+                        6, 8, 2, (4, 6), (9, 11), (64, 96), 46),
+    'modal_mlp': (dict(embed_dims=128, num_layers=1, num_cams=2, use_modal_embeds='MLP', bev_h=6, bev_w=8),
+                  6, 8, 2, (4, 6), (9, 11), (64, 96), 47),
+    'modal_fixed': (dict(embed_dims=128, num_layers=1, num_cams=2, use_modal_embeds='Fixed', feature_norm=None,
+                         fusion_method='avg', bev_h=6, bev_w=8), 6, 8, 2, (4, 6), (9, 11), (64, 96), 48),
+}
+VARIANT_FLAGS = ((1, 1), (1, 0), (0, 1))
+
+
+def gen_variants(mods):
+    """fused_bev_embed of the experimental feature_norm / use_modal_embeds variants under the three
+    modality-flag states.  (1, 1) is the eval forward; the single-modality states are train-mode forwards
+    (every Dropout at p = 0) whose two ``get_probability`` draws are scripted — the flags are
+    otherwise only reachable through np.random (transformer_fusion.py:463-477)."""
+    T = mods['transformer_fusion'].UniBEVTransformer
+    if not torch.cuda.is_available():
+        # the reference builds its flag vectors with ``.cuda()`` (:296-297, 305): identity on this CPU-only box
+        torch.Tensor.cuda = lambda self, *a, **k: self
+    for name, case in VARIANT_CASES.items():
+        kw, bev_h, bev_w, bs, img_hw_f, pts_hw_f, img_hw, seed = case
+        cfg = cfgs.transformer_cfg(**kw)
+        args = dict(cfg)
+        args.pop('type')
+        model = T(**args)
+        model.init_weights()
+        named = seeded_load(model, seed)
+        img, pts, bev_q, bev_pos, oq, metas = encoder_inputs(name, *case)
+        arrays = dict(cfg_json=np.array(json.dumps(cfg)),
+                      param_names=np.array([n for n, _ in named]),
+                      param_shapes=np.array([json.dumps(list(s)) for _, s in named]),
+                      img_ck=checksum(img[0]), pts_ck=checksum(pts[0]), bev_q_ck=checksum(bev_q))
+        for c_flag, l_flag in VARIANT_FLAGS:
+            if (c_flag, l_flag) == (1, 1):
+                model.eval()
+            else:
+                model.train()
+                for m in model.modules():
+                    if isinstance(m, torch.nn.Dropout):
+                        m.p = 0.0
+                model.drop_modality = 0.5
+                script = [True, bool(l_flag)]
+                model.get_probability = lambda prob, s=script: s.pop(0)
+            with torch.no_grad():
+                fused, _, _, _ = model([t(x) for x in img], [t(x) for x in pts], t(bev_q), t(oq), bev_h, bev_w,
+                                       bev_pos=t(bev_pos), img_metas=metas)
+            assert (int(model.c_flag), int(model.l_flag)) == (c_flag, l_flag)
+            arrays[f'fused_{c_flag}{l_flag}'] = fused.numpy().copy()
+        save('variant_' + name, **arrays)
+
+
 def gen_init(mods):
     """init_weights() facts that do not depend on torch's RNG: the sampling_offsets bias grid."""
     T = mods['transformer_fusion'].UniBEVTransformer
@@ -439,6 +506,18 @@ GRID_MASK_CASES = [
 ]
 
 
+GRID_MASK_VARIANTS = [
+    # seed, (n, c, h, w), rotate, offset, mode: rotated grids (a PIL nearest-neighbour rotation by randint(rotate)
+    # degrees, grid_mask.py:111-114) and the random fill of the masked pixels (:120-122)
+    (10, (2, 3, 32, 88), 60, False, 1),
+    (11, (2, 3, 64, 64), 360, False, 0),
+    (12, (1, 2, 20, 50), 1, True, 1),
+    (13, (2, 3, 48, 40), 180, True, 1),
+    (14, (1, 3, 37, 53), 360, True, 0),
+    (15, (1, 3, 64, 64), 91, False, 1),
+]
+
+
 def gen_grid_mask():
     """models/utils/grid_mask.py GridMask.forward as the detector builds it (unibev_detector.py:75:
     GridMask(True, True, rotate=1, offset=False, ratio=0.5, mode=1, prob=0.7)): the mask it multiplies with,
@@ -460,6 +539,21 @@ def gen_grid_mask():
             out[f's{seed}_mask'] = y[0, 0].numpy().astype(np.uint8)
             out[f's{seed}_next'] = np.array([np.random.rand()])
             out[f's{seed}_meta'] = np.array(list(shape) + [int(round(prob * 100))])
+        for seed, shape, rotate, offset, mode in GRID_MASK_VARIANTS:
+            gm = gm_mod.GridMask(True, True, rotate=rotate, offset=offset, ratio=0.5, mode=mode, prob=1.0).train()
+            ys = []
+            for fill in (1.0, 0.0):                            # y(ones) - y(zeros) = mask, y(zeros) = offset * (1 - mask)
+                np.random.seed(seed)
+                ys.append(gm(torch.full(shape, fill)))
+                nxt = np.random.rand()
+            assert (ys[0] == ys[0][:1, :1]).all()
+            out[f'v{seed}_mask'] = (ys[0] - ys[1])[0, 0].numpy().astype(np.uint8)
+            out[f'v{seed}_fill'] = ys[1][0, 0].numpy()
+            out[f'v{seed}_next'] = np.array([nxt])
+            out[f'v{seed}_meta'] = np.array(list(shape) + [rotate, int(offset), mode])
+            np.random.seed(seed)
+            x = torch.from_numpy(syn.seeded_array(f'grid_mask:v{seed}', shape, seed))
+            out[f'v{seed}_y_ck'] = checksum(gm(x).numpy())
     finally:
         torch.Tensor.cuda = cuda
     save('grid_mask', **out)
@@ -551,6 +645,9 @@ def gen_pipelines():
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'pipelines':
         return gen_pipelines()
+    if len(sys.argv) > 1 and sys.argv[1] == 'variants':
+        torch.manual_seed(0)
+        return gen_variants(load_reference())
     torch.manual_seed(0)
     torch.set_num_threads(8)
     mods = load_reference()
@@ -559,6 +656,7 @@ def main():
     gen_sca(mods)
     gen_encoders(mods)
     gen_modality_dropout(mods)
+    gen_variants(mods)
     gen_init(mods)
     gen_fullsize(mods)
     gen_head(mods)

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import golden, t, metas_from, encoder_case, checksum
+from _util import golden, t, metas_from, encoder_case, variant_case, checksum
 import make_golden as mg
 from unibev_amd import synthetic as syn
 
@@ -102,20 +102,21 @@ def test_encoder_gradients_vs_oracle(name, streams):
         TR.set_two_streams(was)
 
 
-def _encoder_gradients_vs_oracle(name, R):
-    cfg, sd, inp, g = encoder_case(name)
-    cot = syn.seeded_array('cot:' + name, g['fused'].shape, 5)
+def _encoder_gradients_vs_oracle(name, R, case=None, flags=(1, 1)):
+    cfg, sd, inp, g = case if case is not None else encoder_case(name)
+    cot = syn.seeded_array('cot:' + name, g['fused' if case is None else 'fused_11'].shape, 5)
     # oracle
     P = {k: v.requires_grad_() for k, v in R.state_dict_to_torch(sd).items()}
     oi = [t(x).requires_grad_() for x in inp['img']]
     op = [t(x).requires_grad_() for x in inp['pts']]
     oq = t(inp['bev_q']).requires_grad_()
     fused_ref = R.transformer_encode_fuse(P, cfg, oi, op, oq, inp['bev_h'], inp['bev_w'],
-                                          t(inp['bev_pos']), inp['metas'])
+                                          t(inp['bev_pos']), inp['metas'], c_flag=flags[0], l_flag=flags[1])
     (fused_ref * t(cot)).sum().backward()
     # product
     model = _build(cfg).to(DEV).eval()
     _load(model, sd)
+    model.forced_flags = tuple(flags)
     gi = [t(x, device=DEV).requires_grad_() for x in inp['img']]
     gp = [t(x, device=DEV).requires_grad_() for x in inp['pts']]
     gq = t(inp['bev_q'], device=DEV).requires_grad_()
@@ -140,8 +141,37 @@ def _encoder_gradients_vs_oracle(name, R):
     for k, p in model.named_parameters():
         if k.startswith('decoder') or k.startswith('reference_points'):
             continue
+        if P[k].grad is None:
+            # a parameter the flag state switches off (e.g. a modality projection whose half is the real feature):
+            # no gradient in the oracle, none or zero here
+            assert p.grad is None or not p.grad.any(), k
+            continue
         assert p.grad is not None, k
         close(p.grad, P[k].grad, k)
+
+
+@pytest.mark.parametrize('name', list(mg.VARIANT_CASES))
+def test_fusion_variants_vs_reference_vectors(name):
+    """The feature_norm / use_modal_embeds variants no shipped config selects (learned per-sample channel weights,
+    modality projection, modal embeddings) under the three modality-flag states, against fused_bev_embed recorded
+    from the reference (tests/golden/make_golden.py::gen_variants)."""
+    cfg, sd, inp, g = variant_case(name)
+    model = _build(cfg).to(DEV).eval()
+    _load(model, sd)
+    for c_flag, l_flag in mg.VARIANT_FLAGS:
+        model.forced_flags = (c_flag, l_flag)
+        with torch.no_grad():
+            fused, _, _ = _run(model, inp)
+        ref = g[f'fused_{c_flag}{l_flag}']
+        np.testing.assert_allclose(fused.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max(),
+                                   err_msg=f'flags {c_flag}{l_flag}')
+
+
+@pytest.mark.parametrize('name,flags', [('mlp_cnw', (1, 1)), ('elu_cnw', (0, 1)), ('modproj_spatial', (1, 1)),
+                                        ('modproj', (1, 0)), ('modal_mlp', (1, 1)), ('modal_fixed', (0, 1))])
+def test_fusion_variant_gradients_vs_oracle(name, flags):
+    from oracle import unibev_ref as R
+    _encoder_gradients_vs_oracle(name, R, case=variant_case(name), flags=flags)
 
 
 def test_sca_modules_vs_reference_vectors():

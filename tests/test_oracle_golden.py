@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import golden, t, metas_from, encoder_case, checksum
+from _util import golden, t, metas_from, encoder_case, variant_case, checksum
 from oracle import unibev_ref as R
 from unibev_amd import synthetic as syn
 
@@ -97,6 +97,19 @@ def test_encoder_and_fusion(name):
     if pts_bev is not None:
         np.testing.assert_allclose(pts_bev.numpy(), g['pts_bev'], rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(fused.numpy(), g['fused'], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('name', list(mg.VARIANT_CASES))
+def test_fusion_variants(name):
+    """The feature_norm / use_modal_embeds variants no shipped config selects, under the three modality-flag
+    states, against the reference's own outputs (tests/golden/make_golden.py::gen_variants)."""
+    cfg, sd, inp, g = variant_case(name)
+    P = R.state_dict_to_torch(sd)
+    for c_flag, l_flag in mg.VARIANT_FLAGS:
+        fused = R.transformer_encode_fuse(P, cfg, [t(x) for x in inp['img']], [t(x) for x in inp['pts']],
+                                          t(inp['bev_q']), inp['bev_h'], inp['bev_w'], t(inp['bev_pos']),
+                                          inp['metas'], c_flag=c_flag, l_flag=l_flag)
+        np.testing.assert_allclose(fused.numpy(), g[f'fused_{c_flag}{l_flag}'], rtol=2e-5, atol=2e-5)
 
 
 @pytest.mark.slow

@@ -238,3 +238,25 @@ def test_detector_constructor_errors_and_modality_switch():
     soft = dict(head, loss_cls=dict(type='CrossEntropyLoss'))
     assert reg.HEADS.build(soft).cls_out_channels == 11 and reg.HEADS.build(head).cls_out_channels == 10
     assert reg.HEADS.build({k: v for k, v in head.items() if k != 'loss_cls'}).cls_out_channels == 11
+
+
+def test_fusion_variants_build_with_the_reference_state_dict_names():
+    """feature_norm / use_modal_embeds variants no shipped config selects (transformer_fusion.py:136-180): the modules
+    build on CPU and expose exactly the parameter names and shapes recorded from the reference's own modules."""
+    import json
+    import os
+    import sys
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, 'golden'))
+    import make_golden as mg
+    from unibev_amd import build_transformer
+    for name in mg.VARIANT_CASES:
+        g = np.load(os.path.join(here, 'golden', f'variant_{name}.npz'))
+        model = build_transformer(json.loads(str(g['cfg_json'])))
+        model.init_weights()
+        want = {str(n): tuple(json.loads(str(s))) for n, s in zip(g['param_names'], g['param_shapes'])}
+        have = {k: tuple(v.shape) for k, v in model.state_dict().items() if not k.startswith('decoder')}
+        assert have == want, name
+    with pytest.raises(AssertionError):                     # the modality projection is defined for cat fusion only
+        build_transformer(configs.transformer_cfg(embed_dims=32, num_layers=1, feature_norm='ModalityProjection'))

@@ -22,15 +22,38 @@ import torch.nn as nn
 from torch.nn.init import constant_, normal_
 
 from .. import functional as UF
-from ..linear import lowp_step_cache
+from ..linear import linear, lowp_step_cache
 from ..registry import (TRANSFORMER, TRANSFORMER_LAYER_SEQUENCE,
                         build_transformer_layer_sequence)
 from .bricks import BaseModule, cast_keep_expand, xavier_init
 from .deform_attn import _DeformAttnBase, index_tensor, shapes_tensor
 
-_UNSUPPORTED_NORMS = ('MLP_ChannelNormWeights', 'Leaky_ReLU_MLP_ChannelNormWeights',
-                      'ELU_MLP_ChannelNormWeights', 'Sigmoid_MLP_ChannelNormWeights',
-                      'ModalityProjection')
+# learned per-(sample, channel) weights: Linear over the token axis of both modalities + this activation
+# (transformer_fusion.py:136-151)
+_MLP_NORMS = {'MLP_ChannelNormWeights': lambda: nn.ReLU(inplace=True),
+              'Leaky_ReLU_MLP_ChannelNormWeights': lambda: nn.LeakyReLU(inplace=True),
+              'ELU_MLP_ChannelNormWeights': lambda: nn.ELU(inplace=True),
+              'Sigmoid_MLP_ChannelNormWeights': nn.Sigmoid}
+
+
+class ModalityProjectionModule(BaseModule):
+    """x + LayerNorm(relu(Linear(x))): the stand-in features of a missing modality, projected from the other one
+    (transformer_fusion.py:26-47; ``net.0`` / ``net.2`` are checkpoint keys).  The Linear is the MFMA GEMM of the
+    encoder layers; ReLU / LayerNorm / residual are framework element-wise ops — no shipped config builds this."""
+
+    def __init__(self, embed_dims, with_norm=True, with_residual=True):
+        super().__init__()
+        layers = [nn.Linear(embed_dims, embed_dims), nn.ReLU(inplace=True)]
+        if with_norm:
+            layers.append(nn.LayerNorm(embed_dims))
+        self.net = nn.Sequential(*layers)
+        self.with_residual = with_residual
+
+    def forward(self, x):
+        out = torch.relu(linear(x, self.net[0].weight, self.net[0].bias))
+        if len(self.net) > 2:
+            out = self.net[2](out)
+        return x + out if self.with_residual else out
 
 
 import os as _os
@@ -112,10 +135,13 @@ class UniBEVTransformer(BaseModule):
             #  no RNG consumed, and a model used before init_weights() / load_state_dict() is finite instead of garbage)
             self.pts_channel_weights = nn.Parameter(torch.zeros(self.embed_dims))
             self.img_channel_weights = nn.Parameter(torch.zeros(self.embed_dims))
-        elif self.feature_norm in _UNSUPPORTED_NORMS:
-            raise NotImplementedError(
-                f'feature_norm={self.feature_norm!r}: experimental variant of the reference '
-                f'(transformer_fusion.py:136-155) that no shipped config selects')
+        elif self.feature_norm in _MLP_NORMS:
+            self.channel_weights_proj = nn.Sequential(nn.Linear(self.bev_h * self.bev_w * 2, 2),
+                                                      _MLP_NORMS[self.feature_norm]())
+        elif self.feature_norm == 'ModalityProjection':
+            assert self.fusion_method == 'cat'
+            self.c_modal_proj = ModalityProjectionModule(self.embed_dims)
+            self.l_modal_proj = ModalityProjectionModule(self.embed_dims)
         if self.spatial_norm == 'SpatialNormWeights':
             self.spatial_norm_layer = nn.Softmax(dim=0)
             self.pts_spatial_weights = nn.Parameter(torch.zeros(self.bev_h * self.bev_w))
@@ -127,9 +153,13 @@ class UniBEVTransformer(BaseModule):
         if self.with_pts_bev_encoder:
             self.pts_level_embeds = nn.Parameter(torch.zeros(self.num_feature_levels,
                                                               self.embed_dims))
-        if self.use_modal_embeds is not None:
-            raise NotImplementedError('use_modal_embeds: unused by every shipped config '
-                                      '(transformer_fusion.py:172-180, 306-312)')
+        if self.use_modal_embeds == 'MLP':
+            self.modal_embbeding_mlp = nn.Sequential(nn.Linear(2, self.embed_dims // 2), nn.ReLU(inplace=True),
+                                                     nn.Linear(self.embed_dims // 2, self.embed_dims),
+                                                     nn.ReLU(inplace=True))
+        elif self.use_modal_embeds == 'Fixed':
+            self.modal_embbeding_C = nn.Parameter(torch.zeros(self.embed_dims))
+            self.modal_embbeding_L = nn.Parameter(torch.zeros(self.embed_dims))
         self.reference_points = nn.Linear(self.embed_dims * self.scale_factor, 3)
 
     def init_weights(self):
@@ -152,10 +182,15 @@ class UniBEVTransformer(BaseModule):
             else:
                 normal_(self.pts_channel_weights)
                 normal_(self.img_channel_weights)
+        # (the reference also calls mmcv's xavier_init on the Sequential containers of the variants below — a no-op,
+        #  a container has no ``weight`` — so their Linears keep the xavier_uniform_ of the first loop above)
         if self.spatial_norm == 'SpatialNormWeights':
             normal_(self.pts_spatial_weights)
             normal_(self.img_spatial_weights)
         xavier_init(self.reference_points, distribution='uniform', bias=0.)
+        if self.use_modal_embeds == 'Fixed':
+            normal_(self.modal_embbeding_C)
+            normal_(self.modal_embbeding_L)
 
     def get_probability(self, prob):
         return True if np.random.random() < prob else False
@@ -220,14 +255,61 @@ class UniBEVTransformer(BaseModule):
             return n[0], n[1]
         return self.spatial_norm_layer(sw[:1])[0], self.spatial_norm_layer(sw[1:])[0]
 
+    def _learned_channel_weights(self, img, pts):
+        """(bs, C) weights of (img, pts) from ``channel_weights_proj`` (transformer_fusion.py:345-358): a 2-way score
+        per (sample, channel) from the 2 Nq tokens of that channel — two (2, Nq) x (Nq, C) products per sample."""
+        lin = self.channel_weights_proj[0]
+        nq = lin.in_features // 2
+        w = lin.weight.to(img.dtype)
+        score = torch.matmul(w[:, :nq], img) + torch.matmul(w[:, nq:], pts) + lin.bias.to(img.dtype)[:, None]
+        score = self.channel_weights_proj[1](score.transpose(1, 2))           # (bs, C, 2)
+        if self.c_flag == 1 and self.l_flag == 1:
+            n = score.softmax(-1)
+            return n[..., 0], n[..., 1]
+        return score[..., :1].softmax(-1)[..., 0], score[..., 1:].softmax(-1)[..., 0]
+
+    def _modal_embedding(self, ref):
+        if self.use_modal_embeds == 'MLP':
+            status = torch.tensor([float(self.c_flag), float(self.l_flag)], dtype=torch.float32, device=ref.device)
+            return self.modal_embbeding_mlp(status)
+        if self.use_modal_embeds == 'Fixed':
+            return self.c_flag * self.modal_embbeding_C + self.l_flag * self.modal_embbeding_L
+        return None
+
     def fuse(self, img_bev_embed, pts_bev_embed):
         """channel_feature_norm -> spatial_feature_norm -> multi_modal_fusion -> permute
-        (transformer_fusion.py:535-549) as one kernel.  Returns (Nq, bs, C*s)."""
+        (transformer_fusion.py:535-549) as one kernel.  Returns (Nq, bs, C*s).
+
+        The variants no shipped config selects keep that kernel for the weighting, the sum / concatenation and the
+        permute; what they add in front of it (a token-axis Linear, the modality projections) or behind it (the
+        modal embedding) runs as device-side framework ops around the MFMA Linear."""
         ref = img_bev_embed if img_bev_embed is not None else pts_bev_embed
         cw_img, cw_pts = self._channel_factors(ref.device)
         sw_img, sw_pts = self._spatial_factors()
-        return UF.bev_fuse(img_bev_embed, pts_bev_embed, cw_img, cw_pts, sw_img, sw_pts,
-                           cat=self.fusion_method == 'cat')
+        cat = self.fusion_method == 'cat'
+        if self.feature_norm in _MLP_NORMS or self.feature_norm == 'ModalityProjection':
+            # (a missing modality is a zero map in these variants, transformer_fusion.py:318-321)
+            img = img_bev_embed if img_bev_embed is not None else torch.zeros_like(ref)
+            pts = pts_bev_embed if pts_bev_embed is not None else torch.zeros_like(ref)
+        if self.feature_norm in _MLP_NORMS:
+            iw, pw = self._learned_channel_weights(img, pts)
+            fused = UF.bev_fuse(img * iw[:, None, :], pts * pw[:, None, :], cw_img, cw_pts, sw_img, sw_pts, cat=cat)
+        elif self.feature_norm == 'ModalityProjection':
+            # [img | proj(img)] * [c | 1 - l] + [proj(pts) | pts] * [1 - c | l]  (:287-300): each half is one
+            # weighted sum of a real and a projected map
+            pseudo_pts = self.l_modal_proj(img)
+            pseudo_img = self.c_modal_proj(pts)
+            one = torch.ones(self.embed_dims, dtype=torch.float32, device=ref.device)
+            c, l = float(self.c_flag), float(self.l_flag)
+            first = UF.bev_fuse(img, pseudo_img, one * c, one * (1.0 - c), sw_img, sw_pts, cat=False)
+            second = UF.bev_fuse(pseudo_pts, pts, one * (1.0 - l), one * l, sw_img, sw_pts, cat=False)
+            fused = torch.cat((first, second), -1)
+        else:
+            fused = UF.bev_fuse(img_bev_embed, pts_bev_embed, cw_img, cw_pts, sw_img, sw_pts, cat=cat)
+        emb = self._modal_embedding(ref)
+        if emb is not None:
+            fused = fused + emb.to(fused.dtype)
+        return fused
 
     # -- forward ---------------------------------------------------------------------------------
     def sample_modality_flags(self, has_img=True, has_pts=True):
