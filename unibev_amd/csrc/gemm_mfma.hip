@@ -170,6 +170,15 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 3 : 2)) void gemm_nt_kernel(const v
   };
 
   const int fr = lane & 31, fk = (lane >> 5) * 8;         // fragment row within a 32-block, k offset
+  // staged epilogue (NT <= 128): a thread of the row phase always handles the same 4 columns, so bias is ONE vector
+  // per thread, fetched here — in the epilogue's write phase it was a load + full wait per 4 columns, 4 NB dependent
+  // L2 round trips at the end of every block's serial chain
+  constexpr bool STAGE_B = NT <= 128 && (256 % (NT / 4)) == 0;
+  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (STAGE_B) {
+    const int bc = n0 + (tid % (NT / 4)) * 4;
+    if (bias != nullptr && bc < N) b4 = *reinterpret_cast<const float4*>(bias + bc);
+  }
   gf32x16_t acc[WMB][WNB];
 #pragma unroll
   for (int i = 0; i < WMB; ++i)
@@ -262,11 +271,11 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 3 : 2)) void gemm_nt_kernel(const v
         for (int g = 0; g < 4; ++g) {
           const int nl = (wn * WNB + j) * 32 + 8 * g + 4 * half, n = n0 + nl;
           float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          if (bias != nullptr && n < N) {
+          if (!STAGE_B && bias != nullptr && n < N) {
             const float4 b = *reinterpret_cast<const float4*>(bias + n);
             v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
           }
-          if (act.mode == 1) {
+          if (!STAGE_B && act.mode == 1) {
             const uint64_t mix = act.thresh != 0u ? drop_mix64(act_seed, (uint64_t)(m * ldy + n) >> 2) : 0ull;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -309,8 +318,17 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 3 : 2)) void gemm_nt_kernel(const v
         const long m = m0 + hh * 64 + rl;
         if (m >= M || n0 + c4 >= N) continue;
         const float4 t4 = *reinterpret_cast<const float4*>(tile + rl * TLD + c4);
-        float v[4] = {t4.x, t4.y, t4.z, t4.w};
+        float v[4] = {t4.x + b4.x, t4.y + b4.y, t4.z + b4.z, t4.w + b4.w};
         const long o = m * ldo + nb + c4;
+        if (STAGE_B && act.mode == 1) {
+          const uint64_t mix = act.thresh != 0u ? drop_mix64(act_seed, (uint64_t)(m * ldy + n0 + c4) >> 2) : 0ull;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float r = fmaxf(v[q], 0.0f);
+            if (act.thresh != 0u) r = drop_keep16(mix, q, act.thresh) ? r * act.scale : 0.0f;
+            v[q] = r;
+          }
+        }
         if (act.mode == 2) {
           float k4[4];
           vec_io<TO, 4>::load((const TO*)act.mask + o, k4);
