@@ -46,6 +46,9 @@ struct GemmAct { int mode; const void* mask; uint32_t thresh; float scale; uint6
                  const void* x2; long ldx2; int k_split; void* y2; long ldy2; int n_split; };
 
 constexpr int kGemmBM = 128;
+#ifndef UBV_GEMM_XD
+#define UBV_GEMM_XD 1
+#endif
 // K is walked in chunks of KC = 32 (f32 data: the hi + lo images double the LDS) or 64 (16-bit data, where
 // a 32-wide chunk is 8 MFMAs per wave between two barriers); LDS rows of KC + 8 halves (80 / 144 bytes)
 // keep the 16-byte fragment reads conflict-free.
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 3 : 2)) void gemm_nt_kernel(const v
                                                       const GemmAct act) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   constexpr int NT = 32 * NB;
-  constexpr int XD = 1;                                   // register sets of X in flight (2 spills under hipcc)
+  constexpr int XD = UBV_GEMM_XD;                         // register sets of X in flight
   constexpr int kGemmKC = KC, kGemmLd = KC + 8;
   constexpr bool TWO_D = (NB % 2) == 0;
   constexpr int WMB = TWO_D ? 2 : 1;                     // row blocks per wave
@@ -105,43 +108,50 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 3 : 2)) void gemm_nt_kernel(const v
   // (rows past M are clamped, not predicated — their results are never stored — so that the loads are
   //  straight-line code and the compiler can count them: a predicated load made it wait for vmcnt(0) at
   //  the top of every chunk, which put the whole prefetch back in series with the MFMAs)
-  long xrow[XI];
+  // 32-bit BYTE offsets from the matrix bases (host check: operands below 4 GB): a load is scalar base + vector
+  // offset, and the address registers of a thread shrink from 20 to 10 — the room the second X set needs
+  constexpr int XB = SPLIT ? 4 : 2;                        // bytes per X element
+  uint32_t xrow[XI];
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
     const long r = m0 + xr + XSTEP * i;
-    xrow[i] = (r < M ? r : M - 1) * ldx + xc;
+    xrow[i] = (uint32_t)(((r < M ? r : M - 1) * ldx + xc) * XB);
   }
-  long xrow2[SPLIT ? XI : 1];
+  uint32_t xrow2[SPLIT ? XI : 1];
   if constexpr (SPLIT) {
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       const long r = m0 + xr + XSTEP * i;
-      xrow2[i] = (r < M ? r : M - 1) * act.ldx2 + xc;
+      xrow2[i] = (uint32_t)(((r < M ? r : M - 1) * act.ldx2 + xc) * XB);
     }
   }
-  long wrow[WI];
+  uint32_t wrow[WI];
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
     const int r = wr + WSTEP * i;
     const int n = n0 + (r < NT ? r : NT - 1);
-    wrow[i] = (long)(n < N ? n : N - 1) * ldw + wc;                   // (a ragged last tile re-reads row N - 1: never stored)
+    wrow[i] = (uint32_t)(((long)(n < N ? n : N - 1) * ldw + wc) * 2);  // (a ragged last tile re-reads row N - 1: never stored)
   }
   auto load_x = [&](int k0, auto setc) {
     constexpr int set = decltype(setc)::value;
+    if constexpr (SPLIT) {
+      const bool second = act.x2 != nullptr && k0 >= act.k_split;            // chunk-uniform (k_split % KC == 0)
+      const char* xb = reinterpret_cast<const char*>(second ? (const float*)act.x2 + (k0 - act.k_split) : (const float*)Xv + k0);
 #pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      if constexpr (SPLIT) {
-        const bool second = act.x2 != nullptr && k0 >= act.k_split;          // chunk-uniform (k_split % KC == 0)
-        const float* xb = second ? (const float*)act.x2 : (const float*)Xv;
-        xf[set][i] = *reinterpret_cast<const gf32x4_t*>(xb + (second ? xrow2[i] + (k0 - act.k_split) : xrow[i] + k0));
-      } else xq[set][i] = *reinterpret_cast<const gu32x4_t*>((const uint16_t*)Xv + xrow[i] + k0);
+      for (int i = 0; i < XI; ++i) xf[set][i] = *reinterpret_cast<const gf32x4_t*>(xb + (second ? xrow2[i] : xrow[i]));
+    } else {
+      const char* xb = reinterpret_cast<const char*>((const uint16_t*)Xv + k0);
+#pragma unroll
+      for (int i = 0; i < XI; ++i) xq[set][i] = *reinterpret_cast<const gu32x4_t*>(xb + xrow[i]);
     }
   };
   auto load_w = [&](int k0) {
+    const char* hb = reinterpret_cast<const char*>(Wh + k0);
+    const char* lb = reinterpret_cast<const char*>(Wl + k0);
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-      wqh[i] = *reinterpret_cast<const gu32x4_t*>(Wh + wrow[i] + k0);
-      if constexpr (SPLIT) wql[i] = *reinterpret_cast<const gu32x4_t*>(Wl + wrow[i] + k0);
+      wqh[i] = *reinterpret_cast<const gu32x4_t*>(hb + wrow[i]);
+      if constexpr (SPLIT) wql[i] = *reinterpret_cast<const gu32x4_t*>(lb + wrow[i]);
     }
   };
   auto store_chunk = [&](auto setc) {
@@ -313,35 +323,54 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 3 : 2)) void gemm_nt_kernel(const v
       const long ldo = second ? act.ldy2 : ldy;
       const int nb = second ? n0 - act.n_split : n0;
       const bool with_r = Rv != nullptr && (act.n_split == 0 || second);
-      for (int e = tid; e < 64 * CPR; e += 256) {
-        const int rl = e / CPR, c4 = (e - rl * CPR) * 4;
-        const long m = m0 + hh * 64 + rl;
-        if (m >= M || n0 + c4 >= N) continue;
-        const float4 t4 = *reinterpret_cast<const float4*>(tile + rl * TLD + c4);
-        float v[4] = {t4.x + b4.x, t4.y + b4.y, t4.z + b4.z, t4.w + b4.w};
-        const long o = m * ldo + nb + c4;
-        if (STAGE_B && act.mode == 1) {
-          const uint64_t mix = act.thresh != 0u ? drop_mix64(act_seed, (uint64_t)(m * ldy + n0 + c4) >> 2) : 0ull;
+      // 4 pieces at a time: the mask / residual operands of a batch are fetched together, ahead of their uses (one
+      // piece at a time, each was a load + full wait — 8 .. 16 dependent round trips at the end of the block's chain)
+      constexpr int PIECES = 64 * CPR, BATCH = 4;
+      for (int e0 = tid; e0 < PIECES; e0 += 256 * BATCH) {
+        long o[BATCH];
+        bool ok[BATCH];
+        float k4[BATCH][4], r4[BATCH][4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float r = fmaxf(v[q], 0.0f);
-            if (act.thresh != 0u) r = drop_keep16(mix, q, act.thresh) ? r * act.scale : 0.0f;
-            v[q] = r;
+        for (int u = 0; u < BATCH; ++u) {
+          const int e = e0 + 256 * u;
+          const int rl = e / CPR, c4 = (e - rl * CPR) * 4;
+          const long m = m0 + hh * 64 + rl;
+          ok[u] = e < PIECES && m < M && n0 + c4 < N;
+          const long mc = ok[u] ? m : m0;                  // (clamped: straight-line loads, the result is dropped)
+          const int cc = ok[u] ? c4 : 0;
+          o[u] = mc * ldo + nb + cc;
+          if (act.mode == 2) vec_io<TO, 4>::load((const TO*)act.mask + o[u], k4[u]);
+          if (with_r) {
+            const long ro = act.res_period > 0 ? (long)((unsigned)mc % (unsigned)act.res_period) * act.res_ld + nb + cc : o[u];
+            vec_io<TO, 4>::load((const TO*)Rv + ro, r4[u]);
           }
         }
-        if (act.mode == 2) {
-          float k4[4];
-          vec_io<TO, 4>::load((const TO*)act.mask + o, k4);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = (k4[q] != 0.0f) ? v[q] * act.scale : 0.0f;
+        for (int u = 0; u < BATCH; ++u) {
+          const int e = e0 + 256 * u;
+          const int rl = (e < PIECES ? e : tid) / CPR, c4 = (e - (e / CPR) * CPR) * 4;
+          const long m = m0 + hh * 64 + rl;
+          const float4 t4 = *reinterpret_cast<const float4*>(tile + rl * TLD + c4);
+          float v[4] = {t4.x + b4.x, t4.y + b4.y, t4.z + b4.z, t4.w + b4.w};
+          if (STAGE_B && act.mode == 1) {
+            const uint64_t mix = act.thresh != 0u ? drop_mix64(act_seed, (uint64_t)(m * ldy + n0 + c4) >> 2) : 0ull;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float r = fmaxf(v[q], 0.0f);
+              if (act.thresh != 0u) r = drop_keep16(mix, q, act.thresh) ? r * act.scale : 0.0f;
+              v[q] = r;
+            }
+          }
+          if (act.mode == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (k4[u][q] != 0.0f) ? v[q] * act.scale : 0.0f;
+          }
+          if (with_r) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += r4[u][q];
+          }
+          if (ok[u]) vec_io<TO, 4>::store(Yo + o[u], v);
         }
-        if (with_r) {
-          float r4[4];
-          const long ro = act.res_period > 0 ? (long)((unsigned)m % (unsigned)act.res_period) * act.res_ld + nb + c4 : o;
-          vec_io<TO, 4>::load((const TO*)Rv + ro, r4);
-          v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
-        }
-        vec_io<TO, 4>::store(Yo + o, v);
       }
     }
   }
@@ -519,6 +548,11 @@ static int gemm_nt_run(const void* x, int64_t ldx, const void* w_hi, const void*
       (act.mode == 2 && ((uintptr_t)act.mask % 8) != 0)) {
     set_error("%s: shape M=%lld N=%d K=%d needs K %% 32 == 0, N %% 32 == 0 and 16-byte aligned rows", who,
               (long long)M, N, K);
+    return UBV_ERR_UNSUPPORTED;
+  }
+  // the kernel addresses X and W with 32-bit byte offsets
+  if (M * ldx * 4 >= (1LL << 32) || (act.x2 != nullptr && M * act.ldx2 * 4 >= (1LL << 32)) || (int64_t)N * ldw * 2 >= (1LL << 32)) {
+    set_error("%s: operand of M=%lld rows x ld=%lld is 4 GB or more", who, (long long)M, (long long)ldx);
     return UBV_ERR_UNSUPPORTED;
   }
   hipStream_t st = as_stream(stream);
