@@ -281,11 +281,11 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 3 : 2)) void gemm_nt_kernel(const v
         for (int g = 0; g < 4; ++g) {
           const int nl = (wn * WNB + j) * 32 + 8 * g + 4 * half, n = n0 + nl;
           float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          if (!STAGE_B && bias != nullptr && n < N) {
+          if (!STAGE && bias != nullptr && n < N) {
             const float4 b = *reinterpret_cast<const float4*>(bias + n);
             v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
           }
-          if (!STAGE_B && act.mode == 1) {
+          if (!STAGE && act.mode == 1) {
             const uint64_t mix = act.thresh != 0u ? drop_mix64(act_seed, (uint64_t)(m * ldy + n) >> 2) : 0ull;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 3 : 2)) void gemm_nt_kernel(const v
       for (int e0 = tid; e0 < PIECES; e0 += 256 * BATCH) {
         long o[BATCH];
         bool ok[BATCH];
-        float k4[BATCH][4], r4[BATCH][4];
+        float k4[BATCH][4], r4[BATCH][4], bq[STAGE_B ? 1 : BATCH][4];
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
           const int e = e0 + 256 * u;
@@ -339,6 +339,9 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 3 : 2)) void gemm_nt_kernel(const v
           const long mc = ok[u] ? m : m0;                  // (clamped: straight-line loads, the result is dropped)
           const int cc = ok[u] ? c4 : 0;
           o[u] = mc * ldo + nb + cc;
+          if constexpr (!STAGE_B) {                        // (NT = 96: the thread's columns change from piece to piece)
+            if (bias != nullptr) vec_io<float, 4>::load(bias + n0 + cc, bq[u]);
+          }
           if (act.mode == 2) vec_io<TO, 4>::load((const TO*)act.mask + o[u], k4[u]);
           if (with_r) {
             const long ro = act.res_period > 0 ? (long)((unsigned)mc % (unsigned)act.res_period) * act.res_ld + nb + cc : o[u];
@@ -352,7 +355,10 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 3 : 2)) void gemm_nt_kernel(const v
           const long m = m0 + hh * 64 + rl;
           const float4 t4 = *reinterpret_cast<const float4*>(tile + rl * TLD + c4);
           float v[4] = {t4.x + b4.x, t4.y + b4.y, t4.z + b4.z, t4.w + b4.w};
-          if (STAGE_B && act.mode == 1) {
+          if constexpr (!STAGE_B) {
+            if (bias != nullptr) { v[0] += bq[u][0]; v[1] += bq[u][1]; v[2] += bq[u][2]; v[3] += bq[u][3]; }
+          }
+          if (act.mode == 1) {
             const uint64_t mix = act.thresh != 0u ? drop_mix64(act_seed, (uint64_t)(m * ldy + n0 + c4) >> 2) : 0ull;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
