@@ -543,3 +543,59 @@ def test_fullsize_training_gradients_16bit_vs_fp32(dtype, fwd_tol, cos_lo, norm_
         assert cos > cos_lo and abs(ratio - 1.0) < norm_tol, (k, cos, ratio)
         checked += 1
     assert checked >= 10
+
+
+@pytest.mark.parametrize('fixture', ['fullsize_init'])
+def test_fullsize_gradients_vs_oracle(fixture):
+    """BASELINE shapes (200x200 BEV, 6 x 8x22 image maps, 180x180 LiDAR map, C = 256, 3 layers, CNW) at the bench's
+    operating point: gradient of sum(fused * cot) w.r.t. the inputs, the BEV queries and every encoder-side
+    parameter, f32 product path against torch autograd through the CPU oracle (the small
+    fixtures were the only gradient parity).  Normwise 1e-3 per tensor — the bar the forward holds — and 1e-2 on
+    the single worst element of a tensor relative to its largest (split-bf16 products, ~40 000-term sums)."""
+    from oracle import unibev_ref as R
+    cfg, sd, inp, g = encoder_case(fixture)
+    nq, bs, width = inp['bev_h'] * inp['bev_w'], inp['bs'], cfg['embed_dims'] * (2 if cfg.get('fusion_method') == 'cat' else 1)
+    cot = syn.seeded_array('cot:' + fixture, (nq, bs, width), 5) / nq ** 0.5
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    P = {k: v.requires_grad_() for k, v in R.state_dict_to_torch(sd).items()}
+    oi = [t(x).requires_grad_() for x in inp['img']]
+    op = [t(x).requires_grad_() for x in inp['pts']]
+    oq = t(inp['bev_q']).requires_grad_()
+    fused_ref = R.transformer_encode_fuse(P, cfg, oi, op, oq, inp['bev_h'], inp['bev_w'], t(inp['bev_pos']), inp['metas'])
+    (fused_ref * t(cot)).sum().backward()
+    model = _build(cfg).to(DEV).eval()
+    _load(model, sd)
+    gi = [t(x, device=DEV).requires_grad_() for x in inp['img']]
+    gp = [t(x, device=DEV).requires_grad_() for x in inp['pts']]
+    gq = t(inp['bev_q'], device=DEV).requires_grad_()
+    fused = model.encode(gi, gp, gq, inp['bev_h'], inp['bev_w'], bev_pos=t(inp['bev_pos'], device=DEV),
+                         img_metas=inp['metas'])
+    (fused * t(cot, device=DEV)).sum().backward()
+    ferr = float((fused.detach().cpu() - fused_ref.detach()).norm() / fused_ref.detach().norm())
+    assert ferr < 1e-3, ferr
+    worst = {}
+
+    def close(a, b, what):
+        a, b = a.detach().cpu().double(), b.detach().double()
+        nb = float(b.norm())
+        if nb == 0.0:
+            assert float(a.norm()) == 0.0, what
+            return
+        nerr = float((a - b).norm()) / nb
+        merr = float((a - b).abs().max()) / float(b.abs().max())
+        worst[what] = (nerr, merr)
+        assert nerr < 1e-3 and merr < 1e-2, (what, nerr, merr)
+    close(gi[0].grad, oi[0].grad, 'img feats')
+    close(gp[0].grad, op[0].grad, 'pts feats')
+    close(gq.grad, oq.grad, 'bev queries')
+    checked = 0
+    for k, p in model.named_parameters():
+        if k.startswith('decoder') or k.startswith('reference_points') or P[k].grad is None:
+            continue
+        assert p.grad is not None, k
+        close(p.grad, P[k].grad, k)
+        checked += 1
+    assert checked > 100, checked
+    w = max(worst.items(), key=lambda kv: kv[1][0])
+    print(f'fullsize gradients: forward {ferr:.1e}, worst normwise {w[0]} {w[1][0]:.1e}, worst element '
+          f'{max(v[1] for v in worst.values()):.1e}')
