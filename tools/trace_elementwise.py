@@ -21,7 +21,7 @@ class Mode(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         out = func(*args, **(kwargs or {}))
         name = str(func)
-        big = [a for a in args if isinstance(a, torch.Tensor) and a.numel() >= 5_000_000]
+        big = [a for a in args if isinstance(a, torch.Tensor) and a.numel() >= int(os.environ.get('UBV_TRACE_MIN', 5_000_000))]
         gemm = any(k in name for k in ('aten.mm', 'aten.addmm', 'aten.bmm', 'aten.linear', 'aten.matmul'))
         if gemm:
             big = [a for a in args if isinstance(a, torch.Tensor)]
