@@ -673,7 +673,13 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
                                                             const int32_t* __restrict__ xidx, long xld,
                                                             const int32_t* __restrict__ yidx,
                                                             const int32_t* __restrict__ cnt,
-                                                            const void* __restrict__ dY2v, int n_split) {
+                                                            const void* __restrict__ dY2v, int n_split,
+                                                            int kvol, int cwsh) {
+  // kvol / cwsh (GATHER with pairs): narrow layers PACK several kernel offsets into one 128-wide tile — offset p of
+  // the block's 128 >> cwsh takes columns [p << cwsh, (p + 1) << cwsh) of BOTH operand planes, each thread gathers the
+  // rows of ITS offset's pair list, and of the 128 x 128 product only the diagonal blocks (same offset on both sides)
+  // are stored.  A 64-channel layer then runs 14 tiles instead of 27 with every load used (a quarter of a one-offset
+  // tile was data, the rest clamped zero loads), a 32-channel layer 7, a 16-channel layer 4.  cwsh = 7: one offset.
   // dY2v / n_split (f32 only, ubv_gemm_wgrad_dual): columns n >= n_split of dY live in a second matrix [M, N - n_split]
   // and the first one is [M, n_split] — the fused value_proj | offsets | logits weight gradient of the BEV self-attention
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
@@ -689,15 +695,22 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
   if (split >= splits) return;
   const int tn = GATHER ? 0 : tile / tiles_k, tk = GATHER ? 0 : tile - tn * tiles_k;
   const int n0 = tn * kWgTile, k0 = tk * kWgTile;
-  if (GATHER) xidx += (long)tile * xld;
-  // GATHER with compacted pairs (ubv_spconv_wgrad_pairs): row i < cnt[tile] of this offset multiplies
+  const int pack = GATHER ? (128 >> cwsh) : 1, cmask = (1 << cwsh) - 1;
+  // GATHER with compacted pairs (ubv_spconv_wgrad_pairs): row i < cnt[kk] of offset kk multiplies
   // dY[yidx[i]] with X[xidx[i]]; rows past the count hold no pair — slabs beyond it store a zero tile at once
-  if (GATHER && yidx != nullptr) yidx += (long)tile * xld;
   const long mbeg = (long)split * rows_per_split;
-  long mend = mbeg + rows_per_split < M ? mbeg + rows_per_split : M;
+  const long slab_end = mbeg + rows_per_split < M ? mbeg + rows_per_split : M;
+  long mend = slab_end;
   // (slabs keep their fixed row ranges: dealing each offset's pairs evenly to the slabs measured slower, 8.5 vs 7.5 ms
   //  per encoder backward — the offsets of one slab then walk different rows of dY and stop sharing them through L2)
-  if (GATHER && cnt != nullptr) mend = mend < (long)cnt[tile] ? mend : (long)cnt[tile];
+  if (GATHER && cnt != nullptr) {
+    long most = 0;
+    for (int q = 0; q < pack; ++q) {
+      const int kq = tile * pack + q;
+      if (kq < kvol) most = most > (long)cnt[kq] ? most : (long)cnt[kq];
+    }
+    mend = mend < most ? mend : most;
+  }
   const int wk = wv >> 1, wn = wv & 1;                    // wave: k groups {wk, wk+2} (+4), n groups {wn, wn+2} (+4)
   const bool want_bias = !GATHER && tk == 0 && wk == 0;
 
@@ -719,8 +732,21 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
   constexpr int CW = SPLIT ? 4 : 8;                       // columns per load
   constexpr int TPR = 128 / CW;                           // threads per row
   const int sc = (tid % TPR) * CW, sr = tid / TPR;        // column within the tile, first row
-  const bool yok = n0 + sc < N, xok = k0 + sc < K;        // N, K multiples of CW (host check)
-  const long ycol = yok ? n0 + sc : 0, xcol = xok ? k0 + sc : 0;
+  // this thread's kernel offset (GATHER): its pair lists, its own row count
+  const int mykk = GATHER ? tile * pack + (sc >> cwsh) : 0;
+  const bool kk_ok = !GATHER || mykk < kvol;
+  const int cl = GATHER ? (sc & cmask) : sc;              // column inside the offset's block
+  if (GATHER) {
+    xidx += (long)(kk_ok ? mykk : 0) * xld;
+    if (yidx != nullptr) yidx += (long)(kk_ok ? mykk : 0) * xld;
+  }
+  long my_end = mend;                                     // rows of THIS thread's operand columns
+  if (GATHER && cnt != nullptr) {
+    const long c = kk_ok ? (long)cnt[kk_ok ? mykk : 0] : 0;
+    my_end = slab_end < c ? slab_end : c;
+  }
+  const bool yok = kk_ok && n0 + cl < N, xok = kk_ok && k0 + cl < K;        // N, K multiples of CW (host check)
+  const long ycol = yok ? n0 + cl : 0, xcol = xok ? k0 + cl : 0;
   const int soff = (sc >> 4) * kWgCS + (sc & 15);         // LDS offset of (row 0, column sc)
   gf32x4_t fy[SPLIT ? NI : 1], fx[SPLIT ? NI : 1];
   gu32x4_t hy[SPLIT ? 1 : NI], hx[SPLIT ? 1 : NI];
@@ -728,9 +754,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const long m = mc + sr + (256 / TPR) * i;
-      const long mm = m < mend ? m : mend - 1;
+      long mm = m < my_end ? m : my_end - 1;
+      mm = mm > 0 ? mm : 0;                               // (an offset with no pair in this slab: row 0, dropped)
       long xm = mm, ym = mm;
-      bool xrow_ok = m < mend;
+      bool xrow_ok = m < my_end;
       if constexpr (GATHER) {
         const int r = xidx[mm];
         xrow_ok = xrow_ok && r >= 0;
@@ -745,12 +772,12 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
         } else
         fy[i] = *reinterpret_cast<const gf32x4_t*>((const float*)dYv + ym * N + ycol);
         fx[i] = *reinterpret_cast<const gf32x4_t*>((const float*)Xv + xm * K + xcol);
-        if (!(m < mend && yok)) fy[i] = gf32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (!(m < my_end && yok)) fy[i] = gf32x4_t{0.f, 0.f, 0.f, 0.f};
         if (!(xrow_ok && xok)) fx[i] = gf32x4_t{0.f, 0.f, 0.f, 0.f};
       } else {
         hy[i] = *reinterpret_cast<const gu32x4_t*>((const uint16_t*)dYv + ym * N + ycol);
         hx[i] = *reinterpret_cast<const gu32x4_t*>((const uint16_t*)Xv + xm * K + xcol);
-        if (!(m < mend && yok)) hy[i] = gu32x4_t{0u, 0u, 0u, 0u};
+        if (!(m < my_end && yok)) hy[i] = gu32x4_t{0u, 0u, 0u, 0u};
         if (!(xrow_ok && xok)) hx[i] = gu32x4_t{0u, 0u, 0u, 0u};
       }
     }
@@ -824,19 +851,28 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
   }
   // ---- partial tile.  D[k][n]: column u = lane & 31 of block j, rows u' = (r & 3) + 8 (r >> 2) + 4 half of
   // block i; block-local index u -> tile index 16 (c + 4 (u >> 4)) + (u & 15) with c the block's first group
-  float* part = partials + ((long)split * (GATHER ? tiles : 1) + (GATHER ? tile : 0)) * ((long)N * K + N);
+  float* part = partials + ((long)split * (GATHER ? kvol : 1)) * ((long)N * K + N);
   const int half = lane >> 5, u = lane & 31;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int n = n0 + 16 * (wn + 2 * j + 4 * (u >> 4)) + (u & 15);
+    const int nt = 16 * (wn + 2 * j + 4 * (u >> 4)) + (u & 15);             // column index inside the tile
+    const int n = GATHER ? (nt & cmask) : n0 + nt;
     if (n >= N) continue;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int uk = 8 * g + 4 * half;                  // 4 consecutive rows, inside one 16-group
-        const int k = k0 + 16 * (wk + 2 * i + 4 * (uk >> 4)) + (uk & 15);
+        const int kt = 16 * (wk + 2 * i + 4 * (uk >> 4)) + (uk & 15);
+        const int k = GATHER ? (kt & cmask) : k0 + kt;
         if (k >= K) continue;                             // K is a multiple of 4 (host check)
+        if constexpr (GATHER) {                           // diagonal blocks only: the same offset on both sides
+          const int pn = nt >> cwsh;
+          if (pn != (kt >> cwsh) || tile * pack + pn >= kvol) continue;
+          *reinterpret_cast<float4*>(part + (long)(tile * pack + pn) * ((long)N * K + N) + (long)n * K + k) =
+              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+          continue;
+        }
         *reinterpret_cast<float4*>(part + (long)n * K + k) =
             make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
       }
@@ -924,11 +960,11 @@ static int gemm_wgrad_run(const void* grad_out, const void* grad_out2, int n_spl
   const size_t lds = (size_t)(dtype == UBV_F32 ? 4 : 2) * kWgPlane * sizeof(uint16_t);
   hipStream_t st = as_stream(stream);
   if (dtype == UBV_F32)
-    hipLaunchKernelGGL((gemm_wgrad_kernel<true, false, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps, (const int32_t*)nullptr, 0L, (const int32_t*)nullptr, (const int32_t*)nullptr, grad_out2, n_split);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<true, false, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps, (const int32_t*)nullptr, 0L, (const int32_t*)nullptr, (const int32_t*)nullptr, grad_out2, n_split, 1, 7);
   else if (dtype == UBV_F16)
-    hipLaunchKernelGGL((gemm_wgrad_kernel<false, true, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps, (const int32_t*)nullptr, 0L, (const int32_t*)nullptr, (const int32_t*)nullptr, grad_out2, n_split);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<false, true, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps, (const int32_t*)nullptr, 0L, (const int32_t*)nullptr, (const int32_t*)nullptr, grad_out2, n_split, 1, 7);
   else
-    hipLaunchKernelGGL((gemm_wgrad_kernel<false, false, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps, (const int32_t*)nullptr, 0L, (const int32_t*)nullptr, (const int32_t*)nullptr, grad_out2, n_split);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<false, false, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps, (const int32_t*)nullptr, 0L, (const int32_t*)nullptr, (const int32_t*)nullptr, grad_out2, n_split, 1, 7);
   const long len = (long)N * K + N;
   hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((len / 4 + 31) / 32)), dim3(256), 0, st, partials, splits, len,
                      grad_wb);
@@ -984,15 +1020,23 @@ static int spconv_wgrad_run(const void* grad_out, const void* feats, const int32
   }
   long rps = (rows + splits - 1) / splits;
   rps = (rps + kWgMC - 1) / kWgMC * kWgMC;
-  const dim3 grid((unsigned)((splits + 7) / 8 * 8 * kvol)), blk(256);
+  // narrow layers with compacted pairs: several offsets per 128-wide tile (see the kernel).  UBV_SPCONV_PACK=0: off
+  static const int pack_env = getenv("UBV_SPCONV_PACK") ? atoi(getenv("UBV_SPCONV_PACK")) : 1;
+  int cwsh = 7;
+  if (out_rows != nullptr && counts != nullptr && pack_env != 0) {
+    const int cmax = Cout > Cin ? Cout : Cin;
+    cwsh = cmax <= 16 ? 4 : cmax <= 32 ? 5 : cmax <= 64 ? 6 : 7;
+  }
+  const int pack = 128 >> cwsh, ptiles = (kvol + pack - 1) / pack;
+  const dim3 grid((unsigned)((splits + 7) / 8 * 8 * ptiles)), blk(256);
   const size_t lds = (size_t)(dtype == UBV_F32 ? 4 : 2) * kWgPlane * sizeof(uint16_t);
   hipStream_t st = as_stream(stream);
   if (dtype == UBV_F32)
-    hipLaunchKernelGGL((gemm_wgrad_kernel<true, false, true>), grid, blk, lds, st, grad_out, feats, partials, (long)rows, Cout, Cin, 1, kvol, splits, (int)rps, nbr, (long)ld, out_rows, counts, (const void*)nullptr, 0);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<true, false, true>), grid, blk, lds, st, grad_out, feats, partials, (long)rows, Cout, Cin, 1, ptiles, splits, (int)rps, nbr, (long)ld, out_rows, counts, (const void*)nullptr, 0, kvol, cwsh);
   else if (dtype == UBV_F16)
-    hipLaunchKernelGGL((gemm_wgrad_kernel<false, true, true>), grid, blk, lds, st, grad_out, feats, partials, (long)rows, Cout, Cin, 1, kvol, splits, (int)rps, nbr, (long)ld, out_rows, counts, (const void*)nullptr, 0);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<false, true, true>), grid, blk, lds, st, grad_out, feats, partials, (long)rows, Cout, Cin, 1, ptiles, splits, (int)rps, nbr, (long)ld, out_rows, counts, (const void*)nullptr, 0, kvol, cwsh);
   else
-    hipLaunchKernelGGL((gemm_wgrad_kernel<false, false, true>), grid, blk, lds, st, grad_out, feats, partials, (long)rows, Cout, Cin, 1, kvol, splits, (int)rps, nbr, (long)ld, out_rows, counts, (const void*)nullptr, 0);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<false, false, true>), grid, blk, lds, st, grad_out, feats, partials, (long)rows, Cout, Cin, 1, ptiles, splits, (int)rps, nbr, (long)ld, out_rows, counts, (const void*)nullptr, 0, kvol, cwsh);
   const long len = (long)kvol * ((long)Cout * Cin + Cout);
   hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((len / 4 + 31) / 32)), dim3(256), 0, st, partials, splits, len, grad_w);
   UBV_CHECK_LAUNCH("spconv_wgrad");
