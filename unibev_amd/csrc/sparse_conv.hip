@@ -181,15 +181,39 @@ __global__ __launch_bounds__(256) void spconv_gather_mma_kernel(const T* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  for (int k = 0; k < kvol; ++k) {
-    int idx[RB];
-    bool any = false;
+  // Software pipeline ACROSS the offsets (round 3, session 5): offset k + 1's neighbour indices are fetched before
+  // offset k's weights are staged, and its first 16-channel gather is issued in the slot of offset k's last step — a
+  // block used to walk index -> barrier -> W copy -> barrier -> first gather as three serial round trips per offset,
+  // 27 times (one block per CU-slot: the block's chain IS the kernel's time).
+  constexpr int NV = SPLIT ? 2 : 1;                        // 16-byte loads per row and step
+  int idx[RB], idn[RB];
+  auto load_idx = [&](int k, int (&d)[RB]) {
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const long row = row0 + i * 32 + m;
-      idx[i] = (wave_live && row < rows) ? nbr[(long)k * ld + row] : -1;
-      any = any || idx[i] >= 0;
+      d[i] = (k < kvol && wave_live && row < rows) ? nbr[(long)k * ld + row] : -1;
     }
+  };
+  // A fragments straight from the gathered rows (rows without a neighbour: zeros)
+  auto load_a = [&](const int (&ix)[RB], int c0, uint4 (&dst)[RB][NV]) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const T* frow = feats + (long)(ix[i] >= 0 ? ix[i] : 0) * Cin + kg * 8 + c0;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        dst[i][v] = reinterpret_cast<const uint4*>(frow)[v];
+        if (ix[i] < 0) dst[i][v] = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  };
+  uint4 raw[RB][NV], nxt[RB][NV];
+  load_idx(0, idx);
+  load_a(idx, 0, raw);
+  for (int k = 0; k < kvol; ++k) {
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) any = any || idx[i] >= 0;
+    load_idx(k + 1, idn);                                 // (past the last offset: -1)
     // ---- W_k -> LDS, by the whole block
     __syncthreads();                                      // the previous offset's fragments are consumed
     {
@@ -203,27 +227,19 @@ __global__ __launch_bounds__(256) void spconv_gather_mma_kernel(const T* __restr
       }
     }
     __syncthreads();
-    if (__ballot(any) == 0ull) continue;                  // no row of this wave has a neighbour at offset k
+    if (__ballot(any) == 0ull) {                          // no row of this wave has a neighbour at offset k
+      load_a(idn, 0, raw);
+#pragma unroll
+      for (int i = 0; i < RB; ++i) idx[i] = idn[i];
+      continue;
+    }
     const uint16_t* wk_hi = s_hi + m * LD + kg * 8;
     const uint16_t* wk_lo = SPLIT ? s_lo + m * LD + kg * 8 : nullptr;
-    // A fragments straight from the gathered rows, the NEXT 16-channel step's loads issued before this step's MFMAs
-    // (the loop is a chain of dependent gathers otherwise: index -> row -> convert -> MFMA)
-    constexpr int NV = SPLIT ? 2 : 1;                      // 16-byte loads per row and step
-    uint4 raw[RB][NV], nxt[RB][NV];
-    auto load_a = [&](int c0, uint4 (&dst)[RB][NV]) {
-#pragma unroll
-      for (int i = 0; i < RB; ++i) {
-        const T* frow = feats + (long)(idx[i] >= 0 ? idx[i] : 0) * Cin + kg * 8 + c0;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          dst[i][v] = reinterpret_cast<const uint4*>(frow)[v];
-          if (idx[i] < 0) dst[i][v] = make_uint4(0u, 0u, 0u, 0u);
-        }
-      }
-    };
-    load_a(0, raw);
     for (int c0 = 0; c0 < Cin; c0 += 16) {
-      if (c0 + 16 < Cin) load_a(c0 + 16, nxt);
+      // the NEXT 16-channel step's loads are issued before this step's MFMAs; the last step fetches the next
+      // OFFSET's first step instead
+      if (c0 + 16 < Cin) load_a(idx, c0 + 16, nxt);
+      else load_a(idn, 0, nxt);
       uint4 a_hi[RB], a_lo[RB];
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
@@ -262,6 +278,8 @@ __global__ __launch_bounds__(256) void spconv_gather_mma_kernel(const T* __restr
 #pragma unroll
         for (int v = 0; v < NV; ++v) raw[i][v] = nxt[i][v];
     }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) idx[i] = idn[i];
   }
   // D[i][n]: this lane holds column n = lane & 31 (output channel within block j), rows (r & 3) + 8 (r >> 2) + 4 kg
   if (!wave_live) return;
