@@ -464,8 +464,7 @@ extern "C" int ubv_add_dropout_layernorm_backward(const void* grad_y, const void
   if (R == 0) return UBV_OK;
   uint32_t th; float sc;
   drop_params(p, th, sc);
-  static const long wcap = getenv("UBV_NORM_BWD_WAVES") ? atol(getenv("UBV_NORM_BWD_WAVES")) : 2048;   // study knob
-  const long waves = R < wcap ? R : wcap;
+  const long waves = R < 2048 ? R : 2048;
   const dim3 grid((unsigned)((waves + 3) / 4));
   hipStream_t st = as_stream(stream);
 #define UBV_NORM_BWD(T, S) norm_bwd_launch<T, S>(grid, st, grad_y, x, identity, gamma, mean, rstd, grad_x, grad_identity, grad_gamma, grad_beta, grad_x_colsum, (long)R, C, th, sc, seed, seed_dev)
