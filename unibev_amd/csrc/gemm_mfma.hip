@@ -916,7 +916,8 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
 
 extern "C" int ubv_gemm_wgrad_splits(int64_t M, int N, int K) {
   const int tiles = ((N + ubv::kWgTile - 1) / ubv::kWgTile) * ((K + ubv::kWgTile - 1) / ubv::kWgTile);
-  long s = (512 + tiles - 1) / tiles;                     // two blocks per CU
+  static const int blocks_env = getenv("UBV_WGRAD_BLOCKS") ? atoi(getenv("UBV_WGRAD_BLOCKS")) : 512;   // study knob
+  long s = (blocks_env + tiles - 1) / tiles;              // two blocks per CU
   const long max_s = (M + 255) / 256;                     // at least 256 rows per split
   if (s > max_s) s = max_s;
   if (s > 256) s = 256;
