@@ -23,6 +23,14 @@ def t(a, dtype=None, device=None):
     return x
 
 
+def tq(q, dtype=None, device=None, grad=False):
+    """BEV query table(s) of a fixture: one array, or [img table, pts table] for ``dual_queries``."""
+    if isinstance(q, (list, tuple)):
+        return [tq(x, dtype, device, grad) for x in q]
+    x = t(q, dtype, device)
+    return x.requires_grad_() if grad else x
+
+
 def checksum(a):
     a = np.asarray(a, dtype=np.float64)
     return np.array([a.sum(), np.abs(a).sum(), float(a.size)])

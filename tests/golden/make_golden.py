@@ -203,6 +203,10 @@ ENCODER_CASES = {
                modalities='L'), 10, 12, 2, None, (9, 11), (64, 96), 26),
     'spatial': (dict(embed_dims=128, num_layers=1, num_cams=2, spatial_norm='SpatialNormWeights',
                      bev_h=10, bev_w=12), 10, 12, 2, (4, 6), (9, 11), (64, 96), 27),
+    # two BEV query tables, one per modality (transformer_fusion.py:493-496; shipped config
+    # unibev_nus_LC_cnw_dual_queries_modality_dropout.py): `bev_q` is the list [img table, pts table]
+    'dual': (dict(embed_dims=128, num_layers=2, num_cams=2, dual_queries=True), 10, 12, 2, (4, 6), (9, 11),
+             (64, 96), 28),
 }
 
 
@@ -213,6 +217,8 @@ def encoder_inputs(name, kw, bev_h, bev_w, bs, img_hw_f, pts_hw_f, img_hw, seed)
     img = None if img_hw_f is None else [syn.seeded_array(f'enc:{name}:img', (bs, nc, C) + img_hw_f, seed)]
     pts = None if pts_hw_f is None else [syn.seeded_array(f'enc:{name}:pts', (bs, C) + pts_hw_f, seed)]
     bev_q = syn.seeded_array(f'enc:{name}:bev_q', (bev_h * bev_w, C), seed)
+    if kw.get('dual_queries'):
+        bev_q = [bev_q, syn.seeded_array(f'enc:{name}:bev_q_pts', (bev_h * bev_w, C), seed)]
     bev_pos = syn.seeded_array(f'enc:{name}:bev_pos', (bs, C, bev_h, bev_w), seed)
     oq = syn.seeded_array(f'enc:{name}:oq', (7, 2 * C * s), seed)
     metas = syn.img_metas(bs, nc, img_hw, jitter_seed=seed)
@@ -239,12 +245,15 @@ def run_reference_transformer(mods, name, case):
         fused, _, _, _ = model(
             None if img is None else [t(x) for x in img],
             None if pts is None else [t(x) for x in pts],
-            t(bev_q), t(oq), bev_h, bev_w, bev_pos=t(bev_pos), img_metas=metas)
+            [t(q) for q in bev_q] if isinstance(bev_q, list) else t(bev_q), t(oq), bev_h, bev_w,
+            bev_pos=t(bev_pos), img_metas=metas)
     return cfg, named, fused, parts, (img, pts, bev_q, bev_pos, metas)
 
 
-def gen_encoders(mods):
+def gen_encoders(mods, only=None):
     for name, case in ENCODER_CASES.items():
+        if only is not None and name not in only:
+            continue
         cfg, named, fused, parts, (img, pts, bev_q, bev_pos, metas) = \
             run_reference_transformer(mods, name, case)
         arrays = dict(cfg_json=np.array(json.dumps(cfg)),
@@ -442,6 +451,9 @@ HEAD_CASES = {
     'cat': (dict(embed_dims=128, bev_h=10, bev_w=12, num_query=7, decoder_layers=2, with_box_refine=False),
             dict(num_layers=1, num_cams=2, fusion_method='cat', feature_norm=None), 1, (4, 6), (9, 11),
             (64, 96), 42),
+    # bev_embedding_img / bev_embedding_pts (unibev_head.py:126-133, 172-174)
+    'dual': (dict(embed_dims=128, bev_h=10, bev_w=12, num_query=8, decoder_layers=1),
+             dict(num_layers=1, num_cams=2, dual_queries=True), 2, (4, 6), (9, 11), (64, 96), 43),
 }
 
 
@@ -452,7 +464,7 @@ def head_inputs(name, hkw, tkw, bs, img_hw_f, pts_hw_f, img_hw, seed):
     return img, pts, syn.img_metas(bs, nc, img_hw, jitter_seed=seed)
 
 
-def gen_head(mods):
+def gen_head(mods, only=None):
     """UniBEV_Head.forward (models/dense_heads/unibev_head.py:145-242) with the reference's
     DetectionTransformerDecoder / CustomMSDeformableAttention (models/modules/decoder.py:51-338),
     eval mode, seeded parameters: class scores, box predictions, decoder states and references."""
@@ -461,6 +473,8 @@ def gen_head(mods):
     sys.modules['refheads'] = pkg
     Head = importlib.import_module('refheads.unibev_head').UniBEV_Head
     for name, case in HEAD_CASES.items():
+        if only is not None and name not in only:
+            continue
         hkw, tkw, bs, img_hw_f, pts_hw_f, img_hw, seed = case
         cfg = cfgs.head_cfg(**hkw, **tkw)
         args = json.loads(json.dumps(cfg))
@@ -483,6 +497,8 @@ def gen_head(mods):
              bev_embed=outs['bev_embed'].numpy(), all_cls_scores=outs['all_cls_scores'].numpy(),
              all_bbox_preds=outs['all_bbox_preds'].numpy(), hs=hs.numpy(),
              init_reference=init_ref.numpy(), inter_references=inter_ref.numpy())
+    if only is not None:
+        return
     # init_weights facts that do not depend on torch's RNG (unibev_head.py:137-143)
     head = Head(**{k: v for k, v in json.loads(json.dumps(cfgs.head_cfg(**HEAD_CASES['cnw'][0],
                                                                           **HEAD_CASES['cnw'][1]))).items()
@@ -648,6 +664,11 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'variants':
         torch.manual_seed(0)
         return gen_variants(load_reference())
+    if len(sys.argv) > 1 and sys.argv[1] == 'dual':
+        torch.manual_seed(0)
+        mods = load_reference()
+        gen_encoders(mods, only=('dual',))
+        return gen_head(mods, only=('dual',))
     torch.manual_seed(0)
     torch.set_num_threads(8)
     mods = load_reference()

@@ -10,7 +10,7 @@ from _util import golden
 
 def test_head_state_dict_names_equal_the_reference():
     from unibev_amd.registry import HEADS
-    for name in ('cnw', 'cat'):
+    for name in ('cnw', 'cat', 'dual'):
         g = golden('head_' + name)
         head = HEADS.build(json.loads(str(g['cfg_json'])))
         mine = {k: tuple(v.shape) for k, v in head.state_dict().items()}

@@ -32,7 +32,7 @@ def build_case(name):
     return head, g, img, pts, metas
 
 
-@pytest.mark.parametrize('name', ['cnw', 'cat'])
+@pytest.mark.parametrize('name', ['cnw', 'cat', 'dual'])
 def test_head_and_decoder_vs_reference_vectors(name):
     head, g, img, pts, metas = build_case(name)
     got = {}

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import golden, t, metas_from, encoder_case, variant_case, checksum
+from _util import golden, t, tq, metas_from, encoder_case, variant_case, checksum
 import make_golden as mg
 from unibev_amd import synthetic as syn
 
@@ -65,7 +65,7 @@ def _build(cfg):
 def _run(model, inp, dtype=torch.float32):
     img = None if inp['img'] is None else [t(x, dtype, DEV) for x in inp['img']]
     pts = None if inp['pts'] is None else [t(x, dtype, DEV) for x in inp['pts']]
-    return model.encode(img, pts, t(inp['bev_q'], dtype, DEV), inp['bev_h'], inp['bev_w'],
+    return model.encode(img, pts, tq(inp['bev_q'], dtype, DEV), inp['bev_h'], inp['bev_w'],
                         bev_pos=t(inp['bev_pos'], dtype, DEV), img_metas=inp['metas'],
                         return_parts=True)
 
@@ -88,7 +88,7 @@ def test_encoder_fusion_vs_reference_vectors(name):
 
 
 @pytest.mark.parametrize('streams', [2, 1])
-@pytest.mark.parametrize('name', ['cnw', 'cat'])
+@pytest.mark.parametrize('name', ['cnw', 'cat', 'dual'])
 def test_encoder_gradients_vs_oracle(name, streams):
     """Backward of the whole path: d(sum(fused * cot)) w.r.t. inputs and every parameter vs torch
     autograd through the oracle — with the two encoders on two HIP streams (the default) and on one."""
@@ -109,7 +109,7 @@ def _encoder_gradients_vs_oracle(name, R, case=None, flags=(1, 1)):
     P = {k: v.requires_grad_() for k, v in R.state_dict_to_torch(sd).items()}
     oi = [t(x).requires_grad_() for x in inp['img']]
     op = [t(x).requires_grad_() for x in inp['pts']]
-    oq = t(inp['bev_q']).requires_grad_()
+    oq = tq(inp['bev_q'], grad=True)
     fused_ref = R.transformer_encode_fuse(P, cfg, oi, op, oq, inp['bev_h'], inp['bev_w'],
                                           t(inp['bev_pos']), inp['metas'], c_flag=flags[0], l_flag=flags[1])
     (fused_ref * t(cot)).sum().backward()
@@ -119,7 +119,7 @@ def _encoder_gradients_vs_oracle(name, R, case=None, flags=(1, 1)):
     model.forced_flags = tuple(flags)
     gi = [t(x, device=DEV).requires_grad_() for x in inp['img']]
     gp = [t(x, device=DEV).requires_grad_() for x in inp['pts']]
-    gq = t(inp['bev_q'], device=DEV).requires_grad_()
+    gq = tq(inp['bev_q'], device=DEV, grad=True)
     fused = model.encode(gi, gp, gq, inp['bev_h'], inp['bev_w'], bev_pos=t(inp['bev_pos'], device=DEV),
                          img_metas=inp['metas'])
     (fused * t(cot, device=DEV)).sum().backward()
@@ -137,7 +137,11 @@ def _encoder_gradients_vs_oracle(name, R, case=None, flags=(1, 1)):
         assert err < 4e-3 and nerr < 1e-3, (what, err, nerr)
     close(gi[0].grad, oi[0].grad, 'img feats')
     close(gp[0].grad, op[0].grad, 'pts feats')
-    close(gq.grad, oq.grad, 'bev queries')
+    if isinstance(gq, list):              # dual_queries: one table per modality
+        close(gq[0].grad, oq[0].grad, 'bev queries (img)')
+        close(gq[1].grad, oq[1].grad, 'bev queries (pts)')
+    else:
+        close(gq.grad, oq.grad, 'bev queries')
     for k, p in model.named_parameters():
         if k.startswith('decoder') or k.startswith('reference_points'):
             continue
@@ -577,7 +581,7 @@ def test_fullsize_gradients_vs_oracle(fixture):
     _load(model, sd)
     gi = [t(x, device=DEV).requires_grad_() for x in inp['img']]
     gp = [t(x, device=DEV).requires_grad_() for x in inp['pts']]
-    gq = t(inp['bev_q'], device=DEV).requires_grad_()
+    gq = tq(inp['bev_q'], device=DEV, grad=True)
     fused = model.encode(gi, gp, gq, inp['bev_h'], inp['bev_w'], bev_pos=t(inp['bev_pos'], device=DEV),
                          img_metas=inp['metas'])
     (fused * t(cot, device=DEV)).sum().backward()

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import golden, t, metas_from, encoder_case, variant_case, checksum
+from _util import golden, t, tq, metas_from, encoder_case, variant_case, checksum
 from oracle import unibev_ref as R
 from unibev_amd import synthetic as syn
 
@@ -84,7 +84,7 @@ def run_oracle(cfg, sd, inp):
     return R.transformer_encode_fuse(
         P, cfg, None if inp['img'] is None else [t(x) for x in inp['img']],
         None if inp['pts'] is None else [t(x) for x in inp['pts']],
-        t(inp['bev_q']), inp['bev_h'], inp['bev_w'], t(inp['bev_pos']), inp['metas'],
+        tq(inp['bev_q']), inp['bev_h'], inp['bev_w'], t(inp['bev_pos']), inp['metas'],
         return_parts=True)
 
 

@@ -48,6 +48,7 @@ def test_build_from_cfg_errors_like_mmcv():
 @have_ref
 @pytest.mark.parametrize('fname,kw', [
     ('unibev_nus_LC_cnw_256_modality_dropout.py', dict()),
+    ('unibev_nus_LC_cnw_dual_queries_modality_dropout.py', dict(dual_queries=True)),
     ('unibev_nus_LC_avg_256_modality_dropout.py', dict(fusion_method='avg', feature_norm=None)),
     ('unibev_nus_LC_cat_128_modality_dropout.py',
      dict(embed_dims=128, fusion_method='cat', feature_norm=None)),
@@ -80,7 +81,11 @@ def test_shipped_configs_load_and_build_unchanged(fname, kw):
         assert layer.attentions[1].deformable_attention.num_points == 8
         assert layer.ffns[0].feedforward_channels == 2 * tcfg.embed_dims
     head = reg.HEADS.build(cfg.model.pts_bbox_head)
-    assert head.bev_embedding.weight.shape == (200 * 200, tcfg.embed_dims)
+    if kw.get('dual_queries'):            # unibev_head.py:126-133: one query table per modality
+        assert model.dual_queries and not hasattr(head, 'bev_embedding')
+        assert head.bev_embedding_img.weight.shape == head.bev_embedding_pts.weight.shape == (200 * 200, tcfg.embed_dims)
+    else:
+        assert head.bev_embedding.weight.shape == (200 * 200, tcfg.embed_dims)
 
 
 @have_ref
