@@ -23,91 +23,9 @@
 #include <stdlib.h>
 
 #include "ubv_common.h"
+#include "bev_lift_core.h"
 
 namespace ubv {
-
-struct LiftArgs {
-  const void* value; const void* offsets; long off_stride; const void* logits; long log_stride;
-  int ol16;                                      // offsets / logits (and their gradients) are f32 (0)
-                                                 // or the value's own 16-bit type (1)
-  const float* ref; const uint8_t* vis0; const float* count;
-  void* out;                                     // fwd
-  const void* gout; float* gvalue; void* goff; long goff_stride; void* glog; long glog_stride;
-  void* gvalue_lp;                               // final grad_value in the value's 16-bit type or null
-  int B, Nc, fh, fw, H, Nq, Z, qw, qh, tiles_x, tiles_per_sample, total_tiles, chunk;
-  unsigned mg_tps, mg_tx;                        // multiply-high reciprocals of tiles_per_sample / tiles_x (0: divide)
-  // GRID backward: sampling points binned by owner tile
-  int* bin_cnt;                                  // [B,H,tiles] points appended per tile (may exceed cap)
-  float4* bins;                                  // [B,H,tiles,cap] (x_pix, y_pix, w/count, query index)
-  int cap;                                       // bucket capacity
-  int* ovf_n; float4* ovf_rec; int* ovf_tile; int ovf_cap;   // the appends that did not fit
-  int cnt_words;                                 // > 0: the query-gradient kernel (first of the op) zeroes bin_cnt[0 .. cnt_words)
-  int ovf_after;                                 // the overflow list is scattered AFTER the owner tiles stored (f32 grad_value)
-  int* cam_list; int* cam_n;                     // per-camera compacted visible queries or null
-  int ext_list;                                  // lists supplied by the caller (ubv_compact_visible)
-  float* slab;                                   // CAMERA: per-chunk partial maps or null
-  const void* vnat_hi; const void* vnat_lo;      // f32 matrix-core CAMERA plan: bf16 hi / lo copies of value (its layout)
-  // MAPS backward (large per-camera maps): exact CSR buckets + work items (bev_lift_maps.inl)
-  int* bin_cur;                                  // fill cursors per bucket
-  int* bin_start;                                // [buckets + 1] first record of each bucket
-  int* item_first;                               // [buckets + 1] first work item of each bucket
-  int* item_bucket;                              // [items] bucket of each work item
-  int* n_items;                                  // device scalar
-  int max_items;
-};
-
-// The wave's index inside its block as a SCALAR: threadIdx.x >> 6 is wave-uniform, but the compiler cannot know, and
-// everything decoded from it (tile, head, bucket, base addresses) would otherwise live in vector registers and be
-// computed with vector instructions.
-__device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
-
-// base (wave-uniform) + element offset as a 32-bit BYTE offset (the host checks that one map / one sample's rows
-// stay below 4 GiB): lets the backend emit global_load with a scalar base and a 32-bit vector offset
-template <typename T> __device__ __forceinline__ const T* gather_ptr(const T* base, unsigned elem_off) {
-  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (unsigned)(elem_off * (unsigned)sizeof(T)));
-}
-
-// Decode (b, q, valid) of the query this lane works on in iteration `it`.
-// n / d through the host-made reciprocal mg = floor(2^32 / d) + 1 (exact while n * d < 2^32; the host
-// passes 0 otherwise): an integer division is ~40 instructions, this is one.
-__device__ __forceinline__ int div_mg(int n, int d, unsigned mg) {
-  return mg != 0u ? (int)__umulhi((unsigned)n, mg) : n / d;
-}
-
-// GRID backward, first kernel of the op: zero the tile counters + the overflow counter the bin kernel (next launch on
-// the stream) appends through — a memset node less per op; every block takes a slice BEFORE any early exit.
-__device__ __forceinline__ void lift_zero_counters(const LiftArgs& a) {
-  if (a.cnt_words > 0)
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.cnt_words; i += gridDim.x * blockDim.x) a.bin_cnt[i] = 0;
-}
-
-__device__ __forceinline__ bool lift_query(const LiftArgs& a, int item, int li, int& b, int& q) {
-  b = div_mg(item, a.tiles_per_sample, a.mg_tps);
-  const int tile = item - b * a.tiles_per_sample;
-  if (a.qw > 0) {
-    const int ty = div_mg(tile, a.tiles_x, a.mg_tx), tx = tile - ty * a.tiles_x;
-    const int qy = ty * 8 + (li >> 3), qx = tx * 8 + (li & 7);
-    q = qy * a.qw + qx;
-    return qy < a.qh && qx < a.qw;
-  }
-  q = tile * 64 + li;
-  return q < a.Nq;
-}
-
-template <int P>
-__device__ __forceinline__ void load_row(const float* p, float (&v)[P]) {
-#pragma unroll
-  for (int i = 0; i < P; i += 4) {
-    const float4 t = *reinterpret_cast<const float4*>(p + i);
-    v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
-  }
-}
-template <int P>
-__device__ __forceinline__ void store_row(float* p, const float (&v)[P]) {
-#pragma unroll
-  for (int i = 0; i < P; i += 4)
-    *reinterpret_cast<float4*>(p + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
-}
 
 // FAST (16-bit data paths): one reciprocal instead of P IEEE divisions — an ulp of f32 that the
 // 16-bit values downstream cannot see.  f32 data keeps the reference's exact divisions.
@@ -273,22 +191,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (P == 8 
 // CAMERA plan (per-camera lists: lift_bwd_value_camera_kernel).
 enum { kAtomAll = 0, kPlanGrid = 1, kAtomNone = 2, kPlanMaps = 3 };
 
-
-// v + (v of the lane whose index differs in bit log2(M)): DPP quad permutes inside a quad (the
-// compiler folds them into the add), a wave shuffle beyond.
-template <int M>
-__device__ __forceinline__ float add_xor(float v) {
-  if constexpr (M == 1)
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
-  else if constexpr (M == 2)
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
-  else if constexpr (M == 4)
-    // third step of a 1-2-4 butterfly: the lanes of a quad already agree, so "the other quad of my 8 lanes" is
-    // as good as "lane ^ 4" — DPP row_half_mirror (lane i <- lane 7 - i) instead of a ds_bpermute through LDS
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));
-  else
-    return v + __shfl_xor(v, M, 64);
-}
 
 template <typename T, int DH, int VEC, int P, int ATOMICS, bool OL16>
 // P = 4 runs best at 3 waves per SIMD (127 -> 96 us); P = 8 loses to its own cache footprint there.
@@ -616,17 +518,6 @@ __global__ __launch_bounds__(256) void lift_ovf_scatter_kernel(const LiftArgs a,
 //          band of full rows (the whole 8x22 map in one band), the points are a share of the
 //          camera's compacted visible-query list; the shares of one camera write partial maps
 //          ("slabs") that slab_reduce_kernel sums.
-struct TileArgs {
-  int mode;            // 1 = GRID, 2 = CAMERA
-  int tile_w, tile_h;  // pixels
-  int tiles_x, tiles_y;
-  int chunks, chunk_q; // CAMERA: query chunks per tile
-  int total, chunk;    // tiles, blocks per XCD
-  int waves;           // waves (= tiles) per block
-  int cap;             // GRID: bucket capacity (records per tile)
-  int balanced;        // CAMERA, matrix-core plans: the waves of a (sample, head) share ALL cameras' lists evenly (cam_share)
-};
-
 // Ordered compaction of each camera's visible queries (vis0[cam, q] != 0): list[cam, 0..n) holds the
 // query indices in ascending order.  One 1024-thread block per camera.
 __global__ __launch_bounds__(1024) void compact_visible_kernel(const uint8_t* __restrict__ vis0,
@@ -654,35 +545,6 @@ __global__ __launch_bounds__(1024) void compact_visible_kernel(const uint8_t* __
   }
   if (threadIdx.x == 0) n_out[cam] = base_s;
 }
-
-// ---- shared pieces of the owner-tile kernel -------------------------------------------------------
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-
-// 16-bit MFMA operand type used for pipeline element type T
-template <typename T> struct mma_traits;
-template <> struct mma_traits<bf16_t> {
-  static constexpr bool kSplit = false;
-  static __device__ __forceinline__ uint16_t enc(float v) { return (uint16_t)float_to_bf16_bits(v); }
-  static __device__ __forceinline__ float dec(uint16_t b) { return bf16_bits_to_float(b); }
-  static __device__ __forceinline__ f32x16_t mma(uint4 a, uint4 b, f32x16_t c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
-                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-  }
-};
-template <> struct mma_traits<f16_t> {
-  static constexpr bool kSplit = false;
-  static __device__ __forceinline__ uint16_t enc(float v) { return __builtin_bit_cast(uint16_t, (_Float16)v); }
-  static __device__ __forceinline__ float dec(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
-  static __device__ __forceinline__ f32x16_t mma(uint4 a, uint4 b, f32x16_t c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a),
-                                                  __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-  }
-};
-template <> struct mma_traits<float> : mma_traits<bf16_t> {     // f32 data: bf16 hi + lo parts
-  static constexpr bool kSplit = true;
-};
 
 struct TileGeom {
   int b, cam, h, ck, x0, y0, tw, th, npx;
@@ -1345,6 +1207,8 @@ static void launch_bwd_query_shared(const LiftArgs& a, hipStream_t st) {
   else hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, OL16, 0>), dim3(8u * a.chunk), dim3(256), 0, st, a);
 }
 
+static bool ref_grid_tile(const LiftArgs& a) { return a.qw > 0 && a.tile_ws != nullptr; }
+
 template <typename T, int DH, int P>
 static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool cam_mfma, void* fwd_ws,
                         hipStream_t st) {
@@ -1399,6 +1263,10 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
       }
     }
     static const int shared_env = getenv("UBV_LIFT_SHARED") ? atoi(getenv("UBV_LIFT_SHARED")) : 1;
+    if (tile_ok(a, DH, P, sizeof(T) == 4 ? UBV_F32 : UBV_BF16)) {   // one lane per (query, point), LDS window (bev_lift_tile.hip)
+      tile_fwd_launch(a, P, st);
+      return;
+    }
     if (shared_env && win_ok<T, DH, P>(a)) {   // BEV-grid queries: corners served from an LDS window (bev_lift_win.inl)
       constexpr int HG = 128 / (DH * (int)sizeof(T));
       const int chunk = (int)(((long)a.total_tiles * (a.H / HG) + 7) / 8);
@@ -1481,14 +1349,16 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     // loop in front of it that kernel measured 177 us instead of 157 (same registers, same occupancy, either launch
     // order: the scheduler's placement of the window fill changed), the gather kernel does not care.  Without
     // ovf_after the caller's memset zeroed the counters and the order is bins -> overflow -> query -> owner tiles.
-    const bool qfirst = a.ovf_after && !win_ok<T, DH, P>(a);
+    const bool tile = tile_ok(a, DH, P, sizeof(T) == 4 ? UBV_F32 : UBV_BF16) && ref_grid_tile(a);
+    const bool qfirst = a.ovf_after && !win_ok<T, DH, P>(a) && !tile;
     if (a.ovf_after && !qfirst) (void)hipMemsetAsync(a.bin_cnt, 0, (size_t)a.cnt_words * sizeof(int), st);
     LiftArgs aq = a;
     if (!qfirst) aq.cnt_words = 0;
     auto run_query = [&]() {
       {
         ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes);
-        if (win_ok<T, DH, P>(a)) {
+        if (tile) tile_bwd_query_launch(aq, P, a.tile_ws, st);
+        else if (win_ok<T, DH, P>(a)) {
           constexpr int HG = 128 / (DH * (int)sizeof(T));
           const int chunk = (int)(((long)a.total_tiles * (a.H / HG) + 7) / 8);
           const dim3 grid(8 * chunk);
@@ -1773,7 +1643,7 @@ static size_t lift_list_bytes(const LiftArgs& a) {
 }
 // GRID workspace: [tile counters + overflow counter][buckets][overflow records][overflow tiles];
 // the overflow list is sized for the worst case (every point overflowing in all of its <= 4 tiles).
-struct GridWs { size_t cnt_bytes, bins_off, ovf_rec_off, ovf_tile_off, total; long ovf_cap; };
+struct GridWs { size_t cnt_bytes, bins_off, ovf_rec_off, ovf_tile_off, tile_off, total; long ovf_cap; };
 static GridWs grid_ws(const LiftArgs& a, const TileArgs& t, int P) {
   GridWs w;
   const size_t tiles = (size_t)a.B * a.H * t.tiles_x * t.tiles_y;
@@ -1782,7 +1652,8 @@ static GridWs grid_ws(const LiftArgs& a, const TileArgs& t, int P) {
   w.ovf_cap = 4L * a.B * a.Nq * a.H * P;
   w.ovf_rec_off = w.bins_off + tiles * t.cap * sizeof(float4);
   w.ovf_tile_off = w.ovf_rec_off + (size_t)w.ovf_cap * sizeof(float4);
-  w.total = w.ovf_tile_off + (((size_t)w.ovf_cap * sizeof(int) + 255) & ~(size_t)255);
+  w.tile_off = w.ovf_tile_off + (((size_t)w.ovf_cap * sizeof(int) + 255) & ~(size_t)255);
+  w.total = w.tile_off + (a.qw > 0 ? tile_bwd_ws_bytes(a, P) : 0);      // TILE plan: records + boxes (bev_lift_tile.hip)
   return w;
 }
 // MAPS workspace: [counts | cursors | n_items] (zeroed per call) [starts][first items][item buckets]
@@ -1874,6 +1745,7 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_g
       a.ovf_tile = (int*)((char*)ws + w.ovf_tile_off);
       a.cap = t.cap;
       a.ovf_cap = (int)min(w.ovf_cap, (long)INT_MAX);
+      a.tile_ws = (char*)ws + w.tile_off;
       static const bool two_env = getenv("UBV_LIFT_TWO_STREAM") != nullptr && atoi(getenv("UBV_LIFT_TWO_STREAM")) != 0;
       a.ovf_after = (a.gvalue_lp == nullptr && !two_env) ? 1 : 0;
       if (a.ovf_after) a.cnt_words = (int)(w.cnt_bytes / sizeof(int));      // zeroed by the query-gradient kernel

@@ -22,36 +22,6 @@
 //    backward kernels recompute the weights and locations with v_exp / v_rcp (~2 ulp: 1e-7 of a gradient, three
 //    orders below its test bar) — exp and the divisions were a fifth of their VALU instructions.
 
-// 8 f32 -> 4 dwords of bf16 hi pairs + 4 dwords of bf16 lo pairs
-__device__ __forceinline__ void split8(const float (&f)[8], uint4& hi, uint4& lo) {
-  uint32_t h[4], l[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    h[k] = cvt_pk_bf16(f[2 * k], f[2 * k + 1]);
-    l[k] = cvt_pk_bf16(f[2 * k] - __uint_as_float(h[k] << 16), f[2 * k + 1] - __uint_as_float(h[k] & 0xffff0000u));
-  }
-  hi = make_uint4(h[0], h[1], h[2], h[3]);
-  lo = make_uint4(l[0], l[1], l[2], l[3]);
-}
-
-// packed coefficient (hi | lo << 16) += c
-__device__ __forceinline__ uint32_t coef_add(uint32_t e, float c) {
-  const float s = (__uint_as_float(e << 16) + c) + __uint_as_float(e & 0xffff0000u);
-  const uint32_t r = cvt_pk_bf16(s, s);
-  const float nl = s - __uint_as_float(r << 16);
-  const uint32_t r2 = cvt_pk_bf16(nl, nl);
-  return (r & 0xffffu) | (r2 << 16);
-}
-
-// 8 consecutive packed coefficients -> MFMA fragment of the hi halves and of the lo halves
-__device__ __forceinline__ void coef_frag(const uint32_t* p, uint4& hi, uint4& lo) {
-  const uint4 e0 = *reinterpret_cast<const uint4*>(p), e1 = *reinterpret_cast<const uint4*>(p + 4);
-  hi = make_uint4((e0.x & 0xffffu) | (e0.y << 16), (e0.z & 0xffffu) | (e0.w << 16),
-                  (e1.x & 0xffffu) | (e1.y << 16), (e1.z & 0xffffu) | (e1.w << 16));
-  lo = make_uint4((e0.x >> 16) | (e0.y & 0xffff0000u), (e0.z >> 16) | (e0.w & 0xffff0000u),
-                  (e1.x >> 16) | (e1.y & 0xffff0000u), (e1.z >> 16) | (e1.w & 0xffff0000u));
-}
-
 // value (f32, [B*Nc][S][H][32]) -> fragment-ordered padded copies of its hi and lo halves (see value_frags_kernel)
 __global__ __launch_bounds__(256) void value_frags32_kernel(const float* __restrict__ value, uint16_t* __restrict__ vf_hi,
                                                             uint16_t* __restrict__ vf_lo, int BNc, int S, int H,

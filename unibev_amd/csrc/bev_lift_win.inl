@@ -14,67 +14,6 @@
 // 256 rows = 36 KB per block, 4 blocks per CU.  Lanes: LP = Dh / VEC per (query, head), HG * LP = 8 per
 // query, 8 queries per wave, 32 per pass, 2 passes.
 
-constexpr int kWin = 16;                                  // window side, pixels
-constexpr int kWinRowB = 128 + 16;                        // bytes per window row
-constexpr int kWinLds = kWin * kWin * kWinRowB;
-
-struct WinGeom { int b, tile, hg, wx0, wy0; };
-
-// (item, head group) of this block.
-template <int HG>
-__device__ __forceinline__ bool win_decode(const LiftArgs& a, int chunk, WinGeom& g) {
-  const int NG = a.H / HG;
-  const int v = xcd_remap(blockIdx.x, chunk);
-  const int item = v / NG;
-  if (item >= a.total_tiles) return false;
-  g.hg = v - item * NG;
-  g.b = div_mg(item, a.tiles_per_sample, a.mg_tps);
-  g.tile = item;
-  return true;
-}
-
-// Window origin = the block's smallest corner column / row (the sampling pattern of a head leans one way: the
-// window follows it instead of sitting centred on the tile), clamped into the map.  Ends with a barrier.
-__device__ __forceinline__ void win_origin(const LiftArgs& a, int minx, int miny, WinGeom& g) {
-  __shared__ int red[4][2];
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) {
-    minx = min(minx, __shfl_xor(minx, m, 64));
-    miny = min(miny, __shfl_xor(miny, m, 64));
-  }
-  const int wv = wave_in_block();
-  if ((threadIdx.x & 63) == 0) { red[wv][0] = minx; red[wv][1] = miny; }
-  __syncthreads();
-  const int bx = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
-  const int by = min(min(red[0][1], red[1][1]), min(red[2][1], red[3][1]));
-  g.wx0 = min(max(bx, 0), max(a.fw - kWin, 0));           // (no valid point at all: INT_MAX -> the last window)
-  g.wy0 = min(max(by, 0), max(a.fh - kWin, 0));
-}
-
-// Copies the window into LDS: one row (pixel) per thread, 128 bytes = the HG heads' channels.  Ends with a barrier.
-template <typename T, int DH, int HG>
-__device__ __forceinline__ void win_load(const LiftArgs& a, const WinGeom& g, unsigned char* __restrict__ win) {
-  static_assert(HG * DH * sizeof(T) == 128, "a window row is one 128-byte line");
-  const int t = threadIdx.x, wy = t >> 4, wx = t & 15;
-  const int py = min(g.wy0 + wy, a.fh - 1), px = min(g.wx0 + wx, a.fw - 1);
-  const long row = (long)a.H * DH;
-  const uint4* __restrict__ src = reinterpret_cast<const uint4*>(
-      (const T*)a.value + ((long)g.b * a.fh * a.fw + (long)py * a.fw + px) * row + g.hg * HG * DH);
-  uint4 v[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = src[i];
-  uint4* dst = reinterpret_cast<uint4*>(win + t * kWinRowB);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) dst[i] = v[i];
-  __syncthreads();
-}
-
-// Window row of the corner at (column xc, row yc), or -1 when it lies outside the window.
-__device__ __forceinline__ int win_row(int xc, int yc, const WinGeom& g) {
-  const int dx = xc - g.wx0, dy = yc - g.wy0;
-  return ((unsigned)dx < (unsigned)kWin && (unsigned)dy < (unsigned)kWin) ? dy * kWin + dx : -1;
-}
-
 template <typename T, int DH, int VEC, int P, bool OL16, int HG>
 __global__ __launch_bounds__(256) void lift_fwd_win_kernel(const LiftArgs a, int chunk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char win[];
