@@ -653,16 +653,6 @@ __device__ __forceinline__ void stage_row(uint16_t* __restrict__ g_hi, uint16_t*
   }
 }
 
-typedef short i16x4_t __attribute__((ext_vector_type(4)));
-// 8 rows (p, p + stride, ...) of the lane's column through two transposing reads of 4 rows each
-__device__ __forceinline__ uint4 tr16_frag(const uint16_t* p, int stride) {
-  typedef __attribute__((address_space(3))) i16x4_t lds_v4;
-  const i16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)p);
-  const i16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p + 4 * stride));
-  const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
-  return make_uint4(ua.x, ua.y, ub.x, ub.y);
-}
-
 // The wave's pending operand tiles: up to 32 point slots filled densely by the owned points of
 // successive batches (slot = fill + rank among the batch's owned lanes); when they are full the
 // MFMA round runs over all 32 slots and the coefficient tile is cleared.
@@ -1207,8 +1197,6 @@ static void launch_bwd_query_shared(const LiftArgs& a, hipStream_t st) {
   else hipLaunchKernelGGL((lift_bwd_query_shared_kernel<T, DH, VEC, P, OL16, 0>), dim3(8u * a.chunk), dim3(256), 0, st, a);
 }
 
-static bool ref_grid_tile(const LiftArgs& a) { return a.qw > 0 && a.tile_ws != nullptr; }
-
 template <typename T, int DH, int P>
 static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool cam_mfma, void* fwd_ws,
                         hipStream_t st) {
@@ -1349,7 +1337,8 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     // loop in front of it that kernel measured 177 us instead of 157 (same registers, same occupancy, either launch
     // order: the scheduler's placement of the window fill changed), the gather kernel does not care.  Without
     // ovf_after the caller's memset zeroed the counters and the order is bins -> overflow -> query -> owner tiles.
-    const bool tile = tile_ok(a, DH, P, sizeof(T) == 4 ? UBV_F32 : UBV_BF16) && ref_grid_tile(a);
+    // TILE plan (bev_lift_tile.hip): the query-gradient kernel also bins its points — no lift_bin_kernel
+    const bool tile = tile_ok(a, DH, P, sizeof(T) == 4 ? UBV_F32 : UBV_BF16) && a.ovf_after && !two;
     const bool qfirst = a.ovf_after && !win_ok<T, DH, P>(a) && !tile;
     if (a.ovf_after && !qfirst) (void)hipMemsetAsync(a.bin_cnt, 0, (size_t)a.cnt_words * sizeof(int), st);
     LiftArgs aq = a;
@@ -1357,7 +1346,7 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     auto run_query = [&]() {
       {
         ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes);
-        if (tile) tile_bwd_query_launch(aq, P, a.tile_ws, st);
+        if (tile) tile_bwd_query_launch(aq, P, true, t.tiles_x, tiles, st);
         else if (win_ok<T, DH, P>(a)) {
           constexpr int HG = 128 / (DH * (int)sizeof(T));
           const int chunk = (int)(((long)a.total_tiles * (a.H / HG) + 7) / 8);
@@ -1383,7 +1372,7 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
       }
     };
     if (qfirst) run_query();
-    {
+    if (!tile) {
       const long waves = (long)a.total_tiles * a.H;
       ProfScope ps(name("bev_lift_bwd_bins"), s2, nb.offlog + nb.ref + nb.rec);
       hipLaunchKernelGGL((lift_bin_kernel<T, DH, P, 0>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
@@ -1643,7 +1632,7 @@ static size_t lift_list_bytes(const LiftArgs& a) {
 }
 // GRID workspace: [tile counters + overflow counter][buckets][overflow records][overflow tiles];
 // the overflow list is sized for the worst case (every point overflowing in all of its <= 4 tiles).
-struct GridWs { size_t cnt_bytes, bins_off, ovf_rec_off, ovf_tile_off, tile_off, total; long ovf_cap; };
+struct GridWs { size_t cnt_bytes, bins_off, ovf_rec_off, ovf_tile_off, total; long ovf_cap; };
 static GridWs grid_ws(const LiftArgs& a, const TileArgs& t, int P) {
   GridWs w;
   const size_t tiles = (size_t)a.B * a.H * t.tiles_x * t.tiles_y;
@@ -1652,8 +1641,7 @@ static GridWs grid_ws(const LiftArgs& a, const TileArgs& t, int P) {
   w.ovf_cap = 4L * a.B * a.Nq * a.H * P;
   w.ovf_rec_off = w.bins_off + tiles * t.cap * sizeof(float4);
   w.ovf_tile_off = w.ovf_rec_off + (size_t)w.ovf_cap * sizeof(float4);
-  w.tile_off = w.ovf_tile_off + (((size_t)w.ovf_cap * sizeof(int) + 255) & ~(size_t)255);
-  w.total = w.tile_off + (a.qw > 0 ? tile_bwd_ws_bytes(a, P) : 0);      // TILE plan: records + boxes (bev_lift_tile.hip)
+  w.total = w.ovf_tile_off + (((size_t)w.ovf_cap * sizeof(int) + 255) & ~(size_t)255);
   return w;
 }
 // MAPS workspace: [counts | cursors | n_items] (zeroed per call) [starts][first items][item buckets]
@@ -1745,7 +1733,6 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_g
       a.ovf_tile = (int*)((char*)ws + w.ovf_tile_off);
       a.cap = t.cap;
       a.ovf_cap = (int)min(w.ovf_cap, (long)INT_MAX);
-      a.tile_ws = (char*)ws + w.tile_off;
       static const bool two_env = getenv("UBV_LIFT_TWO_STREAM") != nullptr && atoi(getenv("UBV_LIFT_TWO_STREAM")) != 0;
       a.ovf_after = (a.gvalue_lp == nullptr && !two_env) ? 1 : 0;
       if (a.ovf_after) a.cnt_words = (int)(w.cnt_bytes / sizeof(int));      // zeroed by the query-gradient kernel

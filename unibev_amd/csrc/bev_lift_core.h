@@ -36,9 +36,6 @@ struct LiftArgs {
   int* item_bucket;                              // [items] bucket of each work item
   int* n_items;                                  // device scalar
   int max_items;
-  // TILE plan (bev_lift_tile.hip): sampling points as records, [unit = (sample, tile, head)][point][x | y | w][64 queries],
-  // and the pixel box of each unit's live corners
-  float* trec; int4* tbox; void* tile_ws;
 };
 
 // The wave's index inside its block as a SCALAR: threadIdx.x >> 6 is wave-uniform, but the compiler cannot know, and
@@ -185,6 +182,17 @@ __device__ __forceinline__ void coef_frag(const uint32_t* p, uint4& hi, uint4& l
 }
 
 
+typedef short i16x4_t __attribute__((ext_vector_type(4)));
+// 8 rows (p, p + stride, ...) of the lane's column through two transposing reads of 4 rows each
+__device__ __forceinline__ uint4 tr16_frag(const uint16_t* p, int stride) {
+  typedef __attribute__((address_space(3))) i16x4_t lds_v4;
+  const i16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)p);
+  const i16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p + 4 * stride));
+  const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+  return make_uint4(ua.x, ua.y, ub.x, ub.y);
+}
+
+
 // ---- LDS window of the value map (bev_lift_win.inl, bev_lift_tile.hip) ----
 constexpr int kWin = 16;                                  // window side, pixels
 constexpr int kWinRowB = 128 + 16;                        // bytes per window row
@@ -251,7 +259,6 @@ __device__ __forceinline__ int win_row(int xc, int yc, const WinGeom& g) {
 // ---- TILE plan (bev_lift_tile.hip): f32 GRID instances, one lane per query ----
 bool tile_ok(const LiftArgs& a, int Dh, int P, int dtype);
 void tile_fwd_launch(const LiftArgs& a, int P, hipStream_t st);
-size_t tile_bwd_ws_bytes(const LiftArgs& a, int P);
-void tile_bwd_query_launch(LiftArgs a, int P, void* ws, hipStream_t st);
+void tile_bwd_query_launch(const LiftArgs& a, int P, bool bins, int tiles_x, int tiles, hipStream_t st);
 
 }  // namespace ubv

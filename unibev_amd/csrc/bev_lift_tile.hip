@@ -1,20 +1,26 @@
-// TILE plan: f32 GRID lifting with ONE LANE PER QUERY (its own translation unit; the argument blocks and the LDS-window
-// helpers win_decode / win_origin / win_load / win_row come from bev_lift_core.h).
+// TILE plan: f32 GRID lifting with ONE LANE PER SAMPLING POINT (its own translation unit; the argument blocks and
+// the query / tile decoding come from bev_lift_core.h).
 //
 // The shared-footprint and LDS-window kernels put the Dh channels of a (query, head) on LP = 8 adjacent lanes: every
 // corner is one coalesced 128-byte gather, but each of its 4 FMAs per lane is paid with a broadcast of the corner's
 // index and coefficient and (backward) a 3-step lane reduction of the dot product — ~1.5 wave instructions per
-// (query, head, corner), and a wave64 VALU instruction occupies its SIMD for 4 cycles.  Once the corners come from an
-// LDS window there is nothing left to coalesce, so here a lane IS a query:
-//   block  = (8x8 query tile, one head): 4 waves, each takes P / 4 of the head's sampling points for all 64 queries;
-//   window = 16x16 pixels of the head's value slice (128 B per pixel) copied into LDS once per block;
-//   corner = 8 ds_read_b128 + 32 FMAs per lane, no cross-lane traffic — 0.63 wave instructions per corner — and all
-//            arithmetic stays plain f32 (no operand splitting);
-//   a lane whose corner falls outside the window fetches that corner's row from global memory itself (the window is
-//   a cache, never an approximation), the other lanes of the wave keep the LDS path.
-// The four waves' partial sums meet in LDS (the window's bytes, after a barrier).
-//
-// Backward (lift_tile_bwd_query_kernel, lift_tile_bwd_value_kernel): see below.
+// (query, head, corner), and PMC shows these kernels bound by VALU issue (a wave64 VALU instruction holds its SIMD for a
+// quad-cycle).  Once the corners come from LDS there is nothing left to coalesce, so here
+//   block  = (8x8 query tile, one head), 4 waves of 16 queries;
+//   lane   = (query, slot pp of 4): it owns the points pp, pp + 4 of its query — loads only their offsets / logit,
+//            builds only their footprints; softmax over the quad with DPP;
+//   window = the pixel box of the block's footprints (at most 16x16) of the head's value slice, copied into LDS with
+//            whole 128-byte lines; only the rows / columns of the box are fetched (a 16x16 window per 8x8 tile would
+//            move 4x the map);
+//   corner = 8 ds_read_b128 + 16 v_pk_fma_f32 per lane, all arithmetic plain f32 (no operand splitting), no cross-lane
+//            traffic; a lane whose corner falls outside the window fetches that row from global memory itself (the
+//            window is a cache, never an approximation);
+//   output = forward: the 4 lanes of a query add their rows with DPP quad permutes and store 32 bytes each;
+//            backward: every lane has its own points' 4 dot products — d(offset), d(logit) need one quad sum.
+// The backward kernel also BINS its points by owner tile (the records lift_bwd_value_kernel reads): the separate
+// lift_bin_kernel recomputed every softmax and footprint for that.
+// Measured at bs = 2 on the 200x200 (P = 4) / 180x180 (P = 8) maps, us: forward 81 -> 71 / 115 -> 92; query gradient
+// (+ bins) 108 + 37 -> 78 (+ bins) / 157 + 65 -> 112 (+ bins).  profiles/r04_tile_*.txt.
 
 #include "bev_lift_core.h"
 
@@ -26,10 +32,9 @@ namespace ubv {
 // distinct quads: quad = (9 dx + 4 dy) mod 16.
 constexpr int kTWinRow = kWin * kWinRowB + 64;
 constexpr int kTWinLds = kWin * kTWinRow;
-constexpr int kRecUnit(int P) { return P * 3 * 64; }          // floats per (sample, tile, head) unit
 
-// min / max over the wave: DPP inside the rows of 16 lanes (quad permutes, row_half_mirror, row_mirror), the four
-// rows through scalar reads
+// min over the wave: DPP inside the rows of 16 lanes (quad permutes, row_half_mirror, row_mirror), the four rows
+// through scalar reads
 __device__ __forceinline__ int wave_min_i32(int v) {
   v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
   v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
@@ -40,33 +45,12 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 }
 __device__ __forceinline__ int wave_max_i32(int v) { return -wave_min_i32(-v); }
 
-// The sampling points of this lane — lane = (query li of the tile, slot pp of 4), points pp + 4 j — as pixel
-// coordinates and softmax weights (0 for a query outside the grid), and the pixel box of the block's live corners
-// (a corner is live when its bilinear weight is non-zero).  Softmax over the 4 lanes of the query with DPP quad
-// permutes.  One barrier.
-// per-slot reductions over the lanes of a row of 16 that share lane & 3 (DPP row rotations by 4 and 8)
-__device__ __forceinline__ int row4_min_i32(int v) {
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false));
-  return min(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));
-}
-
-// Box of the corners a set of points touches
-struct TileBox {
-  int x0, y0, x1, y1;
-  __device__ __forceinline__ void init() { x0 = INT_MAX; y0 = INT_MAX; x1 = -1; y1 = -1; }
-  __device__ __forceinline__ void add(int x, int y) { x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y); }
-};
-
-// The sampling points of this lane — lane = (query li of the tile, slot pp of 4), points pp + 4 j — as pixel
-// coordinates and softmax weights (0 for a query outside the grid), and the pixel box of the block's corners: the
-// corners with a non-zero bilinear weight (forward), every corner inside the map (BWD: a corner of weight 0 still has
-// a derivative).  Softmax over the 4 lanes of the query with DPP quad permutes.  One barrier.
-// BWD also reduces, per point p of the head, the box of the corners with a non-zero COEFFICIENT into pbox[p] (LDS,
-// initialised here): what the owner tiles of the value gradient look at.
+// The sampling points of this lane — lane = (query, slot pp of 4), points pp + 4 j — as pixel coordinates and softmax
+// weights (0 for a query outside the grid), and the pixel box of the block's corners: those with a non-zero bilinear
+// weight (forward), every corner inside the map (BWD: a corner of weight 0 still has a derivative).  One barrier.
 template <int P, bool BWD>
 __device__ __forceinline__ int4 tile_points(const LiftArgs& a, long bq, bool valid, int h, int pp, int wv, int lane,
-                                            float (&rx)[P / 4], float (&ry)[P / 4], float (&rw)[P / 4],
-                                            int (*pbox)[4]) {
+                                            float (&rx)[P / 4], float (&ry)[P / 4], float (&rw)[P / 4]) {
   constexpr int PW = P / 4;
   __shared__ int4 wbox[4];
   const float fwf = (float)a.fw, fhf = (float)a.fh;
@@ -82,23 +66,22 @@ __device__ __forceinline__ int4 tile_points(const LiftArgs& a, long bq, bool val
     ref[j] = *reinterpret_cast<const float2*>(rp + (p % a.Z) * 2);
     lg[j] = lgp[p];
   }
-  if (BWD && threadIdx.x < P) { pbox[threadIdx.x][0] = INT_MAX; pbox[threadIdx.x][1] = INT_MAX; pbox[threadIdx.x][2] = -1; pbox[threadIdx.x][3] = -1; }
-  TileBox wb, cb[PW];
-  wb.init();
+  int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1;
 #pragma unroll
   for (int j = 0; j < PW; ++j) {
     const float lx = ref[j].x + off[j].x / fwf, ly = ref[j].y + off[j].y / fhf;
     rx[j] = lx * fwf - 0.5f; ry[j] = ly * fhf - 0.5f;
     const Footprint f = footprint_px(rx[j], ry[j], a.fh, a.fw);
-    cb[j].init();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (valid && (BWD ? f.m[k] : f.w[k]) != 0.0f) wb.add(f.xc[k & 1], f.yc[k >> 1]);
-      if (BWD && valid && f.w[k] != 0.0f) cb[j].add(f.xc[k & 1], f.yc[k >> 1]);
+      if (valid && (BWD ? f.m[k] : f.w[k]) != 0.0f) {
+        x0 = min(x0, f.xc[k & 1]); x1 = max(x1, f.xc[k & 1]);
+        y0 = min(y0, f.yc[k >> 1]); y1 = max(y1, f.yc[k >> 1]);
+      }
     }
   }
-  const int minx = wave_min_i32(wb.x0), miny = wave_min_i32(wb.y0), maxx = wave_max_i32(wb.x1), maxy = wave_max_i32(wb.y1);
-  if (lane == 0) wbox[wv] = make_int4(minx, miny, maxx, maxy);
+  x0 = wave_min_i32(x0); y0 = wave_min_i32(y0); x1 = wave_max_i32(x1); y1 = wave_max_i32(y1);
+  if (lane == 0) wbox[wv] = make_int4(x0, y0, x1, y1);
   // softmax of the query's P logits: the quad holds them
   float m = lg[0];
 #pragma unroll
@@ -112,19 +95,6 @@ __device__ __forceinline__ int4 tile_points(const LiftArgs& a, long bq, bool val
 #pragma unroll
   for (int j = 0; j < PW; ++j) rw[j] = valid ? rw[j] / ssum : 0.0f;
   __syncthreads();
-  if constexpr (BWD) {
-    // (a weight that underflowed to 0 touches nothing)
-#pragma unroll
-    for (int j = 0; j < PW; ++j) {
-      const bool on = rw[j] != 0.0f;
-      const int x0 = row4_min_i32(on ? cb[j].x0 : INT_MAX), y0 = row4_min_i32(on ? cb[j].y0 : INT_MAX);
-      const int x1 = -row4_min_i32(on ? -cb[j].x1 : 1), y1 = -row4_min_i32(on ? -cb[j].y1 : 1);
-      if ((lane & 12) == 0) {                       // lanes 0..3 of each row: one per slot
-        int* pb = pbox[pp + 4 * j];
-        atomicMin(pb, x0); atomicMin(pb + 1, y0); atomicMax(pb + 2, x1); atomicMax(pb + 3, y1);
-      }
-    }
-  }
   const int4 b0 = wbox[0], b1 = wbox[1], b2 = wbox[2], b3 = wbox[3];
   return make_int4(min(min(b0.x, b1.x), min(b2.x, b3.x)), min(min(b0.y, b1.y), min(b2.y, b3.y)),
                    max(max(b0.z, b1.z), max(b2.z, b3.z)), max(max(b0.w, b1.w), max(b2.w, b3.w)));
@@ -154,7 +124,7 @@ __device__ __forceinline__ float tile_dot32(const float* __restrict__ p, const f
   return d0 + d1;
 }
 
-// Window of a unit from its box: origin (clamped into the map like win_origin) and the rows / columns worth loading.
+// Window of a block from its box: origin (clamped into the map like win_origin) and the rows / columns worth loading.
 struct TileWin { int rows, cols; };
 __device__ __forceinline__ TileWin tile_window(const LiftArgs& a, const int4 bb, WinGeom& g) {
   g.wx0 = min(max(bb.x, 0), max(a.fw - kWin, 0));
@@ -198,11 +168,9 @@ __device__ __forceinline__ int tile_row(int xc, int yc, const WinGeom& g, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Forward.  Block = unit (8x8 query tile, head), wave = 16 queries, lane = (query, slot pp of 4): the lane takes
-// points pp, pp + 4 (P = 8) of its query; the 4 lanes of a query add their rows with DPP quad permutes and store 32
-// bytes each.  Two barriers (block box, window fill).
+// Forward.  Two barriers (block box, window fill).
 template <int P>
-__global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, int chunk, int abl) {
+__global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, int chunk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char win[];
   constexpr int PW = P / 4;
   WinGeom g;
@@ -216,15 +184,14 @@ __global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, in
   const bool valid = lift_query(a, g.tile, li, b, q);
   if (!valid) q = 0;
   const long bq = (long)b * a.Nq + q;
-  const int4 bb = tile_points<P, false>(a, bq, valid, h, pp, wv, lane, rx, ry, rw, nullptr);
+  const int4 bb = tile_points<P, false>(a, bq, valid, h, pp, wv, lane, rx, ry, rw);
   const TileWin tw = tile_window(a, bb, g);
-  if (!(abl & 1)) tile_fill(a, g, tw, h, win); else __syncthreads();
+  tile_fill(a, g, tw, h, win);
   const float* vb = (const float*)a.value + (long)g.b * a.fh * a.fw * rowi + h * 32;      // wave-uniform
 
   float acc[32];
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0f;
-  if (!(abl & 2))
 #pragma unroll
   for (int j = 0; j < PW; ++j) {
     const Footprint f = footprint_px(rx[j], ry[j], a.fh, a.fw);
@@ -236,7 +203,6 @@ __global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, in
       else if (c != 0.0f) tile_axpy32(gather_ptr(vb, (unsigned)(f.idx[k] * rowi)), c, acc);
     }
   }
-  if (abl & 4) { if (acc[0] == 123.456f) ((float*)a.out)[0] = acc[1]; return; }
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = add_xor<2>(add_xor<1>(acc[i]));
   if (valid) {
@@ -251,14 +217,17 @@ __global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, in
 
 // ------------------------------------------------------------------------------------------------
 // Backward, query side: d(offsets), d(logits) — the forward's block with the query's grad_out row in registers and a
-// dot product per corner instead of an axpy; no cross-lane traffic except the softmax sum over the quad.  The kernel
-// also leaves what the value side (lift_tile_bwd_value_kernel) needs: one (x_pix, y_pix, weight) record per sampling
-// point, [unit][point][x | y | w][64 queries], and per (unit, point) the box of the pixels that receive a non-zero
-// coefficient.
-template <int P>
-__global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs a, int chunk) {
+// dot product per corner instead of an axpy.  BINS: the kernel also appends every point to the bucket of each owner
+// tile that holds one of its corners of non-zero coefficient (what lift_bin_kernel<MODE 0> does, same record format,
+// same fixed-capacity buckets + overflow list; see there): ranks inside the wave through LDS counters on an 8x8 torus
+// of tile slots, one returning global atomic per occupied slot.  The caller zeroes the counters.
+template <int P, bool BINS>
+__global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs a, int chunk, int tiles_x, int tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char win[];
-  __shared__ int pbox[P][4];
+  // per wave: a 4x4 torus of tile slots — occupant tile, local count, global base (a wave's 16 queries x 4 points
+  // reach a handful of tiles; two tiles that collide on the torus take the direct global path)
+  __shared__ volatile int slot_tile[4][16];
+  __shared__ int slot_cnt[4][16], slot_base[4][16];
   constexpr int PW = P / 4;
   WinGeom g;
   if (!win_decode<1>(a, chunk, g)) return;
@@ -270,6 +239,7 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
   const bool valid = lift_query(a, g.tile, li, b, q);
   if (!valid) q = 0;
   const long bq = (long)b * a.Nq + q;
+  if (BINS && lane < 16) { slot_tile[wv][lane] = -1; slot_cnt[wv][lane] = 0; }
   float go[32];
   {
     const float4* gp = reinterpret_cast<const float4*>((const float*)a.gout + bq * rowi + h * 32);
@@ -280,21 +250,15 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
     }
   }
   float rx[PW], ry[PW], rw[PW];
-  const int4 bb = tile_points<P, true>(a, bq, valid, h, pp, wv, lane, rx, ry, rw, pbox);
+  const int4 bb = tile_points<P, true>(a, bq, valid, h, pp, wv, lane, rx, ry, rw);
   const TileWin tw = tile_window(a, bb, g);
   tile_fill(a, g, tw, h, win);
   const float* vb = (const float*)a.value + (long)g.b * a.fh * a.fw * rowi + h * 32;      // wave-uniform
-  const long unit = (long)g.tile * a.H + h;
-  if (threadIdx.x < P)                                      // (the fill's barrier ordered the atomics before this read)
-    a.tbox[unit * P + threadIdx.x] = make_int4(pbox[threadIdx.x][0], pbox[threadIdx.x][1], pbox[threadIdx.x][2], pbox[threadIdx.x][3]);
-  float* __restrict__ rec = a.trec + unit * kRecUnit(P) + li;
 
   float gw[PW], gx[PW], gy[PW];
   float sp = 0.0f;
 #pragma unroll
   for (int j = 0; j < PW; ++j) {
-    const int p = pp + 4 * j;
-    rec[p * 192] = rx[j]; rec[p * 192 + 64] = ry[j]; rec[p * 192 + 128] = rw[j];
     const Footprint f = footprint_px(rx[j], ry[j], a.fh, a.fw);
     float d[4];
 #pragma unroll
@@ -310,6 +274,56 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
     gx[j] = (d[1] - d[0]) * hy + (d[3] - d[2]) * f.ly;
     gy[j] = (d[2] - d[0]) * hx + (d[3] - d[1]) * f.lx;
     sp = fmaf(rw[j], gw[j], sp);
+
+    if constexpr (BINS) {
+      // one lane = one point: append it to the bucket of every tile that holds a corner of non-zero coefficient
+      const int tile_base = (g.b * a.H + h) * tiles;
+      int* __restrict__ cntp = a.bin_cnt + tile_base;
+      float4* __restrict__ binp = a.bins + (long)tile_base * a.cap;
+      const float4 rec = make_float4(rx[j], ry[j], rw[j], __int_as_float(q));
+      auto put = [&](int tile, int idx) {
+        if (idx < a.cap) {
+          binp[(long)tile * a.cap + idx] = rec;
+        } else {
+          const int o = atomicAdd(a.ovf_n, 1);
+          if (o < a.ovf_cap) { a.ovf_rec[o] = rec; a.ovf_tile[o] = tile_base + tile; }
+        }
+      };
+      int tk[4], hs[4], rank[4];
+      bool nz[4], lead[4], local[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        nz[k] = rw[j] != 0.0f && f.w[k] != 0.0f;
+        const int tx = f.xc[k & 1] >> 3, ty = f.yc[k >> 1] >> 3;
+        tk[k] = ty * tiles_x + tx;
+        hs[k] = ((ty & 3) << 2) | (tx & 3);
+      }
+      // a tile receives the record once: through its first corner with non-zero weight
+      lead[0] = nz[0];
+      lead[1] = nz[1] && !(nz[0] && tk[1] == tk[0]);
+      lead[2] = nz[2] && !(nz[0] && tk[2] == tk[0]) && !(nz[1] && tk[2] == tk[1]);
+      lead[3] = nz[3] && !(nz[0] && tk[3] == tk[0]) && !(nz[1] && tk[3] == tk[1]) && !(nz[2] && tk[3] == tk[2]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        local[k] = false;
+        rank[k] = 0;
+        if (lead[k]) {
+          volatile int* st = &slot_tile[wv][hs[k]];
+          if (*st == -1) *st = tk[k];
+          local[k] = *st == tk[k];
+          if (local[k]) rank[k] = atomicAdd(&slot_cnt[wv][hs[k]], 1);
+          else put(tk[k], atomicAdd(cntp + tk[k], 1));
+        }
+      }
+      if (lane < 16) {
+        const int c = slot_cnt[wv][lane];
+        if (c > 0) slot_base[wv][lane] = atomicAdd(cntp + slot_tile[wv][lane], c);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (lead[k] && local[k]) put(tk[k], slot_base[wv][hs[k]] + rank[k]);
+      if (lane < 16) { slot_tile[wv][lane] = -1; slot_cnt[wv][lane] = 0; }
+    }
   }
   sp = add_xor<2>(add_xor<1>(sp));
   if (valid) {
@@ -334,27 +348,25 @@ bool tile_ok(const LiftArgs& a, int Dh, int P, int dtype) {
          a.vis0 == nullptr && a.count == nullptr && a.fh >= 1 && a.fw >= 1;
 }
 
-// records + boxes of the backward: [units][P][3][64] floats, [units][P] int4
-static size_t tile_units(const LiftArgs& a) { return (size_t)a.B * (size_t)(((a.qw + 7) / 8) * ((a.qh + 7) / 8)) * a.H; }
-static size_t tile_rec_bytes(const LiftArgs& a, int P) { return ((tile_units(a) * kRecUnit(P) * sizeof(float)) + 255) & ~(size_t)255; }
-size_t tile_bwd_ws_bytes(const LiftArgs& a, int P) {
-  return tile_rec_bytes(a, P) + ((tile_units(a) * P * sizeof(int4) + 255) & ~(size_t)255);
-}
-void tile_bwd_query_launch(LiftArgs a, int P, void* ws, hipStream_t st) {
-  a.trec = (float*)ws;
-  a.tbox = (int4*)((char*)ws + tile_rec_bytes(a, P));
-  const long units = (long)a.total_tiles * a.H;
-  const int chunk = (int)((units + 7) / 8);
-  if (P == 4) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4>), dim3(8 * chunk), dim3(256), kTWinLds, st, a, chunk);
-  else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<8>), dim3(8 * chunk), dim3(256), kTWinLds, st, a, chunk);
-}
-
 void tile_fwd_launch(const LiftArgs& a, int P, hipStream_t st) {
   const long units = (long)a.total_tiles * a.H;
   const int chunk = (int)((units + 7) / 8);
-  const int abl = getenv("UBV_TILE_ABL") ? atoi(getenv("UBV_TILE_ABL")) : 0;
-  if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4>), dim3(8 * chunk), dim3(256), kTWinLds, st, a, chunk, abl);
-  else hipLaunchKernelGGL((lift_tile_fwd_kernel<8>), dim3(8 * chunk), dim3(256), kTWinLds, st, a, chunk, abl);
+  if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4>), dim3(8 * chunk), dim3(256), kTWinLds, st, a, chunk);
+  else hipLaunchKernelGGL((lift_tile_fwd_kernel<8>), dim3(8 * chunk), dim3(256), kTWinLds, st, a, chunk);
+}
+
+// bins: the points are binned here (the caller zeroed a.bin_cnt / a.ovf_n and launches no lift_bin_kernel)
+void tile_bwd_query_launch(const LiftArgs& a, int P, bool bins, int tiles_x, int tiles, hipStream_t st) {
+  const long units = (long)a.total_tiles * a.H;
+  const int chunk = (int)((units + 7) / 8);
+  const dim3 grid(8 * chunk), blk(256);
+  if (P == 4) {
+    if (bins) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles);
+    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4, false>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles);
+  } else {
+    if (bins) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<8, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles);
+    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<8, false>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles);
+  }
 }
 
 }  // namespace ubv
