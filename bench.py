@@ -118,6 +118,12 @@ def parse():
                     help='if HIP-graph capture fails, time eager launches instead of exiting non-zero')
     ap.add_argument('--no-parity', action='store_true',
                     help="skip the run-time distance of each precision mode to the reference-recorded full-size vectors")
+    ap.add_argument('--params', default='both', choices=['init', 'spread', 'both'],
+                    help="sampling parameters of the timed model: 'init' = the reference's init_weights (every query samples "
+                         "the same compass-grid offsets: the headline), 'spread' = seeded sampling_offsets weights that "
+                         "scatter the offsets by ~3 pixels per query (a trained-looking operating point), 'both' = the "
+                         "headline on 'init' and a `spread` sub-record")
+    ap.add_argument('--no-ieee-gemm', action='store_true', help='skip the `ieee_gemm` sub-record (f32 step on library IEEE GEMMs)')
     ap.add_argument('--fp32-stream', action='store_true',
                     help='keep the encoder residual stream in f32 under autocast (default: the '
                          'autocast dtype, as the reference\'s fp16 mode runs it)')
@@ -161,6 +167,28 @@ def build_head(workload, device):
         if n.startswith('query_embedding') or n.startswith('transformer.reference_points'):
             p.requires_grad_(False)
     return head.to(device), tcfg
+
+
+SPREAD_SIGMA_PX = 3.0
+
+
+def set_sampling_params(head, mode):
+    """'init': sampling_offsets weights zero (the reference's init_weights: offsets = the bias' compass grid for every
+    query).  'spread': seeded N(0, (sigma / sqrt(C))^2) weights — on LayerNormed queries the offsets of a (head, point)
+    then scatter by ~SPREAD_SIGMA_PX pixels around the grid from query to query, as a trained layer's do (what
+    tools/bench_lift.py --random-offsets feeds the kernels)."""
+    from unibev_amd import linear as UL
+    g = torch.Generator(device='cpu').manual_seed(77)
+    with torch.no_grad():
+        for m in head.modules():
+            so = getattr(m, 'sampling_offsets', None)
+            if isinstance(so, torch.nn.Linear):
+                if mode == 'spread':
+                    w = torch.randn(so.weight.shape, generator=g) * (SPREAD_SIGMA_PX / so.in_features ** 0.5)
+                    so.weight.copy_(w.to(so.weight.device))
+                else:
+                    so.weight.zero_()
+    UL.mark_weights_changed()
 
 
 def synth_inputs(workload, bs, dtype, device, rank):
@@ -317,7 +345,26 @@ def run_mode(args, name, head, world, rank, device, want_ops):
     barrier()
     dt = time.perf_counter() - t0
     from unibev_amd import dp
+    dt_local = dt
     dt = dp.max_over_ranks(dt, device)
+    dt_min = dp.min_over_ranks(dt_local, device)
+    # per-phase times of the same step (HIP events on the launch stream; 10 more steps, outside the timed region):
+    # graph replay (forward + backward), gradient exchange (one RCCL all-reduce of the flat buffer; 0 for one rank
+    # without a process group), clip + AdamW
+    phases = None
+    if graphed:
+        marks = []
+        for _ in range(min(args.steps, 10)):
+            step(marks)
+            finish()
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append(e)
+        torch.cuda.synchronize()
+        n4 = len(marks) // 4
+        ph = [sum(marks[4 * i + k].elapsed_time(marks[4 * i + k + 1]) for i in range(n4)) / n4 for k in range(3)]
+        phases = {'fwd_bwd_graph_ms_per_step': ph[0], 'allreduce_ms_per_step': dp.max_over_ranks(ph[1], device),
+                  'clip_adamw_ms_per_step': ph[2], 'gradient_bytes': int(gs.grads.flat.numel() * 4)}
     # pure launch cost: the same step enqueued on an IDLE device (host_dt above includes the time the host spends
     # blocked on the full launch queue once it is steps ahead of the GPU)
     launch_dt = 0.0
@@ -329,8 +376,10 @@ def run_mode(args, name, head, world, rank, device, want_ops):
         launch_dt += time.perf_counter() - t1
     torch.cuda.synchronize()
     launch_dt /= min(args.steps, 10)
-    nsteps_run = args.warmup + 1 + args.steps + min(args.steps, 10)       # (profilers divide by this)
+    nsteps_run = args.warmup + 1 + args.steps + min(args.steps, 10) * (2 if graphed else 1)       # (profilers divide by this)
     rec = {'dtype': name, 'value': world * args.bs * args.steps / dt, 'ms_per_step': 1e3 * dt / args.steps,
+           'ms_per_step_rank_min': 1e3 * dt_min / args.steps, 'ms_per_step_rank_max': 1e3 * dt / args.steps,
+           'phases': phases,
            'host_enqueue_ms_per_step': 1e3 * launch_dt, 'host_loop_ms_per_step': 1e3 * host_dt / args.steps,
            'hip_graphs': graphed, 'steps_run': nsteps_run,
            'residual_stream': 'f32' if (args.fp32_stream or name == 'fp32') else name}
@@ -349,6 +398,15 @@ def run_mode(args, name, head, world, rank, device, want_ops):
         torch.cuda.synchronize()
         prof_ops = UF.kernel_profile()
         UF.kernel_profile(False)
+        # how many sampling-point records did not fit their owner tile's fixed-capacity bucket and went through the
+        # (exact, atomic) overflow list of the GRID backward: one more eager step with the counters read back
+        UF.lift_overflow_probe(True)
+        gs.eager_step()
+        torch.cuda.synchronize()
+        rec['grid_overflow'] = {f'map {fh}x{fw} P={P}': {'overflow_records': n, 'sampling_points': tot,
+                                                        'fraction': n / max(tot, 1)}
+                                for (fh, fw, P), (n, tot) in UF.lift_overflow_probe().items()}
+        UF.lift_overflow_probe(False)
         UF.kernel_profile(True)                         # pass 2: every kernel inside them
         for _ in range(min(args.steps, 10)):
             gs.eager_step()
@@ -531,7 +589,10 @@ def voxel_record(device):
 
 def middle_encoder_record(device, feats, coors, bs=2):
     """SparseEncoder of the shipped L / LC configs (41 x 1440 x 1440 grid, basic blocks) on `bs` copies of the
-    cloud: forward and forward + backward (training mode), per batch.  Rulebooks are rebuilt every pass."""
+    cloud: forward and forward + backward (training mode), per batch.  ``forward_ms`` / ``forward_backward_ms``
+    REBUILD the rulebooks (hash tables, neighbour maps, compacted pairs, the strided layers' host-read output
+    counts) on every pass, as a training step with new clouds does; the ``*_kept_rulebooks`` numbers are the same
+    passes with the module's opt-in cache (``keep_rulebooks``: gradient accumulation / checkpointing of one cloud)."""
     from unibev_amd.registry import MIDDLE_ENCODERS, build_from_cfg
     cfg = dict(type='SparseEncoder', in_channels=5, sparse_shape=[41, 1440, 1440], output_channels=128,
                order=('conv', 'norm', 'act'),
@@ -553,19 +614,22 @@ def middle_encoder_record(device, feats, coors, bs=2):
         enc(f, c, bs).sum().backward()
 
     out = {}
-    for name, fn in (('forward_ms', fwd), ('forward_backward_ms', fwd_bwd)):
-        for _ in range(2):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        out[name] = e0.elapsed_time(e1) / 5
+    for keep in (False, True):
+        enc.keep_rulebooks = keep
+        for name, fn in (('forward_ms', fwd), ('forward_backward_ms', fwd_bwd)):
+            for _ in range(2):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            out[name + ('_kept_rulebooks' if keep else '')] = e0.elapsed_time(e1) / 5
     out.update(batch=bs, voxels_per_sample=int(feats.shape[0]), out_shape=list(fwd().shape),
                note='SubM / strided sparse convs as gather + MFMA over neighbour maps; weight gradients on the split-K MFMA '
-                    'kernel over gathered rows; 4 host syncs per pass (output counts of the strided convs)')
+                    'kernel over compacted pairs; forward_ms / forward_backward_ms rebuild the rulebooks every pass (4 host '
+                    'reads of the strided convs\' output counts), *_kept_rulebooks reuse them (opt-in cache)')
     return out
 
 
@@ -627,7 +691,26 @@ def main():
     head, tcfg = build_head(args.workload, device)
     head.train(not args.eval_mode)
     names = ['fp32', 'bf16', 'fp16'] if args.dtype == 'all' else [args.dtype]
+    set_sampling_params(head, 'spread' if args.params == 'spread' else 'init')
     recs = [run_mode(args, n, head, world, rank, device, want_ops=True) for n in names]
+    spread = ieee = None
+    if args.params == 'both':
+        # second operating point of the headline precision: offsets scattered per query (trained-looking)
+        set_sampling_params(head, 'spread')
+        spread = run_mode(args, names[0], head, world, rank, device, want_ops=True)
+        spread['sampling_params'] = f'spread: seeded sampling_offsets weights, ~{SPREAD_SIGMA_PX:g} px offset scatter per query'
+        set_sampling_params(head, 'init')
+    if names[0] == 'fp32' and not args.no_ieee_gemm:
+        # the same f32 step with every Linear on the library's IEEE f32 GEMM instead of the split-bf16 MFMA kernels
+        from unibev_amd.linear import set_f32_gemm
+        prev = set_f32_gemm('library')
+        try:
+            ieee = run_mode(args, 'fp32', head, world, rank, device, want_ops=False)
+            if rank == 0 and not args.no_parity:
+                ieee['parity'] = parity_record(args.workload, ['fp32'], device, args.fp32_stream)['fp32']
+        finally:
+            set_f32_gemm(prev)
+        ieee['gemm_arithmetic'] = 'IEEE f32 library GEMMs (hipBLASLt)'
     if rank == 0 and not args.no_parity:
         par = parity_record(args.workload, names, device, args.fp32_stream)
         for r in recs:
@@ -639,6 +722,8 @@ def main():
             'metric': 'nuScenes samples/sec BEV-encoder fwd+bwd', 'value': main_rec['value'],
             'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': main_rec['ms_per_step'],
+            'ms_per_step_rank_min': main_rec['ms_per_step_rank_min'], 'ms_per_step_rank_max': main_rec['ms_per_step_rank_max'],
+            'phases': main_rec['phases'],
             'host_enqueue_ms_per_step': main_rec['host_enqueue_ms_per_step'],
             'host_loop_ms_per_step': main_rec['host_loop_ms_per_step'],
             'higher_is_better': True, 'scaling': 'weak',
@@ -647,6 +732,13 @@ def main():
                        'global_batch': world * args.bs, 'encoder_layers': 3,
                        'mode': 'eval' if args.eval_mode else 'train (dropout 0.1, modality dropout)',
                        'residual_stream': main_rec['residual_stream'],
+                       'gemm_arithmetic': ('f32 storage; every Linear is a split-bf16 x3 MFMA product (x_hi w_hi + x_hi w_lo + '
+                                           'x_lo w_hi, ~2^-17 per product) with f32 accumulation; sampling kernels plain f32; '
+                                           'the IEEE-GEMM run of the same step rides along as `ieee_gemm`')
+                       if main_rec['dtype'] == 'fp32' else 'autocast ' + main_rec['dtype'],
+                       'sampling_params': ('spread' if args.params == 'spread' else
+                                           "init: the reference's init_weights (zero offset weights, compass-grid bias); "
+                                           "`spread` sub-record: scattered offsets"),
                        'step': 'fwd + bwd (HIP graphs) + flat-gradient all-reduce + clip + AdamW'
                                if main_rec['hip_graphs'] else 'fwd + bwd + flat-gradient all-reduce + clip + AdamW',
                        'optimizer': 'flat-buffer clip + AdamW kernels' if args.flat_optimizer else 'torch clip_grad_norm_ + fused AdamW',
@@ -658,7 +750,12 @@ def main():
                        'parity': main_rec.get('parity')},
             'roofline': main_rec.get('roofline'),
             'roofline_ops': main_rec.get('roofline_ops'),
+            'grid_overflow': main_rec.get('grid_overflow'),
         }
+        if spread is not None:
+            out['spread'] = spread
+        if ieee is not None:
+            out['ieee_gemm'] = ieee
         if len(recs) > 1:
             out['lowp'] = recs[1:]
         if world == 1 and not args.no_extras:

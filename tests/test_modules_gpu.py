@@ -88,21 +88,30 @@ def test_encoder_fusion_vs_reference_vectors(name):
 
 
 @pytest.mark.parametrize('streams', [2, 1])
-@pytest.mark.parametrize('name', ['cnw', 'cat', 'dual'])
-def test_encoder_gradients_vs_oracle(name, streams):
-    """Backward of the whole path: d(sum(fused * cot)) w.r.t. inputs and every parameter vs torch
-    autograd through the oracle — with the two encoders on two HIP streams (the default) and on one."""
+@pytest.mark.parametrize('name,gemm', [('cnw', 'mfma'), ('cat', 'mfma'), ('cnw', 'library'), ('dual', 'library')])
+def test_encoder_gradients_vs_oracle(name, gemm, streams):
+    """Backward of the whole path: d(sum(fused * cot)) w.r.t. inputs and every parameter vs torch autograd through
+    the oracle — with the two encoders on two HIP streams (the default) and on one.  ``gemm``: 'mfma' = the default
+    split-bf16 Linear layers at the 1e-3 bar; 'library' = IEEE f32 GEMMs, where the sampling / normalisation / fusion
+    kernels and every gradient route must agree with the oracle to f32 round-off (bars 1e-4 element-wise, 3e-5
+    normwise; measured 5e-6).  The two-layer ``dual`` fixture (two query tables) is checked in that mode only: its
+    random sampling parameters put points within the split-bf16 round-off of a pixel boundary, where d/d(offset) jumps
+    (one flipped point moves every upstream gradient by ~1e-2; seeds 28-31 each flip in one of the two branches, while
+    the forward holds 4e-5) — the discontinuity is the reference's own (bilinear kinks), not a routing difference."""
     from oracle import unibev_ref as R
+    from unibev_amd.linear import set_f32_gemm
     from unibev_amd.modules import transformer as TR
     was = TR._TWO_STREAMS[0]
     TR.set_two_streams(streams == 2)
+    prev = set_f32_gemm(gemm)
     try:
-        _encoder_gradients_vs_oracle(name, R)
+        _encoder_gradients_vs_oracle(name, R, bars=(4e-3, 1e-3) if gemm == 'mfma' else (1e-4, 3e-5))
     finally:
+        set_f32_gemm(prev)
         TR.set_two_streams(was)
 
 
-def _encoder_gradients_vs_oracle(name, R, case=None, flags=(1, 1)):
+def _encoder_gradients_vs_oracle(name, R, case=None, flags=(1, 1), bars=(4e-3, 1e-3)):
     cfg, sd, inp, g = case if case is not None else encoder_case(name)
     cot = syn.seeded_array('cot:' + name, g['fused' if case is None else 'fused_11'].shape, 5)
     # oracle
@@ -134,7 +143,7 @@ def _encoder_gradients_vs_oracle(name, R, case=None, flags=(1, 1)):
         s = max(np.abs(b).max(), 1e-6)
         err = np.abs(a - b).max() / s
         nerr = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12)
-        assert err < 4e-3 and nerr < 1e-3, (what, err, nerr)
+        assert err < bars[0] and nerr < bars[1], (what, err, nerr)
     close(gi[0].grad, oi[0].grad, 'img feats')
     close(gp[0].grad, op[0].grad, 'pts feats')
     if isinstance(gq, list):              # dual_queries: one table per modality

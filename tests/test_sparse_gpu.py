@@ -197,6 +197,8 @@ def test_rulebooks_are_kept_while_the_same_coordinates_come_back():
                encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)), block_type='basicblock')
     torch.manual_seed(0)
     enc = build_from_cfg(cfg, MIDDLE_ENCODERS).to(DEV).train()
+    assert enc.keep_rulebooks is False            # opt-in: the cache trusts the tensor's identity + version counter
+    enc.keep_rulebooks = True
     coors = _cloud(rs, 2, cfg['sparse_shape'], 2000).to(DEV)
     feats = torch.from_numpy(rs.standard_normal((2000, 5)).astype(np.float32)).to(DEV).requires_grad_()
     outs, grads = [], []
@@ -219,6 +221,7 @@ def test_rulebooks_are_kept_while_the_same_coordinates_come_back():
     fresh = build_from_cfg(cfg, MIDDLE_ENCODERS).to(DEV).train()
     fresh.load_state_dict(enc.state_dict())
     torch.testing.assert_close(enc(feats, coors, 2), fresh(feats, coors.clone(), 2), rtol=0, atol=0)
+    assert not fresh._rulebooks                   # the default keeps nothing
 
 
 @pytest.mark.parametrize('C,relu', [(16, True), (32, False), (64, True), (128, True)])

@@ -13,6 +13,7 @@ cfg = dict(type='SparseEncoder', in_channels=5, sparse_shape=[41, 1440, 1440], o
            encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)), block_type='basicblock')
 torch.manual_seed(0)
 enc = build_from_cfg(cfg, MIDDLE_ENCODERS).to(dev).train()
+enc.keep_rulebooks = os.environ.get('UBV_KEEP_RULEBOOKS', '1') != '0'
 bs = 2
 f = torch.cat([mean[:m]] * bs).float().contiguous(); zyx = coors[:m, -3:]
 c = torch.cat([torch.cat((torch.full_like(zyx[:, :1], b), zyx), 1) for b in range(bs)]).contiguous()

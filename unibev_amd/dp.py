@@ -96,6 +96,11 @@ def max_over_ranks(value, device='cpu'):
     return float(t.item())
 
 
+def min_over_ranks(value, device='cpu'):
+    """MIN of a python float over all ranks."""
+    return -max_over_ranks(-float(value), device)
+
+
 def barrier(device=None):
     """All ranks reach this point (an all-reduce of one element; see ``all_reduce`` for why not ``dist.barrier``)."""
     if dist.is_initialized() and dist.get_world_size() > 1:

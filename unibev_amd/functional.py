@@ -217,6 +217,19 @@ def bev_lift_supported(num_heads, head_dim, num_points, dtype):
     return bool(lib().ubv_bev_lift_supported(num_heads, head_dim, num_points, _DT.get(dtype, -1)))
 
 
+# Overflow-list occupancy of the GRID lifting backward (diagnostics: bench.py's second operating point).  When enabled,
+# every grid-plan backward reads its overflow counter back (one blocking 4-byte copy per call) and the largest count per
+# instance is kept: {(fh, fw, P): (records that did not fit their owner tile's bucket, sampling points of the call)}.
+_OVF_PROBE = None
+
+
+def lift_overflow_probe(enable=None):
+    global _OVF_PROBE
+    if enable is None:
+        return dict(_OVF_PROBE or {})
+    _OVF_PROBE = {} if enable else None
+
+
 class _BevLift(Function):
     @staticmethod
     def forward(ctx, value, offlog, ref, vis0, count, center, lists, geom):
@@ -273,6 +286,12 @@ class _BevLift(Function):
                     B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh,
                     int(grid), _dt(value), _p(lists), _p(ws), int(nws), _stream()),
                       'bev_lift_backward')
+            if _OVF_PROBE is not None and grid and ws is not None:
+                # GRID workspace: [B * H * tiles counters][overflow counter] ... (csrc/bev_lift.hip grid_ws)
+                tiles = B * H * ((fw + 7) // 8) * ((fh + 7) // 8)
+                n = int(ws[4 * tiles:4 * tiles + 4].view(torch.int32).item())
+                key = (fh, fw, P)
+                _OVF_PROBE[key] = (max(n, _OVF_PROBE.get(key, (0, 0))[0]), B * Nq * H * P)
             gvalue = gv_lp if gv_lp is not None else gv
             return gvalue, gol.to(ctx.ol_dtype), None, None, None, None, None, None
 

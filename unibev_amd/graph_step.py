@@ -116,13 +116,23 @@ class GraphedStep:
         self.grads.attach()
         self.grads.all_reduce_mean()
 
-    def step(self):
+    def step(self, marks=None):
         """Replay the graph of this step's modality flags, then average the gradients over the
-        ranks.  Returns the flags."""
+        ranks.  Returns the flags.  ``marks``: a list that receives three timing events recorded on the current
+        stream — before the replay, after it, after the gradient exchange (bench.py's per-phase times)."""
         combo = self.tr.sample_modality_flags(*self.has) if len(self.graphs) > 1 \
             else next(iter(self.graphs))
+
+        def mark():
+            if marks is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append(e)
+        mark()
         self.graphs[combo].replay()
+        mark()
         self.grads.all_reduce_mean()
+        mark()
         return combo
 
     def close(self):

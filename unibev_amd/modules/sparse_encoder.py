@@ -287,6 +287,10 @@ class SparseEncoder(nn.Module):
         self.encoder_channels, self.encoder_paddings = encoder_channels, encoder_paddings
         self.stage_num = len(encoder_channels)
         self.fp16_enabled = False
+        # rulebook cache: OFF unless the caller opts in (``keep_rulebooks = True``): it trusts the identity and the
+        # version counter of the coordinate tensor, which writes that bypass the counter (.data, dlpack / numpy
+        # aliases, a HIP-graph replay or memcpy into a static buffer) do not move, and it holds the tensor alive
+        self.keep_rulebooks = False
         self._rulebooks = {}
         if self.order[0] != 'conv':                 # pre-activation structure
             self.conv_input = make_sparse_convmodule(in_channels, base_channels, 3, 'subm1', padding=1,
@@ -328,18 +332,21 @@ class SparseEncoder(nn.Module):
         """voxel_features [N, in_channels], coors [N, 4] (batch, z, y, x) -> (batch, C * D, H, W)."""
         if voxel_features.shape[0] == 0:
             raise ValueError('SparseEncoder: no voxels (BatchNorm over an empty set is undefined)')
-        # rulebooks (hash tables, neighbour maps, compacted pairs) are kept across calls while the SAME coordinate
-        # tensor comes back unmodified (identity + version counter): a cloud evaluated twice — gradient accumulation,
-        # checkpointing, a benchmark loop — pays for them once, and the 4 host reads of the strided layers' output
-        # counts disappear with them.  A new cloud is a new tensor: rebuilt.
-        hit = self._rulebooks.get(id(coors))
+        # With ``keep_rulebooks`` the rulebooks (hash tables, neighbour maps, compacted pairs) are kept across calls
+        # while the SAME coordinate tensor comes back unmodified (identity + version counter): a cloud evaluated twice
+        # — gradient accumulation, checkpointing — pays for them once, and the 4 host reads of the strided layers'
+        # output counts disappear with them.  Default: rebuilt on every call, as a training step with new clouds does.
+        hit = self._rulebooks.get(id(coors)) if self.keep_rulebooks else None
         if hit is not None and hit[0] is coors and hit[1] == coors._version and hit[2] == int(batch_size):
             indice_dict = hit[3]
         else:
             indice_dict = {}
-            if len(self._rulebooks) >= 2:
+            if self.keep_rulebooks:
+                if len(self._rulebooks) >= 2:
+                    self._rulebooks.clear()
+                self._rulebooks[id(coors)] = (coors, coors._version, int(batch_size), indice_dict)
+            elif self._rulebooks:
                 self._rulebooks.clear()
-            self._rulebooks[id(coors)] = (coors, coors._version, int(batch_size), indice_dict)
         coors = coors.int()
         x = SparseConvTensor(voxel_features, coors.contiguous(), self.sparse_shape, batch_size, indice_dict)
         x = self.conv_input(x)
