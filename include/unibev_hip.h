@@ -256,8 +256,14 @@ int ubv_bev_fuse_backward(const void* grad_out, const void* img, const void* pts
  *   grad_gamma, grad_beta [C] f32 ACCUMULATED (caller zeroes);  grad_x [R, C] dtype
  *   grad_x_colsum [C] f32 or NULL, ACCUMULATED: column sums of grad_x as stored — the bias
  *            gradient of the Linear that produced x (its backward then need not re-read grad_x)
+ *   ordered_workspace  NULL: the column sums (grad_gamma, grad_beta, grad_x_colsum) are accumulated with f32 atomics, one
+ *            per column per block — their last bits depend on the order the blocks retire in.  Otherwise a scratch
+ *            buffer of ubv_add_dropout_layernorm_backward_workspace(C) bytes (contents irrelevant, used on `stream`):
+ *            the blocks' partial sums are written there and added in block order by a second small launch —
+ *            bit-reproducible 1-D parameter gradients.
  *   C % 4 == 0, C <= 1024.
  */
+int64_t ubv_add_dropout_layernorm_backward_workspace(int C);
 int ubv_add_dropout_layernorm_forward(const void* x, const void* identity, const float* gamma,
                                       const float* beta, void* y, float* mean, float* rstd,
                                       int64_t R, int C, float eps, float p, uint64_t seed,
@@ -268,7 +274,7 @@ int ubv_add_dropout_layernorm_backward(const void* grad_y, const void* x, const 
                                        void* grad_x, void* grad_identity, float* grad_gamma,
                                        float* grad_beta, float* grad_x_colsum, int64_t R, int C,
                                        float p, uint64_t seed, const uint64_t* seed_dev, int dtype,
-                                       int stream_dtype, void* stream);
+                                       int stream_dtype, void* ordered_workspace, void* stream);
 
 /* FFN activation of the encoder layers, y = dropout(relu(x)) in one pass ([ext] mmcv FFN:
  * Sequential(Linear, ReLU, Dropout(ffn_drop)); configs/unibev: feedforward_channels=512,

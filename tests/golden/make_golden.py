@@ -276,6 +276,9 @@ FULLSIZE_CASES = {
     # adversarial case); 'init': the reference's initial sampling parameters + box-filtered maps.
     'fullsize': ((dict(embed_dims=256, num_layers=3), 200, 200, 1, (8, 22), (180, 180), (256, 704), 31), 'random'),
     'fullsize_init': ((dict(embed_dims=256, num_layers=3), 200, 200, 1, (8, 22), (180, 180), (256, 704), 33), 'init'),
+    # gradient-parity fixture: box-filtered maps (d/d(location) nearly continuous across the bilinear kinks) and
+    # sampling parameters shifted off the pixel centres (synthetic.smooth_like_state_dict): well conditioned
+    'fullsize_smooth': ((dict(embed_dims=256, num_layers=3), 200, 200, 1, (8, 22), (180, 180), (256, 704), 34), 'smooth'),
     # cfg5: cat fusion, C = 128, 800x1440 images -> 25x45 maps
     'fullsize_cat128': ((dict(embed_dims=128, num_layers=3, fusion_method='cat', feature_norm=None),
                          200, 200, 1, (25, 45), (180, 180), (800, 1440), 32), 'random'),
@@ -286,7 +289,7 @@ def fullsize_inputs(name):
     """(img, pts, bev_q, bev_pos, oq, metas) of a full-size case, profile applied."""
     case, profile = FULLSIZE_CASES[name]
     img, pts, bev_q, bev_pos, oq, metas = encoder_inputs('full' if name == 'fullsize' else name, *case)
-    if profile == 'init':
+    if profile in ('init', 'smooth'):
         img = [syn.smooth_maps(x) for x in img]
         pts = [syn.smooth_maps(x) for x in pts]
     return img, pts, bev_q, bev_pos, oq, metas
@@ -295,6 +298,8 @@ def fullsize_inputs(name):
 def fullsize_state_dict(name, named):
     case, profile = FULLSIZE_CASES[name]
     sd = syn.seeded_state_dict(named, case[-1])
+    if profile == 'smooth':
+        return syn.smooth_like_state_dict(sd, case[-1])
     return syn.init_like_state_dict(sd) if profile == 'init' else sd
 
 
@@ -664,6 +669,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'variants':
         torch.manual_seed(0)
         return gen_variants(load_reference())
+    if len(sys.argv) > 1 and sys.argv[1] == 'fullsize':            # python make_golden.py fullsize <name> ...
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        return gen_fullsize(load_reference(), only=tuple(sys.argv[2:]))
     if len(sys.argv) > 1 and sys.argv[1] == 'dual':
         torch.manual_seed(0)
         mods = load_reference()

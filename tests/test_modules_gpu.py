@@ -388,6 +388,31 @@ def test_add_dropout_layernorm_16bit_stream(dtype):
     torch.testing.assert_close(gb16, gb32, rtol=1e-5, atol=1e-4)
 
 
+def test_add_dropout_layernorm_backward_column_sums_are_ordered():
+    """gamma / beta gradients (and the bias column sums that ride along) of the fused residual + dropout + LayerNorm
+    backward at the step's size (80 000 x 256): the blocks' partial sums are added in block order
+    (ubv_add_dropout_layernorm_backward ordered_workspace), so repeated passes agree BIT FOR BIT — with one f32 atomic
+    per column per block they moved in the last bits from run to run — and they agree with an f64 reduction."""
+    from unibev_amd.functional import add_dropout_layernorm
+    torch.manual_seed(3)
+    R, C = 80000, 256
+    x = torch.randn(R, C, device=DEV)
+    idn = torch.randn(R, C, device=DEV)
+    go = torch.randn(R, C, device=DEV)
+    runs = []
+    for _ in range(3):
+        xa = x.clone().requires_grad_()
+        g = (1.0 + 0.1 * torch.randn(C, device=DEV, generator=torch.Generator(DEV).manual_seed(5))).requires_grad_()
+        b = torch.zeros(C, device=DEV, requires_grad=True)
+        y = add_dropout_layernorm(xa, idn, g, b, 0.0, training=False)
+        y.backward(go)
+        runs.append((g.grad.clone(), b.grad.clone(), xa.grad.sum(0)))
+    for r in runs[1:]:
+        assert torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1])
+    ref_b = go.double().sum(0)
+    torch.testing.assert_close(runs[0][1].double(), ref_b, rtol=1e-5, atol=1e-5 * float(ref_b.abs().max()))
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_add_dropout_layernorm_vs_torch(dtype):
     """Fused residual + dropout + LayerNorm: eval mode equals F.layer_norm(x + identity) forward and
@@ -558,6 +583,28 @@ def test_fullsize_training_gradients_16bit_vs_fp32(dtype, fwd_tol, cos_lo, norm_
     assert checked >= 10
 
 
+@pytest.mark.parametrize('gemm,bar', [('library', 2.5e-3), ('mfma', 4e-3)])
+def test_fullsize_gradient_parity_statement(gemm, bar):
+    """The gradient-parity STATEMENT at BASELINE's shapes: fixture ``fullsize_smooth`` — box-filtered maps and sampling
+    parameters shifted off the pixel centres (synthetic.smooth_like_state_dict), recorded from the reference — is well
+    conditioned (no sample on a kink of the bilinear interpolant, d/d(location) nearly continuous), so EVERY tensor is
+    held to ONE normwise bar with no exclusions and no allowance for 1-D parameters: the inputs, the BEV queries, every
+    encoder-side parameter including the self-attention ``sampling_offsets``.
+
+    The bars are the f32 reference's own round-off floor: the oracle (the reference's arithmetic) run in float32 sits
+    1.2e-3 (median over the tensors) to 2.7e-3 (worst: a layer-0 attention_weights bias) from its float64 run on this
+    fixture (tools/oracle_f32_floor.py, profiles/r04_gradient_floor.txt) — three layers of sampling amplify a unit
+    round-off ~1000x whatever computes them.  Measured on MI355X against the f32 oracle: IEEE library GEMMs worst
+    2.0e-3 (forward 1.3e-6), the default split-bf16 MFMA Linear layers worst 3.1e-3; against the float64 oracle the
+    library path is 3.0e-3 at worst, i.e. as far from exact as the reference is."""
+    from unibev_amd.linear import set_f32_gemm
+    prev = set_f32_gemm(gemm)
+    try:
+        _fullsize_gradients('fullsize_smooth', norm_bar=bar, elem_bar=0.1, fwd_bar=1e-4, allow_1d=1.0, skip_kinks=False)
+    finally:
+        set_f32_gemm(prev)
+
+
 @pytest.mark.parametrize('fixture', ['fullsize_init', 'fullsize'])
 def test_fullsize_gradients_vs_oracle(fixture):
     """BASELINE shapes (200x200 BEV, 6 x 8x22 image maps, 180x180 LiDAR map, C = 256, 3 layers, CNW): gradient of
@@ -573,19 +620,24 @@ def test_fullsize_gradients_vs_oracle(fixture):
     its one-sided values and a 1-ulp difference in the location picks the side — the self-attention
     `sampling_offsets` gradients of that fixture (0.3 - 0.5 apart, with library GEMMs too) are left out; on the
     random-parameter fixture they agree like every other tensor."""
-    from oracle import unibev_ref as R
     NORM_BAR, ELEM_BAR = (5e-3, 6e-2) if fixture == 'fullsize_init' else (9e-2, 0.7)
-    FWD_BAR = 1e-3
+    _fullsize_gradients(fixture, NORM_BAR, ELEM_BAR, 1e-3, allow_1d=4.0, skip_kinks=fixture == 'fullsize_init')
+
+
+def _fullsize_gradients(fixture, norm_bar, elem_bar, fwd_bar, allow_1d, skip_kinks, oracle_dtype=torch.float32):
+    from oracle import unibev_ref as R
+    NORM_BAR, ELEM_BAR, FWD_BAR = norm_bar, elem_bar, fwd_bar
     cfg, sd, inp, g = encoder_case(fixture)
     nq, bs, width = inp['bev_h'] * inp['bev_w'], inp['bs'], cfg['embed_dims'] * (2 if cfg.get('fusion_method') == 'cat' else 1)
     cot = syn.seeded_array('cot:' + fixture, (nq, bs, width), 5) / nq ** 0.5
     torch.set_num_threads(min(16, torch.get_num_threads()))
-    P = {k: v.requires_grad_() for k, v in R.state_dict_to_torch(sd).items()}
-    oi = [t(x).requires_grad_() for x in inp['img']]
-    op = [t(x).requires_grad_() for x in inp['pts']]
-    oq = t(inp['bev_q']).requires_grad_()
-    fused_ref = R.transformer_encode_fuse(P, cfg, oi, op, oq, inp['bev_h'], inp['bev_w'], t(inp['bev_pos']), inp['metas'])
-    (fused_ref * t(cot)).sum().backward()
+    od = oracle_dtype
+    P = {k: v.to(od).requires_grad_() for k, v in R.state_dict_to_torch(sd).items()}
+    oi = [t(x, od).requires_grad_() for x in inp['img']]
+    op = [t(x, od).requires_grad_() for x in inp['pts']]
+    oq = t(inp['bev_q'], od).requires_grad_()
+    fused_ref = R.transformer_encode_fuse(P, cfg, oi, op, oq, inp['bev_h'], inp['bev_w'], t(inp['bev_pos'], od), inp['metas'])
+    (fused_ref * t(cot, od)).sum().backward()
     model = _build(cfg).to(DEV).eval()
     _load(model, sd)
     gi = [t(x, device=DEV).requires_grad_() for x in inp['img']]
@@ -594,7 +646,7 @@ def test_fullsize_gradients_vs_oracle(fixture):
     fused = model.encode(gi, gp, gq, inp['bev_h'], inp['bev_w'], bev_pos=t(inp['bev_pos'], device=DEV),
                          img_metas=inp['metas'])
     (fused * t(cot, device=DEV)).sum().backward()
-    ferr = float((fused.detach().cpu() - fused_ref.detach()).norm() / fused_ref.detach().norm())
+    ferr = float((fused.detach().cpu().to(od) - fused_ref.detach()).norm() / fused_ref.detach().norm())
     assert ferr < FWD_BAR, ferr
     worst = {}
 
@@ -608,7 +660,7 @@ def test_fullsize_gradients_vs_oracle(fixture):
         merr = float((a - b).abs().max()) / float(b.abs().max())
         # 1-D parameters (biases, norm scales) are sums of ~80 000 signed terms accumulated with f32 atomics in
         # arrival order: their distance moves from run to run (one sampling_offsets bias: 2.0e-3 .. 5.9e-3 over 8 runs)
-        worst[what] = (nerr / (4.0 if b.dim() == 1 else 1.0), merr)
+        worst[what] = (nerr / (allow_1d if b.dim() == 1 else 1.0), merr)
     close(gi[0].grad, oi[0].grad, 'img feats')
     close(gp[0].grad, op[0].grad, 'pts feats')
     close(gq.grad, oq.grad, 'bev queries')
@@ -617,7 +669,7 @@ def test_fullsize_gradients_vs_oracle(fixture):
         if k.startswith('decoder') or k.startswith('reference_points') or P[k].grad is None:
             continue
         assert p.grad is not None, k
-        if fixture == 'fullsize_init' and '.attentions.0.sampling_offsets.' in k:
+        if skip_kinks and '.attentions.0.sampling_offsets.' in k:
             continue                                        # samples on the interpolant's kinks, see above
         close(p.grad, P[k].grad, k)
         checked += 1

@@ -27,6 +27,22 @@ def test_msda_forward_and_grads(case):
     np.testing.assert_allclose(o32.numpy(), g[f'{case}_out'], rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize('case', [c[0] for c in mg.MSDA_CASES])
+def test_msda_c_oracle_vs_reference_vectors(case):
+    """oracle/msda_ref.c (the C restatement the k1 GPU tests check against) is itself pinned to the vectors recorded
+    from the reference's own ``multi_scale_deformable_attn_pytorch`` (msda.npz: f64 output and gradients of the f32
+    inputs): f32 inputs, f64 accumulation inside -> agreement to f32 round-off of the outputs."""
+    from oracle import c_ref
+    g = golden('msda')
+    v, l, w, go = g[f'{case}_value'], g[f'{case}_loc'], g[f'{case}_w'], g[f'{case}_gout']
+    out = c_ref.msda_forward(v, g[f'{case}_shapes'], l, w)
+    np.testing.assert_allclose(out, g[f'{case}_out64'], rtol=2e-6, atol=2e-6)
+    gv, gl, gw = c_ref.msda_backward(v, g[f'{case}_shapes'], l, w, go)
+    np.testing.assert_allclose(gv, g[f'{case}_gvalue'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gl, g[f'{case}_gloc'], rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(g[f'{case}_gloc']).max())))
+    np.testing.assert_allclose(gw, g[f'{case}_gw'], rtol=2e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize('tag', ['small', 'mid'])
 def test_reference_points_and_point_sampling(tag):
     g = golden('point_sampling')

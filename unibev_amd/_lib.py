@@ -45,7 +45,8 @@ SIGNATURES = {
     'ubv_add_dropout_layernorm_forward': (c_int, [_P] * 7 + [c_int64, c_int, c_float, c_float, c_uint64,
                                                           _P, c_int, c_int, _P]),
     'ubv_add_dropout_layernorm_backward': (c_int, [_P] * 11 + [c_int64, c_int, c_float, c_uint64,
-                                                            _P, c_int, c_int, _P]),
+                                                            _P, c_int, c_int, _P, _P]),
+    'ubv_add_dropout_layernorm_backward_workspace': (c_int64, [c_int]),
     'ubv_relu_dropout_forward': (c_int, [_P, _P, c_int64, c_float, c_uint64, _P, c_int, _P]),
     'ubv_relu_dropout_backward': (c_int, [_P, _P, _P, c_int64, c_float, c_int, _P]),
     'ubv_linear_workspace': (c_int64, []),

@@ -14,6 +14,7 @@
 namespace ubv {
 
 constexpr int kNormChunks = 4;      // C <= 64 lanes * 4 floats * 4 chunks = 1024
+constexpr int kNormBwdBlocks = 512; // backward grid: 2048 waves
 
 template <typename T>
 __device__ __forceinline__ void load4(const T* p, float (&v)[4]) { vec_io<T, 4>::load(p, v); }
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void add_norm_bwd_rows_kernel(
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
     T* __restrict__ gx, S* __restrict__ gid, float* __restrict__ dgamma,
     float* __restrict__ dbeta, float* __restrict__ dxsum, long R, int C, uint32_t thresh,
-    float scale, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+    float scale, uint64_t seed, const uint64_t* __restrict__ seed_dev, int* __restrict__ ordered_ws) {
   if (seed_dev != nullptr) seed += *seed_dev;   // per-step base kept on the device (graph replays)
   constexpr int VEC = 16 / elem<T>::kBytes, G = 64 / LPR;
   __shared__ float red[3][4][64][VEC];
@@ -316,7 +317,14 @@ __global__ __launch_bounds__(256) void add_norm_bwd_rows_kernel(
     red[0][wv][lane][i] = ag[i]; red[1][wv][lane][i] = ab[i]; red[2][wv][lane][i] = ax[i];
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < (dxsum != nullptr ? 3 : 2) * C; t += 256) {
+  const int NC = (dxsum != nullptr ? 3 : 2) * C;
+  // ORDERED mode (ordered_ws != null): the block's column sums go to its row of a partials table instead of into
+  // f32 atomics; add_norm_colsum_final_kernel (next launch) adds the rows in block order: the same bits on every run,
+  // whatever order the blocks retire in (f32 atomics gave the 1-D parameter gradients a run-to-run spread).
+  // (Summing in this launch — the last block of a group, then the last group, found through tickets — needs an
+  //  agent-scope release / acquire per block, i.e. an L2 write-back on every XCD: 15.0 -> 17.7 ms per step measured.)
+  float* __restrict__ part = reinterpret_cast<float*>(ordered_ws);
+  for (int t = threadIdx.x; t < NC; t += 256) {
     const int which = t / C, col = t - which * C;
     const int cl = col / VEC, e = col - cl * VEC;
     float sum = 0.0f;
@@ -324,7 +332,34 @@ __global__ __launch_bounds__(256) void add_norm_bwd_rows_kernel(
     for (int w = 0; w < 4; ++w)
 #pragma unroll
       for (int gq = 0; gq < G; ++gq) sum += red[which][w][gq * LPR + cl][e];
-    atomic_add_f32((which == 0 ? dgamma : which == 1 ? dbeta : dxsum) + col, sum);
+    if (part != nullptr) part[(long)blockIdx.x * NC + t] = sum;
+    else atomic_add_f32((which == 0 ? dgamma : which == 1 ? dbeta : dxsum) + col, sum);
+  }
+}
+
+// Ordered mode, second launch: out[col] += sum over the blocks' partial rows IN BLOCK ORDER.  16 columns x 16 row groups
+// per block; a thread adds its group's rows one after the other, the 16 groups are then added in group order.
+__global__ __launch_bounds__(256) void add_norm_colsum_final_kernel(const float* __restrict__ part, int nrows, int NC, int C,
+                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                    float* __restrict__ dxsum) {
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int t = blockIdx.x * 16 + cl;
+  const int per = (nrows + 15) / 16;
+  float sum = 0.0f;
+  if (t < NC) {
+    const int r0 = rg * per, r1 = min(nrows, r0 + per);
+    for (int r = r0; r < r1; ++r) sum += part[(long)r * NC + t];
+  }
+  red[rg][cl] = sum;
+  __syncthreads();
+  if (rg == 0 && t < NC) {
+    float tot = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) tot += red[g][cl];
+    const int which = t / C, col = t - which * C;
+    float* dst = (which == 0 ? dgamma : which == 1 ? dbeta : dxsum) + col;
+    *dst += tot;
   }
 }
 
@@ -405,17 +440,27 @@ template <typename T, typename S>
 static void norm_bwd_launch(dim3 grid, hipStream_t st, const void* gy, const void* x,
                             const void* identity, const float* gamma, const float* mean,
                             const float* rstd, void* gx, void* gid, float* dgamma, float* dbeta,
-                            float* dxsum, long R, int C, uint32_t th, float sc, uint64_t seed, const uint64_t* seed_dev) {
+                            float* dxsum, long R, int C, uint32_t th, float sc, uint64_t seed, const uint64_t* seed_dev,
+                            int* ordered_ws) {
   constexpr int VEC = 16 / elem<T>::kBytes;
   const int lpr = (C % VEC == 0) ? C / VEC : 0;
   auto run = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, (const S*)gy, (const T*)x, (const S*)identity,
+                       gamma, mean, rstd, (T*)gx, (S*)gid, dgamma, dbeta, dxsum, R, C, th, sc, seed, seed_dev, ordered_ws);
+  };
+  auto run_plain = [&](auto kernel) {       // rare widths: one row per wave, atomics
     hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, (const S*)gy, (const T*)x, (const S*)identity,
                        gamma, mean, rstd, (T*)gx, (S*)gid, dgamma, dbeta, dxsum, R, C, th, sc, seed, seed_dev);
   };
   if (lpr == 64) run(add_norm_bwd_rows_kernel<T, S, 64>);
   else if (lpr == 32) run(add_norm_bwd_rows_kernel<T, S, 32>);
   else if (lpr == 16) run(add_norm_bwd_rows_kernel<T, S, 16>);
-  else run(add_norm_bwd_kernel<T, S>);
+  else { run_plain(add_norm_bwd_kernel<T, S>); return; }
+  if (ordered_ws != nullptr) {
+    const int NC = (dxsum != nullptr ? 3 : 2) * C;
+    hipLaunchKernelGGL(add_norm_colsum_final_kernel, dim3((NC + 15) / 16), dim3(256), 0, st, (const float*)ordered_ws,
+                       (int)grid.x, NC, C, dgamma, dbeta, dxsum);
+  }
 }
 
 }  // namespace ubv
@@ -448,6 +493,11 @@ extern "C" int ubv_add_dropout_layernorm_forward(const void* x, const void* iden
   return UBV_OK;
 }
 
+// ordered-mode workspace: one row of 3 C sums per block
+extern "C" int64_t ubv_add_dropout_layernorm_backward_workspace(int C) {
+  return (int64_t)ubv::kNormBwdBlocks * 3 * (int64_t)C * 4;
+}
+
 extern "C" int ubv_add_dropout_layernorm_backward(const void* grad_y, const void* x,
                                                   const void* identity, const float* gamma,
                                                   const float* mean, const float* rstd, void* grad_x,
@@ -455,10 +505,11 @@ extern "C" int ubv_add_dropout_layernorm_backward(const void* grad_y, const void
                                                   float* grad_beta, float* grad_x_colsum,
                                                   int64_t R, int C, float p,
                                                   uint64_t seed, const uint64_t* seed_dev, int dtype,
-                                                  int stream_dtype, void* stream) {
+                                                  int stream_dtype, void* ordered_workspace, void* stream) {
   using namespace ubv;
   UBV_CHECK_ARG(grad_y && x && identity && gamma && mean && rstd && grad_x && grad_identity &&
                     grad_gamma && grad_beta, "add_norm_backward: null pointer");
+  UBV_CHECK_ARG(((uintptr_t)ordered_workspace % 16) == 0, "add_norm_backward: ordered_workspace must be 16-byte aligned");
   int rc = norm_check(R, C, dtype, stream_dtype, "add_norm_backward");
   if (rc) return rc;
   if (R == 0) return UBV_OK;
@@ -467,7 +518,7 @@ extern "C" int ubv_add_dropout_layernorm_backward(const void* grad_y, const void
   const long waves = R < 2048 ? R : 2048;
   const dim3 grid((unsigned)((waves + 3) / 4));
   hipStream_t st = as_stream(stream);
-#define UBV_NORM_BWD(T, S) norm_bwd_launch<T, S>(grid, st, grad_y, x, identity, gamma, mean, rstd, grad_x, grad_identity, grad_gamma, grad_beta, grad_x_colsum, (long)R, C, th, sc, seed, seed_dev)
+#define UBV_NORM_BWD(T, S) norm_bwd_launch<T, S>(grid, st, grad_y, x, identity, gamma, mean, rstd, grad_x, grad_identity, grad_gamma, grad_beta, grad_x_colsum, (long)R, C, th, sc, seed, seed_dev, (int*)ordered_workspace)
   const bool lowp = stream_dtype != UBV_F32;
   switch (dtype) {
     case UBV_F32: UBV_NORM_BWD(float, float); break;

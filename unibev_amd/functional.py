@@ -537,7 +537,7 @@ class _AddDropoutNorm(Function):
                                                            _p(rstd), _p(gx), _p(gid), _p(dg), _p(db),
                                                            _p(dxs), R, C, ctx.p, ctx.seed,
                                                            _p(ctx.seed_base), _dt(x2), _dt(id2),
-                                                           _stream()),
+                                                           _p(_ordered_ws(C, x2.device)), _stream()),
                   'add_dropout_layernorm_backward')
             gx = gx.view(ctx.shape)
             # column sums of grad_x ride along: if x came straight out of a Linear, its backward takes
@@ -546,6 +546,16 @@ class _AddDropoutNorm(Function):
             gid = gid.view(ctx.shape).to(ctx.dts[0])
             tag_grad(gid, '_ubv_owned', True)   # fresh, single consumer: linear._Linear may accumulate into it
             return (gx, gid, dg.to(ctx.dts[1]), db.to(ctx.dts[2]), None, None)
+
+
+_NORM_ORDERED = os.environ.get('UBV_NORM_ORDERED', '1') != '0'      # 0: f32 atomics instead of ordered sums (A/B runs)
+
+
+def _ordered_ws(C, device):
+    """Scratch of the ordered column sums of ``ubv_add_dropout_layernorm_backward`` (the stream's shared scratch)."""
+    if not _NORM_ORDERED:
+        return None
+    return _workspace(int(lib().ubv_add_dropout_layernorm_backward_workspace(int(C))), device)
 
 
 def add_dropout_layernorm(x, identity, gamma, beta, p=0.0, training=False, eps=1e-5):

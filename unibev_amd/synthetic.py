@@ -134,6 +134,27 @@ def init_like_state_dict(sd, num_heads=8):
     return out
 
 
+def smooth_like_state_dict(sd, seed=0, num_heads=8):
+    """Well-conditioned sampling parameters for gradient parity at full size: the reference's initial compass grid
+    SHIFTED off the pixel centres (each offset component + a seeded fraction in [0.2, 0.45]: no sample within 0.02 px of
+    a kink of the bilinear interpolant on the BEV grids), small seeded ``sampling_offsets`` weights (offsets move by
+    ~0.05 px from query to query, so their gradients are exercised) and small non-zero ``attention_weights`` (a
+    non-uniform softmax).  Everything else is kept."""
+    out = init_like_state_dict(sd, num_heads)
+    for name, a in sd.items():
+        leaf = name.split('.')[-1]
+        rs = np.random.RandomState((int(seed) * 1000003 + zlib.crc32(('smooth:' + name).encode())) & 0x7FFFFFFF)
+        if 'sampling_offsets' in name and leaf == 'bias':
+            out[name] = (out[name] + rs.uniform(0.2, 0.45, a.shape)).astype(np.float32)
+        elif 'sampling_offsets' in name and leaf == 'weight':
+            out[name] = (rs.standard_normal(a.shape) * (0.05 / math.sqrt(a.shape[-1]))).astype(np.float32)
+        elif 'attention_weights' in name and leaf == 'weight':
+            out[name] = (rs.standard_normal(a.shape) * (0.3 / math.sqrt(a.shape[-1]))).astype(np.float32)
+        elif 'attention_weights' in name and leaf == 'bias':
+            out[name] = (rs.standard_normal(a.shape) * 0.5).astype(np.float32)
+    return out
+
+
 def smooth_maps(x, k=5):
     """Box filter over the last two axes (window k, mean over the in-range part, times k): feature
     maps with the spatial correlation backbone outputs have, instead of i.i.d. pixels."""
