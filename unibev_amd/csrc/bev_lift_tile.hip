@@ -33,6 +33,17 @@ namespace ubv {
 constexpr int kTWinRow = kWin * kWinRowB + 64;
 constexpr int kTWinLds = kWin * kTWinRow;
 
+// (tile, head) of this block with H = 8 heads (tile_ok): head fastest, XCD x owns a contiguous range of units
+__device__ __forceinline__ bool tile_decode8(const LiftArgs& a, int chunk, WinGeom& g) {
+  const int v = xcd_remap(blockIdx.x, chunk);
+  const int item = v >> 3;
+  if (item >= a.total_tiles) return false;
+  g.hg = v & 7;
+  g.b = div_mg(item, a.tiles_per_sample, a.mg_tps);
+  g.tile = item;
+  return true;
+}
+
 // min over the wave: DPP inside the rows of 16 lanes (quad permutes, row_half_mirror, row_mirror), the four rows
 // through scalar reads
 __device__ __forceinline__ int wave_min_i32(int v) {
@@ -144,13 +155,17 @@ __device__ __forceinline__ void tile_fill(const LiftArgs& a, const WinGeom& g, c
   const int cdx = min(dx, max(t.cols - 1, 0));            // columns past the box re-read its last one (same line: free)
   const int rowi = a.H * 32;
   const float* vb = (const float*)a.value + (long)g.b * a.fh * a.fw * rowi + h * 32 + piece * 4;
+  // element offset of this thread's pixel in pass 0, and the (uniform) step of a pass = 2 map rows; a pass whose second
+  // row lies past the box re-reads its first one (dyl = 1 lanes step back one row)
+  const unsigned off0 = (unsigned)(((g.wy0 + dyl) * a.fw + g.wx0 + cdx) * rowi);
+  const unsigned step = (unsigned)(2 * a.fw * rowi), back = (unsigned)(dyl * a.fw * rowi);
   uint4 v[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     uint4 x = make_uint4(0u, 0u, 0u, 0u);
     if (2 * i < t.rows) {                                  // block-uniform
-      const int dy = min(2 * i + dyl, t.rows - 1);
-      x = *reinterpret_cast<const uint4*>(gather_ptr(vb, (unsigned)(((g.wy0 + dy) * a.fw + g.wx0 + cdx) * rowi)));
+      const unsigned o = off0 + (unsigned)i * step - ((2 * i + 1 < t.rows) ? 0u : back);
+      x = *reinterpret_cast<const uint4*>(gather_ptr(vb, o));
     }
     v[i] = x;
   }
@@ -174,10 +189,10 @@ __global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, in
   extern __shared__ __attribute__((aligned(16))) unsigned char win[];
   constexpr int PW = P / 4;
   WinGeom g;
-  if (!win_decode<1>(a, chunk, g)) return;
+  if (!tile_decode8(a, chunk, g)) return;
   const int lane = threadIdx.x & 63, wv = wave_in_block();
   const int h = g.hg;
-  const int rowi = a.H * 32;
+  constexpr int rowi = 8 * 32;
   const int li = wv * 16 + (lane >> 2), pp = lane & 3;
   float rx[PW], ry[PW], rw[PW];
   int b, q;
@@ -195,12 +210,26 @@ __global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, in
 #pragma unroll
   for (int j = 0; j < PW; ++j) {
     const Footprint f = footprint_px(rx[j], ry[j], a.fh, a.fw);
+    float c[4];
+    int wr[4];
+    bool miss = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float c = rw[j] * f.w[k];
-      const int wr = tile_row(f.xc[k & 1], f.yc[k >> 1], g, tw);
-      if (wr >= 0) tile_axpy32(reinterpret_cast<const float*>(win + (unsigned)wr), c, acc);
-      else if (c != 0.0f) tile_axpy32(gather_ptr(vb, (unsigned)(f.idx[k] * rowi)), c, acc);
+      c[k] = rw[j] * f.w[k];
+      wr[k] = tile_row(f.xc[k & 1], f.yc[k >> 1], g, tw);
+      miss = miss || (wr[k] < 0 && c[k] != 0.0f);
+    }
+    if (__ballot(miss) == 0ull) {
+      // the wave's corners are all in the window (or weightless: any row will do): straight-line code, the 32 LDS reads
+      // of the point in flight together
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tile_axpy32(reinterpret_cast<const float*>(win + (unsigned)max(wr[k], 0)), c[k], acc);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (wr[k] >= 0) tile_axpy32(reinterpret_cast<const float*>(win + (unsigned)wr[k]), c[k], acc);
+        else if (c[k] != 0.0f) tile_axpy32(gather_ptr(vb, (unsigned)(f.idx[k] * rowi)), c[k], acc);
+      }
     }
   }
 #pragma unroll
@@ -230,10 +259,10 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
   __shared__ int slot_cnt[4][16], slot_base[4][16];
   constexpr int PW = P / 4;
   WinGeom g;
-  if (!win_decode<1>(a, chunk, g)) return;
+  if (!tile_decode8(a, chunk, g)) return;
   const int lane = threadIdx.x & 63, wv = wave_in_block();
   const int h = g.hg;
-  const int rowi = a.H * 32;
+  constexpr int rowi = 8 * 32;
   const int li = wv * 16 + (lane >> 2), pp = lane & 3;
   int b, q;
   const bool valid = lift_query(a, g.tile, li, b, q);
@@ -261,13 +290,24 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
   for (int j = 0; j < PW; ++j) {
     const Footprint f = footprint_px(rx[j], ry[j], a.fh, a.fw);
     float d[4];
+    int wr[4];
+    bool miss = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int wr = tile_row(f.xc[k & 1], f.yc[k >> 1], g, tw);
-      d[k] = 0.0f;
-      if (wr >= 0) d[k] = tile_dot32(reinterpret_cast<const float*>(win + (unsigned)wr), go);
-      else if (valid && f.m[k] != 0.0f) d[k] = tile_dot32(gather_ptr(vb, (unsigned)(f.idx[k] * rowi)), go);
-      d[k] *= f.m[k];
+      wr[k] = tile_row(f.xc[k & 1], f.yc[k >> 1], g, tw);
+      miss = miss || (wr[k] < 0 && valid && f.m[k] != 0.0f);
+    }
+    if (__ballot(miss) == 0ull) {          // all in the window (or masked out): straight-line code
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k] = tile_dot32(reinterpret_cast<const float*>(win + (unsigned)max(wr[k], 0)), go) * f.m[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        d[k] = 0.0f;
+        if (wr[k] >= 0) d[k] = tile_dot32(reinterpret_cast<const float*>(win + (unsigned)wr[k]), go);
+        else if (valid && f.m[k] != 0.0f) d[k] = tile_dot32(gather_ptr(vb, (unsigned)(f.idx[k] * rowi)), go);
+        d[k] *= f.m[k];
+      }
     }
     const float hx = 1.0f - f.lx, hy = 1.0f - f.ly;
     gw[j] = hy * hx * d[0] + hy * f.lx * d[1] + f.ly * hx * d[2] + f.ly * f.lx * d[3];
@@ -344,7 +384,7 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
 // SCA-pts instances.  UBV_LIFT_TILE=0 switches the plan off (A/B runs against the window / gather kernels).
 bool tile_ok(const LiftArgs& a, int Dh, int P, int dtype) {
   static const int env = getenv("UBV_LIFT_TILE") ? atoi(getenv("UBV_LIFT_TILE")) : 1;
-  return env != 0 && dtype == UBV_F32 && Dh == 32 && (P == 4 || P == 8) && a.ol16 == 0 && a.Nc == 1 && a.qw > 0 &&
+  return env != 0 && dtype == UBV_F32 && Dh == 32 && a.H == 8 && (P == 4 || P == 8) && a.ol16 == 0 && a.Nc == 1 && a.qw > 0 &&
          a.vis0 == nullptr && a.count == nullptr && a.fh >= 1 && a.fw >= 1;
 }
 
