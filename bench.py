@@ -123,6 +123,10 @@ def parse():
                          "the same compass-grid offsets: the headline), 'spread' = seeded sampling_offsets weights that "
                          "scatter the offsets by ~3 pixels per query (a trained-looking operating point), 'both' = the "
                          "headline on 'init' and a `spread` sub-record")
+    ap.add_argument('--exchange', default='auto', choices=['auto', 'split', 'single'],
+                    help="gradient exchange: 'split' = the backward is two HIP graphs cut at the first encoder layers and the "
+                         "upper layers' segment of the flat gradient buffer is all-reduced beside the second graph; 'single' = "
+                         "one graph, one message after it; 'auto' = split when there is a process group (N > 1)")
     ap.add_argument('--no-ieee-gemm', action='store_true', help='skip the `ieee_gemm` sub-record (f32 step on library IEEE GEMMs)')
     ap.add_argument('--fp32-stream', action='store_true',
                     help='keep the encoder residual stream in f32 under autocast (default: the '
@@ -296,9 +300,14 @@ def run_mode(args, name, head, world, rank, device, want_ops):
     s = 2 if kw.get('fusion_method') == 'cat' else 1
     C = kw['embed_dims']
     cot = torch.randn(200 * 200, args.bs, C * s, device=device) / 200.0
+    split = args.exchange == 'split' or (args.exchange == 'auto' and dist.is_initialized())
+    tr = head.transformer
+    encs = [getattr(tr, n) for n in ('img_bev_encoder', 'pts_bev_encoder') if getattr(tr, n, None) is not None]
+    cut = encs if split else None
     gs = GraphedStep(head.transformer, lambda: head.forward_bev(img, pts, metas), cot, params,
                      inputs=(img or []) + (pts or []), has_img='C' in mods, has_pts='L' in mods,
-                     autocast_dtype=None if dtype == torch.float32 else dtype)
+                     autocast_dtype=None if dtype == torch.float32 else dtype, split_after=cut)
+    params = gs.params                              # (a split backward puts the upper layers' parameters first)
 
     if args.flat_optimizer:
         # clip (max_norm 35) + AdamW as two streaming passes over the flat parameter / gradient / moment buffers
@@ -382,6 +391,9 @@ def run_mode(args, name, head, world, rank, device, want_ops):
            'phases': phases,
            'host_enqueue_ms_per_step': 1e3 * launch_dt, 'host_loop_ms_per_step': 1e3 * host_dt / args.steps,
            'hip_graphs': graphed, 'steps_run': nsteps_run,
+           'gradient_exchange': ('split: 2 HIP graphs, segment 0 (%d of %d bytes) all-reduced beside the second graph'
+                                 % (gs.grads.segments[0].numel() * 4, gs.grads.flat.numel() * 4))
+           if len(gs.grads.segments) == 2 else ('single message after the graph' + (f' ({gs.split_note})' if getattr(gs, 'split_note', None) else '')),
            'residual_stream': 'f32' if (args.fp32_stream or name == 'fp32') else name}
     # ---- per-op roofline: the same step, eager, HIP events on the launch stream around every
     # sampling kernel / op (events cannot be read back from inside a captured graph)

@@ -135,3 +135,79 @@ def test_graph_replay_matches_eager_and_follows_the_modality_protocol():
     np.testing.assert_array_equal(np.asarray(seen), flags)
     gs.close()
     torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+def test_split_backward_graphs_equal_the_single_backward():
+    """GraphedStep(split_after=first encoder layers): the backward cut in two graphs at the first layers' outputs (what
+    lets the gradient exchange of the upper layers overlap the rest of the backward, graph_step.py) gives the same
+    gradients as the single backward — parameter by parameter, inputs included — eagerly and replayed, for every
+    modality-flag outcome; the parameters above the cut are the first segment of the flat buffer."""
+    import numpy as np
+    import torch
+    from _util import encoder_case, t
+    from unibev_amd import build_transformer
+    from unibev_amd.graph_step import GraphedStep
+    dev = 'cuda'
+    torch.cuda.set_stream(torch.cuda.Stream())
+    cfg, sd, inp, g = encoder_case('cnw')
+    cfg = json.loads(json.dumps(cfg))
+    cfg['drop_modality'] = 0.5
+    model = build_transformer(cfg).to(dev).train()
+    model.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    img = [t(x, device=dev).requires_grad_() for x in inp['img']]
+    pts = [t(x, device=dev).requires_grad_() for x in inp['pts']]
+    bev_q, bev_pos = t(inp['bev_q'], device=dev).requires_grad_(), t(inp['bev_pos'], device=dev)
+    fwd = lambda: model.encode(img, pts, bev_q, inp['bev_h'], inp['bev_w'], bev_pos=bev_pos,   # noqa: E731
+                               img_metas=inp['metas'])
+    named = [(n, p) for n, p in model.named_parameters() if not n.startswith('reference_points')]
+    params = [p for _, p in named]
+    cot = torch.randn(inp['bev_h'] * inp['bev_w'], inp['bs'], 128, device=dev)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if hasattr(m, 'ffn_drop'):
+            m.ffn_drop = 0.0
+    one = GraphedStep(model, fwd, cot, params, inputs=img + pts + [bev_q])
+    two = GraphedStep(model, fwd, cot, params, inputs=img + pts + [bev_q],
+                      split_after=[model.img_bev_encoder, model.pts_bev_encoder])
+    assert two.split_note is None, two.split_note
+    assert 0 < two.n_upper < len(params) and len(two.grads.segments) == 2
+    names = {id(p): n for n, p in named}
+    upper = [names[id(p)] for p in two.params[:two.n_upper]]
+    assert all('_bev_encoder.layers.1.' in n or 'channel_weights' in n for n in upper), upper
+    assert sum('_bev_encoder.layers.1.' in n for n in upper) == sum('_bev_encoder.layers.1.' in n for n, _ in named)
+
+    def grads_of(gs):
+        out = {names[id(p)]: v.clone() for p, v in zip(gs.params, gs.grads.views)}
+        out.update({f'in{i}': x.grad.clone() for i, x in enumerate(gs.inputs) if x.grad is not None})
+        return out
+
+    for combo in ((1, 1), (1, 0), (0, 1)):
+        ref = None
+        for gs in (one, two):
+            model.forced_flags = combo
+            gs._clear_grads()
+            gs._fwd_bwd()
+            model.forced_flags = None
+            got = grads_of(gs)
+            if ref is None:
+                ref = got
+                continue
+            assert set(got) == set(ref)
+            for k in ref:
+                scale = max(float(ref[k].abs().max()), 1e-6)
+                torch.testing.assert_close(got[k], ref[k], rtol=1e-4, atol=2e-5 * scale, msg=lambda m, k=k: f'{k}: {m}')
+    two.capture()
+    assert all(isinstance(v, tuple) for v in two.graphs.values())
+    np.random.seed(7)
+    for _ in range(6):
+        combo = two.step()
+        replayed = two.grads.flat.clone()
+        model.forced_flags = combo
+        two._clear_grads()
+        two._fwd_bwd()
+        model.forced_flags = None
+        scale = float(replayed.abs().max())
+        torch.testing.assert_close(replayed, two.grads.flat, rtol=1e-4, atol=1e-5 * scale)
+    two.close()
+    torch.cuda.set_stream(torch.cuda.default_stream())

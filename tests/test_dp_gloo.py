@@ -63,6 +63,23 @@ def _worker(rank, world, port, ret):
     flat = torch.cat([p.grad.flatten() for p in net3.parameters()])
     ok = ok and torch.allclose(flat, ref, rtol=1e-5, atol=1e-6) and torch.equal(flat, fg.flat) \
         and all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(net3.parameters(), fg.views))
+    # the segmented exchange of a split backward (graph_step.GraphedStep(split_after=...)): the first parameters form
+    # segment 0, collected and sent on its way first, the rest follows; same averages as the single message
+    torch.manual_seed(0)
+    net4 = torch.nn.Sequential(
+        build_feedforward_network(dict(type='FFN', embed_dims=32, feedforward_channels=64,
+                                       ffn_drop=0.0)),
+        torch.nn.LayerNorm(32))
+    (net4(data[mine]).square().sum() / len(mine)).backward()
+    ps = list(net4.parameters())
+    fs = dp.FlatGradients(ps, first_segment=2)
+    assert len(fs.segments) == 2 and fs.segments[0].numel() == ps[0].numel() + ps[1].numel()
+    fs.collect(0, 2, [ps[0].grad, ps[1].grad])
+    fs.start_segment(0)                                   # in flight while "the rest of the backward" is collected
+    fs.collect(2, len(ps))
+    fs.start_segment(1)
+    fs.finish_segments()
+    ok = ok and torch.allclose(fs.flat, ref, rtol=1e-5, atol=1e-6) and not fs.missing and not fs._pending
     tmax = dp.max_over_ranks(1.0 + rank)
     dp.barrier()
     ret[rank] = (ok, mine, tmax)

@@ -122,7 +122,10 @@ class FlatGradients:
     graph; the collective is issued eagerly behind the replay, on the same stream).
     """
 
-    def __init__(self, params, dtype=torch.float32):
+    def __init__(self, params, dtype=torch.float32, first_segment=None):
+        """``first_segment``: number of leading parameters that form the FIRST segment of the buffer — the ones whose
+        gradients are complete first (``graph_step.GraphedStep`` with a split backward puts the upper layers there):
+        the buffer is then exchanged as two messages, the first one while the rest of the backward still runs."""
         self.params = [p for p in params]
         dev = self.params[0].device
         self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dtype, device=dev)
@@ -131,28 +134,59 @@ class FlatGradients:
         for p in self.params:
             self.views.append(self.flat[o:o + p.numel()].view_as(p))
             o += p.numel()
+        n0 = sum(p.numel() for p in self.params[:first_segment]) if first_segment else 0
+        self.first_segment = int(first_segment or 0)
+        self.segments = [self.flat[:n0], self.flat[n0:]] if 0 < n0 < self.flat.numel() else [self.flat]
+        self._pending = []
 
-    def collect(self):
-        """Copy every parameter's current ``.grad`` into its view (one multi-tensor copy)."""
+    def collect(self, lo=0, hi=None, grads=None):
+        """Copy the current ``.grad`` of parameters [lo, hi) — or the given ``grads`` — into their views (one
+        multi-tensor copy)."""
         # parameters without a gradient in this pass are zero-filled here; ``missing`` names them so that an
         # optimizer with torch semantics (AdamW SKIPS a parameter whose grad is None: no decay, no moment update) can
         # refuse instead of silently decaying them (optim.FlatAdamW.step)
-        self.missing = [i for i, p in enumerate(self.params) if p.grad is None]
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-        torch._foreach_copy_(self.views, grads)
+        hi = len(self.params) if hi is None else hi
+        ps = self.params[lo:hi]
+        gs = [p.grad for p in ps] if grads is None else list(grads)
+        miss = [lo + i for i, g in enumerate(gs) if g is None]
+        self.missing = miss if (lo == 0 and hi == len(self.params)) else sorted(set(
+            [i for i in self.missing if not lo <= i < hi] + miss))
+        gs = [g if g is not None else torch.zeros_like(p) for g, p in zip(gs, ps)]
+        torch._foreach_copy_(self.views[lo:hi], gs)
 
     def attach(self):
         """Make the views the parameters' ``.grad`` (what the optimizer then reads)."""
         for p, v in zip(self.params, self.views):
             p.grad = v
 
+    def _active(self):
+        return dist.is_initialized() and (dist.get_world_size() > 1 or force_ddp())
+
     def all_reduce_mean(self):
         """Average over the ranks (no-op for a single process): RCCL's AVG, or SUM / world on
-        back-ends without it (gloo)."""
-        if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_ddp()):
+        back-ends without it (gloo).  ONE message for the whole buffer."""
+        if not self._active():
             return
         if dist.get_backend() == 'nccl':
             all_reduce(self.flat, dist.ReduceOp.AVG)
         else:
             all_reduce(self.flat, dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
+
+    def start_segment(self, i):
+        """Issue the rank average of segment ``i`` as an ASYNC collective (it runs on the process group's own stream,
+        behind everything the current stream has been given so far) and return at once: what the caller enqueues next
+        — the rest of the backward — overlaps with it.  ``finish_segments`` makes the current stream wait."""
+        if not self._active():
+            return
+        seg = self.segments[i]
+        avg = dist.get_backend() == 'nccl'
+        work = dist.all_reduce(seg, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
+        self._pending.append((work, None if avg else seg))
+
+    def finish_segments(self):
+        for work, seg in self._pending:
+            work.wait()
+            if seg is not None:
+                seg.div_(dist.get_world_size())
+        self._pending = []

@@ -38,7 +38,9 @@ class GraphedStep:
     """
 
     def __init__(self, transformer, forward, cotangent, params, inputs=(), has_img=True,
-                 has_pts=True, autocast_dtype=None):
+                 has_pts=True, autocast_dtype=None, split_after=None, cut_layer=1):
+        """``split_after``: the encoders (``ImgEncoder`` / ``PtsEncoder``) whose backward is cut in two after their first
+        ``cut_layer`` layers — see "split backward" below; None = one backward, one gradient message."""
         self.tr = transformer
         self.forward = forward
         self.cot = cotangent
@@ -49,8 +51,90 @@ class GraphedStep:
         self.graphs = {}
         self.pool = None
         self.seed_base = torch.zeros(1, dtype=torch.int64, device=self.params[0].device)
-        self.grads = FlatGradients(self.params)
+        self.split_after = [m for m in (split_after or []) if m is not None]
+        self.cut_layer = int(cut_layer)
+        self.split_note = None
+        self.n_upper = 0
+        if self.split_after:
+            self._order_params_for_split()
+        self.grads = FlatGradients(self.params, first_segment=self.n_upper)
         self.out = None
+
+    # ---- split backward: the gradient exchange of the upper layers overlaps the backward of the first layer -----
+    # The reference's MMDistributedDataParallel overlaps its gradient buckets with the backward (tools/train_UniBEV.py:
+    # 242-249).  Here the backward is one captured HIP graph and RCCL stays outside the graphs, so the overlap comes from
+    # CUTTING the backward where the first encoder layers end: graph A = forward + backward down to the cut (every
+    # parameter used only above the cut — layers 2 and 3 of both encoders, the fusion weights — is then final: the
+    # first segment of the flat buffer), graph B = the rest.  step(): replay A, start the all-reduce of segment 0 on
+    # RCCL's stream, replay B beside it, all-reduce segment 1, wait.  The encoders sever their autograd graph at the cut
+    # themselves (``cut_after``: what the upper layers read from below — the first layers' output, the embedded feature
+    # tokens, the positional table — reaches them as fresh leaves, encoders._EncoderBase._sever): part 1 is a backward
+    # from the loss to those leaves and the upper parameters, part 2 continues from the severed tensors with the leaves'
+    # gradients.
+    def _trace(self):
+        for e in self.split_after:
+            e.cut_after = self.cut_layer
+        try:
+            with torch.autocast('cuda', dtype=self.adt or torch.bfloat16, enabled=self.adt is not None):
+                out = self.forward()
+        finally:
+            for e in self.split_after:
+                e.cut_after = 0
+        return out, [c for e in self.split_after for c in getattr(e, '_cuts', [])]
+
+    def _reached(self, roots):
+        """Indices of the parameters whose AccumulateGrad nodes are reached from the given graph nodes."""
+        pid = {id(p): i for i, p in enumerate(self.params)}
+        found, seen, stack = set(), set(), [r for r in roots if r is not None]
+        while stack:
+            n = stack.pop()
+            if n in seen:
+                continue
+            seen.add(n)
+            v = getattr(n, 'variable', None)
+            if v is not None and id(v) in pid:
+                found.add(pid[id(v)])
+            stack.extend(f for f, _ in n.next_functions if f is not None)
+        return found
+
+    def _order_params_for_split(self):
+        """One traced forward: parameters used only above the cut go first (segment 0 of the flat buffer)."""
+        self.tr.forced_flags = self._combos()[0]
+        try:
+            out, cuts = self._trace()
+            loss = (out.float() * self.cot).sum()
+            up = self._reached([loss.grad_fn])
+            low = self._reached([o.grad_fn for o, _ in cuts])
+        finally:
+            self.tr.forced_flags = None
+        mixed = up & low
+        upper = [i for i in range(len(self.params)) if i in up]
+        rest = [i for i in range(len(self.params)) if i not in up]
+        self.split_note = None
+        if not cuts or not upper or not rest or mixed:
+            self.split_note = ('no split: %d parameter(s) are used above and below the cut' % len(mixed)) if mixed \
+                else 'no split: nothing to cut'
+            self.split_after = []
+            return
+        self.params = [self.params[i] for i in upper + rest]
+        self.n_upper = len(upper)
+
+    def _part1(self, out, cuts):
+        """Backward from the loss down to the cut; segment 0 of the flat buffer is complete afterwards."""
+        loss = (out.float() * self.cot).sum()
+        nu = self.n_upper
+        torch.autograd.backward(loss, inputs=self.params[:nu] + [leaf for _, leaf in cuts])
+        self.grads.collect(0, nu)
+        return cuts
+
+    def _part2(self, cuts):
+        """The cut gradients flow on through the first layers; segment 1 is complete afterwards."""
+        nu = self.n_upper
+        roots = [(o, leaf.grad) for o, leaf in cuts if leaf.grad is not None]
+        if roots:
+            torch.autograd.backward([o for o, _ in roots], [g for _, g in roots],
+                                    inputs=self.params[nu:] + self.inputs)
+        self.grads.collect(nu, len(self.params))
 
     def _combos(self):
         tr = self.tr
@@ -58,12 +142,25 @@ class GraphedStep:
             return [(1 if self.has[0] else 0, 1 if self.has[1] else 0)]
         return [(1, 1), (1, 0), (0, 1)]
 
-    def _fwd_bwd(self):
-        self.seed_base.add_(0x5DEECE66D)                 # fresh dropout masks per replay
-        with torch.autocast('cuda', dtype=self.adt or torch.bfloat16, enabled=self.adt is not None):
-            out = self.forward()
-        (out.float() * self.cot).sum().backward()
-        self.grads.collect()
+    def _fwd_bwd(self, part=None, between=None):
+        """One forward + backward.  With a split backward: ``part`` 'A' = forward + part 1 (returns the state part 'B'
+        continues from), None = both parts back to back (eager), ``between`` called after part 1."""
+        if not self.split_after:
+            self.seed_base.add_(0x5DEECE66D)             # fresh dropout masks per replay
+            with torch.autocast('cuda', dtype=self.adt or torch.bfloat16, enabled=self.adt is not None):
+                out = self.forward()
+            (out.float() * self.cot).sum().backward()
+            self.grads.collect()
+            return out
+        self.seed_base.add_(0x5DEECE66D)
+        out, cuts = self._trace()
+        state = self._part1(out, cuts)
+        if part == 'A':
+            self._state = state
+            return out
+        if between is not None:
+            between()
+        self._part2(state)
         return out
 
     def _clear_grads(self):
@@ -98,9 +195,15 @@ class GraphedStep:
             g = torch.cuda.CUDAGraph()
             # thread-local capture mode: other threads (RCCL's watchdog polling its events) stay free to call into HIP
             with torch.cuda.graph(g, pool=self.pool, stream=self.stream, capture_error_mode='thread_local'):
-                self.out = self._fwd_bwd()
+                self.out = self._fwd_bwd(part='A' if self.split_after else None)
             if self.pool is None:
                 self.pool = g.pool()
+            if self.split_after:
+                g2 = torch.cuda.CUDAGraph()          # the backward below the cut: replayed beside segment 0's all-reduce
+                with torch.cuda.graph(g2, pool=self.pool, stream=self.stream, capture_error_mode='thread_local'):
+                    self._part2(self._state)
+                self._state = None
+                g = (g, g2)
             self.graphs[combo] = g
         cur.wait_stream(self.stream)
         self.tr.forced_flags = None
@@ -112,6 +215,12 @@ class GraphedStep:
         are taken on): forward + backward, gradients into the flat buffer, rank average."""
         self._clear_grads()
         self.tr.forced_flags = None
+        if self.split_after:
+            self._fwd_bwd(between=lambda: self.grads.start_segment(0))
+            self.grads.attach()
+            self.grads.start_segment(1)
+            self.grads.finish_segments()
+            return
         self._fwd_bwd()
         self.grads.attach()
         self.grads.all_reduce_mean()
@@ -129,9 +238,18 @@ class GraphedStep:
                 e.record()
                 marks.append(e)
         mark()
-        self.graphs[combo].replay()
-        mark()
-        self.grads.all_reduce_mean()
+        g = self.graphs[combo]
+        if isinstance(g, tuple):                 # split backward: segment 0 travels while graph B runs
+            g[0].replay()
+            self.grads.start_segment(0)
+            g[1].replay()
+            mark()
+            self.grads.start_segment(1)
+            self.grads.finish_segments()
+        else:
+            g.replay()
+            mark()
+            self.grads.all_reduce_mean()
         mark()
         return combo
 

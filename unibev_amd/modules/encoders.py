@@ -98,14 +98,40 @@ class _EncoderBase(TransformerLayerSequence):
             ws += [att.sampling_offsets.weight, att.attention_weights.weight]
             sizes.append(att.sampling_offsets.weight.shape[0] + att.attention_weights.weight.shape[0])
         from ..linear import linear_cat
+        # ``cut_after`` = k: the first k layers' terms come from their own GEMM (graph_step.GraphedStep cuts the backward
+        # after layer k: with one GEMM for all layers the upper layers' weights would sit in the lower half's graph)
+        k = int(getattr(self, 'cut_after', 0) or 0)
+        if 0 < k < len(self.layers):
+            lo = linear_cat(base, ws[:2 * k], [None] * (2 * k))
+            hi = linear_cat(self._sever(base), ws[2 * k:], [None] * (len(ws) - 2 * k))
+            return list(torch.split(lo, sizes[:k], dim=1)) + list(torch.split(hi, sizes[k:], dim=1))
         terms = linear_cat(base, ws, [None] * len(ws))               # (Nq, sum of sizes), no bias: the layers add theirs
         return list(torch.split(terms, sizes, dim=1))
+
+    def _sever(self, x):
+        """``cut_after``: a tensor of the lower layers that the upper layers read is handed to them as a fresh LEAF (no
+        copy); the (tensor, leaf) pair is kept in ``self._cuts`` so that the backward can be run in two parts — from the
+        loss down to the leaves, then from the tensors on with the leaves' gradients (graph_step.GraphedStep)."""
+        if not torch.is_tensor(x) or not x.requires_grad or not torch.is_grad_enabled():
+            return x
+        leaf = x.detach().requires_grad_()
+        self._cuts.append((x, leaf))
+        return leaf
 
     def _run_layers(self, bev_query, key, value, args, layer_kwargs):
         intermediate = []
         output = bev_query
+        self._cuts = []
+        cut = int(getattr(self, 'cut_after', 0) or 0)
         pos_terms = self._fold_pos_terms(layer_kwargs.pop('bev_pos_base', None), bev_query)
         for li, layer in enumerate(self.layers):
+            if cut and li == cut:
+                same = value is key
+                bev_query = self._sever(bev_query)
+                key = self._sever(key)
+                value = key if same else self._sever(value)
+                if layer_kwargs.get('bev_pos') is not None:
+                    layer_kwargs['bev_pos'] = self._sever(layer_kwargs['bev_pos'])
             if pos_terms is not None:
                 layer_kwargs['pos_term'] = pos_terms[li]
             output = layer(bev_query, key, value, *args, **layer_kwargs)
