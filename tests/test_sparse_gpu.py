@@ -260,3 +260,21 @@ def test_rows_batch_norm_vs_torch(C, relu, dtype):
         assert rel(bn.weight.grad, ref.weight.grad) < tol and rel(bn.bias.grad, ref.bias.grad) < tol
         assert rel(bn.running_mean, ref.running_mean) < 1e-5 and rel(bn.running_var, ref.running_var) < 1e-5
         assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
+def test_rows_batch_norm_large_mean_and_module_edge_cases():
+    """Statistics are sums of x - x[0]: a channel whose mean is 1000x its spread keeps its variance (E[x^2] - mean^2 of the
+    raw f32 values cancels there); one row in training mode and non-f32 running statistics are left to the module."""
+    from unibev_amd.functional import rows_batch_norm
+    rs = np.random.RandomState(0)
+    N, C = 20000, 32
+    x = torch.from_numpy((rs.standard_normal((N, C)) * 0.5 + 500.0).astype(np.float32))
+    bn = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).to(DEV).train()
+    y = rows_batch_norm(x.to(DEV), bn)
+    ref = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).double().train()(x.double())
+    assert float((y.double().cpu() - ref).abs().max()) < 2e-3            # (the inputs' own f32 spacing at 500 is 3e-5)
+    v = x.double().var(0, unbiased=True)
+    assert float(((bn.running_var.double().cpu() - 0.99) / 0.01 - v).abs().max() / v.max()) < 1e-3
+    assert rows_batch_norm(x[:1].to(DEV), bn) is None                    # torch raises for one value per channel
+    half = torch.nn.BatchNorm1d(C).to(DEV).half().train()
+    assert rows_batch_norm(x.to(DEV), half) is None

@@ -40,13 +40,17 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x
 #pragma unroll
     for (int i = 0; i < 4; ++i) { mu[i] = mean[cq * 4 + i]; rs[i] = rstd[cq * 4 + i]; g[i] = gamma[cq * 4 + i]; b[i] = beta[cq * 4 + i]; }
   }
+  // forward statistics are sums of x - x[0] (per channel): E[x^2] - mean^2 of the raw values cancels when |mean| is much
+  // larger than the spread; shifted by a sample of the channel it does not (bn_finalize_kernel adds the shift back)
+  float sh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (!BWD) bn_load4<T>(x + cq * 4, sh);
   if (rl < RL) {
     for (long r = r0 + rl; r < r1; r += RL) {
       float v[4];
       bn_load4<T>(x + r * C + cq * 4, v);
       if (!BWD) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { s1[i] += v[i]; s2[i] = fmaf(v[i], v[i], s2[i]); }
+        for (int i = 0; i < 4; ++i) { const float u = v[i] - sh[i]; s1[i] += u; s2[i] = fmaf(u, u, s2[i]); }
       } else {
         float d[4];
         bn_load4<T>(dy + r * C + cq * 4, d);
@@ -95,17 +99,20 @@ __device__ __forceinline__ void bn_block_sums(const float* __restrict__ partial,
 }
 
 // forward: mean / rstd (+ running statistics); one block per channel
+template <typename T>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int blocks, long N, int C,
-                                                          float eps, float momentum, float* __restrict__ mean,
+                                                          float eps, float momentum, const T* __restrict__ x,
+                                                          float* __restrict__ mean,
                                                           float* __restrict__ rstd, float* __restrict__ running_mean,
                                                           float* __restrict__ running_var) {
   const int c = blockIdx.x;
   double s1, s2;
   bn_block_sums(partial, blocks, C, c, s1, s2);
   if (threadIdx.x != 0) return;
-  const double m = s1 / (double)N;
-  double var = s2 / (double)N - m * m;
+  const double ms = s1 / (double)N;                            // mean of x - x[0]
+  double var = s2 / (double)N - ms * ms;
   var = var > 0.0 ? var : 0.0;
+  const double m = ms + (double)elem<T>::to_float(x[c]);
   mean[c] = (float)m;
   rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
   if (running_mean != nullptr) {
@@ -171,8 +178,8 @@ static void bn_forward_T(const void* x, const float* gamma, const float* beta, f
     const long rpb = (N + blocks - 1) / blocks;
     hipLaunchKernelGGL((bn_partial_kernel<T, false>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)nullptr,
                        nullptr, nullptr, nullptr, nullptr, N, C, 0, rpb, partial);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, partial, blocks, N, C, eps, momentum,
-                       mean, rstd, rm, rv);
+    hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3(C), dim3(256), 0, st, partial, blocks, N, C, eps, momentum,
+                       (const T*)x, mean, rstd, rm, rv);
   }
   const long pieces = N * (C / 4);
   hipLaunchKernelGGL((bn_apply_kernel<T, 0>), dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, (const T*)x,

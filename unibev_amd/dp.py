@@ -84,7 +84,23 @@ def drain_watchdog(timeout_s=30.0):
     if wait is None:                                  # pragma: no cover - torch without the binding
         raise RuntimeError('drain_watchdog: this torch build has no ProcessGroup._wait_for_pending_works; '
                            'cannot guarantee that RCCL\'s watchdog is idle before a HIP-graph capture')
-    wait()
+    # (the call blocks inside the process group; a collective that never completes would hang the capture: wait in a
+    #  helper thread and give up after ``timeout_s``)
+    import threading
+    done = threading.Event()
+    err = []
+
+    def _run():
+        try:
+            wait()
+        except Exception as e:                        # pragma: no cover
+            err.append(e)
+        done.set()
+    threading.Thread(target=_run, daemon=True).start()
+    if not done.wait(timeout_s):
+        raise RuntimeError(f'drain_watchdog: RCCL still holds unfinished work after {timeout_s:.0f} s (a hung collective?)')
+    if err:
+        raise err[0]
 
 
 def max_over_ranks(value, device='cpu'):

@@ -1175,6 +1175,7 @@ def spconv_gather_mma(feats, nbr, w_hi, w_lo, cout):
 
 
 _SPWG_MULT = int(os.environ.get('UBV_SPWG_MULT', '4'))
+_SPWG_WS_MB = int(os.environ.get('UBV_SPWG_WS_MB', '96'))       # budget of the weight-gradient partial sums
 
 
 @torch.no_grad()
@@ -1205,6 +1206,9 @@ def spconv_wgrad(grad_out, feats, nbr, pairs=None):
             # 1x 10.9 ms, 2x 7.5 ms, 4x 5.8 ms, 8x 5.4 ms + a 0.4 ms longer slab sum)
             S = max(1, min(_SPWG_MULT * S, (rows + 255) // 256))
         blk = cout * cin + cout
+        # the partial sums live in the persistent per-stream scratch: cap them at _SPWG_WS_MB (wide layers fill the chip
+        # with their kvol tiles anyway; at 128 x 128 channels, kvol = 27 the uncapped 4 S slabs were ~200 MB)
+        S = max(1, min(S, (_SPWG_WS_MB << 20) // (4 * kvol * blk)))
         part = _workspace(4 * S * kvol * blk, feats.device)
         out = torch.empty(kvol, blk, dtype=torch.float32, device=feats.device)
         if pairs is not None:
@@ -1280,6 +1284,13 @@ def rows_batch_norm(x, bn, relu=False):
             (bn.training and bn.momentum is None) or x.dtype not in _DT:
         return None
     training = bn.training or bn.running_mean is None
+    # the module's own edge cases stay the module's: one row in training mode (torch raises "Expected more than 1 value
+    # per channel"), running statistics that are not f32 (the kernels take raw f32 pointers)
+    if training and x.shape[0] < 2:
+        return None
+    if bn.track_running_stats and bn.running_mean is not None and \
+            (bn.running_mean.dtype != torch.float32 or bn.running_var.dtype != torch.float32):
+        return None
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     rm = bn.running_mean if bn.track_running_stats else None

@@ -49,6 +49,7 @@ class GraphedStep:
         self.has = (has_img, has_pts)
         self.adt = autocast_dtype
         self.graphs = {}
+        self.missing = {}
         self.pool = None
         self.seed_base = torch.zeros(1, dtype=torch.int64, device=self.params[0].device)
         self.split_after = [m for m in (split_after or []) if m is not None]
@@ -205,6 +206,9 @@ class GraphedStep:
                 self._state = None
                 g = (g, g2)
             self.graphs[combo] = g
+            # which parameters this combination leaves without a gradient (zero-filled in the graph): what the optimizer's
+            # "every parameter received a gradient" check must see when THIS graph is replayed
+            self.missing[combo] = list(self.grads.missing)
         cur.wait_stream(self.stream)
         self.tr.forced_flags = None
         self.grads.attach()                              # the optimizer reads the flat buffer
@@ -239,6 +243,7 @@ class GraphedStep:
                 marks.append(e)
         mark()
         g = self.graphs[combo]
+        self.grads.missing = self.missing.get(combo, [])
         if isinstance(g, tuple):                 # split backward: segment 0 travels while graph B runs
             g[0].replay()
             self.grads.start_segment(0)
