@@ -103,8 +103,7 @@ class GraphedStep:
         self.tr.forced_flags = self._combos()[0]
         try:
             out, cuts = self._trace()
-            loss = (out.float() * self.cot).sum()
-            up = self._reached([loss.grad_fn])
+            up = self._reached([out.grad_fn])
             low = self._reached([o.grad_fn for o, _ in cuts])
         finally:
             self.tr.forced_flags = None
@@ -122,9 +121,8 @@ class GraphedStep:
 
     def _part1(self, out, cuts):
         """Backward from the loss down to the cut; segment 0 of the flat buffer is complete afterwards."""
-        loss = (out.float() * self.cot).sum()
         nu = self.n_upper
-        torch.autograd.backward(loss, inputs=self.params[:nu] + [leaf for _, leaf in cuts])
+        torch.autograd.backward(out, self.cot.to(out.dtype), inputs=self.params[:nu] + [leaf for _, leaf in cuts])
         self.grads.collect(0, nu)
         return cuts
 
@@ -150,7 +148,9 @@ class GraphedStep:
             self.seed_base.add_(0x5DEECE66D)             # fresh dropout masks per replay
             with torch.autocast('cuda', dtype=self.adt or torch.bfloat16, enabled=self.adt is not None):
                 out = self.forward()
-            (out.float() * self.cot).sum().backward()
+            # d(sum(out * cot)) / d(out) = cot: the cotangent is fed to the backward directly (forming the scalar costs a
+            # product, a sum and an expanded product over the 82 MB output)
+            torch.autograd.backward(out, self.cot.to(out.dtype))
             self.grads.collect()
             return out
         self.seed_base.add_(0x5DEECE66D)
