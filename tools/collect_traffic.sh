@@ -1,7 +1,6 @@
 #!/bin/bash
 # On the GPU box: PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, --kernel-trace only) per sampling op,
 # then tools/make_traffic.py -> $OUT/traffic.json
-set -e
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=${1:-$ROOT/gpurun_out/traffic}
 mkdir -p $OUT
@@ -9,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 for dt in bf16 fp32; do
 for op in self pts img; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $ctr --kernel-trace -d /tmp/traffic_db -o ${op}_${dt}_${ctr} -- python $ROOT/tools/bench_lift.py --only $op --iters 3 --dtype $dt > /dev/null 2>&1
+    timeout 240 rocprofv3 --pmc $ctr --kernel-trace -d /tmp/traffic_db -o ${op}_${dt}_${ctr} -- python $ROOT/tools/bench_lift.py --only $op --iters 3 --dtype $dt > /dev/null 2>&1
   done
 done
 done

@@ -1,13 +1,13 @@
 #!/bin/bash
 # On the GPU box: everything profiles/r0N_* is made from.  tools/profile_job.sh <name> -> gpurun_out/<name>/
-#   gpurun --timeout 2400 -- 'bash tools/profile_job.sh r2fin'
+#   gpurun --timeout 3000 -- 'UBV_COMMIT=<sha> bash tools/profile_job.sh r4a'
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/${1:-prof}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python $ROOT/bench.py"
 # 1. the judged tests
-(cd $ROOT && timeout 1500 python -m pytest tests -q -m gpu > $OUT/tests.txt 2>&1)
+(cd $ROOT && timeout 1500 python -m pytest tests -q -m gpu > $OUT/tests.txt 2>&1; tail -3 $OUT/tests.txt)
 # 2. bench lines: default (f32 headline + 16-bit sub-records + gemm / voxel records + CPU baseline), cat-128, one stream
 (cd $ROOT && $B --cpu-baseline-plan > $OUT/bench.json 2> $OUT/bench.err)
 (cd $ROOT && $B --workload LC_cat128 --no-cpu-baseline --no-extras > $OUT/bench_cat128.json 2> $OUT/bench_cat128.err)
@@ -19,15 +19,17 @@ python $ROOT/tools/db_table.py /tmp/prof_cmd/cmd_results.db 1 80 > $OUT/bench_co
 # 4. per-step kernel tables: eager launches, one stream, 10 + 3 steps
 for dt in fp32 bf16; do
   rocprofv3 --kernel-trace -d /tmp/prof_$dt -o e -- $B --dtype $dt --no-graph --single-stream --no-extras \
-      --no-cpu-baseline --no-kernel-timing --steps 10 --warmup 3 > $OUT/bench_${dt}_eager.json 2>/dev/null
+      --no-cpu-baseline --no-kernel-timing --no-parity --params init --no-ieee-gemm --steps 10 --warmup 3 > $OUT/bench_${dt}_eager.json 2>/dev/null
   python $ROOT/tools/db_table.py /tmp/prof_$dt/e_results.db 24 60 > $OUT/${dt}_eager_kernel_table.txt
 done
 # 5. operator micro-benchmarks
 for dt in bf16 fp32; do
   python $ROOT/tools/bench_lift.py --dtype $dt > $OUT/bench_lift_$dt.txt 2>&1
+  python $ROOT/tools/bench_lift.py --dtype $dt --random-offsets > $OUT/bench_lift_${dt}_spread.txt 2>&1
   python $ROOT/tools/bench_lift.py --dtype $dt --img-hw 800 1440 --dh 16 > $OUT/bench_lift_cat128_$dt.txt 2>&1
 done
 python $ROOT/tools/bench_gemm.py > $OUT/bench_gemm.txt 2>&1
+python $ROOT/tools/bench_gemm_cold.py > $OUT/bench_gemm_cold.txt 2>&1
 python $ROOT/tools/bench_backbone.py 2>&1 | grep -v '^/opt' > $OUT/bench_backbone.txt
 # 6. HBM traffic per op (PMC passes)
 UBV_COMMIT=${UBV_COMMIT:-unrecorded} bash $ROOT/tools/collect_traffic.sh $OUT > $OUT/traffic.log 2>&1
