@@ -154,25 +154,39 @@ template <> struct spc_mma<f16_t> {
 };
 template <> struct spc_mma<float> : spc_mma<bf16_t> {};
 
-// RB: 32-row blocks per wave.  The weight block W_k of an offset is staged ONCE PER BLOCK in LDS (80 - 272-byte rows:
-// conflict-free 16-byte fragment reads) and feeds the 4 waves x RB row blocks of the block.  Before, every wave
-// fetched its B fragments from L2 itself: 1.8 MB of W per 64 output rows at 128 x 128 channels — 578 us per
-// convolution of the 128-channel stage, bound by those reads (round 2: one row block per wave, 9.6 TB/s of L2 reads).
-template <typename T, int NB, int RB>
-__global__ __launch_bounds__(256) void spconv_gather_mma_kernel(const T* __restrict__ feats, const int32_t* __restrict__ nbr,
-                                                                long ld, long rows, const uint16_t* __restrict__ w_hi,
-                                                                const uint16_t* __restrict__ w_lo, T* __restrict__ out,
-                                                                int Cin, int Cout, int kvol) {
+__device__ __attribute__((aligned(16))) float spc_zero_row[128];     // (the gather target of "no neighbour")
+
+// A block of NW waves owns 64 NW consecutive output rows (a wave: two 32-row MFMA blocks x all output channels, the
+// accumulators in registers over all offsets).  The weight block W_k of an offset is staged ONCE PER BLOCK in LDS
+// (80 - 272-byte rows: conflict-free 16-byte fragment reads).  History: round 2 fetched the B fragments from L2 in
+// every wave (1.8 MB of W per 64 rows at 128 x 128 channels, 578 us per convolution); round 3 staged W_k between two
+// barriers per offset (383 us: 340 registers = ONE wave per SIMD at 128 channels, so the barrier, the L2 round trip of
+// the copy and every gather latency were exposed 27 times).  Round 4: the channel counts are template parameters
+// (KS = Cin / 16), the LDS holds TWO weight buffers and W_{k+1} is copied piecewise in the slots of offset k's
+// 16-channel steps (global load in one step, LDS store in the next) — one barrier per offset, nothing waits for
+// the copy — and at 128 output channels a block is 8 waves (2 per SIMD, <= 256 registers) so a wave's gather
+// latency hides behind its neighbour's MFMAs.
+template <typename T, int NB, int KS, int NW, int DBG = 0>
+__global__ __launch_bounds__(64 * NW) void spconv_gather_mma_kernel(const T* __restrict__ feats, const int32_t* __restrict__ nbr,
+                                                                    long ld, long rows, const uint16_t* __restrict__ w_hi,
+                                                                    const uint16_t* __restrict__ w_lo, T* __restrict__ out,
+                                                                    int Cout, int kvol, int nblk) {
   extern __shared__ __attribute__((aligned(16))) uint16_t wlds[];
   constexpr bool SPLIT = sizeof(T) == 4;
+  constexpr int RB = 2, THREADS = 64 * NW, Cin = KS * 16;
+  constexpr int LD = Cin + 8;                              // halves per staged row
+  constexpr int PLANE = NB * 32 * LD, PL = SPLIT ? 2 : 1, BUF = PL * PLANE;
+  constexpr int CPR = Cin / 8, PIECES = NB * 32 * CPR;     // 16-byte pieces per row / per plane
+  constexpr int IT = (PIECES + THREADS - 1) / THREADS;     // piece rounds per thread and offset
+  static_assert(IT <= KS, "one piece round per 16-channel step");
+  constexpr int NV = SPLIT ? 2 : 1;                        // 16-byte loads per row and step
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const long row0 = ((long)blockIdx.x * 4 + wv) * (32 * RB);
-  const bool wave_live = row0 < rows;                     // (idle waves of the last block still take the barriers)
+  // consecutive row blocks share neighbours: give each XCD (blockIdx mod 8) a contiguous range of them
+  const int per = (nblk + 7) >> 3;
+  const int bid = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  const long row0 = ((long)bid * NW + wv) * (32 * RB);
+  const bool wave_live = bid < nblk && row0 < rows;        // (idle waves still copy weights and take the barriers)
   const int m = lane & 31, kg = lane >> 5;
-  const int LD = Cin + 8;                                 // halves per staged row
-  uint16_t* __restrict__ s_hi = wlds;
-  uint16_t* __restrict__ s_lo = wlds + NB * 32 * LD;
-  const int cpr = Cin / 8, pieces = NB * 32 * cpr;        // 16-byte pieces per row / per plane
   sf32x16_t acc[RB][NB];
 #pragma unroll
   for (int i = 0; i < RB; ++i)
@@ -181,11 +195,6 @@ __global__ __launch_bounds__(256) void spconv_gather_mma_kernel(const T* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  // Software pipeline ACROSS the offsets (round 3, session 5): offset k + 1's neighbour indices are fetched before
-  // offset k's weights are staged, and its first 16-channel gather is issued in the slot of offset k's last step — a
-  // block used to walk index -> barrier -> W copy -> barrier -> first gather as three serial round trips per offset,
-  // 27 times (one block per CU-slot: the block's chain IS the kernel's time).
-  constexpr int NV = SPLIT ? 2 : 1;                        // 16-byte loads per row and step
   int idx[RB], idn[RB];
   auto load_idx = [&](int k, int (&d)[RB]) {
 #pragma unroll
@@ -194,92 +203,152 @@ __global__ __launch_bounds__(256) void spconv_gather_mma_kernel(const T* __restr
       d[i] = (k < kvol && wave_live && row < rows) ? nbr[(long)k * ld + row] : -1;
     }
   };
-  // A fragments straight from the gathered rows (rows without a neighbour: zeros)
+  // A fragments straight from the gathered rows.  Rows without a neighbour read a row of zeros: zeroing the registers
+  // behind the load instead made the wave wait for the load it had just issued whenever one of its rows had no
+  // neighbour (s_waitcnt vmcnt(0) under the lane mask) — the prefetch was no prefetch.
   auto load_a = [&](const int (&ix)[RB], int c0, uint4 (&dst)[RB][NV]) {
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      const T* frow = feats + (long)(ix[i] >= 0 ? ix[i] : 0) * Cin + kg * 8 + c0;
+      const T* frow = (ix[i] >= 0 ? feats + (long)ix[i] * Cin : reinterpret_cast<const T*>(spc_zero_row)) + kg * 8 + c0;
 #pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        dst[i][v] = reinterpret_cast<const uint4*>(frow)[v];
-        if (ix[i] < 0) dst[i][v] = make_uint4(0u, 0u, 0u, 0u);
-      }
+      for (int v = 0; v < NV; ++v) dst[i][v] = reinterpret_cast<const uint4*>(frow)[v];
     }
   };
-  uint4 raw[RB][NV], nxt[RB][NV];
-  load_idx(0, idx);
-  load_a(idx, 0, raw);
-  for (int k = 0; k < kvol; ++k) {
-    bool any = false;
-#pragma unroll
-    for (int i = 0; i < RB; ++i) any = any || idx[i] >= 0;
-    load_idx(k + 1, idn);                                 // (past the last offset: -1)
-    // ---- W_k -> LDS, by the whole block
-    __syncthreads();                                      // the previous offset's fragments are consumed
-    {
-      const uint16_t* gh = w_hi + (long)k * NB * 32 * Cin;
-      const uint16_t* gl = SPLIT ? w_lo + (long)k * NB * 32 * Cin : nullptr;
-      for (int p = threadIdx.x; p < pieces; p += 256) {
-        const int r = p / cpr, c8 = (p - r * cpr) * 8;
-        *reinterpret_cast<uint4*>(s_hi + r * LD + c8) = *reinterpret_cast<const uint4*>(gh + (long)r * Cin + c8);
-        if constexpr (SPLIT)
-          *reinterpret_cast<uint4*>(s_lo + r * LD + c8) = *reinterpret_cast<const uint4*>(gl + (long)r * Cin + c8);
-      }
+  // the weight copy, one round = one 16-byte piece per plane and thread
+  struct WPiece { uint4 hi, lo; };
+  auto w_fetch = [&](int k, int it) -> WPiece {
+    WPiece h;
+    h.hi = h.lo = make_uint4(0u, 0u, 0u, 0u);
+    const int p = it * THREADS + (int)threadIdx.x;
+    if (PIECES % THREADS == 0 || p < PIECES) {
+      const int r = p / CPR, c8 = (p - r * CPR) * 8;
+      h.hi = *reinterpret_cast<const uint4*>(w_hi + ((long)k * NB * 32 + r) * Cin + c8);
+      if constexpr (SPLIT) h.lo = *reinterpret_cast<const uint4*>(w_lo + ((long)k * NB * 32 + r) * Cin + c8);
     }
+    return h;
+  };
+  auto w_store = [&](uint16_t* buf, int it, const WPiece h) {
+    const int p = it * THREADS + (int)threadIdx.x;
+    if (PIECES % THREADS == 0 || p < PIECES) {
+      const int r = p / CPR, c8 = (p - r * CPR) * 8;
+      *reinterpret_cast<uint4*>(buf + r * LD + c8) = h.hi;
+      if constexpr (SPLIT) *reinterpret_cast<uint4*>(buf + PLANE + r * LD + c8) = h.lo;
+    }
+  };
+  // Offsets NO row of the block has a neighbour at are left out (the rows are in key order at the strided levels:
+  // the z = 0 / z = D - 1 planes miss a third of the offsets): their bit mask is gathered first, and the loops
+  // below walk the set bits.  (A per-wave test inside the offset loop — round 3 — put a branch around the step loop,
+  // and the compiler then carried the accumulators in VGPRs and copied all of them into and out of the accumulation
+  // registers for every offset: 340 registers and 2 x 128 moves per offset at 128 channels.)
+  __shared__ unsigned s_mask;
+  if (threadIdx.x == 0) s_mask = 0u;
+  __syncthreads();
+  {
+    unsigned mine = 0u;
+    for (int k = 0; k < kvol; ++k) {
+      int d[RB];
+      load_idx(k, d);
+      bool any = false;
+#pragma unroll
+      for (int i = 0; i < RB; ++i) any = any || d[i] >= 0;
+      if (__ballot(any) != 0ull) mine |= 1u << k;
+    }
+    if (lane == 0 && mine) atomicOr(&s_mask, mine);
+  }
+  __syncthreads();
+  unsigned mask = s_mask;
+  // gathered rows are requested PD 16-channel steps ahead of their MFMAs (a step of one wave is ~0.35 us of matrix
+  // work, a gather out of L2 / MALL ~0.8 us: one step ahead left the latency exposed even with two waves per SIMD)
+  constexpr int PD = KS % 2 == 0 ? 2 : 1;
+  uint4 raw[PD][RB][NV];
+  if (mask != 0u) {
+    int k = __builtin_ctz(mask);
+    mask &= mask - 1u;
+    load_idx(k, idx);
+    load_a(idx, 0, raw[0]);
+    if constexpr (PD == 2) load_a(idx, 16, raw[1]);
+#pragma unroll 1
+    for (int it = 0; it < IT; ++it) w_store(wlds, it, w_fetch(k, it));
     __syncthreads();
-    if (__ballot(any) == 0ull) {                          // no row of this wave has a neighbour at offset k
-      load_a(idn, 0, raw);
-#pragma unroll
-      for (int i = 0; i < RB; ++i) idx[i] = idn[i];
-      continue;
-    }
-    const uint16_t* wk_hi = s_hi + m * LD + kg * 8;
-    const uint16_t* wk_lo = SPLIT ? s_lo + m * LD + kg * 8 : nullptr;
-    for (int c0 = 0; c0 < Cin; c0 += 16) {
-      // the NEXT 16-channel step's loads are issued before this step's MFMAs; the last step fetches the next
-      // OFFSET's first step instead
-      if (c0 + 16 < Cin) load_a(idx, c0 + 16, nxt);
-      else load_a(idn, 0, nxt);
-      uint4 a_hi[RB], a_lo[RB];
-#pragma unroll
-      for (int i = 0; i < RB; ++i) {
-        if constexpr (SPLIT) {
-          const float4 v0 = __builtin_bit_cast(float4, raw[i][0]);
-          const float4 v1 = __builtin_bit_cast(float4, raw[i][1]);
-          uint4 h, l;
-          h.x = cvt_pk_bf16(v0.x, v0.y); h.y = cvt_pk_bf16(v0.z, v0.w);
-          h.z = cvt_pk_bf16(v1.x, v1.y); h.w = cvt_pk_bf16(v1.z, v1.w);
-          l.x = cvt_pk_bf16(v0.x - __uint_as_float(h.x << 16), v0.y - __uint_as_float(h.x & 0xffff0000u));
-          l.y = cvt_pk_bf16(v0.z - __uint_as_float(h.y << 16), v0.w - __uint_as_float(h.y & 0xffff0000u));
-          l.z = cvt_pk_bf16(v1.x - __uint_as_float(h.z << 16), v1.y - __uint_as_float(h.z & 0xffff0000u));
-          l.w = cvt_pk_bf16(v1.z - __uint_as_float(h.w << 16), v1.w - __uint_as_float(h.w & 0xffff0000u));
-          a_hi[i] = h; a_lo[i] = l;
-        } else {
-          a_hi[i] = raw[i][0];
-          a_lo[i] = make_uint4(0u, 0u, 0u, 0u);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const uint4 b_hi = *reinterpret_cast<const uint4*>(wk_hi + j * 32 * LD + c0);
-        uint4 b_lo = make_uint4(0u, 0u, 0u, 0u);
-        if constexpr (SPLIT) b_lo = *reinterpret_cast<const uint4*>(wk_lo + j * 32 * LD + c0);
+    int par = 0;
+    for (;;) {
+      const int kn = mask ? __builtin_ctz(mask) : -1;
+      mask &= mask - 1u;                                  // (0 stays 0)
+      load_idx(kn >= 0 ? kn : kvol, idn);                 // (past the last offset: -1)
+      const uint16_t* wk = wlds + par * BUF + m * LD + kg * 8;
+      uint16_t* oth = wlds + (par ^ 1) * BUF;
+      WPiece hold;
+      hold.hi = hold.lo = make_uint4(0u, 0u, 0u, 0u);
+      int it_next = kn >= 0 ? 0 : IT;                     // W_kn: the next piece round to request
+      bool pending = false;
+      auto step = [&](const int s, uint4 (&rw)[RB][NV]) {
+        const int c0 = s * 16;
+        // last step's piece of W_kn -> LDS, this step's piece -> registers
+        if (pending) w_store(oth, it_next - 1, hold);
+        pending = it_next < IT;
+        if (pending) hold = w_fetch(kn, it_next++);
+        uint4 a_hi[RB], a_lo[RB];
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-          acc[i][j] = spc_mma<T>::run(a_hi[i], b_hi, acc[i][j]);
           if constexpr (SPLIT) {
-            acc[i][j] = spc_mma<T>::run(a_hi[i], b_lo, acc[i][j]);
-            acc[i][j] = spc_mma<T>::run(a_lo[i], b_hi, acc[i][j]);
+            const float4 v0 = __builtin_bit_cast(float4, rw[i][0]);
+            const float4 v1 = __builtin_bit_cast(float4, rw[i][1]);
+            uint4 h, l;
+            h.x = cvt_pk_bf16(v0.x, v0.y); h.y = cvt_pk_bf16(v0.z, v0.w);
+            h.z = cvt_pk_bf16(v1.x, v1.y); h.w = cvt_pk_bf16(v1.z, v1.w);
+            l.x = cvt_pk_bf16(v0.x - __uint_as_float(h.x << 16), v0.y - __uint_as_float(h.x & 0xffff0000u));
+            l.y = cvt_pk_bf16(v0.z - __uint_as_float(h.y << 16), v0.w - __uint_as_float(h.y & 0xffff0000u));
+            l.z = cvt_pk_bf16(v1.x - __uint_as_float(h.z << 16), v1.y - __uint_as_float(h.z & 0xffff0000u));
+            l.w = cvt_pk_bf16(v1.z - __uint_as_float(h.w << 16), v1.w - __uint_as_float(h.w & 0xffff0000u));
+            a_hi[i] = h; a_lo[i] = l;
+          } else {
+            a_hi[i] = rw[i][0];
+            a_lo[i] = make_uint4(0u, 0u, 0u, 0u);
           }
         }
+        // step s + PD's rows are requested before this step's MFMAs, into the registers the conversion just freed
+        // (PD = 2: the two halves of raw alternate — moving a landing load's registers would wait for it); the last
+        // PD steps fetch the next OFFSET's first steps instead
+        {
+          const int t = s + PD;
+          if (!(DBG & 1)) {
+            if (t >= KS) load_a(idn, (t - KS) * 16, rw);
+            else load_a(idx, t * 16, rw);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const uint4 b_hi = *reinterpret_cast<const uint4*>(wk + j * 32 * LD + c0);
+          uint4 b_lo = make_uint4(0u, 0u, 0u, 0u);
+          if constexpr (SPLIT) b_lo = *reinterpret_cast<const uint4*>(wk + PLANE + j * 32 * LD + c0);
+#pragma unroll
+          for (int i = 0; i < RB; ++i) {
+            if (DBG & 2) { acc[i][j][0] += __uint_as_float(a_hi[i].x ^ b_hi.x ^ a_lo[i].y ^ b_lo.z); continue; }
+            acc[i][j] = spc_mma<T>::run(a_hi[i], b_hi, acc[i][j]);
+            if constexpr (SPLIT) {
+              acc[i][j] = spc_mma<T>::run(a_hi[i], b_lo, acc[i][j]);
+              acc[i][j] = spc_mma<T>::run(a_lo[i], b_hi, acc[i][j]);
+            }
+          }
+        }
+      };
+      if constexpr (PD == 2) {
+#pragma unroll 1
+        for (int s2 = 0; s2 < KS; s2 += 2) {
+          step(s2, raw[0]);
+          step(s2 + 1, raw[1]);
+        }
+      } else {
+#pragma unroll 1
+        for (int s = 0; s < KS; ++s) step(s, raw[0]);
       }
+      if (pending) w_store(oth, it_next - 1, hold);
 #pragma unroll
-      for (int i = 0; i < RB; ++i)
-#pragma unroll
-        for (int v = 0; v < NV; ++v) raw[i][v] = nxt[i][v];
+      for (int i = 0; i < RB; ++i) idx[i] = idn[i];
+      if (!(DBG & 4)) __syncthreads();                    // W_kn complete, W_k's readers done
+      if (kn < 0) break;
+      par ^= 1;
     }
-#pragma unroll
-    for (int i = 0; i < RB; ++i) idx[i] = idn[i];
   }
   // D[i][n]: this lane holds column n = lane & 31 (output channel within block j), rows (r & 3) + 8 (r >> 2) + 4 kg
   if (!wave_live) return;
@@ -297,28 +366,41 @@ __global__ __launch_bounds__(256) void spconv_gather_mma_kernel(const T* __restr
     }
 }
 
+template <typename T, int NB, int KS>
+static void spconv_launch_one(const void* feats, const int32_t* nbr, long ld, long rows, const void* w_hi, const void* w_lo,
+                              void* out, int Cout, int kvol, hipStream_t st) {
+  constexpr int NW = NB >= 4 ? 8 : 4;
+  constexpr int LD = KS * 16 + 8;
+  constexpr size_t lds = (size_t)2 * (sizeof(T) == 4 ? 2 : 1) * NB * 32 * LD * sizeof(uint16_t);
+  const int nblk = (int)((rows + 64 * NW - 1) / (64 * NW));
+  const dim3 grid((unsigned)((nblk + 7) / 8 * 8)), blk(64 * NW);
+  auto fn = spconv_gather_mma_kernel<T, NB, KS, NW>;
+  if constexpr (NB == 4 && KS == 8 && sizeof(T) == 4) {
+    static const int dbg = getenv("UBV_SPC_DBG") ? atoi(getenv("UBV_SPC_DBG")) : 0;
+    if (dbg == 1) fn = spconv_gather_mma_kernel<T, NB, KS, NW, 1>;
+    if (dbg == 2) fn = spconv_gather_mma_kernel<T, NB, KS, NW, 2>;
+    if (dbg == 4) fn = spconv_gather_mma_kernel<T, NB, KS, NW, 4>;
+  }
+  // (more than 64 KB of dynamic LDS at 128 output channels: ask for it explicitly)
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(fn, grid, blk, lds, st, (const T*)feats, nbr, ld, rows, (const uint16_t*)w_hi, (const uint16_t*)w_lo,
+                     (T*)out, Cout, kvol, nblk);
+}
+
 template <typename T>
 static int spconv_launch(const void* feats, const int32_t* nbr, long ld, long rows, const void* w_hi, const void* w_lo,
                          void* out, int Cin, int Cout, int kvol, hipStream_t st) {
-  const int nb = (Cout + 31) / 32;
-  constexpr int RB = 2;
-  const dim3 grid((unsigned)((rows + 128 * RB - 1) / (128 * RB))), blk(256);
-  const size_t lds = (size_t)(sizeof(T) == 4 ? 2 : 1) * nb * 32 * (Cin + 8) * sizeof(uint16_t);
-  // (more than 64 KB of dynamic LDS at 128 x 128 f32 channels: ask for it explicitly)
-#define UBV_SPC(NBV)                                                                                            \
-  case NBV:                                                                                                     \
-    if (lds > 64 * 1024)                                                                                        \
-      (void)hipFuncSetAttribute((const void*)spconv_gather_mma_kernel<T, NBV, RB>,                              \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
-    hipLaunchKernelGGL((spconv_gather_mma_kernel<T, NBV, RB>), grid, blk, lds, st, (const T*)feats, nbr, ld, rows, \
-                       (const uint16_t*)w_hi, (const uint16_t*)w_lo, (T*)out, Cin, Cout, kvol);                 \
-    break;
-  switch (nb) {
-    UBV_SPC(1) UBV_SPC(2) UBV_SPC(3) UBV_SPC(4)
-    default: return UBV_ERR_UNSUPPORTED;
+  const int nb = (Cout + 31) / 32, ks = Cin / 16;
+#define UBV_SPC(NBV, KSV)                                                                                       \
+  if (nb == NBV && ks == KSV) {                                                                                 \
+    spconv_launch_one<T, NBV, KSV>(feats, nbr, ld, rows, w_hi, w_lo, out, Cout, kvol, st);                      \
+    return UBV_OK;                                                                                              \
   }
+#define UBV_SPC_ROW(NBV) UBV_SPC(NBV, 1) UBV_SPC(NBV, 2) UBV_SPC(NBV, 3) UBV_SPC(NBV, 4) UBV_SPC(NBV, 5) UBV_SPC(NBV, 6) UBV_SPC(NBV, 7) UBV_SPC(NBV, 8)
+  UBV_SPC_ROW(1) UBV_SPC_ROW(2) UBV_SPC_ROW(3) UBV_SPC_ROW(4)
+#undef UBV_SPC_ROW
 #undef UBV_SPC
-  return UBV_OK;
+  return UBV_ERR_UNSUPPORTED;
 }
 
 static bool sp_geom(SpGeom& g, int B, const int* in_dims, const int* tgt_dims, const int* ksize, const int* stride,
@@ -403,8 +485,8 @@ extern "C" int ubv_spconv_gather_mma(const void* feats, const int32_t* nbr, int6
   UBV_CHECK_ARG(feats && nbr && w_hi && out && rows >= 0 && ld >= rows && kvol > 0, "spconv_gather_mma: bad arguments");
   UBV_CHECK_ARG(dtype >= 0 && dtype <= 2, "spconv_gather_mma: unknown dtype %d", dtype);
   UBV_CHECK_ARG((dtype == UBV_F32) == (w_lo != nullptr), "spconv_gather_mma: f32 features take split weights (hi, lo)");
-  if (Cin % 16 != 0 || Cout <= 0 || Cout > 128 || ((uintptr_t)feats % 16) != 0 || ((uintptr_t)w_hi % 16) != 0) {
-    set_error("spconv_gather_mma: Cin=%d must be a multiple of 16, Cout=%d at most 128, buffers 16-byte aligned", Cin, Cout);
+  if (Cin % 16 != 0 || Cin > 128 || Cout <= 0 || Cout > 128 || ((uintptr_t)feats % 16) != 0 || ((uintptr_t)w_hi % 16) != 0) {
+    set_error("spconv_gather_mma: Cin=%d must be a multiple of 16 up to 128, Cout=%d at most 128, buffers 16-byte aligned", Cin, Cout);
     return UBV_ERR_UNSUPPORTED;
   }
   if (rows == 0) return UBV_OK;
@@ -413,7 +495,7 @@ extern "C" int ubv_spconv_gather_mma(const void* feats, const int32_t* nbr, int6
   if (dtype == UBV_F32) rc = spconv_launch<float>(feats, nbr, ld, rows, w_hi, w_lo, out, Cin, Cout, kvol, st);
   else if (dtype == UBV_F16) rc = spconv_launch<f16_t>(feats, nbr, ld, rows, w_hi, nullptr, out, Cin, Cout, kvol, st);
   else rc = spconv_launch<bf16_t>(feats, nbr, ld, rows, w_hi, nullptr, out, Cin, Cout, kvol, st);
-  if (rc != UBV_OK) { set_error("spconv_gather_mma: no kernel for Cout=%d", Cout); return rc; }
+  if (rc != UBV_OK) { set_error("spconv_gather_mma: no kernel for Cin=%d Cout=%d", Cin, Cout); return rc; }
   UBV_CHECK_LAUNCH("spconv_gather_mma");
   return UBV_OK;
 }
