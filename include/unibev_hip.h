@@ -472,9 +472,16 @@ int ubv_sparse_to_dense(const float* feats, const int32_t* coors, const int32_t*
  *        transposed = 0: target = row * stride - pad + k      (output rows -> inputs; SubM: stride 1, pad k/2)
  *        transposed = 1: target = (row + pad - k) / stride where divisible (input rows -> outputs: the map
  *                        of the input gradient)
- *   ubv_spconv_candidates            cand [kvol, n] int64: key of the output each (input, offset) reaches or -1
- *                                    (a strided convolution's output set = the unique keys, ascending)
- *   ubv_spconv_keys_to_coors         keys [n] of a (D, H, W) map -> coors [n, 4]
+ *   ubv_spconv_output_sites          the output set of a strided convolution, built on the device: inputs mark one bit
+ *                                    per output cell they reach, a popcount scan ranks the bits, out_coors [cap, 4]
+ *                                    come out in ascending key order and count_dev[0] holds their number.  The input
+ *                                    count is read from n_dev when given (else n), so the layers of an encoder chain
+ *                                    back to back and the host reads all counts in one copy.  bitmap:
+ *                                    ubv_spconv_sites_words(B, out_dims) int32, sums: words / 256 + 2 int32 (scratch).
+ *   ubv_spconv_pairs                 compacted rulebook of a neighbour map (the weight gradient's form): per offset the
+ *                                    rows with a neighbour, in row order — out_rows[k][i] = row, in_rows[k][i] =
+ *                                    nbr[k][row] for i < counts[k] (entries past the count are not written);
+ *                                    chunk_sums: kvol * ubv_spconv_pairs_chunks(rows) int32 of scratch.
  * Product:
  *   ubv_spconv_gather_mma            out[row, :] = sum_k feats[nbr[k][row], :] . w[k]^T on the matrix cores.
  *        feats [*, Cin] (dtype), w_hi (and w_lo for f32: split-bf16 halves) [kvol, 32*ceil(Cout/32), Cin] in the
@@ -521,9 +528,14 @@ int ubv_spconv_neighbors(const int32_t* coors, int64_t rows, int B, const int* r
                          const int* ksize, const int* stride, const int* pad, int transposed,
                          const int64_t* table_keys, const int32_t* table_vals, int64_t slots, int32_t* nbr,
                          int64_t ld, void* stream);
-int ubv_spconv_candidates(const int32_t* coors, int64_t n, int B, const int* in_dims, const int* out_dims,
-                          const int* ksize, const int* stride, const int* pad, int64_t* cand, void* stream);
-int ubv_spconv_keys_to_coors(const int64_t* keys, int64_t n, int D, int H, int W, int32_t* coors, void* stream);
+int64_t ubv_spconv_sites_words(int B, const int* out_dims);
+int ubv_spconv_output_sites(const int32_t* coors, const int32_t* n_dev, int64_t n, int B, const int* in_dims,
+                            const int* out_dims, const int* ksize, const int* stride, const int* pad, int32_t* bitmap,
+                            int64_t words, int32_t* sums, int32_t* out_coors, int64_t cap, int32_t* count_dev,
+                            void* stream);
+int64_t ubv_spconv_pairs_chunks(int64_t rows);
+int ubv_spconv_pairs(const int32_t* nbr, int64_t ld, int64_t rows, int kvol, int32_t* chunk_sums, int32_t* out_rows,
+                     int32_t* in_rows, int32_t* counts, void* stream);
 int ubv_spconv_gather_mma(const void* feats, const int32_t* nbr, int64_t ld, int64_t rows, const void* w_hi,
                           const void* w_lo, void* out, int Cin, int Cout, int kvol, int dtype, void* stream);
 

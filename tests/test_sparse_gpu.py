@@ -278,3 +278,65 @@ def test_rows_batch_norm_large_mean_and_module_edge_cases():
     assert rows_batch_norm(x[:1].to(DEV), bn) is None                    # torch raises for one value per channel
     half = torch.nn.BatchNorm1d(C).to(DEV).half().train()
     assert rows_batch_norm(x.to(DEV), half) is None
+
+
+def _np_sites(coors, B, in_dims, ksize, stride, pad):
+    """Reference output set of a strided sparse convolution (numpy): ascending keys -> coordinates."""
+    out_dims = tuple((d + 2 * p - k) // s + 1 for d, k, s, p in zip(in_dims, ksize, stride, pad))
+    keys = set()
+    c = coors.numpy()
+    for kz in range(ksize[0]):
+        for ky in range(ksize[1]):
+            for kx in range(ksize[2]):
+                num = c[:, 1:] + np.array(pad) - np.array([kz, ky, kx])
+                ok = (num >= 0).all(1) & (num % np.array(stride) == 0).all(1)
+                t = num // np.array(stride)
+                ok &= (t < np.array(out_dims)).all(1)
+                k = ((c[:, 0].astype(np.int64) * out_dims[0] + t[:, 0]) * out_dims[1] + t[:, 1]) * out_dims[2] + t[:, 2]
+                keys.update(k[ok].tolist())
+    keys = np.array(sorted(keys), dtype=np.int64)
+    x = keys % out_dims[2]; r = keys // out_dims[2]
+    y = r % out_dims[1]; r //= out_dims[1]
+    z = r % out_dims[0]; b = r // out_dims[0]
+    return np.stack([b, z, y, x], 1).astype(np.int32), out_dims
+
+
+def test_output_sites_chain_matches_the_layer_by_layer_sets():
+    """ubv_spconv_output_sites: bit-exact against a host enumeration, for a chain of three strided layers built with
+    one host read (device-side input counts) and for an empty input."""
+    from unibev_amd import functional as UF
+    rs = np.random.RandomState(11)
+    B, shape = 2, (17, 40, 36)
+    coors = _cloud(rs, B, shape, 3000)
+    layers = [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0))]
+    chain = UF.spconv_site_chain(coors.to(DEV), B, shape, layers)
+    cur, dims = coors, shape
+    for (oc, od), (k, s, p) in zip(chain, layers):
+        ref, rd = _np_sites(cur, B, dims, k, s, p)
+        assert tuple(od) == tuple(rd)
+        assert oc.shape == ref.shape and np.array_equal(oc.cpu().numpy(), ref)
+        cur, dims = torch.from_numpy(ref), rd
+    # a stride-1 SparseConv3d dilates the set (27 candidate outputs per input)
+    (oc, od), = UF.spconv_site_chain(coors.to(DEV), B, shape, [((3, 3, 3), (1, 1, 1), (1, 1, 1))])
+    ref, rd = _np_sites(coors, B, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    assert np.array_equal(oc.cpu().numpy(), ref)
+    # no input rows: no output rows
+    (oc, od), = UF.spconv_site_chain(coors[:0].to(DEV), B, shape, layers[:1])
+    assert oc.shape == (0, 4)
+
+
+def test_compacted_pairs_match_a_stable_sort_of_the_neighbour_map():
+    from unibev_amd import functional as UF
+    rs = np.random.RandomState(12)
+    for rows in (1, 63, 2048, 2049, 7001):
+        nbr = torch.from_numpy(rs.randint(-3, rows, size=(27, rows)).astype(np.int32)).clamp_(min=-1)
+        nbr[5] = -1                                           # an offset without any pair
+        nbr[6] = torch.arange(rows, dtype=torch.int32)        # a full one
+        out_rows, in_rows, counts = UF.spconv_pairs(nbr.to(DEV))
+        out_rows, in_rows, counts = out_rows.cpu(), in_rows.cpu(), counts.cpu()
+        for k in range(27):
+            valid = torch.nonzero(nbr[k] >= 0)[:, 0]
+            n = int(counts[k])
+            assert n == valid.numel()
+            assert torch.equal(out_rows[k, :n].long(), valid)
+            assert torch.equal(in_rows[k, :n], nbr[k][valid])

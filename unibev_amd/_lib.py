@@ -75,8 +75,10 @@ SIGNATURES = {
     'ubv_spconv_wgrad_pairs': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ubv_spconv_hash_build': (c_int, [_P, c_int64, c_int, c_int, c_int, _P, _P, c_int64, _P]),
     'ubv_spconv_neighbors': (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, c_int64, _P, c_int64, _P]),
-    'ubv_spconv_candidates': (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P]),
-    'ubv_spconv_keys_to_coors': (c_int, [_P, c_int64, c_int, c_int, c_int, _P, _P]),
+    'ubv_spconv_sites_words': (c_int64, [c_int, _P]),
+    'ubv_spconv_output_sites': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P]),
+    'ubv_spconv_pairs_chunks': (c_int64, [c_int64]),
+    'ubv_spconv_pairs': (c_int, [_P, c_int64, c_int64, c_int, _P, _P, _P, _P, _P]),
     'ubv_spconv_gather_mma': (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'ubv_gemm_wgrad_splits': (c_int, [c_int64, c_int, c_int]),
     'ubv_gemm_wgrad': (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P]),

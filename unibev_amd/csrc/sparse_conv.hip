@@ -109,33 +109,147 @@ __global__ __launch_bounds__(256) void spc_neighbors_kernel(const int32_t* __res
   nbr[(long)k * ld + row] = idx;
 }
 
-// Candidate output keys of a strided convolution: cand[k][i] = key of the output that input i reaches
-// through offset k, or -1.  (The host sorts / uniques them: the output set in ascending key order.)
-__global__ __launch_bounds__(256) void spc_candidates_kernel(const int32_t* __restrict__ coors, long n,
-                                                             const SpGeom g, long long* __restrict__ cand) {
+// ---- output sites of a strided convolution, on the device ---------------------------------------------------
+// spconv's get_indice_pairs builds the output set with a hash / unique pass and hands its SIZE to the host.  Here the
+// set is a bit per output cell (2.7 MB for the 21 x 720 x 720 x 2 map of the first strided layer): inputs MARK the
+// cells they reach, a popcount scan ranks the set bits, and the coordinates come out in ascending key order without
+// a sort.  Every kernel takes its input count from device memory (n_dev), so a chain of strided layers is built
+// back to back and the host reads all their counts in ONE copy (round 3: torch.unique + a boolean-mask index per
+// layer, four host reads per pass).
+constexpr int kSiteBlk = 256;                             // bitmap words per block of the count / emit kernels
+
+__global__ __launch_bounds__(256) void spc_mark_kernel(const int32_t* __restrict__ coors, const int32_t* __restrict__ n_dev,
+                                                       long n_host, const SpGeom g, uint32_t* __restrict__ bitmap) {
+  const long n = n_dev != nullptr ? (long)*n_dev : n_host;
   const int kvol = g.ksize[0] * g.ksize[1] * g.ksize[2];
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= n * kvol) return;
-  const long row = t % n;
-  const int k = (int)(t / n);
-  const int kx = k % g.ksize[2], ky = (k / g.ksize[2]) % g.ksize[1], kz = k / (g.ksize[2] * g.ksize[1]);
-  const int32_t* c = coors + row * 4;
-  int tc[3];
-  long long key = -1;
-  if (spc_target(g, c, kz, ky, kx, tc))
-    key = (((long long)c[0] * g.tgt_dims[0] + tc[0]) * g.tgt_dims[1] + tc[1]) * g.tgt_dims[2] + tc[2];
-  cand[t] = key;
+  const long total = n * kvol;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const long row = t % n;                               // consecutive threads: consecutive rows of one offset
+    const int k = (int)(t / n);
+    const int kx = k % g.ksize[2], ky = (k / g.ksize[2]) % g.ksize[1], kz = k / (g.ksize[2] * g.ksize[1]);
+    const int32_t* c = coors + row * 4;
+    int tc[3];
+    if (!spc_target(g, c, kz, ky, kx, tc)) continue;
+    const long long key = (((long long)c[0] * g.tgt_dims[0] + tc[0]) * g.tgt_dims[1] + tc[1]) * g.tgt_dims[2] + tc[2];
+    const uint32_t bit = 1u << (key & 31);
+    uint32_t* w = bitmap + (key >> 5);
+    if (!(__builtin_nontemporal_load(w) & bit)) atomicOr(w, bit);      // (a stale read only costs a redundant atomic)
+  }
 }
 
-__global__ __launch_bounds__(256) void spc_keys_to_coors_kernel(const long long* __restrict__ keys, long n, int D,
-                                                                int H, int W, int32_t* __restrict__ coors) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  long long k = keys[i];
-  const int x = (int)(k % W); k /= W;
-  const int y = (int)(k % H); k /= H;
-  const int z = (int)(k % D); k /= D;
-  reinterpret_cast<int4*>(coors)[i] = make_int4((int)k, z, y, x);
+__device__ __forceinline__ int spc_block_scan(int v, int* s_w, int& total) {      // exclusive, 256 threads
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  __syncthreads();
+  if (lane == 63) s_w[wv] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int i = 0; i < wv; ++i) base += s_w[i];
+  total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void spc_site_count_kernel(const uint32_t* __restrict__ bitmap, long words,
+                                                             int32_t* __restrict__ sums) {
+  __shared__ int s_w[4];
+  const long w = (long)blockIdx.x * kSiteBlk + threadIdx.x;
+  int total;
+  (void)spc_block_scan(w < words ? __popc(bitmap[w]) : 0, s_w, total);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// sums[0 .. nb) -> exclusive prefix in place, sums[nb] = count_out[0] = the total (one block)
+__global__ __launch_bounds__(256) void spc_site_scan_kernel(int32_t* __restrict__ sums, long nb, int32_t* __restrict__ count_out) {
+  __shared__ int s_w[4];
+  int carry = 0;
+  for (long b0 = 0; b0 < nb; b0 += 256) {
+    const long i = b0 + threadIdx.x;
+    const int v = i < nb ? sums[i] : 0;
+    int total;
+    const int ex = spc_block_scan(v, s_w, total);
+    if (i < nb) sums[i] = carry + ex;
+    carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { sums[nb] = carry; count_out[0] = carry; }
+}
+
+__global__ __launch_bounds__(256) void spc_site_emit_kernel(const uint32_t* __restrict__ bitmap, long words,
+                                                            const int32_t* __restrict__ sums, int D, int H, int W,
+                                                            int32_t* __restrict__ coors, long cap) {
+  __shared__ int s_w[4];
+  const long w = (long)blockIdx.x * kSiteBlk + threadIdx.x;
+  uint32_t bits = w < words ? bitmap[w] : 0u;
+  int total;
+  long rank = (long)sums[blockIdx.x] + spc_block_scan(__popc(bits), s_w, total);
+  while (bits) {
+    const int b = __builtin_ctz(bits);
+    bits &= bits - 1u;
+    long long k = (long long)w * 32 + b;
+    const int x = (int)(k % W); k /= W;
+    const int y = (int)(k % H); k /= H;
+    const int z = (int)(k % D); k /= D;
+    if (rank < cap) reinterpret_cast<int4*>(coors)[rank] = make_int4((int)k, z, y, x);
+    ++rank;
+  }
+}
+
+// ---- compacted pairs of a neighbour map (spconv's rulebook form, for the weight gradient) -----------------------
+// per offset k: the rows with a neighbour, in row order.  Three small kernels: counts per 2048-row chunk, a scan of
+// the chunk counts per offset, ranked writes.  (Round 3: a stable torch.argsort over the [kvol, rows] validity map.)
+constexpr int kPairChunk = 2048;
+
+__global__ __launch_bounds__(256) void spc_pair_count_kernel(const int32_t* __restrict__ nbr, long ld, long rows,
+                                                             int chunks, int32_t* __restrict__ sums) {
+  __shared__ int s_w[4];
+  const int k = blockIdx.y;
+  const long r0 = (long)blockIdx.x * kPairChunk + threadIdx.x * 8;
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) c += (r0 + i < rows && nbr[(long)k * ld + r0 + i] >= 0) ? 1 : 0;
+  int total;
+  (void)spc_block_scan(c, s_w, total);
+  if (threadIdx.x == 0) sums[(long)k * chunks + blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void spc_pair_scan_kernel(int32_t* __restrict__ sums, int chunks, int32_t* __restrict__ counts) {
+  __shared__ int s_w[4];
+  int32_t* mine = sums + (long)blockIdx.x * chunks;
+  int carry = 0;
+  for (int b0 = 0; b0 < chunks; b0 += 256) {
+    const int i = b0 + threadIdx.x;
+    const int v = i < chunks ? mine[i] : 0;
+    int total;
+    const int ex = spc_block_scan(v, s_w, total);
+    if (i < chunks) mine[i] = carry + ex;
+    carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) counts[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(256) void spc_pair_write_kernel(const int32_t* __restrict__ nbr, long ld, long rows,
+                                                             int chunks, const int32_t* __restrict__ sums,
+                                                             int32_t* __restrict__ out_rows, int32_t* __restrict__ in_rows) {
+  __shared__ int s_w[4];
+  const int k = blockIdx.y;
+  const long r0 = (long)blockIdx.x * kPairChunk + threadIdx.x * 8;
+  int v[8], c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i] = r0 + i < rows ? nbr[(long)k * ld + r0 + i] : -1;
+    c += v[i] >= 0 ? 1 : 0;
+  }
+  int total;
+  long at = (long)k * ld + sums[(long)k * chunks + blockIdx.x] + spc_block_scan(c, s_w, total);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (v[i] >= 0) { out_rows[at] = (int32_t)(r0 + i); in_rows[at] = v[i]; ++at; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -166,7 +280,7 @@ __device__ __attribute__((aligned(16))) float spc_zero_row[128];     // (the gat
 // 16-channel steps (global load in one step, LDS store in the next) — one barrier per offset, nothing waits for
 // the copy — and at 128 output channels a block is 8 waves (2 per SIMD, <= 256 registers) so a wave's gather
 // latency hides behind its neighbour's MFMAs.
-template <typename T, int NB, int KS, int NW, int DBG = 0>
+template <typename T, int NB, int KS, int NW>
 __global__ __launch_bounds__(64 * NW) void spconv_gather_mma_kernel(const T* __restrict__ feats, const int32_t* __restrict__ nbr,
                                                                     long ld, long rows, const uint16_t* __restrict__ w_hi,
                                                                     const uint16_t* __restrict__ w_lo, T* __restrict__ out,
@@ -311,10 +425,8 @@ __global__ __launch_bounds__(64 * NW) void spconv_gather_mma_kernel(const T* __r
         // PD steps fetch the next OFFSET's first steps instead
         {
           const int t = s + PD;
-          if (!(DBG & 1)) {
-            if (t >= KS) load_a(idn, (t - KS) * 16, rw);
-            else load_a(idx, t * 16, rw);
-          }
+          if (t >= KS) load_a(idn, (t - KS) * 16, rw);
+          else load_a(idx, t * 16, rw);
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -323,7 +435,6 @@ __global__ __launch_bounds__(64 * NW) void spconv_gather_mma_kernel(const T* __r
           if constexpr (SPLIT) b_lo = *reinterpret_cast<const uint4*>(wk + PLANE + j * 32 * LD + c0);
 #pragma unroll
           for (int i = 0; i < RB; ++i) {
-            if (DBG & 2) { acc[i][j][0] += __uint_as_float(a_hi[i].x ^ b_hi.x ^ a_lo[i].y ^ b_lo.z); continue; }
             acc[i][j] = spc_mma<T>::run(a_hi[i], b_hi, acc[i][j]);
             if constexpr (SPLIT) {
               acc[i][j] = spc_mma<T>::run(a_hi[i], b_lo, acc[i][j]);
@@ -345,7 +456,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_gather_mma_kernel(const T* __r
       if (pending) w_store(oth, it_next - 1, hold);
 #pragma unroll
       for (int i = 0; i < RB; ++i) idx[i] = idn[i];
-      if (!(DBG & 4)) __syncthreads();                    // W_kn complete, W_k's readers done
+      __syncthreads();                                    // W_kn complete, W_k's readers done
       if (kn < 0) break;
       par ^= 1;
     }
@@ -375,12 +486,6 @@ static void spconv_launch_one(const void* feats, const int32_t* nbr, long ld, lo
   const int nblk = (int)((rows + 64 * NW - 1) / (64 * NW));
   const dim3 grid((unsigned)((nblk + 7) / 8 * 8)), blk(64 * NW);
   auto fn = spconv_gather_mma_kernel<T, NB, KS, NW>;
-  if constexpr (NB == 4 && KS == 8 && sizeof(T) == 4) {
-    static const int dbg = getenv("UBV_SPC_DBG") ? atoi(getenv("UBV_SPC_DBG")) : 0;
-    if (dbg == 1) fn = spconv_gather_mma_kernel<T, NB, KS, NW, 1>;
-    if (dbg == 2) fn = spconv_gather_mma_kernel<T, NB, KS, NW, 2>;
-    if (dbg == 4) fn = spconv_gather_mma_kernel<T, NB, KS, NW, 4>;
-  }
   // (more than 64 KB of dynamic LDS at 128 output channels: ask for it explicitly)
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(fn, grid, blk, lds, st, (const T*)feats, nbr, ld, rows, (const uint16_t*)w_hi, (const uint16_t*)w_lo,
@@ -455,27 +560,60 @@ extern "C" int ubv_spconv_neighbors(const int32_t* coors, int64_t rows, int B, c
   return UBV_OK;
 }
 
-extern "C" int ubv_spconv_candidates(const int32_t* coors, int64_t n, int B, const int* in_dims, const int* out_dims,
-                                     const int* ksize, const int* stride, const int* pad, int64_t* cand, void* stream) {
+extern "C" int64_t ubv_spconv_sites_words(int B, const int* out_dims) {
+  if (!out_dims || B <= 0 || out_dims[0] <= 0 || out_dims[1] <= 0 || out_dims[2] <= 0) return 0;
+  const int64_t cells = (int64_t)B * out_dims[0] * out_dims[1] * out_dims[2];
+  return (cells + 31) / 32;
+}
+
+extern "C" int ubv_spconv_output_sites(const int32_t* coors, const int32_t* n_dev, int64_t n, int B, const int* in_dims,
+                                       const int* out_dims, const int* ksize, const int* stride, const int* pad,
+                                       int32_t* bitmap, int64_t words, int32_t* sums, int32_t* out_coors, int64_t cap,
+                                       int32_t* count_dev, void* stream) {
   using namespace ubv;
-  UBV_CHECK_ARG(coors && cand && n >= 0, "spconv_candidates: bad arguments");
+  UBV_CHECK_ARG((coors || n == 0) && bitmap && sums && out_coors && count_dev && n >= 0 && cap >= 0, "spconv_output_sites: bad arguments");
   SpGeom g;
-  UBV_CHECK_ARG(sp_geom(g, B, in_dims, out_dims, ksize, stride, pad, 1), "spconv_candidates: bad geometry");
-  if (n == 0) return UBV_OK;
+  UBV_CHECK_ARG(sp_geom(g, B, in_dims, out_dims, ksize, stride, pad, 1), "spconv_output_sites: bad geometry");
+  UBV_CHECK_ARG(words == ubv_spconv_sites_words(B, out_dims) && words < (int64_t)1 << 31, "spconv_output_sites: bitmap of %lld words expected", (long long)ubv_spconv_sites_words(B, out_dims));
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(bitmap, 0, (size_t)words * sizeof(int32_t), st) != hipSuccess) {
+    set_error("spconv_output_sites: memset failed");
+    return UBV_ERR_LAUNCH;
+  }
   const long total = (long)n * ksize[0] * ksize[1] * ksize[2];
-  hipLaunchKernelGGL(spc_candidates_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), coors,
-                     (long)n, g, (long long*)cand);
-  UBV_CHECK_LAUNCH("spconv_candidates");
+  if (total > 0) {
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(spc_mark_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, coors, n_dev,
+                       (long)n, g, (uint32_t*)bitmap);
+  }
+  const long nb = (words + kSiteBlk - 1) / kSiteBlk;
+  hipLaunchKernelGGL(spc_site_count_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const uint32_t*)bitmap, (long)words, sums);
+  hipLaunchKernelGGL(spc_site_scan_kernel, dim3(1), dim3(256), 0, st, sums, nb, count_dev);
+  hipLaunchKernelGGL(spc_site_emit_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const uint32_t*)bitmap, (long)words,
+                     (const int32_t*)sums, out_dims[0], out_dims[1], out_dims[2], out_coors, (long)cap);
+  UBV_CHECK_LAUNCH("spconv_output_sites");
   return UBV_OK;
 }
 
-extern "C" int ubv_spconv_keys_to_coors(const int64_t* keys, int64_t n, int D, int H, int W, int32_t* coors, void* stream) {
+extern "C" int64_t ubv_spconv_pairs_chunks(int64_t rows) { return rows <= 0 ? 0 : (rows + ubv::kPairChunk - 1) / ubv::kPairChunk; }
+
+extern "C" int ubv_spconv_pairs(const int32_t* nbr, int64_t ld, int64_t rows, int kvol, int32_t* chunk_sums,
+                                int32_t* out_rows, int32_t* in_rows, int32_t* counts, void* stream) {
   using namespace ubv;
-  UBV_CHECK_ARG(keys && coors && n >= 0 && D > 0 && H > 0 && W > 0, "spconv_keys_to_coors: bad arguments");
-  if (n == 0) return UBV_OK;
-  hipLaunchKernelGGL(spc_keys_to_coors_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
-                     (const long long*)keys, (long)n, D, H, W, coors);
-  UBV_CHECK_LAUNCH("spconv_keys_to_coors");
+  UBV_CHECK_ARG(nbr && chunk_sums && out_rows && in_rows && counts && rows >= 0 && ld >= rows && kvol > 0 && kvol < 65536,
+                "spconv_pairs: bad arguments");
+  hipStream_t st = as_stream(stream);
+  if (rows == 0) {
+    if (hipMemsetAsync(counts, 0, (size_t)kvol * sizeof(int32_t), st) != hipSuccess) { set_error("spconv_pairs: memset failed"); return UBV_ERR_LAUNCH; }
+    return UBV_OK;
+  }
+  const int chunks = (int)ubv_spconv_pairs_chunks(rows);
+  const dim3 grid((unsigned)chunks, (unsigned)kvol);
+  hipLaunchKernelGGL(spc_pair_count_kernel, grid, dim3(256), 0, st, nbr, (long)ld, (long)rows, chunks, chunk_sums);
+  hipLaunchKernelGGL(spc_pair_scan_kernel, dim3((unsigned)kvol), dim3(256), 0, st, chunk_sums, chunks, counts);
+  hipLaunchKernelGGL(spc_pair_write_kernel, grid, dim3(256), 0, st, nbr, (long)ld, (long)rows, chunks,
+                     (const int32_t*)chunk_sums, out_rows, in_rows);
+  UBV_CHECK_LAUNCH("spconv_pairs");
   return UBV_OK;
 }
 

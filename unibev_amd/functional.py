@@ -1122,23 +1122,52 @@ def spconv_subm_map(coors, batch_size, dims, ksize):
 
 
 @torch.no_grad()
-def spconv_strided_maps(coors, batch_size, in_dims, ksize, stride, pad):
+def spconv_site_chain(coors, batch_size, in_dims, layers):
+    """Output sites of a CHAIN of strided sparse convolutions (``layers``: (ksize, stride, pad) each, every layer's
+    inputs the previous one's outputs) -> [(out_coors [M, 4] int32 in ascending key order, out_dims)].  Built on the
+    device back to back (``ubv_spconv_output_sites``: mark bits, popcount scan, emit); the host reads all the counts
+    in ONE copy at the end (spconv's get_indice_pairs reads one per layer)."""
+    with _need_cuda(coors):
+        cur = coors.contiguous()
+        dev = cur.device
+        L = len(layers)
+        counts = torch.empty(max(L, 1), dtype=torch.int32, device=dev)
+        bound, n_dev, dims, bufs = cur.shape[0], None, tuple(int(d) for d in in_dims), []
+        for l, (ksize, stride, pad) in enumerate(layers):
+            out_dims = spconv_out_dims(dims, ksize, stride, pad)
+            words = int(lib().ubv_spconv_sites_words(int(batch_size), _i3(out_dims)))
+            if words <= 0:
+                raise ValueError(f'sparse convolution: empty output map {out_dims}')
+            reach = 1
+            for k, s_ in zip(ksize, stride):
+                reach *= -(-int(k) // int(s_))                 # offsets per axis that can hit a stride-aligned cell
+            cap = max(1, min(reach * bound, int(batch_size) * out_dims[0] * out_dims[1] * out_dims[2]))
+            bitmap = torch.empty(words, dtype=torch.int32, device=dev)
+            sums = torch.empty(words // 256 + 2, dtype=torch.int32, device=dev)
+            buf = torch.empty(cap, 4, dtype=torch.int32, device=dev)
+            check(lib().ubv_spconv_output_sites(_p(cur), _p(n_dev), bound, int(batch_size), _i3(dims), _i3(out_dims),
+                                                _i3(ksize), _i3(stride), _i3(pad), _p(bitmap), words, _p(sums), _p(buf),
+                                                cap, _p(counts[l:l + 1]), _stream()), 'spconv_output_sites')
+            bufs.append((buf, out_dims))
+            cur, n_dev, bound, dims = buf, counts[l:l + 1], cap, out_dims
+        host = counts.cpu().tolist()                           # the one host read
+        out = []
+        for (buf, od), m in zip(bufs, host):
+            out.append((buf[:m].clone() if buf.shape[0] > 2 * m else buf[:m], od))
+        return out
+
+
+@torch.no_grad()
+def spconv_strided_maps(coors, batch_size, in_dims, ksize, stride, pad, sites=None):
     """Rulebook of a strided sparse convolution: (out_coors [M, 4] in ascending key order, out_dims,
-    nbr_fwd [kvol, M] (inputs of each output), nbr_bwd [kvol, N] (outputs of each input)).  Reads the
-    output count back (one host sync, as spconv's get_indice_pairs does)."""
+    nbr_fwd [kvol, M] (inputs of each output), nbr_bwd [kvol, N] (outputs of each input)).  ``sites`` =
+    (out_coors, out_dims) when the caller planned the output set already (``spconv_site_chain``); otherwise it is
+    built here (one host read of its size, as spconv's get_indice_pairs does)."""
     with _need_cuda(coors):
         coors = coors.contiguous()
-        N = coors.shape[0]
-        out_dims = spconv_out_dims(in_dims, ksize, stride, pad)
-        kvol = int(ksize[0]) * int(ksize[1]) * int(ksize[2])
-        cand = torch.empty(kvol * N, dtype=torch.int64, device=coors.device)
-        check(lib().ubv_spconv_candidates(_p(coors), N, int(batch_size), _i3(in_dims), _i3(out_dims), _i3(ksize),
-                                          _i3(stride), _i3(pad), _p(cand), _stream()), 'spconv_candidates')
-        keys = torch.unique(cand[cand >= 0])                   # ascending; the host learns M here
-        M = keys.numel()
-        out_coors = torch.empty(M, 4, dtype=torch.int32, device=coors.device)
-        check(lib().ubv_spconv_keys_to_coors(_p(keys), M, int(out_dims[0]), int(out_dims[1]), int(out_dims[2]),
-                                             _p(out_coors), _stream()), 'spconv_keys_to_coors')
+        if sites is None:
+            sites = spconv_site_chain(coors, batch_size, in_dims, [(ksize, stride, pad)])[0]
+        out_coors, out_dims = sites
         t_in = spconv_hash(coors, in_dims)
         t_out = spconv_hash(out_coors, out_dims)
         nbr_fwd = spconv_neighbors(out_coors, batch_size, out_dims, in_dims, ksize, stride, pad, t_in)
@@ -1180,12 +1209,19 @@ _SPWG_WS_MB = int(os.environ.get('UBV_SPWG_WS_MB', '96'))       # budget of the 
 
 @torch.no_grad()
 def spconv_pairs(nbr):
-    """Compacted rulebook of a neighbour map [kvol, rows]: per offset the rows that HAVE a neighbour first, in row
-    order (stable) -> (out_rows, in_rows, counts) int32.  Deterministic, nothing read back; built once per indice key."""
-    valid = nbr >= 0
-    order = torch.argsort((~valid).to(torch.uint8), dim=1, stable=True).to(torch.int32)
-    in_rows = torch.gather(nbr, 1, order.long())
-    return order.contiguous(), in_rows.contiguous(), valid.sum(1, dtype=torch.int32).contiguous()
+    """Compacted rulebook of a neighbour map [kvol, rows] (``ubv_spconv_pairs``): per offset the rows that HAVE a
+    neighbour, in row order -> (out_rows, in_rows, counts) int32; entries past counts[k] are unspecified.
+    Deterministic, nothing read back; built once per indice key."""
+    with _need_cuda(nbr):
+        nbr = nbr.contiguous()
+        kvol, rows = nbr.shape
+        out_rows, in_rows = torch.empty_like(nbr), torch.empty_like(nbr)
+        counts = torch.empty(kvol, dtype=torch.int32, device=nbr.device)
+        chunks = int(lib().ubv_spconv_pairs_chunks(rows))
+        sums = torch.empty(max(1, kvol * chunks), dtype=torch.int32, device=nbr.device)
+        check(lib().ubv_spconv_pairs(_p(nbr), rows, rows, kvol, _p(sums), _p(out_rows), _p(in_rows), _p(counts),
+                                     _stream()), 'spconv_pairs')
+        return out_rows, in_rows, counts
 
 
 @torch.no_grad()

@@ -150,8 +150,14 @@ class _SparseConvBase(nn.Module):
             rec = (x.indices, x.spatial_shape,
                    UF.spconv_subm_map(x.indices, x.batch_size, x.spatial_shape, self.kernel_size), None, {})
         else:
+            # the output set: planned by the encoder for its whole chain of strided layers (one host read for all of
+            # them, SparseEncoder._plan_sites) or built here (one read for this layer)
+            planned = x.indice_dict.get(('sites', id(self)))
+            if planned is not None and planned[0] is not x.indices:
+                planned = None                                 # (not the input the plan was made for)
             oc, od, nf, nb = UF.spconv_strided_maps(x.indices, x.batch_size, x.spatial_shape, self.kernel_size,
-                                                    self.stride, self.padding)
+                                                    self.stride, self.padding,
+                                                    sites=None if planned is None else planned[1])
             rec = (oc, od, nf, nb, {})
         if self.indice_key is not None:
             x.indice_dict[self.indice_key] = rec
@@ -328,14 +334,28 @@ class SparseEncoder(nn.Module):
             self.encoder_layers.add_module(f'encoder_layer{i + 1}', SparseSequential(*blocks_list))
         return in_channels
 
+    def _plan_sites(self, coors, batch_size, indice_dict):
+        """Output sets of every strided layer, in one device pass with ONE host read (``UF.spconv_site_chain``): the
+        layers run in module order and each one's inputs are the previous one's outputs (submanifold layers keep the
+        sites), so the chain is known before any feature is computed."""
+        strided = [m for m in self.modules() if isinstance(m, SparseConv3d)]
+        if not strided:
+            return
+        chain = UF.spconv_site_chain(coors, batch_size, self.sparse_shape,
+                                     [(m.kernel_size, m.stride, m.padding) for m in strided])
+        cur = coors
+        for m, (oc, od) in zip(strided, chain):
+            indice_dict[('sites', id(m))] = (cur, (oc, od))
+            cur = oc
+
     def forward(self, voxel_features, coors, batch_size):
         """voxel_features [N, in_channels], coors [N, 4] (batch, z, y, x) -> (batch, C * D, H, W)."""
         if voxel_features.shape[0] == 0:
             raise ValueError('SparseEncoder: no voxels (BatchNorm over an empty set is undefined)')
         # With ``keep_rulebooks`` the rulebooks (hash tables, neighbour maps, compacted pairs) are kept across calls
         # while the SAME coordinate tensor comes back unmodified (identity + version counter): a cloud evaluated twice
-        # — gradient accumulation, checkpointing — pays for them once, and the 4 host reads of the strided layers'
-        # output counts disappear with them.  Default: rebuilt on every call, as a training step with new clouds does.
+        # — gradient accumulation, checkpointing — pays for them once, and the host read of the strided layers' output
+        # counts disappears with them.  Default: rebuilt on every call, as a training step with new clouds does.
         hit = self._rulebooks.get(id(coors)) if self.keep_rulebooks else None
         if hit is not None and hit[0] is coors and hit[1] == coors._version and hit[2] == int(batch_size):
             indice_dict = hit[3]
@@ -347,8 +367,10 @@ class SparseEncoder(nn.Module):
                 self._rulebooks[id(coors)] = (coors, coors._version, int(batch_size), indice_dict)
             elif self._rulebooks:
                 self._rulebooks.clear()
-        coors = coors.int()
-        x = SparseConvTensor(voxel_features, coors.contiguous(), self.sparse_shape, batch_size, indice_dict)
+        coors = coors.int().contiguous()
+        if not indice_dict:
+            self._plan_sites(coors, batch_size, indice_dict)
+        x = SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size, indice_dict)
         x = self.conv_input(x)
         for stage in self.encoder_layers:
             x = stage(x)
