@@ -602,8 +602,8 @@ def voxel_record(device):
 def middle_encoder_record(device, feats, coors, bs=2):
     """SparseEncoder of the shipped L / LC configs (41 x 1440 x 1440 grid, basic blocks) on `bs` copies of the
     cloud: forward and forward + backward (training mode), per batch.  ``forward_ms`` / ``forward_backward_ms``
-    REBUILD the rulebooks (hash tables, neighbour maps, compacted pairs, the strided layers' host-read output
-    counts) on every pass, as a training step with new clouds does; the ``*_kept_rulebooks`` numbers are the same
+    REBUILD the rulebooks (the strided layers' output sites — one host read of the four counts —, hash tables,
+    neighbour maps, compacted pairs) on every pass, as a training step with new clouds does; the ``*_kept_rulebooks`` numbers are the same
     passes with the module's opt-in cache (``keep_rulebooks``: gradient accumulation / checkpointing of one cloud)."""
     from unibev_amd.registry import MIDDLE_ENCODERS, build_from_cfg
     cfg = dict(type='SparseEncoder', in_channels=5, sparse_shape=[41, 1440, 1440], output_channels=128,
@@ -640,8 +640,9 @@ def middle_encoder_record(device, feats, coors, bs=2):
             out[name + ('_kept_rulebooks' if keep else '')] = e0.elapsed_time(e1) / 5
     out.update(batch=bs, voxels_per_sample=int(feats.shape[0]), out_shape=list(fwd().shape),
                note='SubM / strided sparse convs as gather + MFMA over neighbour maps; weight gradients on the split-K MFMA '
-                    'kernel over compacted pairs; forward_ms / forward_backward_ms rebuild the rulebooks every pass (4 host '
-                    'reads of the strided convs\' output counts), *_kept_rulebooks reuse them (opt-in cache)')
+                    'kernel over compacted pairs; forward_ms / forward_backward_ms rebuild the rulebooks every pass on the '
+                    'device (ONE host read: the four strided layers\' output counts), *_kept_rulebooks reuse them '
+                    '(opt-in cache)')
     return out
 
 

@@ -514,14 +514,17 @@ int ubv_spconv_wgrad_pairs(const void* grad_out, const void* feats, const int32_
  * training != 0: batch statistics (mean / rstd [C] are WRITTEN, running_* updated when given); else mean / rstd are
  * INPUTS (the caller derives them from the running statistics).  y = relu?(gamma * (x - mean) * rstd + beta).
  * partial: ubv_rows_bn_partial_elems(C) floats of scratch.  Deterministic (fixed-order two-level sums).
- * backward: grad_x, grad_gamma [C], grad_beta [C] written; relu != 0 masks grad_y where the forward output was 0. */
+ * backward: grad_x, grad_gamma [C], grad_beta [C] written; relu != 0 masks grad_y where the forward output was 0.
+ * residual [N, C] (optional): y = relu?(bn(x) + residual) — the tail of mmdet3d's SparseBasicBlock
+ * (out = relu(bn2(conv2(.)) + identity)); its backward takes the stored output y_out (the ReLU mask) and also writes
+ * grad_residual = the masked grad_y. */
 int64_t ubv_rows_bn_partial_elems(int C);
-int ubv_rows_bn_forward(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                        float* mean, float* rstd, float* partial, void* y, int64_t N, int C, float eps, float momentum,
-                        int relu, int training, int dtype, void* stream);
-int ubv_rows_bn_backward(const void* x, const void* grad_y, const float* gamma, const float* beta, const float* mean,
-                         const float* rstd, float* partial, float* grad_gamma, float* grad_beta, void* grad_x, int64_t N,
-                         int C, int relu, int dtype, void* stream);
+int ubv_rows_bn_forward(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, float* mean, float* rstd, float* partial, void* y, int64_t N, int C,
+                        float eps, float momentum, int relu, int training, int dtype, void* stream);
+int ubv_rows_bn_backward(const void* x, const void* grad_y, const void* y_out, const float* gamma, const float* beta,
+                         const float* mean, const float* rstd, float* partial, float* grad_gamma, float* grad_beta,
+                         void* grad_x, void* grad_residual, int64_t N, int C, int relu, int dtype, void* stream);
 int ubv_spconv_hash_build(const int32_t* coors, int64_t n, int D, int H, int W, int64_t* table_keys,
                           int32_t* table_vals, int64_t slots, void* stream);
 int ubv_spconv_neighbors(const int32_t* coors, int64_t rows, int B, const int* row_dims, const int* target_dims,
@@ -536,6 +539,11 @@ int ubv_spconv_output_sites(const int32_t* coors, const int32_t* n_dev, int64_t 
 int64_t ubv_spconv_pairs_chunks(int64_t rows);
 int ubv_spconv_pairs(const int32_t* nbr, int64_t ld, int64_t rows, int kvol, int32_t* chunk_sums, int32_t* out_rows,
                      int32_t* in_rows, int32_t* counts, void* stream);
+/* w [kvol][Cin][Cout] (spconv's stored layout, dtype) -> ubv_spconv_gather_mma's operand [kvol][32*ceil(rows/32)][K]:
+ * transpose != 0 (forward): rows = Cout, K = Cin; transpose == 0 (input gradient): rows = Cin, K = Cout, offsets mirrored
+ * when flip != 0 (submanifold layers).  f32: bf16 halves w_hi + w_lo; 16-bit: w_hi only (w_lo NULL). */
+int ubv_spconv_weight_operand(const void* w, int kvol, int Cin, int Cout, int transpose, int flip, int dtype,
+                              void* w_hi, void* w_lo, void* stream);
 int ubv_spconv_gather_mma(const void* feats, const int32_t* nbr, int64_t ld, int64_t rows, const void* w_hi,
                           const void* w_lo, void* out, int Cin, int Cout, int kvol, int dtype, void* stream);
 

@@ -340,3 +340,61 @@ def test_compacted_pairs_match_a_stable_sort_of_the_neighbour_map():
             assert n == valid.numel()
             assert torch.equal(out_rows[k, :n].long(), valid)
             assert torch.equal(in_rows[k, :n], nbr[k][valid])
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('relu', [False, True])
+def test_rows_batch_norm_with_residual_vs_torch(relu, dtype):
+    """The basic block's tail relu?(bn(x) + identity) as one pass each way: output and the gradients of x, the identity,
+    gamma and beta equal torch in f64; training and eval mode; counters under ``batched_bn_ticks``."""
+    from unibev_amd.functional import batched_bn_ticks, rows_batch_norm
+    rs = np.random.RandomState(7)
+    N, C = 4111, 64
+    x = torch.from_numpy(rs.standard_normal((N, C)).astype(np.float32) * 2 + 0.5).to(dtype)
+    idn = torch.from_numpy(rs.standard_normal((N, C)).astype(np.float32)).to(dtype)
+    cot = torch.from_numpy(rs.standard_normal((N, C)).astype(np.float32)).to(dtype)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for training in (True, False):
+        bn = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).to(DEV).train(training)
+        ref = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).double().train(training)
+        with torch.no_grad():
+            bn.weight.copy_(torch.from_numpy(rs.uniform(0.5, 1.5, C)))
+            bn.bias.copy_(torch.from_numpy(rs.standard_normal(C) * 0.3))
+            bn.running_var.copy_(torch.from_numpy(rs.uniform(0.5, 2.0, C)))
+            ref.weight.copy_(bn.weight.double().cpu()); ref.bias.copy_(bn.bias.double().cpu())
+            ref.running_var.copy_(bn.running_var.double().cpu())
+        xg, ig = x.to(DEV).requires_grad_(), idn.to(DEV).requires_grad_()
+        with batched_bn_ticks():
+            y = rows_batch_norm(xg, bn, relu=relu, residual=ig)
+            assert int(bn.num_batches_tracked) == 0                    # (deferred to the context's exit)
+        assert int(bn.num_batches_tracked) == (1 if training else 0)
+        assert y is not None and y.dtype == dtype
+        x64, i64 = x.double().requires_grad_(), idn.double().requires_grad_()
+        r = ref(x64) + i64
+        r = torch.relu(r) if relu else r
+        (y.float() * cot.to(DEV).float()).sum().backward()
+        (r * cot.double()).sum().backward()
+        rel = lambda a, b: float((a.double().cpu() - b).norm() / b.norm().clamp_min(1e-30))
+        assert rel(y, r.detach()) < tol
+        gt = tol if dtype == torch.float32 else 4e-2
+        assert rel(xg.grad, x64.grad) < gt and rel(ig.grad, i64.grad) < gt
+        assert rel(bn.weight.grad, ref.weight.grad) < tol and rel(bn.bias.grad, ref.bias.grad) < tol
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_weight_operand_kernel_equals_the_framework_composition(dtype):
+    """ubv_spconv_weight_operand (transpose / mirror / pad / split in one launch) is bit-identical to
+    reshape + transpose / flip + pad + split."""
+    from unibev_amd import functional as UF
+    rs = np.random.RandomState(3)
+    for cin, cout in ((16, 48), (64, 128), (32, 16)):
+        w = torch.from_numpy(rs.standard_normal((27, cin, cout)).astype(np.float32)).to(DEV, dtype)
+        for transpose, flip in ((True, False), (False, False), (False, True)):
+            hi, lo = UF.spconv_weight_operand(w, transpose, flip)
+            src = w.transpose(1, 2) if transpose else (w.flip(0) if flip else w)
+            rhi, rlo = UF.spconv_operand(src)
+            assert torch.equal(hi.view(torch.int16).flatten(), rhi.view(torch.int16).flatten())
+            if dtype == torch.float32:
+                assert torch.equal(lo.view(torch.int16).flatten(), rlo.view(torch.int16).flatten())
+            else:
+                assert lo is None and rlo is None

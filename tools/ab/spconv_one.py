@@ -20,6 +20,16 @@ torch.manual_seed(0)
 f = torch.randn(rows, ch, device=dev)
 w = torch.randn(27, ch, ch, device=dev) * 0.05
 hi, lo = UF.spconv_operand(w)
+if len(sys.argv) > 2 and sys.argv[2] == 'wgrad':
+    g = torch.randn(rows, ch, device=dev)
+    pairs = UF.spconv_pairs(nbr)
+    for _ in range(3): out = UF.spconv_wgrad(g, f, nbr, pairs)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(20): out = UF.spconv_wgrad(g, f, nbr, pairs)
+    e1.record(); torch.cuda.synchronize()
+    print(os.environ.get('TAG', ''), f'wgrad rows {rows} pairs {int(pairs[2].sum())}  {e0.elapsed_time(e1) / 20 * 1e3:.1f} us  checksum {float(out.double().abs().sum()):.6e}')
+    sys.exit(0)
 for _ in range(3): out = UF.spconv_gather_mma(f, nbr, hi, lo, ch)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize(); e0.record()

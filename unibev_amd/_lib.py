@@ -70,8 +70,8 @@ SIGNATURES = {
     'ubv_spconv_wgrad_splits': (c_int, [c_int64, c_int]),
     'ubv_spconv_wgrad': (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ubv_rows_bn_partial_elems': (c_int64, [c_int]),
-    'ubv_rows_bn_forward': (c_int, [_P] * 9 + [c_int64, c_int, c_float, c_float, c_int, c_int, c_int, _P]),
-    'ubv_rows_bn_backward': (c_int, [_P] * 10 + [c_int64, c_int, c_int, c_int, _P]),
+    'ubv_rows_bn_forward': (c_int, [_P] * 10 + [c_int64, c_int, c_float, c_float, c_int, c_int, c_int, _P]),
+    'ubv_rows_bn_backward': (c_int, [_P] * 12 + [c_int64, c_int, c_int, c_int, _P]),
     'ubv_spconv_wgrad_pairs': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ubv_spconv_hash_build': (c_int, [_P, c_int64, c_int, c_int, c_int, _P, _P, c_int64, _P]),
     'ubv_spconv_neighbors': (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, c_int64, _P, c_int64, _P]),
@@ -79,6 +79,7 @@ SIGNATURES = {
     'ubv_spconv_output_sites': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P]),
     'ubv_spconv_pairs_chunks': (c_int64, [c_int64]),
     'ubv_spconv_pairs': (c_int, [_P, c_int64, c_int64, c_int, _P, _P, _P, _P, _P]),
+    'ubv_spconv_weight_operand': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     'ubv_spconv_gather_mma': (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'ubv_gemm_wgrad_splits': (c_int, [c_int64, c_int, c_int]),
     'ubv_gemm_wgrad': (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P]),

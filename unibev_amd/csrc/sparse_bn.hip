@@ -5,6 +5,8 @@
 // N is 55 k - 185 k rows, C is 16 - 128 channels: a row is 64 - 512 bytes.  The framework's batch norm treats the
 // matrix as a channels-last image and spends 73 us on the statistics and 85 us on the backward reduction of each of
 // the 21 layers — latency-bound reductions over few channels (4 ms of a 25 ms encoder pass).  Here:
+// The basic block's tail  relu(bn2(conv2) + identity)  is the same pass with a residual operand (forward: added before
+// the ReLU; backward: the mask comes from the stored output, the masked gradient is also the identity's gradient).
 //   forward   bn_stats_kernel (one streaming pass: per-block partial sums of x and x^2, 16-byte loads, fixed block ->
 //             rows map) + bn_finalize_kernel (partials summed IN BLOCK ORDER: deterministic; mean, 1 / sqrt(var +
 //             eps), running statistics with the unbiased variance as torch does) + bn_apply_kernel (normalise,
@@ -25,6 +27,7 @@ __device__ __forceinline__ void bn_load4(const T* p, float (&v)[4]) { vec_io<T, 
 // Thread t: channel quad cq = t % (C / 4), row lane rl = t / (C / 4); rows [r0, r1) of the block in steps of RL.
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                         const T* __restrict__ yout,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          long N, int C, int relu, long rows_per_block,
@@ -52,12 +55,14 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const float u = v[i] - sh[i]; s1[i] += u; s2[i] = fmaf(u, u, s2[i]); }
       } else {
-        float d[4];
+        float d[4], yo[4] = {1.f, 1.f, 1.f, 1.f};
         bn_load4<T>(dy + r * C + cq * 4, d);
+        if (yout != nullptr) bn_load4<T>(yout + r * C + cq * 4, yo);       // (residual form: the mask is the stored output)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float xh = (v[i] - mu[i]) * rs[i];
-          const float dd = (relu && fmaf(xh, g[i], b[i]) <= 0.0f) ? 0.0f : d[i];
+          const float yv = yout != nullptr ? yo[i] : fmaf(xh, g[i], b[i]);
+          const float dd = (relu && yv <= 0.0f) ? 0.0f : d[i];
           s1[i] += dd;
           s2[i] = fmaf(dd, xh, s2[i]);
         }
@@ -133,21 +138,24 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   dgamma[c] = (float)s2;
 }
 
-// MODE 0: y = act(xhat * gamma + beta).  MODE 1: dx = gamma * rstd * (dy' - s1 / N - xhat * s2 / N)
+// MODE 0: y = act(xhat * gamma + beta (+ res)).  MODE 1: dx = gamma * rstd * (dy' - s1 / N - xhat * s2 / N), and with a
+// residual (res = the stored forward output, the ReLU mask) dres = dy'
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                       const T* __restrict__ res,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ s1, const float* __restrict__ s2,
-                                                       long N, int C, int relu, T* __restrict__ out) {
+                                                       long N, int C, int relu, T* __restrict__ out, T* __restrict__ dres) {
   const long i4 = (long)blockIdx.x * 256 + threadIdx.x;              // one 4-channel piece per thread
   const long total = N * (C / 4);
   if (i4 >= total) return;
   const int c0 = (int)(i4 % (C / 4)) * 4;
   float v[4], o[4];
   bn_load4<T>(x + i4 * 4, v);
-  float d[4] = {0.f, 0.f, 0.f, 0.f};
+  float d[4] = {0.f, 0.f, 0.f, 0.f}, rr[4] = {0.f, 0.f, 0.f, 0.f}, dr[4];
   if (MODE == 1) bn_load4<T>(dy + i4 * 4, d);
+  if (res != nullptr) bn_load4<T>(res + i4 * 4, rr);
   const float invn = 1.0f / (float)N;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -155,13 +163,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     const float xh = (v[i] - mean[c]) * rstd[c];
     const float y = fmaf(xh, gamma[c], beta[c]);
     if (MODE == 0) {
-      o[i] = (relu && y <= 0.0f) ? 0.0f : y;
+      const float yr = y + rr[i];
+      o[i] = (relu && yr <= 0.0f) ? 0.0f : yr;
     } else {
-      const float dd = (relu && y <= 0.0f) ? 0.0f : d[i];
+      const float yv = res != nullptr ? rr[i] : y;
+      const float dd = (relu && yv <= 0.0f) ? 0.0f : d[i];
+      dr[i] = dd;
       o[i] = gamma[c] * rstd[c] * (dd - s1[c] * invn - xh * s2[c] * invn);
     }
   }
   vec_io<T, 4>::store(out + i4 * 4, o);
+  if (MODE == 1 && dres != nullptr) vec_io<T, 4>::store(dres + i4 * 4, dr);
 }
 
 static int bn_blocks(long N) {
@@ -170,41 +182,42 @@ static int bn_blocks(long N) {
 }
 
 template <typename T>
-static void bn_forward_T(const void* x, const float* gamma, const float* beta, float* rm, float* rv, float* mean,
-                         float* rstd, float* partial, void* y, long N, int C, float eps, float momentum, int relu,
-                         int training, hipStream_t st) {
+static void bn_forward_T(const void* x, const void* res, const float* gamma, const float* beta, float* rm, float* rv,
+                         float* mean, float* rstd, float* partial, void* y, long N, int C, float eps, float momentum,
+                         int relu, int training, hipStream_t st) {
   if (training) {
     const int blocks = bn_blocks(N);
     const long rpb = (N + blocks - 1) / blocks;
     hipLaunchKernelGGL((bn_partial_kernel<T, false>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)nullptr,
-                       nullptr, nullptr, nullptr, nullptr, N, C, 0, rpb, partial);
+                       (const T*)nullptr, nullptr, nullptr, nullptr, nullptr, N, C, 0, rpb, partial);
     hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3(C), dim3(256), 0, st, partial, blocks, N, C, eps, momentum,
                        (const T*)x, mean, rstd, rm, rv);
   }
   const long pieces = N * (C / 4);
   hipLaunchKernelGGL((bn_apply_kernel<T, 0>), dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, (const T*)x,
-                     (const T*)nullptr, mean, rstd, gamma, beta, nullptr, nullptr, N, C, relu, (T*)y);
+                     (const T*)nullptr, (const T*)res, mean, rstd, gamma, beta, nullptr, nullptr, N, C, relu, (T*)y,
+                     (T*)nullptr);
 }
 
 template <typename T>
-static void bn_backward_T(const void* x, const void* dy, const float* gamma, const float* beta, const float* mean,
-                          const float* rstd, float* partial, float* dgamma, float* dbeta, void* dx, long N, int C,
-                          int relu, hipStream_t st) {
+static void bn_backward_T(const void* x, const void* dy, const void* yout, const float* gamma, const float* beta,
+                          const float* mean, const float* rstd, float* partial, float* dgamma, float* dbeta, void* dx,
+                          void* dres, long N, int C, int relu, hipStream_t st) {
   const int blocks = bn_blocks(N);
   const long rpb = (N + blocks - 1) / blocks;
-  hipLaunchKernelGGL((bn_partial_kernel<T, true>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)dy, mean, rstd,
-                     gamma, beta, N, C, relu, rpb, partial);
+  hipLaunchKernelGGL((bn_partial_kernel<T, true>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)dy,
+                     (const T*)yout, mean, rstd, gamma, beta, N, C, relu, rpb, partial);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, partial, blocks, C, dbeta, dgamma);
   const long pieces = N * (C / 4);
   hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, (const T*)x,
-                     (const T*)dy, mean, rstd, gamma, beta, dbeta, dgamma, N, C, relu, (T*)dx);
+                     (const T*)dy, (const T*)yout, mean, rstd, gamma, beta, dbeta, dgamma, N, C, relu, (T*)dx, (T*)dres);
 }
 
 }  // namespace ubv
 
 extern "C" int64_t ubv_rows_bn_partial_elems(int C) { return (int64_t)ubv::kBnBlocks * 2 * C; }
 
-extern "C" int ubv_rows_bn_forward(const void* x, const float* gamma, const float* beta, float* running_mean,
+extern "C" int ubv_rows_bn_forward(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
                                    float* running_var, float* mean, float* rstd, float* partial, void* y, int64_t N,
                                    int C, float eps, float momentum, int relu, int training, int dtype, void* stream) {
   using namespace ubv;
@@ -216,29 +229,30 @@ extern "C" int ubv_rows_bn_forward(const void* x, const float* gamma, const floa
     return UBV_ERR_UNSUPPORTED;
   }
   hipStream_t st = as_stream(stream);
-  if (dtype == UBV_F32) bn_forward_T<float>(x, gamma, beta, running_mean, running_var, mean, rstd, partial, y, N, C, eps, momentum, relu, training, st);
-  else if (dtype == UBV_F16) bn_forward_T<f16_t>(x, gamma, beta, running_mean, running_var, mean, rstd, partial, y, N, C, eps, momentum, relu, training, st);
-  else bn_forward_T<bf16_t>(x, gamma, beta, running_mean, running_var, mean, rstd, partial, y, N, C, eps, momentum, relu, training, st);
+  if (dtype == UBV_F32) bn_forward_T<float>(x, residual, gamma, beta, running_mean, running_var, mean, rstd, partial, y, N, C, eps, momentum, relu, training, st);
+  else if (dtype == UBV_F16) bn_forward_T<f16_t>(x, residual, gamma, beta, running_mean, running_var, mean, rstd, partial, y, N, C, eps, momentum, relu, training, st);
+  else bn_forward_T<bf16_t>(x, residual, gamma, beta, running_mean, running_var, mean, rstd, partial, y, N, C, eps, momentum, relu, training, st);
   UBV_CHECK_LAUNCH("rows_bn_forward");
   return UBV_OK;
 }
 
-extern "C" int ubv_rows_bn_backward(const void* x, const void* grad_y, const float* gamma, const float* beta,
-                                    const float* mean, const float* rstd, float* partial, float* grad_gamma,
-                                    float* grad_beta, void* grad_x, int64_t N, int C, int relu, int dtype,
-                                    void* stream) {
+extern "C" int ubv_rows_bn_backward(const void* x, const void* grad_y, const void* y_out, const float* gamma,
+                                    const float* beta, const float* mean, const float* rstd, float* partial,
+                                    float* grad_gamma, float* grad_beta, void* grad_x, void* grad_residual, int64_t N,
+                                    int C, int relu, int dtype, void* stream) {
   using namespace ubv;
   UBV_CHECK_ARG(x && grad_y && gamma && beta && mean && rstd && partial && grad_gamma && grad_beta && grad_x && N > 0 &&
                     C > 0, "rows_bn_backward: bad arguments");
   UBV_CHECK_ARG(dtype >= 0 && dtype <= 2, "rows_bn_backward: unknown dtype %d", dtype);
+  UBV_CHECK_ARG((y_out == nullptr) == (grad_residual == nullptr), "rows_bn_backward: y_out and grad_residual come together");
   if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0) {
     set_error("rows_bn_backward: C=%d must be a multiple of 4 with C / 4 dividing 256", C);
     return UBV_ERR_UNSUPPORTED;
   }
   hipStream_t st = as_stream(stream);
-  if (dtype == UBV_F32) bn_backward_T<float>(x, grad_y, gamma, beta, mean, rstd, partial, grad_gamma, grad_beta, grad_x, N, C, relu, st);
-  else if (dtype == UBV_F16) bn_backward_T<f16_t>(x, grad_y, gamma, beta, mean, rstd, partial, grad_gamma, grad_beta, grad_x, N, C, relu, st);
-  else bn_backward_T<bf16_t>(x, grad_y, gamma, beta, mean, rstd, partial, grad_gamma, grad_beta, grad_x, N, C, relu, st);
+  if (dtype == UBV_F32) bn_backward_T<float>(x, grad_y, y_out, gamma, beta, mean, rstd, partial, grad_gamma, grad_beta, grad_x, grad_residual, N, C, relu, st);
+  else if (dtype == UBV_F16) bn_backward_T<f16_t>(x, grad_y, y_out, gamma, beta, mean, rstd, partial, grad_gamma, grad_beta, grad_x, grad_residual, N, C, relu, st);
+  else bn_backward_T<bf16_t>(x, grad_y, y_out, gamma, beta, mean, rstd, partial, grad_gamma, grad_beta, grad_x, grad_residual, N, C, relu, st);
   UBV_CHECK_LAUNCH("rows_bn_backward");
   return UBV_OK;
 }

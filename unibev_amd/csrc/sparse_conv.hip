@@ -508,6 +508,34 @@ static int spconv_launch(const void* feats, const int32_t* nbr, long ld, long ro
   return UBV_ERR_UNSUPPORTED;
 }
 
+// Weight blocks as stored by spconv, w [kvol][Cin][Cout], -> the product kernel's operand [kvol][rowsP][K]
+// (rowsP = rows padded to 32, zero rows past them) in ONE launch:  transpose != 0 (forward): rows = Cout, K = Cin,
+// op[k][co][ci] = w[k][ci][co];  transpose == 0 (input gradient): rows = Cin, K = Cout, op[k][ci][co] = w[k'][ci][co]
+// with k' = kvol - 1 - k when flip (submanifold layers read the forward map with mirrored offsets).  f32 weights come out
+// as bf16 hi + lo halves.  (Round 3: reshape / transpose / flip / pad / contiguous framework copies and a split kernel.)
+template <typename T>
+__global__ __launch_bounds__(256) void spc_weight_operand_kernel(const T* __restrict__ w, int kvol, int cin, int cout,
+                                                                 int rowsP, int transpose, int flip,
+                                                                 uint16_t* __restrict__ hi, uint16_t* __restrict__ lo) {
+  const int K = transpose ? cin : cout, rows = transpose ? cout : cin;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)kvol * rowsP * K) return;
+  const int c = (int)(t % K), r = (int)((t / K) % rowsP), k = (int)(t / ((long)K * rowsP));
+  const int ks = flip ? kvol - 1 - k : k;
+  if constexpr (sizeof(T) == 4) {
+    float v = 0.0f;
+    if (r < rows) v = transpose ? w[((long)ks * cin + c) * cout + r] : w[((long)ks * cin + r) * cout + c];
+    const uint16_t h = (uint16_t)float_to_bf16_bits(v);
+    hi[t] = h;
+    lo[t] = (uint16_t)float_to_bf16_bits(v - bf16_bits_to_float(h));
+  } else {
+    uint16_t v = 0;
+    const uint16_t* w16 = reinterpret_cast<const uint16_t*>(w);
+    if (r < rows) v = transpose ? w16[((long)ks * cin + c) * cout + r] : w16[((long)ks * cin + r) * cout + c];
+    hi[t] = v;
+  }
+}
+
 static bool sp_geom(SpGeom& g, int B, const int* in_dims, const int* tgt_dims, const int* ksize, const int* stride,
                     const int* pad, int mode) {
   g.B = B; g.mode = mode;
@@ -614,6 +642,27 @@ extern "C" int ubv_spconv_pairs(const int32_t* nbr, int64_t ld, int64_t rows, in
   hipLaunchKernelGGL(spc_pair_write_kernel, grid, dim3(256), 0, st, nbr, (long)ld, (long)rows, chunks,
                      (const int32_t*)chunk_sums, out_rows, in_rows);
   UBV_CHECK_LAUNCH("spconv_pairs");
+  return UBV_OK;
+}
+
+extern "C" int ubv_spconv_weight_operand(const void* w, int kvol, int Cin, int Cout, int transpose, int flip, int dtype,
+                                         void* w_hi, void* w_lo, void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(w && w_hi && kvol > 0 && Cin > 0 && Cout > 0, "spconv_weight_operand: bad arguments");
+  UBV_CHECK_ARG(dtype >= 0 && dtype <= 2, "spconv_weight_operand: unknown dtype %d", dtype);
+  UBV_CHECK_ARG((dtype == UBV_F32) == (w_lo != nullptr), "spconv_weight_operand: f32 weights come out as two halves (hi, lo)");
+  const int rows = transpose ? Cout : Cin, K = transpose ? Cin : Cout;
+  const int rowsP = (rows + 31) / 32 * 32;
+  const long total = (long)kvol * rowsP * K;
+  const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+  hipStream_t st = as_stream(stream);
+  if (dtype == UBV_F32)
+    hipLaunchKernelGGL(spc_weight_operand_kernel<float>, grid, blk, 0, st, (const float*)w, kvol, Cin, Cout, rowsP,
+                       transpose, flip, (uint16_t*)w_hi, (uint16_t*)w_lo);
+  else
+    hipLaunchKernelGGL(spc_weight_operand_kernel<uint16_t>, grid, blk, 0, st, (const uint16_t*)w, kvol, Cin, Cout, rowsP,
+                       transpose, flip, (uint16_t*)w_hi, (uint16_t*)nullptr);
+  UBV_CHECK_LAUNCH("spconv_weight_operand");
   return UBV_OK;
 }
 

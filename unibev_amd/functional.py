@@ -1178,7 +1178,8 @@ def spconv_strided_maps(coors, batch_size, in_dims, ksize, stride, pad, sites=No
 @torch.no_grad()
 def spconv_operand(w):
     """Weight blocks [kvol, Cout, Cin] (any float dtype) -> the kernel's operand: rows padded to a multiple of
-    32 per block; f32 -> (hi, lo) bf16 halves, 16-bit -> (w, None)."""
+    32 per block; f32 -> (hi, lo) bf16 halves, 16-bit -> (w, None).  (Generic form; the layers use
+    ``spconv_weight_operand`` on the stored layout.)"""
     kvol, cout, cin = w.shape
     coutp = (cout + 31) // 32 * 32
     if coutp != cout:
@@ -1188,6 +1189,24 @@ def spconv_operand(w):
         hi, lo, _, _ = split_weight(w.view(kvol * coutp, cin), transposed=False)
         return hi, lo
     return w, None
+
+
+@torch.no_grad()
+def spconv_weight_operand(w, transpose, flip=False):
+    """spconv's stored weight [kvol, Cin, Cout] -> ``spconv_gather_mma``'s operand in one launch
+    (``ubv_spconv_weight_operand``): ``transpose`` = forward ([kvol, CoutP, Cin]), else the input gradient's
+    ([kvol, CinP, Cout], offsets mirrored when ``flip``)."""
+    with _need_cuda(w):
+        w = w.contiguous()
+        kvol, cin, cout = w.shape
+        rows, K = (cout, cin) if transpose else (cin, cout)
+        rowsp = (rows + 31) // 32 * 32
+        f32 = w.dtype == torch.float32
+        hi = torch.empty(kvol, rowsp, K, dtype=torch.bfloat16 if f32 else w.dtype, device=w.device)
+        lo = torch.empty_like(hi) if f32 else None
+        check(lib().ubv_spconv_weight_operand(_p(w), kvol, cin, cout, 1 if transpose else 0, 1 if flip else 0, _dt(w),
+                                              _p(hi), _p(lo), _stream()), 'spconv_weight_operand')
+        return hi, lo
 
 
 @torch.no_grad()
@@ -1269,10 +1288,11 @@ class _RowsBatchNorm(Function):
     """BatchNorm1d (+ ReLU) over the rows of a sparse feature matrix (``ubv_rows_bn_forward`` / ``_backward``)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, residual=None):
         with _need_cuda(x, gamma, beta, running_mean, running_var):
             x = x.contiguous()
             N, C = x.shape
+            res = None if residual is None else residual.to(x.dtype).contiguous()
             g, b = gamma.float().contiguous(), beta.float().contiguous()
             y = torch.empty_like(x)
             if training:
@@ -1282,37 +1302,43 @@ class _RowsBatchNorm(Function):
                 mean = running_mean.float().contiguous()
                 rstd = torch.rsqrt(running_var.float() + eps).contiguous()
             part = _f32_scratch(int(lib().ubv_rows_bn_partial_elems(C)), x.device) if training else None
-            check(lib().ubv_rows_bn_forward(_p(x), _p(g), _p(b), _p(running_mean if training else None),
+            check(lib().ubv_rows_bn_forward(_p(x), _p(res), _p(g), _p(b), _p(running_mean if training else None),
                                             _p(running_var if training else None), _p(mean), _p(rstd), _p(part), _p(y),
                                             N, C, float(eps), float(momentum), int(relu), int(training), _dt(x),
                                             _stream()), 'rows_bn_forward')
-            ctx.save_for_backward(x, g, b, mean, rstd)
+            # (with a residual the ReLU mask of the backward is the stored output itself)
+            ctx.save_for_backward(x, g, b, mean, rstd, y if res is not None else None)
             ctx.relu, ctx.training, ctx.dts = int(relu), bool(training), (gamma.dtype, beta.dtype)
+            ctx.res_dt = None if residual is None else residual.dtype
             return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_y):
         with _need_cuda(grad_y):
-            x, g, b, mean, rstd = ctx.saved_tensors
+            x, g, b, mean, rstd, yout = ctx.saved_tensors
             N, C = x.shape
             gy = grad_y.to(x.dtype).contiguous()
             if not ctx.training:                 # running statistics are constants: an affine map (+ ReLU mask)
                 xh = (x.float() - mean) * rstd
-                dyp = gy.float() * ((xh * g + b) > 0) if ctx.relu else gy.float()
+                pos = (yout > 0) if yout is not None else ((xh * g + b) > 0)
+                dyp = gy.float() * pos if ctx.relu else gy.float()
                 return ((dyp * (g * rstd)).to(x.dtype), (dyp * xh).sum(0).to(ctx.dts[0]), dyp.sum(0).to(ctx.dts[1]),
-                        None, None, None, None, None, None)
+                        None, None, None, None, None, None, None if yout is None else dyp.to(ctx.res_dt))
             gx = torch.empty_like(x)
+            gres = torch.empty_like(x) if yout is not None else None
             dg = torch.empty(C, dtype=torch.float32, device=x.device)
             db = torch.empty(C, dtype=torch.float32, device=x.device)
             part = _f32_scratch(int(lib().ubv_rows_bn_partial_elems(C)), x.device)
-            check(lib().ubv_rows_bn_backward(_p(x), _p(gy), _p(g), _p(b), _p(mean), _p(rstd), _p(part), _p(dg), _p(db),
-                                             _p(gx), N, C, ctx.relu, _dt(x), _stream()), 'rows_bn_backward')
-            return gx, dg.to(ctx.dts[0]), db.to(ctx.dts[1]), None, None, None, None, None, None
+            check(lib().ubv_rows_bn_backward(_p(x), _p(gy), _p(yout), _p(g), _p(b), _p(mean), _p(rstd), _p(part), _p(dg),
+                                             _p(db), _p(gx), _p(gres), N, C, ctx.relu, _dt(x), _stream()),
+                  'rows_bn_backward')
+            return (gx, dg.to(ctx.dts[0]), db.to(ctx.dts[1]), None, None, None, None, None, None,
+                    None if gres is None else gres.to(ctx.res_dt))
 
 
-def rows_batch_norm(x, bn, relu=False):
-    """``relu?(bn(x))`` for a ``torch.nn.BatchNorm1d`` ``bn`` over the rows of ``x`` [N, C] in one fused pass each way;
+def rows_batch_norm(x, bn, relu=False, residual=None):
+    """``relu?(bn(x) (+ residual))`` for a ``torch.nn.BatchNorm1d`` ``bn`` over the rows of ``x`` [N, C] in one fused pass each way;
     updates ``bn``'s running statistics in training mode exactly as the module would (momentum, unbiased variance,
     ``num_batches_tracked``).  None when the shape is outside the kernels' reach (caller uses the module)."""
     C = x.shape[1]
@@ -1327,14 +1353,42 @@ def rows_batch_norm(x, bn, relu=False):
     if bn.track_running_stats and bn.running_mean is not None and \
             (bn.running_mean.dtype != torch.float32 or bn.running_var.dtype != torch.float32):
         return None
+    if residual is not None and (residual.shape != x.shape or not residual.is_cuda):
+        return None
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        if _BN_TICKS is not None:
+            _BN_TICKS.append(bn.num_batches_tracked)           # (one fused increment per encoder pass)
+        else:
+            bn.num_batches_tracked.add_(1)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     if not training and rm is None:
         return None
     return _RowsBatchNorm.apply(x, bn.weight, bn.bias, rm, rv, training, bn.momentum if bn.momentum is not None else 0.0,
-                                bn.eps, relu)
+                                bn.eps, relu, residual)
+
+
+_BN_TICKS = None
+
+
+class batched_bn_ticks:
+    """Inside this context ``rows_batch_norm`` collects the ``num_batches_tracked`` counters it would increment and the
+    exit adds 1 to all of them in one multi-tensor launch (21 tiny kernels per middle-encoder pass otherwise)."""
+
+    def __enter__(self):
+        global _BN_TICKS
+        self._outer, _BN_TICKS = _BN_TICKS, []
+        return self
+
+    def __exit__(self, *exc):
+        global _BN_TICKS
+        ticks, _BN_TICKS = _BN_TICKS, self._outer
+        if ticks:
+            if self._outer is not None:
+                self._outer.extend(ticks)
+            else:
+                torch._foreach_add_(ticks, 1)
+        return False
 
 
 # ----------------------------------------------------------------------------------------------- GridMask

@@ -76,7 +76,7 @@ class _SparseConv(Function):
         kvol = nbr_fwd.shape[0]
         cin, cout = weight.shape[-2], weight.shape[-1]
         w = weight.detach().reshape(kvol, cin, cout).to(feats.dtype)
-        hi, lo = UF.spconv_operand(w.transpose(1, 2))          # [kvol, Cout, Cin]: K-contiguous blocks
+        hi, lo = UF.spconv_weight_operand(w, transpose=True)   # [kvol, Cout, Cin]: K-contiguous blocks
         out = UF.spconv_gather_mma(feats, nbr_fwd, hi, lo, cout)
         ctx.save_for_backward(feats, weight, nbr_fwd, nbr_bwd if nbr_bwd is not None else nbr_fwd)
         ctx.subm = nbr_bwd is None
@@ -92,9 +92,9 @@ class _SparseConv(Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             w = weight.detach().reshape(kvol, cin, cout).to(g.dtype)
-            if ctx.subm:
-                w = w.flip(0)          # j is o's neighbour at offset k  <=>  o is j's neighbour at kvol - 1 - k
-            hi, lo = UF.spconv_operand(w)                      # [kvol, Cin (out), Cout (in)] as stored
+            # [kvol, Cin (out), Cout (in)] as stored; submanifold: j is o's neighbour at offset k  <=>  o is j's
+            # neighbour at kvol - 1 - k
+            hi, lo = UF.spconv_weight_operand(w, transpose=False, flip=ctx.subm)
             gx = UF.spconv_gather_mma(g, nbr_bwd, hi, lo, cin)
         if ctx.needs_input_grad[1]:
             # compacted (output row, input row) pairs per offset — spconv's rulebook form: ~70 % of the (row, offset)
@@ -268,11 +268,13 @@ class SparseBasicBlock(nn.Module):
         y = UF.rows_batch_norm(out.features, self.bn1, relu=True)
         out = out.replace(y if y is not None else self.relu(self.bn1(out.features)))
         out = self.conv2(out)
-        f = UF.rows_batch_norm(out.features, self.bn2, relu=False)
-        if f is None:
-            f = self.bn2(out.features)
         if self.downsample is not None:
             identity = self.downsample(x).features
+        # relu(bn2(.) + identity) as one pass each way (the residual operand of the rows BatchNorm)
+        f = UF.rows_batch_norm(out.features, self.bn2, relu=True, residual=identity)
+        if f is not None:
+            return out.replace(f)
+        f = self.bn2(out.features)
         return out.replace(self.relu(f + identity.to(f.dtype)))
 
 
@@ -371,10 +373,11 @@ class SparseEncoder(nn.Module):
         if not indice_dict:
             self._plan_sites(coors, batch_size, indice_dict)
         x = SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size, indice_dict)
-        x = self.conv_input(x)
-        for stage in self.encoder_layers:
-            x = stage(x)
-        out = self.conv_out(x)
+        with UF.batched_bn_ticks():
+            x = self.conv_input(x)
+            for stage in self.encoder_layers:
+                x = stage(x)
+            out = self.conv_out(x)
         dense = out.dense()
         N, C, D, H, W = dense.shape
         return dense.view(N, C * D, H, W)
