@@ -580,9 +580,8 @@ def voxel_record(device):
     for nb in (2, 8):
         clouds = [torch.from_numpy(syn.lidar_points(30000, seed=s)).to(device) for s in range(nb)]
 
-        def front_b():
-            v, c, n, m_ = UF.hard_voxelize_batch(clouds, syn.VOXEL_SIZE, syn.PC_RANGE, 10, 90000)
-            return UF.voxel_mean(v.view(-1, 10, F), n.view(-1))
+        def front_b():             # (the VFE mean rides in the chain's gather launch: what extract_pts_feat runs)
+            return UF.hard_voxelize_batch(clouds, syn.VOXEL_SIZE, syn.PC_RANGE, 10, 90000, with_mean=True)[4]
         for _ in range(3):
             front_b()
         e0.record()
@@ -593,8 +592,9 @@ def voxel_record(device):
         batch[f'us_per_cloud_batch{nb}'] = 1e3 * e0.elapsed_time(e1) / 10 / nb
     rec = {'points': N, 'voxels': m, 'us_per_cloud': us, 'points_per_s': N / us * 1e6,
            'algorithmic_bytes': nbytes, 'GBps': nbytes / us / 1e3, **batch,
-           'note': 'hard voxelize + VFE mean; one cloud per chain (us_per_cloud) is latency-bound: 8 launches + 2 '
-                   'fills; a batch shares the chain (us_per_cloud_batchN)'}
+           'note': 'hard voxelize + VFE mean; one cloud per chain (us_per_cloud: ubv_hard_voxelize + ubv_voxel_mean, '
+                   '6 launches) is latency-bound; a batch shares one 5-launch chain with the mean written by its gather '
+                   '(us_per_cloud_batchN: ubv_hard_voxelize_batch_vfe)'}
     rec['middle_encoder'] = middle_encoder_record(device, mean[:m], coors[:m])
     return rec
 

@@ -422,6 +422,13 @@ int ubv_hard_voxelize_batch(const float* const* points_host, const int* n_host, 
                             int32_t* num_points, int32_t* voxel_num, void* workspace, int64_t workspace_bytes, int F,
                             const float* voxel_size_host, const float* range_host, int max_points, int max_voxels,
                             void* stream);
+/* The same chain with [ext] HardSimpleVFE on the way (models/detectors/unibev_detector.py:117, `pts_voxel_encoder`):
+ * mean [B, max_voxels, F] f32 = the sum of each voxel's stored points / num_points (rows past voxel_num zero), written
+ * by the gather launch — bit-identical to ubv_voxel_mean on the voxel slab. */
+int ubv_hard_voxelize_batch_vfe(const float* const* points_host, const int* n_host, int B, float* voxels, int32_t* coors,
+                                int32_t* num_points, int32_t* voxel_num, float* mean, void* workspace,
+                                int64_t workspace_bytes, int F, const float* voxel_size_host, const float* range_host,
+                                int max_points, int max_voxels, void* stream);
 
 /* [ext] mmdet3d dynamic_voxelize: coors [N, 3] int32 (z, y, x), or (-1,-1,-1) when outside. */
 int ubv_dynamic_voxelize(const float* points, int32_t* coors, int N, int F,
@@ -449,7 +456,7 @@ int ubv_dynamic_point_to_voxel_forward(const float* feats, const int32_t* coors,
                                        void* stream);
 
 /* [ext] HardSimpleVFE: mean [M, F] = voxels[:, :, :F].sum(1) / num_points.  M is read from the
- * device counter `voxel_num` (rows >= *voxel_num are left untouched); max_voxels bounds the launch. */
+ * device counter `voxel_num` (rows >= *voxel_num are written as zeros); max_voxels bounds the launch. */
 int ubv_voxel_mean(const float* voxels, const int32_t* num_points, const int32_t* voxel_num,
                    float* mean, int max_voxels, int max_points, int F, void* stream);
 

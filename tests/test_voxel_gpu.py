@@ -230,3 +230,27 @@ def test_hard_voxelize_batch_is_bit_identical_to_per_sample_calls():
     assert torch.equal(voxels, torch.cat([p[0] for p in per])) and torch.equal(num, torch.cat([p[2] for p in per]))
     assert torch.equal(coors[:, 1:], torch.cat([p[1] for p in per]))
     assert coors[:, 0].tolist() == sum(([b] * len(p[1]) for b, p in enumerate(per)), [])
+
+
+def test_voxelization_chain_with_the_vfe_mean_on_the_way():
+    """``ubv_hard_voxelize_batch_vfe``: the HardSimpleVFE means written by the chain's gather launch equal
+    ``ubv_voxel_mean`` of the voxel slab bit for bit (dense voxels with up to T points, a voxel cap that bites, an empty
+    cloud), rows past the count are zero, and ``extract_pts_feat`` takes them from there."""
+    from unibev_amd.functional import hard_voxelize_batch, voxel_mean
+    from unibev_amd.modules.voxel import HardSimpleVFE, Voxelization, voxelize_cat
+    rs = np.random.RandomState(5)
+    dense = np.concatenate([rs.uniform(-2, 2, (40000, 2)), rs.uniform(-1.5, -0.5, (40000, 1)),
+                            rs.uniform(0, 1, (40000, 2))], 1).astype(np.float32)
+    clouds = [syn.lidar_points(30000, seed=6), dense, np.zeros((0, 5), np.float32)]
+    dev = [t(c, device=DEV) for c in clouds]
+    for cap in (90000, 700):
+        v, c, n, m, mean = hard_voxelize_batch(dev, syn.VOXEL_SIZE, syn.PC_RANGE, 10, cap, with_mean=True)
+        v0, c0, n0, m0 = hard_voxelize_batch(dev, syn.VOXEL_SIZE, syn.PC_RANGE, 10, cap)
+        assert torch.equal(v, v0) and torch.equal(n, n0) and torch.equal(m, m0) and torch.equal(c, c0)
+        for b in range(len(clouds)):
+            ref = voxel_mean(v[b], n[b], m[b:b + 1])
+            assert torch.equal(mean[b], ref)
+            assert torch.all(mean[b, int(m[b]):] == 0)
+    layer = Voxelization(syn.VOXEL_SIZE, syn.PC_RANGE, 10, (90000, 120000)).eval()
+    voxels, num, coors, mean = voxelize_cat(layer, dev, with_mean=True)
+    assert torch.equal(mean[:, :4].contiguous(), HardSimpleVFE(4)(voxels, num, coors))

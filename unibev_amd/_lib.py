@@ -89,6 +89,8 @@ SIGNATURES = {
     'ubv_hard_voxelize_batch_workspace': (c_int64, [c_int, c_int, c_int, c_int]),
     'ubv_hard_voxelize_batch': (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, c_int64, c_int, ctypes.POINTER(c_float),
                                         ctypes.POINTER(c_float), c_int, c_int, _P]),
+    'ubv_hard_voxelize_batch_vfe': (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int, ctypes.POINTER(c_float),
+                                            ctypes.POINTER(c_float), c_int, c_int, _P]),
     'ubv_hard_voxelize': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int,
                                   ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_int,
                                   _P]),

@@ -73,75 +73,7 @@ __device__ __forceinline__ void vox_key_insert_body(const int bid,
   }
 }
 
-// head[i] = 1 iff point i is the first point of its voxel; first[i] = first point of i's voxel.
-__device__ __forceinline__ void vox_head_body(const int bid, 
-    const uint32_t* __restrict__ keys, int N, const unsigned long long* __restrict__ table,
-    uint32_t mask, int* __restrict__ first, int* __restrict__ head) {
-  const int i = bid * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const uint32_t key = keys[i];
-  int f = -1;
-  if (key != kBadKey) {
-    uint32_t h = hash_u32(key) & mask;
-    for (;;) {
-      const unsigned long long cur = table[h];
-      if ((uint32_t)(cur >> 32) == key) { f = (int)(uint32_t)cur; break; }
-      h = (h + 1) & mask;
-    }
-  }
-  first[i] = f;
-  head[i] = (f == i) ? 1 : 0;
-}
-
-// ---- exclusive scan over int32 (3 kernels: per-block, block sums, add) ------------------------------
-constexpr int kScanBlock = 1024;
-
-__device__ __forceinline__ void scan_block_body(const int bid, const int* __restrict__ in,
-                                                         int* __restrict__ out,
-                                                         int* __restrict__ sums, int N) {
-  __shared__ int wave_tot[4];
-  const int base = bid * kScanBlock + threadIdx.x * 4;
-  int v[4], s = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { v[k] = (base + k < N) ? in[base + k] : 0; s += v[k]; }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int incl = s;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int t = __shfl_up(incl, d, 64);
-    if (lane >= d) incl += t;
-  }
-  if (lane == 63) wave_tot[wv] = incl;
-  __syncthreads();
-  int off = 0;
-  for (int w = 0; w < wv; ++w) off += wave_tot[w];
-  int run = off + incl - s;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (base + k < N) out[base + k] = run;
-    run += v[k];
-  }
-  if (threadIdx.x == 255) sums[bid] = off + incl;
-}
-
-__device__ __forceinline__ void scan_sums_body(int* __restrict__ sums, int nblocks, int* __restrict__ total,
-                                 int clamp) {
-  // one wave, sequential over chunks of 64 block sums
-  const int lane = threadIdx.x;
-  int carry = 0;
-  for (int base = 0; base < nblocks; base += 64) {
-    const int v = (base + lane < nblocks) ? sums[base + lane] : 0;
-    int incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int t = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += t;
-    }
-    if (base + lane < nblocks) sums[base + lane] = carry + incl - v;
-    carry += __shfl(incl, 63, 64);
-  }
-  if (lane == 0) *total = carry < clamp ? carry : clamp;
-}
+constexpr int kScanBlock = 1024;        // points per block of the head-flag scan
 
 // Adds the block offsets and, per point, pushes it into its voxel's slot chain.
 __device__ __forceinline__ void vox_assign_body(const int bid, 
@@ -173,22 +105,38 @@ __device__ __forceinline__ void vox_assign_body(const int bid,
 __device__ __forceinline__ void vox_gather_body(const int bid, 
     const float* __restrict__ points, int F, const int* __restrict__ slots,
     const int* __restrict__ voxel_num, int max_points, float* __restrict__ voxels,
-    int32_t* __restrict__ num_points, int max_voxels) {
-  // one thread per (voxel, slot, feature)
+    int32_t* __restrict__ num_points, int32_t* __restrict__ coors, float* __restrict__ mean, int max_voxels) {
+  // one thread per (voxel, slot): the point's F features (round 1: one thread per feature — 5x the threads, each
+  // re-reading the slot)
   const long t = (long)bid * blockDim.x + threadIdx.x;
-  const long per_v = (long)max_points * F;
-  if (t >= (long)max_voxels * per_v) return;
-  const int v = (int)(t / per_v);
-  const int r = (int)(t - (long)v * per_v);
-  const int slot = r / F, f = r - slot * F;
+  if (t >= (long)max_voxels * max_points) return;
+  const int v = (int)(t / max_points);
+  const int slot = (int)(t - (long)v * max_points);
   const bool live = v < *voxel_num;
-  const int idx = live ? slots[(long)v * max_points + slot] : kSlotEmpty;
-  voxels[t] = (idx != kSlotEmpty) ? points[(long)idx * F + f] : 0.0f;
-  if (r == 0) {
+  const int idx = live ? slots[t] : kSlotEmpty;
+  float* out = voxels + t * F;
+  if (idx != kSlotEmpty) {
+    const float* p = points + (long)idx * F;
+    for (int f = 0; f < F; ++f) out[f] = p[f];
+  } else {
+    for (int f = 0; f < F; ++f) out[f] = 0.0f;
+  }
+  if (slot == 0) {
     int n = 0;
     if (live)
       for (int k = 0; k < max_points; ++k) n += slots[(long)v * max_points + k] != kSlotEmpty;
+    else
+      coors[3 * (long)v] = coors[3 * (long)v + 1] = coors[3 * (long)v + 2] = 0;      // (rows past the count: zeros)
     num_points[v] = n;
+    if (mean != nullptr) {
+      // HardSimpleVFE on the way: sum of the stored points in slot order (the valid slots come first, ascending) / n —
+      // the additions ubv_voxel_mean makes, the zero padding left out
+      for (int f = 0; f < F; ++f) {
+        float sum = 0.0f;
+        for (int k = 0; k < n; ++k) sum += points[(long)slots[(long)v * max_points + k] * F + f];
+        mean[(long)v * F + f] = n > 0 ? sum / (float)n : 0.0f;
+      }
+    }
   }
 }
 
@@ -200,69 +148,117 @@ struct VoxBatch {
   const float* points[kVoxMaxBatch];
   int n[kVoxMaxBatch];
   long ws_stride;                 // bytes of workspace per sample
-  long key_off, first_off, head_off, scan_off, sums_off, table_off, slots_off;   // offsets inside a sample's workspace
+  long key_off, first_off, scan_off, sums_off, table_off, slots_off;   // offsets inside a sample's workspace
   uint32_t mask;                  // table capacity - 1 (sized for the largest cloud)
 };
 
-__global__ __launch_bounds__(256) void vox_key_insert_kernel(const float* __restrict__ points, int N, int F, VoxGeom g,
-                                                             uint32_t* __restrict__ keys,
-                                                             unsigned long long* __restrict__ table, uint32_t mask) {
-  vox_key_insert_body(blockIdx.x, points, N, F, g, keys, table, mask);
-}
-__global__ __launch_bounds__(256) void vox_head_kernel(const uint32_t* __restrict__ keys, int N,
-                                                       const unsigned long long* __restrict__ table, uint32_t mask,
-                                                       int* __restrict__ first, int* __restrict__ head) {
-  vox_head_body(blockIdx.x, keys, N, table, mask, first, head);
-}
-__global__ __launch_bounds__(256) void scan_block_kernel(const int* __restrict__ in, int* __restrict__ out,
-                                                         int* __restrict__ sums, int N) {
-  scan_block_body(blockIdx.x, in, out, sums, N);
-}
-__global__ void scan_sums_kernel(int* __restrict__ sums, int nblocks, int* __restrict__ total, int clamp) {
-  scan_sums_body(sums, nblocks, total, clamp);
-}
-__global__ __launch_bounds__(256) void vox_assign_kernel(const uint32_t* __restrict__ keys, const int* __restrict__ first,
-                                                         const int* __restrict__ scan, const int* __restrict__ sums, int N,
-                                                         VoxGeom g, int max_points, int max_voxels, int* __restrict__ slots,
-                                                         int32_t* __restrict__ coors) {
-  vox_assign_body(blockIdx.x, keys, first, scan, sums, N, g, max_points, max_voxels, slots, coors);
-}
-__global__ __launch_bounds__(256) void vox_gather_kernel(const float* __restrict__ points, int F, const int* __restrict__ slots,
-                                                         const int* __restrict__ voxel_num, int max_points,
-                                                         float* __restrict__ voxels, int32_t* __restrict__ num_points,
-                                                         int max_voxels) {
-  vox_gather_body(blockIdx.x, points, F, slots, voxel_num, max_points, voxels, num_points, max_voxels);
-}
-
 #define UBV_VOX_WS(type, off) ((type*)(ws + (long)blockIdx.y * vb.ws_stride + vb.off))
+// The chain is FIVE launches for any batch (round 3: 2 fills per cloud + 8 kernels; a 30 000-point cloud is ~20 us of
+// kernel work, so the chain's time was its launch gaps):
+//   fill (tables 0xFF.., slot chains 0x7f7f7f7f, every sample) | keys + insert | head flags + per-1024 scan (one
+//   block owns its 1024 points: no pass between them) | block-sum scan in LDS by every block + slot chains +
+//   coordinates + voxel count | gather.
+// (One cooperative kernel with grid-wide barriers between the phases measured SLOWER — 113 us against 68 for the
+//  chain at 120 k voxels: each barrier is an agent-scope release / acquire across the 8 XCDs' L2s, ~12 us.)
+constexpr int kVoxMaxScanBlocks = 1024;                    // block sums scanned in LDS: clouds up to 1 M points
+
+__global__ __launch_bounds__(256) void vox_fill_batch_kernel(VoxBatch vb, char* ws, long table_bytes, long slot_bytes) {
+  uint4* t = UBV_VOX_WS(uint4, table_off);
+  const uint4 ff = make_uint4(~0u, ~0u, ~0u, ~0u);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < table_bytes / 16; i += (long)gridDim.x * 256) t[i] = ff;
+  uint4* sl = UBV_VOX_WS(uint4, slots_off);
+  const uint4 e = make_uint4((uint32_t)kSlotEmpty, (uint32_t)kSlotEmpty, (uint32_t)kSlotEmpty, (uint32_t)kSlotEmpty);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < slot_bytes / 16; i += (long)gridDim.x * 256) sl[i] = e;
+}
 __global__ __launch_bounds__(256) void vox_key_insert_batch_kernel(VoxBatch vb, char* ws, int F, VoxGeom g) {
   vox_key_insert_body(blockIdx.x, vb.points[blockIdx.y], vb.n[blockIdx.y], F, g, UBV_VOX_WS(uint32_t, key_off),
                       UBV_VOX_WS(unsigned long long, table_off), vb.mask);
 }
-__global__ __launch_bounds__(256) void vox_head_batch_kernel(VoxBatch vb, char* ws) {
-  vox_head_body(blockIdx.x, UBV_VOX_WS(uint32_t, key_off), vb.n[blockIdx.y], UBV_VOX_WS(unsigned long long, table_off),
-                vb.mask, UBV_VOX_WS(int, first_off), UBV_VOX_WS(int, head_off));
-}
-__global__ __launch_bounds__(256) void scan_block_batch_kernel(VoxBatch vb, char* ws) {
-  scan_block_body(blockIdx.x, UBV_VOX_WS(int, head_off), UBV_VOX_WS(int, scan_off), UBV_VOX_WS(int, sums_off),
-                  vb.n[blockIdx.y]);
-}
-__global__ void scan_sums_batch_kernel(VoxBatch vb, char* ws, int* __restrict__ voxel_num, int clamp) {
+// blockIdx.x = one 1024-point scan block.  A thread looks up the first points of ITS four consecutive points (the four
+// probes in flight together), keeps the head flags in registers and scans them: the flags never go through memory.
+__global__ __launch_bounds__(256) void vox_head_scan_batch_kernel(VoxBatch vb, char* ws) {
+  __shared__ int wave_tot[4];
   const int n = vb.n[blockIdx.y];
-  scan_sums_body(UBV_VOX_WS(int, sums_off), (n + kScanBlock - 1) / kScanBlock, voxel_num + blockIdx.y, clamp);
+  const uint32_t* __restrict__ keys = UBV_VOX_WS(uint32_t, key_off);
+  const unsigned long long* __restrict__ table = UBV_VOX_WS(unsigned long long, table_off);
+  int* __restrict__ first = UBV_VOX_WS(int, first_off);
+  int* __restrict__ scan = UBV_VOX_WS(int, scan_off);
+  const int base = blockIdx.x * kScanBlock + threadIdx.x * 4;
+  uint32_t key[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) key[k] = base + k < n ? keys[base + k] : kBadKey;
+  int v[4], s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int f = -1;
+    if (key[k] != kBadKey) {
+      uint32_t h = hash_u32(key[k]) & vb.mask;
+      for (;;) {
+        const unsigned long long cur = table[h];
+        if ((uint32_t)(cur >> 32) == key[k]) { f = (int)(uint32_t)cur; break; }
+        h = (h + 1) & vb.mask;
+      }
+    }
+    if (base + k < n) first[base + k] = f;
+    v[k] = (f == base + k && f >= 0) ? 1 : 0;
+    s += v[k];
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int incl = s;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wave_tot[wv] = incl;
+  __syncthreads();
+  int off = 0;
+  for (int w = 0; w < wv; ++w) off += wave_tot[w];
+  int run = off + incl - s;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (base + k < n) scan[base + k] = run;
+    run += v[k];
+  }
+  if (threadIdx.x == 255) UBV_VOX_WS(int, sums_off)[blockIdx.x] = off + incl;
 }
 __global__ __launch_bounds__(256) void vox_assign_batch_kernel(VoxBatch vb, char* ws, VoxGeom g, int max_points,
-                                                               int max_voxels, int32_t* __restrict__ coors) {
-  vox_assign_body(blockIdx.x, UBV_VOX_WS(uint32_t, key_off), UBV_VOX_WS(int, first_off), UBV_VOX_WS(int, scan_off),
-                  UBV_VOX_WS(int, sums_off), vb.n[blockIdx.y], g, max_points, max_voxels, UBV_VOX_WS(int, slots_off),
-                  coors + (long)blockIdx.y * max_voxels * 3);
+                                                               int max_voxels, int32_t* __restrict__ coors,
+                                                               int32_t* __restrict__ voxel_num) {
+  // every block scans the block sums itself (at most kVoxMaxScanBlocks of them): no pass of its own
+  __shared__ int s_pre[kVoxMaxScanBlocks];
+  const int n = vb.n[blockIdx.y], sb = (n + kScanBlock - 1) / kScanBlock;
+  const int* sums = UBV_VOX_WS(int, sums_off);
+  for (int i = threadIdx.x; i < sb; i += 256) s_pre[i] = sums[i];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    int carry = 0;
+    for (int base = 0; base < sb; base += 64) {
+      const int v = (base + lane < sb) ? s_pre[base + lane] : 0;
+      int incl = v;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+      }
+      if (base + lane < sb) s_pre[base + lane] = carry + incl - v;
+      carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0 && blockIdx.x == 0) voxel_num[blockIdx.y] = carry < max_voxels ? carry : max_voxels;
+  }
+  __syncthreads();
+  vox_assign_body(blockIdx.x, UBV_VOX_WS(uint32_t, key_off), UBV_VOX_WS(int, first_off), UBV_VOX_WS(int, scan_off), s_pre, n,
+                  g, max_points, max_voxels, UBV_VOX_WS(int, slots_off), coors + (long)blockIdx.y * max_voxels * 3);
 }
 __global__ __launch_bounds__(256) void vox_gather_batch_kernel(VoxBatch vb, char* ws, int F, const int* __restrict__ voxel_num,
                                                                int max_points, float* __restrict__ voxels,
-                                                               int32_t* __restrict__ num_points, int max_voxels) {
+                                                               int32_t* __restrict__ num_points, int32_t* __restrict__ coors,
+                                                               float* __restrict__ mean, int max_voxels) {
   vox_gather_body(blockIdx.x, vb.points[blockIdx.y], F, UBV_VOX_WS(int, slots_off), voxel_num + blockIdx.y, max_points,
                   voxels + (long)blockIdx.y * max_voxels * max_points * F, num_points + (long)blockIdx.y * max_voxels,
-                  max_voxels);
+                  coors + (long)blockIdx.y * max_voxels * 3,
+                  mean != nullptr ? mean + (long)blockIdx.y * max_voxels * F : nullptr, max_voxels);
 }
 #undef UBV_VOX_WS
 
@@ -286,7 +282,7 @@ __global__ __launch_bounds__(256) void voxel_mean_kernel(const float* __restrict
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long)max_voxels * F) return;
   const int v = (int)(t / F), f = (int)(t - (long)v * F);
-  if (voxel_num != nullptr && v >= *voxel_num) return;
+  if (voxel_num != nullptr && v >= *voxel_num) { mean[t] = 0.0f; return; }
   float s = 0.0f;
   for (int k = 0; k < T; ++k) s += voxels[((long)v * T + k) * F + f];
   const int np_ = num_points[v];
@@ -325,7 +321,7 @@ static uint32_t table_capacity(int N) {
 }
 
 struct VoxWs {
-  size_t keys, first, head, scan, sums, table, slots, total;
+  size_t keys, first, scan, sums, table, slots, total;
 };
 static VoxWs vox_layout(int N, int max_points, int max_voxels) {
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -334,13 +330,41 @@ static VoxWs vox_layout(int N, int max_points, int max_voxels) {
   const size_t n = (size_t)(N > 0 ? N : 1);
   w.keys = o; o += up(n * 4);
   w.first = o; o += up(n * 4);
-  w.head = o; o += up(n * 4);
   w.scan = o; o += up(n * 4);
   w.sums = o; o += up(((n + kScanBlock - 1) / kScanBlock) * 4);
   w.table = o; o += up((size_t)table_capacity(N) * 8);
   w.slots = o; o += up((size_t)max_voxels * max_points * 4);
   w.total = o;
   return w;
+}
+
+
+// the five launches over B samples (vb filled by the caller)
+static int vox_run(VoxBatch& vb, int B, int n_max, char* ws, const VoxWs& w, int F, const VoxGeom& g, int max_points,
+                   int max_voxels, float* voxels, int32_t* coors, int32_t* num_points, int32_t* voxel_num, float* mean,
+                   hipStream_t st) {
+  vb.ws_stride = (long)w.total;
+  vb.key_off = (long)w.keys; vb.first_off = (long)w.first; vb.scan_off = (long)w.scan;
+  vb.sums_off = (long)w.sums; vb.table_off = (long)w.table; vb.slots_off = (long)w.slots;
+  vb.mask = table_capacity(n_max) - 1;
+  const int nb = (n_max + 255) / 256, sb = (n_max + kScanBlock - 1) / kScanBlock;
+  if (sb > kVoxMaxScanBlocks) return UBV_ERR_UNSUPPORTED;
+  const long table_bytes = (long)(w.slots - w.table), slot_bytes = (long)(w.total - w.slots);
+  const long fill16 = (table_bytes + slot_bytes) / 16;
+  const unsigned fb = (unsigned)((fill16 / 4 + 255) / 256);                  // ~4 stores of 16 bytes per thread
+  hipLaunchKernelGGL(vox_fill_batch_kernel, dim3(fb < 1 ? 1 : (fb > 1024 ? 1024 : fb), B), dim3(256), 0, st, vb, ws,
+                     table_bytes, slot_bytes);
+  if (n_max > 0) {
+    hipLaunchKernelGGL(vox_key_insert_batch_kernel, dim3(nb, B), dim3(256), 0, st, vb, ws, F, g);
+    hipLaunchKernelGGL(vox_head_scan_batch_kernel, dim3(sb, B), dim3(256), 0, st, vb, ws);
+  }
+  // (no points: one block per sample still writes voxel_num = 0)
+  hipLaunchKernelGGL(vox_assign_batch_kernel, dim3(nb > 0 ? nb : 1, B), dim3(256), 0, st, vb, ws, g, max_points, max_voxels,
+                     coors, voxel_num);
+  const long nt = (long)max_voxels * max_points;
+  hipLaunchKernelGGL(vox_gather_batch_kernel, dim3((unsigned)((nt + 255) / 256), B), dim3(256), 0, st, vb, ws, F, voxel_num,
+                     max_points, voxels, num_points, coors, mean, max_voxels);
+  return UBV_OK;
 }
 
 }  // namespace ubv
@@ -366,52 +390,27 @@ extern "C" int ubv_hard_voxelize(const float* points, float* voxels, int32_t* co
   const VoxWs w = vox_layout(N, max_points, max_voxels);
   UBV_CHECK_ARG(workspace_bytes >= (int64_t)w.total, "hard_voxelize: workspace %lld < %lld bytes",
                 (long long)workspace_bytes, (long long)w.total);
-  hipStream_t st = as_stream(stream);
-  char* ws = (char*)workspace;
-  uint32_t* keys = (uint32_t*)(ws + w.keys);
-  int* first = (int*)(ws + w.first);
-  int* head = (int*)(ws + w.head);
-  int* scan = (int*)(ws + w.scan);
-  int* sums = (int*)(ws + w.sums);
-  unsigned long long* table = (unsigned long long*)(ws + w.table);
-  int* slots = (int*)(ws + w.slots);
-  const uint32_t cap = table_capacity(N);
-  if (hipMemsetAsync(table, 0xFF, (size_t)cap * 8, st) != hipSuccess ||
-      hipMemsetAsync(slots, 0x7f, (size_t)max_voxels * max_points * 4, st) != hipSuccess) {
-    set_error("hard_voxelize: memset failed");
-    return UBV_ERR_LAUNCH;
+  VoxBatch vb{};
+  vb.points[0] = points;
+  vb.n[0] = N;
+  if (vox_run(vb, 1, N, (char*)workspace, w, F, g, max_points, max_voxels, voxels, coors, num_points, voxel_num, nullptr,
+              as_stream(stream)) != UBV_OK) {
+    set_error("hard_voxelize: clouds of more than %d points are not supported", kVoxMaxScanBlocks * kScanBlock);
+    return UBV_ERR_UNSUPPORTED;
   }
-  const int nb = (N + 255) / 256;
-  const int sb = (N + kScanBlock - 1) / kScanBlock;
-  if (N > 0) {
-    hipLaunchKernelGGL(vox_key_insert_kernel, dim3(nb), dim3(256), 0, st, points, N, F, g, keys,
-                       table, cap - 1);
-    hipLaunchKernelGGL(vox_head_kernel, dim3(nb), dim3(256), 0, st, keys, N, table, cap - 1, first,
-                       head);
-    hipLaunchKernelGGL(scan_block_kernel, dim3(sb), dim3(256), 0, st, head, scan, sums, N);
-  }
-  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(64), 0, st, sums, N > 0 ? sb : 0, voxel_num,
-                     max_voxels);
-  if (N > 0)
-    hipLaunchKernelGGL(vox_assign_kernel, dim3(nb), dim3(256), 0, st, keys, first, scan, sums, N, g,
-                       max_points, max_voxels, slots, coors);
-  const long nt = (long)max_voxels * max_points * F;
-  hipLaunchKernelGGL(vox_gather_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, points,
-                     F, slots, voxel_num, max_points, voxels, num_points, max_voxels);
   UBV_CHECK_LAUNCH("hard_voxelize");
   return UBV_OK;
 }
-
 
 extern "C" int64_t ubv_hard_voxelize_batch_workspace(int B, int n_max, int max_points, int max_voxels) {
   if (B <= 0 || B > ubv::kVoxMaxBatch || n_max < 0 || max_points <= 0 || max_voxels <= 0) return -1;
   return (int64_t)B * (int64_t)ubv::vox_layout(n_max, max_points, max_voxels).total;
 }
 
-extern "C" int ubv_hard_voxelize_batch(const float* const* points_host, const int* n_host, int B, float* voxels,
-                                       int32_t* coors, int32_t* num_points, int32_t* voxel_num, void* workspace,
-                                       int64_t workspace_bytes, int F, const float* voxel_size_host,
-                                       const float* range_host, int max_points, int max_voxels, void* stream) {
+static int hard_voxelize_batch_impl(const float* const* points_host, const int* n_host, int B, float* voxels,
+                                    int32_t* coors, int32_t* num_points, int32_t* voxel_num, float* mean, void* workspace,
+                                    int64_t workspace_bytes, int F, const float* voxel_size_host,
+                                    const float* range_host, int max_points, int max_voxels, void* stream) {
   using namespace ubv;
   UBV_CHECK_ARG(points_host && n_host && voxels && coors && num_points && voxel_num && workspace && voxel_size_host &&
                     range_host, "hard_voxelize_batch: null pointer");
@@ -431,35 +430,30 @@ extern "C" int ubv_hard_voxelize_batch(const float* const* points_host, const in
   const VoxWs w = vox_layout(n_max, max_points, max_voxels);
   UBV_CHECK_ARG(workspace_bytes >= (int64_t)B * (int64_t)w.total, "hard_voxelize_batch: workspace %lld < %lld bytes",
                 (long long)workspace_bytes, (long long)B * (long long)w.total);
-  vb.ws_stride = (long)w.total;
-  vb.key_off = (long)w.keys; vb.first_off = (long)w.first; vb.head_off = (long)w.head; vb.scan_off = (long)w.scan;
-  vb.sums_off = (long)w.sums; vb.table_off = (long)w.table; vb.slots_off = (long)w.slots;
-  const uint32_t cap = table_capacity(n_max);
-  vb.mask = cap - 1;
-  hipStream_t st = as_stream(stream);
-  char* ws = (char*)workspace;
-  // tables (0xFF) and slot chains (0x7f7f7f7f) of every sample: their regions sit at fixed offsets of each stride
-  for (int b = 0; b < B; ++b) {
-    if (hipMemsetAsync(ws + (size_t)b * w.total + w.table, 0xFF, (size_t)cap * 8, st) != hipSuccess ||
-        hipMemsetAsync(ws + (size_t)b * w.total + w.slots, 0x7f, (size_t)max_voxels * max_points * 4, st) != hipSuccess) {
-      set_error("hard_voxelize_batch: memset failed");
-      return UBV_ERR_LAUNCH;
-    }
+  if (vox_run(vb, B, n_max, (char*)workspace, w, F, g, max_points, max_voxels, voxels, coors, num_points, voxel_num, mean,
+              as_stream(stream)) != UBV_OK) {
+    set_error("hard_voxelize_batch: clouds of more than %d points are not supported", kVoxMaxScanBlocks * kScanBlock);
+    return UBV_ERR_UNSUPPORTED;
   }
-  const int nb = (n_max + 255) / 256, sb = (n_max + kScanBlock - 1) / kScanBlock;
-  if (n_max > 0) {
-    hipLaunchKernelGGL(vox_key_insert_batch_kernel, dim3(nb, B), dim3(256), 0, st, vb, ws, F, g);
-    hipLaunchKernelGGL(vox_head_batch_kernel, dim3(nb, B), dim3(256), 0, st, vb, ws);
-    hipLaunchKernelGGL(scan_block_batch_kernel, dim3(sb, B), dim3(256), 0, st, vb, ws);
-  }
-  hipLaunchKernelGGL(scan_sums_batch_kernel, dim3(1, B), dim3(64), 0, st, vb, ws, voxel_num, max_voxels);
-  if (n_max > 0)
-    hipLaunchKernelGGL(vox_assign_batch_kernel, dim3(nb, B), dim3(256), 0, st, vb, ws, g, max_points, max_voxels, coors);
-  const long nt = (long)max_voxels * max_points * F;
-  hipLaunchKernelGGL(vox_gather_batch_kernel, dim3((unsigned)((nt + 255) / 256), B), dim3(256), 0, st, vb, ws, F, voxel_num,
-                     max_points, voxels, num_points, max_voxels);
   UBV_CHECK_LAUNCH("hard_voxelize_batch");
   return UBV_OK;
+}
+
+extern "C" int ubv_hard_voxelize_batch(const float* const* points_host, const int* n_host, int B, float* voxels,
+                                       int32_t* coors, int32_t* num_points, int32_t* voxel_num, void* workspace,
+                                       int64_t workspace_bytes, int F, const float* voxel_size_host,
+                                       const float* range_host, int max_points, int max_voxels, void* stream) {
+  return hard_voxelize_batch_impl(points_host, n_host, B, voxels, coors, num_points, voxel_num, nullptr, workspace,
+                                  workspace_bytes, F, voxel_size_host, range_host, max_points, max_voxels, stream);
+}
+
+extern "C" int ubv_hard_voxelize_batch_vfe(const float* const* points_host, const int* n_host, int B, float* voxels,
+                                           int32_t* coors, int32_t* num_points, int32_t* voxel_num, float* mean,
+                                           void* workspace, int64_t workspace_bytes, int F, const float* voxel_size_host,
+                                           const float* range_host, int max_points, int max_voxels, void* stream) {
+  if (mean == nullptr) { ubv::set_error("hard_voxelize_batch_vfe: null mean"); return UBV_ERR_INVALID; }
+  return hard_voxelize_batch_impl(points_host, n_host, B, voxels, coors, num_points, voxel_num, mean, workspace,
+                                  workspace_bytes, F, voxel_size_host, range_host, max_points, max_voxels, stream);
 }
 
 extern "C" int ubv_dynamic_voxelize(const float* points, int32_t* coors, int N, int F,

@@ -962,7 +962,7 @@ def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels):
         N, F = pts.shape
         dev = pts.device
         voxels = torch.empty(max_voxels, max_points, F, dtype=torch.float32, device=dev)
-        coors = torch.zeros(max_voxels, 3, dtype=torch.int32, device=dev)
+        coors = torch.empty(max_voxels, 3, dtype=torch.int32, device=dev)       # (rows past the count: zeroed by the op)
         num = torch.empty(max_voxels, dtype=torch.int32, device=dev)
         vnum = torch.empty(1, dtype=torch.int32, device=dev)
         nbytes = lib().ubv_hard_voxelize_workspace(N, max_points, max_voxels)
@@ -975,19 +975,22 @@ def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels):
 
 
 @torch.no_grad()
-def hard_voxelize_batch(clouds, voxel_size, coors_range, max_points, max_voxels):
+def hard_voxelize_batch(clouds, voxel_size, coors_range, max_points, max_voxels, with_mean=False):
     """A list of clouds in ONE launch chain (``ubv_hard_voxelize_batch``; up to 16 per call, longer lists in chunks):
     per-sample slabs voxels (B, max_voxels, max_points, F), coors (B, max_voxels, 3) int32 zyx, num_points
-    (B, max_voxels) int32, voxel_num (B,) int32 ON DEVICE — sample b bit-identical to ``hard_voxelize(clouds[b])``."""
+    (B, max_voxels) int32, voxel_num (B,) int32 ON DEVICE — sample b bit-identical to ``hard_voxelize(clouds[b])``.
+    ``with_mean``: also the HardSimpleVFE means (B, max_voxels, F), written by the same chain
+    (``ubv_hard_voxelize_batch_vfe``; equal to ``voxel_mean`` of the slab bit for bit)."""
     with _need_cuda(*clouds):
         pts = [c.float().contiguous() for c in clouds]
         B, F = len(pts), pts[0].shape[1]
         assert B > 0 and all(p.dim() == 2 and p.shape[1] == F for p in pts)
         dev = pts[0].device
         voxels = torch.empty(B, max_voxels, max_points, F, dtype=torch.float32, device=dev)
-        coors = torch.zeros(B, max_voxels, 3, dtype=torch.int32, device=dev)
+        coors = torch.empty(B, max_voxels, 3, dtype=torch.int32, device=dev)
         num = torch.empty(B, max_voxels, dtype=torch.int32, device=dev)
         vnum = torch.empty(B, dtype=torch.int32, device=dev)
+        mean = torch.empty(B, max_voxels, F, dtype=torch.float32, device=dev) if with_mean else None
         for b0 in range(0, B, 16):
             chunk = pts[b0:b0 + 16]
             nb = len(chunk)
@@ -996,11 +999,17 @@ def hard_voxelize_batch(clouds, voxel_size, coors_range, max_points, max_voxels)
             ws = _workspace(nbytes, dev)
             ptrs = (ctypes.c_void_p * nb)(*[p.data_ptr() if p.numel() else None for p in chunk])
             counts = (ctypes.c_int * nb)(*ns)
+            if with_mean:
+                check(lib().ubv_hard_voxelize_batch_vfe(ptrs, counts, nb, _p(voxels[b0:]), _p(coors[b0:]), _p(num[b0:]),
+                                                        _p(vnum[b0:]), _p(mean[b0:]), _p(ws), ws.numel(), F,
+                                                        _lib.float_array(voxel_size), _lib.float_array(coors_range),
+                                                        max_points, max_voxels, _stream()), 'hard_voxelize_batch_vfe')
+                continue
             check(lib().ubv_hard_voxelize_batch(ptrs, counts, nb, _p(voxels[b0:]), _p(coors[b0:]), _p(num[b0:]),
                                                 _p(vnum[b0:]), _p(ws), ws.numel(), F, _lib.float_array(voxel_size),
                                                 _lib.float_array(coors_range), max_points, max_voxels, _stream()),
                   'hard_voxelize_batch')
-        return voxels, coors, num, vnum
+        return (voxels, coors, num, vnum, mean) if with_mean else (voxels, coors, num, vnum)
 
 
 @torch.no_grad()
@@ -1055,7 +1064,7 @@ def voxel_mean(voxels, num_points, voxel_num=None):
     """[ext] HardSimpleVFE: per-voxel mean of the stored points."""
     with _need_cuda(voxels, num_points):
         M, T, F = voxels.shape
-        mean = torch.zeros(M, F, dtype=torch.float32, device=voxels.device)
+        mean = torch.empty(M, F, dtype=torch.float32, device=voxels.device)     # (rows past voxel_num: zeroed by the op)
         check(lib().ubv_voxel_mean(_p(voxels.contiguous()), _p(num_points.contiguous()), _p(voxel_num),
                                    _p(mean), M, T, F, _stream()), 'voxel_mean')
         return mean

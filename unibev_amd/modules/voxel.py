@@ -173,19 +173,24 @@ def voxelize_batch(voxel_layer, points):
     return voxelize_cat(voxel_layer, points)
 
 
-def voxelize_cat(voxel_layer, points):
+def voxelize_cat(voxel_layer, points, with_mean=False):
     """Hard voxelization of a list of clouds in one launch chain, then the reference's concatenated form (one read of
-    the B voxel counts instead of one per sample).  Dynamic voxelization keeps the per-sample calls."""
+    the B voxel counts instead of one per sample).  Dynamic voxelization keeps the per-sample calls.  ``with_mean``: a
+    fourth result, the per-voxel point means (sum M, F) from the same chain (None when the chain was not used)."""
     if voxel_layer.max_num_points == -1 or voxel_layer._limit() == -1 or len(points) == 0:
         out = [voxel_layer(res) for res in points]
         coors = [F.pad(c, (1, 0), mode='constant', value=i) for i, (_, c, _) in enumerate(out)]
-        return torch.cat([o[0] for o in out], 0), torch.cat([o[2] for o in out], 0), torch.cat(coors, 0)
-    v, c, n, m = UF.hard_voxelize_batch(list(points), voxel_layer.voxel_size, voxel_layer.point_cloud_range,
-                                        voxel_layer.max_num_points, voxel_layer._limit())
+        res = (torch.cat([o[0] for o in out], 0), torch.cat([o[2] for o in out], 0), torch.cat(coors, 0))
+        return res + (None,) if with_mean else res
+    got = UF.hard_voxelize_batch(list(points), voxel_layer.voxel_size, voxel_layer.point_cloud_range,
+                                 voxel_layer.max_num_points, voxel_layer._limit(), with_mean=with_mean)
+    v, c, n, m = got[:4]
     counts = m.tolist()
     voxels = torch.cat([v[b, :k] for b, k in enumerate(counts)], 0)
     num_points = torch.cat([n[b, :k] for b, k in enumerate(counts)], 0)
     coors = torch.cat([F.pad(c[b, :k], (1, 0), mode='constant', value=b) for b, k in enumerate(counts)], 0)
+    if with_mean:
+        return voxels, num_points, coors, torch.cat([got[4][b, :k] for b, k in enumerate(counts)], 0)
     return voxels, num_points, coors
 
 
@@ -201,8 +206,14 @@ def extract_pts_feat(points, voxel_layer, voxel_encoder, middle_encoder, backbon
     through — the 2-D backbone / neck: list of per-sample point clouds -> voxelize (``voxelize_batch``) ->
     voxel encoder -> middle encoder (``SparseEncoder``: (B, 256, 180, 180) at the shipped configs).  The batch
     size is taken from the list, not read back from ``coors[-1, 0]`` as the reference does."""
-    voxels, num_points, coors = voxelize_batch(voxel_layer, points)
-    voxel_features = voxel_encoder(voxels, num_points, coors)
+    if type(voxel_encoder) is HardSimpleVFE:
+        # the mean of each voxel's points comes out of the voxelization chain itself (ubv_hard_voxelize_batch_vfe)
+        voxels, num_points, coors, mean = voxelize_cat(voxel_layer, points, with_mean=True)
+        voxel_features = (mean[:, :voxel_encoder.num_features].contiguous() if mean is not None
+                          else voxel_encoder(voxels, num_points, coors))
+    else:
+        voxels, num_points, coors = voxelize_batch(voxel_layer, points)
+        voxel_features = voxel_encoder(voxels, num_points, coors)
     x = middle_encoder(voxel_features, coors, len(points))
     if backbone is not None:
         x = backbone(x)
