@@ -25,7 +25,7 @@ class Mode(TorchDispatchMode):
         gemm = any(k in name for k in ('aten.mm', 'aten.addmm', 'aten.bmm', 'aten.linear', 'aten.matmul'))
         if gemm:
             big = [a for a in args if isinstance(a, torch.Tensor)]
-        if big and (gemm or any(k in name for k in ('add', 'clone', 'copy', 'mul', 'sum', 'cat', 'contiguous', 'div', 'to.', '_to_copy'))):
+        if big and (gemm or any(k in name for k in ('add', 'clone', 'copy', 'mul', 'sum', 'cat', 'contiguous', 'div', 'to.', '_to_copy', 'zero', 'fill', 'softmax', 'index', 'stack', 'sub', 'neg', 'where'))):
             st = traceback.extract_stack()
             site = [f'{os.path.basename(f.filename)}:{f.lineno}:{f.name}' for f in st if 'unibev_amd' in f.filename][-2:]
             log[(name, tuple(big[0].shape), tuple(big[0].stride()), ' <- '.join(reversed(site)) or 'autograd engine')] += 1

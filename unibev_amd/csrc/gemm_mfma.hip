@@ -750,6 +750,22 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
   const int soff = (sc >> 4) * kWgCS + (sc & 15);         // LDS offset of (row 0, column sc)
   gf32x4_t fy[SPLIT ? NI : 1], fx[SPLIT ? NI : 1];
   gu32x4_t hy[SPLIT ? 1 : NI], hx[SPLIT ? 1 : NI];
+  // GATHER: the pair indices of a chunk are fetched ONE CHUNK BEFORE its rows (pidx holds the next chunk's), so a
+  // chunk's rows go out without waiting for an index load — index -> row was two round trips in series per 64-row
+  // chunk, with 48 MFMAs per wave to hide them behind (MFMA busy 18 % at 128 channels)
+  int pix[GATHER ? NI : 1], piy[GATHER ? NI : 1];
+  auto load_idx = [&](long mc) {
+    if constexpr (GATHER) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const long m = mc + sr + (256 / TPR) * i;
+        long mm = m < my_end ? m : my_end - 1;
+        mm = mm > 0 ? mm : 0;                             // (an offset with no pair in this slab: row 0, dropped)
+        pix[i] = xidx[mm];
+        piy[i] = yidx != nullptr ? yidx[mm] : (int)mm;
+      }
+    }
+  };
   auto load_chunk = [&](long mc) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -759,10 +775,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
       long xm = mm, ym = mm;
       bool xrow_ok = m < my_end;
       if constexpr (GATHER) {
-        const int r = xidx[mm];
+        const int r = pix[i];
         xrow_ok = xrow_ok && r >= 0;
         xm = r >= 0 ? r : 0;
-        if (yidx != nullptr) { const int ry = yidx[mm]; ym = ry >= 0 ? ry : 0; }
+        ym = piy[i] >= 0 ? piy[i] : 0;
       }
       if constexpr (SPLIT) {
         if (n_split > 0) {
@@ -809,12 +825,19 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
   const uint32_t one2 = F16 ? 0x3C003C00u : 0x3F803F80u;
   const uint4 ones = make_uint4(one2, one2, one2, one2);
 
-  if (mbeg < mend) load_chunk(mbeg);
+  if (mbeg < mend) {
+    load_idx(mbeg);
+    load_chunk(mbeg);
+    if (mbeg + kWgMC < mend) load_idx(mbeg + kWgMC);
+  }
   for (long mc = mbeg; mc < mend; mc += kWgMC) {
     __syncthreads();
     store_chunk();
     __syncthreads();
-    if (mc + kWgMC < mend) load_chunk(mc + kWgMC);
+    if (mc + kWgMC < mend) {
+      load_chunk(mc + kWgMC);
+      if (mc + 2 * kWgMC < mend) load_idx(mc + 2 * kWgMC);
+    }
 #pragma unroll
     for (int ks = 0; ks < kWgMC; ks += 16) {
       uint4 ah[2], al[2], bh[2], bl[2];
