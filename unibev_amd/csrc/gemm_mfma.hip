@@ -766,7 +766,13 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
       }
     }
   };
+  // Rows past the slab and columns past N / K are clamped for the load and ZEROED WHEN THE CHUNK IS STORED TO LDS
+  // (ymask / xmask: one bit per load).  Zeroing them right behind the load — rounds 2 - 4 — made the compiler wait for
+  // every load of the NEXT chunk (vmcnt 14 .. 0) before the first MFMA of the current one: the prefetch ran in series
+  // with the arithmetic.
+  uint32_t ymask = 0u, xmask = 0u;
   auto load_chunk = [&](long mc) {
+    ymask = 0u; xmask = 0u;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const long m = mc + sr + (256 / TPR) * i;
@@ -788,14 +794,12 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
         } else
         fy[i] = *reinterpret_cast<const gf32x4_t*>((const float*)dYv + ym * N + ycol);
         fx[i] = *reinterpret_cast<const gf32x4_t*>((const float*)Xv + xm * K + xcol);
-        if (!(m < my_end && yok)) fy[i] = gf32x4_t{0.f, 0.f, 0.f, 0.f};
-        if (!(xrow_ok && xok)) fx[i] = gf32x4_t{0.f, 0.f, 0.f, 0.f};
       } else {
         hy[i] = *reinterpret_cast<const gu32x4_t*>((const uint16_t*)dYv + ym * N + ycol);
         hx[i] = *reinterpret_cast<const gu32x4_t*>((const uint16_t*)Xv + xm * K + xcol);
-        if (!(m < my_end && yok)) hy[i] = gu32x4_t{0u, 0u, 0u, 0u};
-        if (!(xrow_ok && xok)) hx[i] = gu32x4_t{0u, 0u, 0u, 0u};
       }
+      ymask |= (m < my_end && yok) ? (1u << i) : 0u;
+      xmask |= (xrow_ok && xok) ? (1u << i) : 0u;
     }
   };
   auto split_store = [&](uint16_t* th, uint16_t* tl, int o, const gf32x4_t v) {
@@ -809,12 +813,13 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int o = soff + (sr + (256 / TPR) * i) * 16;
+      const bool ky = (ymask >> i) & 1u, kx = (xmask >> i) & 1u;
       if constexpr (SPLIT) {
-        split_store(ty_h, ty_l, o, fy[i]);
-        split_store(tx_h, tx_l, o, fx[i]);
+        split_store(ty_h, ty_l, o, ky ? fy[i] : gf32x4_t{0.f, 0.f, 0.f, 0.f});
+        split_store(tx_h, tx_l, o, kx ? fx[i] : gf32x4_t{0.f, 0.f, 0.f, 0.f});
       } else {
-        *reinterpret_cast<gu32x4_t*>(ty_h + o) = hy[i];
-        *reinterpret_cast<gu32x4_t*>(tx_h + o) = hx[i];
+        *reinterpret_cast<gu32x4_t*>(ty_h + o) = ky ? hy[i] : gu32x4_t{0u, 0u, 0u, 0u};
+        *reinterpret_cast<gu32x4_t*>(tx_h + o) = kx ? hx[i] : gu32x4_t{0u, 0u, 0u, 0u};
       }
     }
   };
