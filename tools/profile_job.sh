@@ -31,6 +31,14 @@ done
 python $ROOT/tools/bench_gemm.py > $OUT/bench_gemm.txt 2>&1
 python $ROOT/tools/bench_gemm_cold.py > $OUT/bench_gemm_cold.txt 2>&1
 python $ROOT/tools/bench_backbone.py 2>&1 | grep -v '^/opt' > $OUT/bench_backbone.txt
+# 5b. LiDAR front end: middle-encoder kernel table (rebuilt rulebooks), host / device time of the voxel chain,
+#     SQ / TCP counters of the 128-channel sparse convolution and its weight gradient
+rocprofv3 --kernel-trace -d /tmp/prof_me -o m -- python $ROOT/tools/profile_middle_encoder.py bwd > /dev/null 2>&1
+python $ROOT/tools/db_table.py /tmp/prof_me/m_results.db 6 60 > $OUT/middle_encoder_bwd_kernel_table.txt
+python $ROOT/tools/ab/vox_host.py 2>&1 | grep -v '^/opt' > $OUT/voxel_chain.txt
+for c in 128 64 32 16; do python $ROOT/tools/ab/spconv_one.py $c 2>&1 | grep -v '^/opt'; python $ROOT/tools/ab/spconv_one.py $c wgrad 2>&1 | grep -v '^/opt'; done > $OUT/bench_spconv.txt
+bash $ROOT/tools/pmc_spconv.sh $OUT/pmc_spconv128.txt 128 conv spconv_gather
+bash $ROOT/tools/pmc_spconv.sh $OUT/pmc_spconv_wgrad128.txt 128 wgrad gemm_wgrad
 # 6. HBM traffic per op (PMC passes)
 UBV_COMMIT=${UBV_COMMIT:-unrecorded} bash $ROOT/tools/collect_traffic.sh $OUT > $OUT/traffic.log 2>&1
 ls -la $OUT
