@@ -760,9 +760,12 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
       for (int i = 0; i < NI; ++i) {
         const long m = mc + sr + (256 / TPR) * i;
         long mm = m < my_end ? m : my_end - 1;
-        mm = mm > 0 ? mm : 0;                             // (an offset with no pair in this slab: row 0, dropped)
-        pix[i] = xidx[mm];
-        piy[i] = yidx != nullptr ? yidx[mm] : (int)mm;
+        mm = mm > 0 ? mm : 0;
+        // (an offset with no pair in this slab reads no index — list entries past an offset's count are not written,
+        //  ubv_spconv_pairs — and gathers row 0, dropped)
+        const bool have = my_end > 0;
+        pix[i] = have ? xidx[mm] : -1;
+        piy[i] = yidx != nullptr ? (have ? yidx[mm] : 0) : (int)mm;
       }
     }
   };
