@@ -261,19 +261,24 @@ int ubv_bev_fuse_backward(const void* grad_out, const void* img, const void* pts
  *            buffer of ubv_add_dropout_layernorm_backward_workspace(C) bytes (contents irrelevant, used on `stream`):
  *            the blocks' partial sums are written there and added in block order by a second small launch —
  *            bit-reproducible 1-D parameter gradients.
+ *   bcast_rows  0, or the number of rows x and identity really hold: they REPEAT over the R rows (row r reads row
+ *            r % bcast_rows; R % bcast_rows == 0) — the first encoder layer's self-attention, whose queries are one
+ *            table for every sample (encoder_unibev_detr_img.py: bev_query.unsqueeze(1).repeat(1, bs, 1)); y, mean,
+ *            rstd, the dropout mask, grad_x and grad_identity stay per row (the caller sums the gradients over the
+ *            repeats).  C = 64, 128 or 256 channels per 16-byte-lane row only.
  *   C % 4 == 0, C <= 1024.
  */
 int64_t ubv_add_dropout_layernorm_backward_workspace(int C);
 int ubv_add_dropout_layernorm_forward(const void* x, const void* identity, const float* gamma,
                                       const float* beta, void* y, float* mean, float* rstd,
-                                      int64_t R, int C, float eps, float p, uint64_t seed,
+                                      int64_t R, int64_t bcast_rows, int C, float eps, float p, uint64_t seed,
                                       const uint64_t* seed_dev, int dtype, int stream_dtype,
                                       void* stream);
 int ubv_add_dropout_layernorm_backward(const void* grad_y, const void* x, const void* identity,
                                        const float* gamma, const float* mean, const float* rstd,
                                        void* grad_x, void* grad_identity, float* grad_gamma,
-                                       float* grad_beta, float* grad_x_colsum, int64_t R, int C,
-                                       float p, uint64_t seed, const uint64_t* seed_dev, int dtype,
+                                       float* grad_beta, float* grad_x_colsum, int64_t R, int64_t bcast_rows,
+                                       int C, float p, uint64_t seed, const uint64_t* seed_dev, int dtype,
                                        int stream_dtype, void* ordered_workspace, void* stream);
 
 /* FFN activation of the encoder layers, y = dropout(relu(x)) in one pass ([ext] mmcv FFN:

@@ -681,3 +681,56 @@ def _fullsize_gradients(fixture, norm_bar, elem_bar, fwd_bar, allow_1d, skip_kin
         print(f'   {k:70s} {v[0]:.2e} {v[1]:.2e}')
     bad = {k: v for k, v in worst.items() if not (v[0] < NORM_BAR and v[1] < ELEM_BAR)}
     assert not bad, bad
+
+
+def test_first_self_attention_shared_across_the_batch_equals_per_sample():
+    """The first encoder layer's queries are one table for every sample, so its self-attention (projections, sampling,
+    output_proj) runs for ONE sample and the samples part at the dropout of the fused add + LayerNorm (row-period reads,
+    ``bcast_rows``).  Training mode with dropout on, same seeds: the BEV features equal the per-sample run bit for bit
+    (every row sees the same arithmetic and the same mask) and every gradient agrees to f32 round-off (the batch sum of
+    the shared rows' gradients moves from behind the GEMMs to in front of them)."""
+    from unibev_amd.modules import encoders as E
+    cfg, sd, inp, g = encoder_case('cnw')
+    model = _build(cfg).to(DEV).train()
+    _load(model, sd)
+    model.forced_flags = (1, 1)
+    img = [t(x, torch.float32, DEV).requires_grad_() for x in inp['img']]
+    pts = [t(x, torch.float32, DEV).requires_grad_() for x in inp['pts']]
+    bev_q = tq(inp['bev_q'], torch.float32, DEV, grad=True)
+    bs = inp['bs']
+    assert bs > 1
+    bev_pos = t(inp['bev_pos'], torch.float32, DEV)[:1].expand(bs, -1, -1, -1)  # one positional table, as the model's
+    params = [p for n, p in model.named_parameters() if p.requires_grad and not n.startswith('reference_points')]
+    cot = torch.randn(inp['bev_h'] * inp['bev_w'], bs, g['fused'].shape[-1], device=DEV,
+                      generator=torch.Generator(DEV).manual_seed(3))
+    calls = []
+    orig = E.UF.add_dropout_layernorm
+
+    def spy(*a, **k):
+        calls.append(int(k.get('batch', 0) or 0))
+        return orig(*a, **k)
+
+    def run(share):
+        E._SHARE_FIRST = share
+        torch.manual_seed(11)                                   # the dropout seeds come from torch's CPU generator
+        for x in params + img + pts + [bev_q]:
+            x.grad = None
+        out = model.encode(img, pts, bev_q, inp['bev_h'], inp['bev_w'], bev_pos=bev_pos, img_metas=inp['metas'])
+        (out * cot).sum().backward()
+        return out.detach().clone(), [None if x.grad is None else x.grad.clone() for x in params + img + pts + [bev_q]]
+
+    try:
+        E.UF.add_dropout_layernorm = spy
+        out1, g1 = run(True)
+        shared_calls = list(calls)
+        calls.clear()
+        out0, g0 = run(False)
+    finally:
+        E.UF.add_dropout_layernorm = orig
+        E._SHARE_FIRST = True
+    assert shared_calls.count(bs) == 2 and calls.count(bs) == 0, (shared_calls, calls)   # one per encoder, first layer
+    assert torch.equal(out1, out0)
+    for a, b in zip(g1, g0):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert float((a - b).norm()) <= 2e-5 * float(b.norm()) + 1e-12

@@ -42,9 +42,9 @@ SIGNATURES = {
     'ubv_flatten_embed_backward': (c_int, [_P, _P, _P] + [c_int] * 4 + [_P]),
     'ubv_bev_fuse_forward': (c_int, [_P] * 7 + [c_int] * 5 + [_P]),
     'ubv_bev_fuse_backward': (c_int, [_P] * 11 + [c_int] * 5 + [_P]),
-    'ubv_add_dropout_layernorm_forward': (c_int, [_P] * 7 + [c_int64, c_int, c_float, c_float, c_uint64,
+    'ubv_add_dropout_layernorm_forward': (c_int, [_P] * 7 + [c_int64, c_int64, c_int, c_float, c_float, c_uint64,
                                                           _P, c_int, c_int, _P]),
-    'ubv_add_dropout_layernorm_backward': (c_int, [_P] * 11 + [c_int64, c_int, c_float, c_uint64,
+    'ubv_add_dropout_layernorm_backward': (c_int, [_P] * 11 + [c_int64, c_int64, c_int, c_float, c_uint64,
                                                             _P, c_int, c_int, _P, _P]),
     'ubv_add_dropout_layernorm_backward_workspace': (c_int64, [c_int]),
     'ubv_relu_dropout_forward': (c_int, [_P, _P, c_int64, c_float, c_uint64, _P, c_int, _P]),

@@ -184,7 +184,10 @@ template <typename T, typename S, int LPR>
 __global__ __launch_bounds__(256) void add_norm_fwd_rows_kernel(
     const T* __restrict__ x, const S* __restrict__ identity, const float* __restrict__ gamma,
     const float* __restrict__ beta, S* __restrict__ y, float* __restrict__ mean,
-    float* __restrict__ rstd, long R, int C, float eps, uint32_t thresh, float scale, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+    float* __restrict__ rstd, long R, int C, float eps, uint32_t thresh, float scale, uint64_t seed, const uint64_t* __restrict__ seed_dev,
+    long period) {
+  // period > 0: x and identity hold `period` rows that REPEAT (row r reads row r % period) — the first encoder layer's
+  // self-attention, whose queries are one table for every sample of the batch; the dropout mask is per output row
   if (seed_dev != nullptr) seed += *seed_dev;   // per-step base kept on the device (graph replays)
   constexpr int VEC = 16 / elem<T>::kBytes, G = 64 / LPR;
   const int lane = threadIdx.x & 63, sub = lane / LPR, c = (lane % LPR) * VEC;
@@ -205,12 +208,13 @@ __global__ __launch_bounds__(256) void add_norm_fwd_rows_kernel(
     const long r = r0 + sub;
     const bool ok = r < R;
     const long rr = ok ? r : 0;
+    const long rs_ = period > 0 ? (long)((unsigned)rr % (unsigned)period) : rr;      // source row of x / identity
     float xv[VEC], iv[VEC], s[VEC];
-    vec_io<T, VEC>::load(x + rr * C + c, xv);
+    vec_io<T, VEC>::load(x + rs_ * C + c, xv);
 #pragma unroll
     for (int i = 0; i < VEC; i += 4) {
       float t4[4];
-      load4<S>(identity + rr * C + c + i, t4);
+      load4<S>(identity + rs_ * C + c + i, t4);
 #pragma unroll
       for (int k = 0; k < 4; ++k) iv[i + k] = t4[k];
     }
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(256) void add_norm_bwd_rows_kernel(
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
     T* __restrict__ gx, S* __restrict__ gid, float* __restrict__ dgamma,
     float* __restrict__ dbeta, float* __restrict__ dxsum, long R, int C, uint32_t thresh,
-    float scale, uint64_t seed, const uint64_t* __restrict__ seed_dev, int* __restrict__ ordered_ws) {
+    float scale, uint64_t seed, const uint64_t* __restrict__ seed_dev, int* __restrict__ ordered_ws, long period) {
   if (seed_dev != nullptr) seed += *seed_dev;   // per-step base kept on the device (graph replays)
   constexpr int VEC = 16 / elem<T>::kBytes, G = 64 / LPR;
   __shared__ float red[3][4][64][VEC];
@@ -267,12 +271,13 @@ __global__ __launch_bounds__(256) void add_norm_bwd_rows_kernel(
     const bool ok = r < R;
     const long rr = ok ? r : 0;
     const float mu = mean[rr], rs = rstd[rr];
+    const long rs_ = period > 0 ? (long)((unsigned)rr % (unsigned)period) : rr;      // source row of x / identity
     float xv[VEC], iv[VEC], go[VEC], xh[VEC], dxh[VEC], keep[VEC];
-    vec_io<T, VEC>::load(x + rr * C + c, xv);
+    vec_io<T, VEC>::load(x + rs_ * C + c, xv);
 #pragma unroll
     for (int i = 0; i < VEC; i += 4) {
       float t4[4];
-      load4<S>(identity + rr * C + c + i, t4);
+      load4<S>(identity + rs_ * C + c + i, t4);
 #pragma unroll
       for (int k = 0; k < 4; ++k) iv[i + k] = t4[k];
       load4<S>(gy + rr * C + c + i, t4);
@@ -409,6 +414,19 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const T* __restri
   }
 }
 
+// bcast_rows > 0: x / identity are [bcast_rows, C] and repeat over the R rows (rows kernels only: C / (16-byte lanes) in
+// {16, 32, 64}; R below 2^31)
+static int bcast_check(long R, long bcast_rows, int C, int dtype, const char* who) {
+  if (bcast_rows == 0) return UBV_OK;
+  const int vec = dtype == UBV_F32 ? 4 : 8;
+  const int lpr = (C % vec == 0) ? C / vec : 0;
+  if (bcast_rows < 0 || R % bcast_rows != 0 || R >= (1L << 31) || !(lpr == 16 || lpr == 32 || lpr == 64)) {
+    set_error("%s: repeated rows need R %% bcast_rows == 0, R < 2^31 and a row of 16, 32 or 64 16-byte lanes (C = %d)", who, C);
+    return UBV_ERR_UNSUPPORTED;
+  }
+  return UBV_OK;
+}
+
 static int norm_check(long R, int C, int dtype, int stream_dtype, const char* who) {
   UBV_CHECK_ARG(R >= 0 && C > 0 && C % 4 == 0 && C <= 64 * 4 * kNormChunks,
                 "%s: C=%d must be a multiple of 4 and <= %d", who, C, 64 * 4 * kNormChunks);
@@ -423,17 +441,19 @@ template <typename T, typename S>
 static void norm_fwd_launch(dim3 grid, hipStream_t st, const void* x, const void* identity,
                             const float* gamma, const float* beta, void* y, float* mean,
                             float* rstd, long R, int C, float eps, uint32_t th, float sc,
-                            uint64_t seed, const uint64_t* seed_dev) {
+                            uint64_t seed, const uint64_t* seed_dev, long period) {
   constexpr int VEC = 16 / elem<T>::kBytes;
   const int lpr = (C % VEC == 0) ? C / VEC : 0;
   auto run = [&](auto kernel) {
     hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, (const T*)x, (const S*)identity, gamma, beta,
-                       (S*)y, mean, rstd, R, C, eps, th, sc, seed, seed_dev);
+                       (S*)y, mean, rstd, R, C, eps, th, sc, seed, seed_dev, period);
   };
   if (lpr == 64) run(add_norm_fwd_rows_kernel<T, S, 64>);
   else if (lpr == 32) run(add_norm_fwd_rows_kernel<T, S, 32>);
   else if (lpr == 16) run(add_norm_fwd_rows_kernel<T, S, 16>);
-  else run(add_norm_fwd_kernel<T, S>);
+  else
+    hipLaunchKernelGGL((add_norm_fwd_kernel<T, S>), grid, dim3(256), 0, st, (const T*)x, (const S*)identity, gamma, beta,
+                       (S*)y, mean, rstd, R, C, eps, th, sc, seed, seed_dev);
 }
 
 template <typename T, typename S>
@@ -441,12 +461,12 @@ static void norm_bwd_launch(dim3 grid, hipStream_t st, const void* gy, const voi
                             const void* identity, const float* gamma, const float* mean,
                             const float* rstd, void* gx, void* gid, float* dgamma, float* dbeta,
                             float* dxsum, long R, int C, uint32_t th, float sc, uint64_t seed, const uint64_t* seed_dev,
-                            int* ordered_ws) {
+                            int* ordered_ws, long period) {
   constexpr int VEC = 16 / elem<T>::kBytes;
   const int lpr = (C % VEC == 0) ? C / VEC : 0;
   auto run = [&](auto kernel) {
     hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, (const S*)gy, (const T*)x, (const S*)identity,
-                       gamma, mean, rstd, (T*)gx, (S*)gid, dgamma, dbeta, dxsum, R, C, th, sc, seed, seed_dev, ordered_ws);
+                       gamma, mean, rstd, (T*)gx, (S*)gid, dgamma, dbeta, dxsum, R, C, th, sc, seed, seed_dev, ordered_ws, period);
   };
   auto run_plain = [&](auto kernel) {       // rare widths: one row per wave, atomics
     hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, (const S*)gy, (const T*)x, (const S*)identity,
@@ -467,13 +487,15 @@ static void norm_bwd_launch(dim3 grid, hipStream_t st, const void* gy, const voi
 
 extern "C" int ubv_add_dropout_layernorm_forward(const void* x, const void* identity,
                                                  const float* gamma, const float* beta, void* y,
-                                                 float* mean, float* rstd, int64_t R, int C,
-                                                 float eps, float p, uint64_t seed,
+                                                 float* mean, float* rstd, int64_t R, int64_t bcast_rows,
+                                                 int C, float eps, float p, uint64_t seed,
                                                  const uint64_t* seed_dev, int dtype,
                                                  int stream_dtype, void* stream) {
   using namespace ubv;
   UBV_CHECK_ARG(x && identity && gamma && beta && y && mean && rstd, "add_norm_forward: null pointer");
   int rc = norm_check(R, C, dtype, stream_dtype, "add_norm_forward");
+  if (rc) return rc;
+  rc = bcast_check(R, bcast_rows, C, dtype, "add_norm_forward");
   if (rc) return rc;
   if (R == 0) return UBV_OK;
   uint32_t th; float sc;
@@ -481,7 +503,7 @@ extern "C" int ubv_add_dropout_layernorm_forward(const void* x, const void* iden
   const long waves = R < 8192 ? R : 8192;
   const dim3 grid((unsigned)((waves + 3) / 4));
   hipStream_t st = as_stream(stream);
-#define UBV_NORM_FWD(T, S) norm_fwd_launch<T, S>(grid, st, x, identity, gamma, beta, y, mean, rstd, (long)R, C, eps, th, sc, seed, seed_dev)
+#define UBV_NORM_FWD(T, S) norm_fwd_launch<T, S>(grid, st, x, identity, gamma, beta, y, mean, rstd, (long)R, C, eps, th, sc, seed, seed_dev, (long)bcast_rows)
   const bool lowp = stream_dtype != UBV_F32;
   switch (dtype) {
     case UBV_F32: UBV_NORM_FWD(float, float); break;
@@ -503,7 +525,7 @@ extern "C" int ubv_add_dropout_layernorm_backward(const void* grad_y, const void
                                                   const float* mean, const float* rstd, void* grad_x,
                                                   void* grad_identity, float* grad_gamma,
                                                   float* grad_beta, float* grad_x_colsum,
-                                                  int64_t R, int C, float p,
+                                                  int64_t R, int64_t bcast_rows, int C, float p,
                                                   uint64_t seed, const uint64_t* seed_dev, int dtype,
                                                   int stream_dtype, void* ordered_workspace, void* stream) {
   using namespace ubv;
@@ -512,13 +534,15 @@ extern "C" int ubv_add_dropout_layernorm_backward(const void* grad_y, const void
   UBV_CHECK_ARG(((uintptr_t)ordered_workspace % 16) == 0, "add_norm_backward: ordered_workspace must be 16-byte aligned");
   int rc = norm_check(R, C, dtype, stream_dtype, "add_norm_backward");
   if (rc) return rc;
+  rc = bcast_check(R, bcast_rows, C, dtype, "add_norm_backward");
+  if (rc) return rc;
   if (R == 0) return UBV_OK;
   uint32_t th; float sc;
   drop_params(p, th, sc);
   const long waves = R < 2048 ? R : 2048;
   const dim3 grid((unsigned)((waves + 3) / 4));
   hipStream_t st = as_stream(stream);
-#define UBV_NORM_BWD(T, S) norm_bwd_launch<T, S>(grid, st, grad_y, x, identity, gamma, mean, rstd, grad_x, grad_identity, grad_gamma, grad_beta, grad_x_colsum, (long)R, C, th, sc, seed, seed_dev, (int*)ordered_workspace)
+#define UBV_NORM_BWD(T, S) norm_bwd_launch<T, S>(grid, st, grad_y, x, identity, gamma, mean, rstd, grad_x, grad_identity, grad_gamma, grad_beta, grad_x_colsum, (long)R, C, th, sc, seed, seed_dev, (int*)ordered_workspace, (long)bcast_rows)
   const bool lowp = stream_dtype != UBV_F32;
   switch (dtype) {
     case UBV_F32: UBV_NORM_BWD(float, float); break;

@@ -496,7 +496,7 @@ def _next_seed():
 
 class _AddDropoutNorm(Function):
     @staticmethod
-    def forward(ctx, x, identity, gamma, beta, p, eps):
+    def forward(ctx, x, identity, gamma, beta, p, eps, batch=0):
         with _need_cuda(x, identity, gamma, beta):
             C = x.shape[-1]
             x2 = x.reshape(-1, C).contiguous()
@@ -505,6 +505,12 @@ class _AddDropoutNorm(Function):
             sdt = x2.dtype if lowp else torch.float32
             id2 = identity.reshape(-1, C).to(sdt).contiguous()
             R = x2.shape[0]
+            # batch > 1: x and identity are ONE sample's rows shared by `batch` samples (the first encoder layer's
+            # self-attention): the kernel reads them with a row period, y / mean / rstd / the dropout mask are per sample
+            period = 0
+            if batch and batch > 1:
+                assert x.shape[0] == 1 and identity.shape[0] == 1 and id2.shape[0] == R
+                period, R = R, R * int(batch)
             g, b = gamma.float().contiguous(), beta.float().contiguous()
             y = torch.empty(R, C, dtype=sdt, device=x.device)
             mean = torch.empty(R, dtype=torch.float32, device=x.device)
@@ -512,7 +518,7 @@ class _AddDropoutNorm(Function):
             # seed from torch's CPU generator: reproducible under torch.manual_seed, no device sync
             seed = _next_seed() if p > 0 else 0
             check(lib().ubv_add_dropout_layernorm_forward(_p(x2), _p(id2), _p(g), _p(b), _p(y), _p(mean),
-                                                          _p(rstd), R, C, float(eps), float(p), seed,
+                                                          _p(rstd), R, period, C, float(eps), float(p), seed,
                                                           _p(_SEED_BASE[0]), _dt(x2), _DT[sdt],
                                                           _stream()),
                   'add_dropout_layernorm_forward')
@@ -520,32 +526,40 @@ class _AddDropoutNorm(Function):
             ctx.p, ctx.seed, ctx.shape = float(p), seed, x.shape
             ctx.seed_base = _SEED_BASE[0]
             ctx.dts = (identity.dtype, gamma.dtype, beta.dtype)
-            return y.view(x.shape)
+            ctx.period, ctx.rows = period, R
+            return y.view(x.shape) if not period else y.view(int(batch), *x.shape[1:])
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_y):
         with _need_cuda(grad_y):
             x2, id2, g, mean, rstd = ctx.saved_tensors
-            R, C = x2.shape
+            R, C = ctx.rows, x2.shape[1]
             gy = grad_y.reshape(R, C).to(id2.dtype).contiguous()
-            gx = torch.empty_like(x2)
-            gid = torch.empty_like(id2)
+            gx = torch.empty(R, C, dtype=x2.dtype, device=x2.device)
+            gid = torch.empty(R, C, dtype=id2.dtype, device=x2.device)
             dg, db = zeros_f32(C, x2.device), zeros_f32(C, x2.device)
             dxs = zeros_f32(C, x2.device)
             check(lib().ubv_add_dropout_layernorm_backward(_p(gy), _p(x2), _p(id2), _p(g), _p(mean),
                                                            _p(rstd), _p(gx), _p(gid), _p(dg), _p(db),
-                                                           _p(dxs), R, C, ctx.p, ctx.seed,
+                                                           _p(dxs), R, ctx.period, C, ctx.p, ctx.seed,
                                                            _p(ctx.seed_base), _dt(x2), _dt(id2),
                                                            _p(_ordered_ws(C, x2.device)), _stream()),
                   'add_dropout_layernorm_backward')
+            if ctx.period:                       # one sample's rows were shared: their gradients add up over the samples
+                n = R // ctx.period
+                gx, gid = gx.view(n, ctx.period, C), gid.view(n, ctx.period, C)
+                sx, si = gx[0] + gx[1], gid[0] + gid[1]
+                for b_ in range(2, n):
+                    sx, si = sx + gx[b_], si + gid[b_]
+                gx, gid = sx, si
             gx = gx.view(ctx.shape)
             # column sums of grad_x ride along: if x came straight out of a Linear, its backward takes
             # them as the bias gradient instead of reducing grad_x again (linear._Linear.backward)
             tag_grad(gx, '_ubv_colsum', dxs)
             gid = gid.view(ctx.shape).to(ctx.dts[0])
             tag_grad(gid, '_ubv_owned', True)   # fresh, single consumer: linear._Linear may accumulate into it
-            return (gx, gid, dg.to(ctx.dts[1]), db.to(ctx.dts[2]), None, None)
+            return (gx, gid, dg.to(ctx.dts[1]), db.to(ctx.dts[2]), None, None, None)
 
 
 _NORM_ORDERED = os.environ.get('UBV_NORM_ORDERED', '1') != '0'      # 0: f32 atomics instead of ordered sums (A/B runs)
@@ -558,9 +572,11 @@ def _ordered_ws(C, device):
     return _workspace(int(lib().ubv_add_dropout_layernorm_backward_workspace(int(C))), device)
 
 
-def add_dropout_layernorm(x, identity, gamma, beta, p=0.0, training=False, eps=1e-5):
-    """LayerNorm(identity + dropout(x)) in one pass each way (``ubv_add_dropout_layernorm_*``)."""
-    return _AddDropoutNorm.apply(x, identity, gamma, beta, float(p) if training else 0.0, eps)
+def add_dropout_layernorm(x, identity, gamma, beta, p=0.0, training=False, eps=1e-5, batch=0):
+    """LayerNorm(identity + dropout(x)) in one pass each way (``ubv_add_dropout_layernorm_*``).  ``batch`` > 1: x and
+    identity are (1, ...) — one sample's rows shared by ``batch`` samples — and the result is (batch, ...) with its own
+    dropout mask per sample; their gradients are summed over the samples."""
+    return _AddDropoutNorm.apply(x, identity, gamma, beta, float(p) if training else 0.0, eps, int(batch or 0))
 
 
 # ----------------------------------------------------------------------------------------------- zero arena

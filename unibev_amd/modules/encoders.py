@@ -271,6 +271,9 @@ class PtsEncoder(_EncoderBase):
         return self._run_layers(bev_query, key, value, args, layer_kwargs)
 
 
+_SHARE_FIRST = os.environ.get('UBV_SHARE_FIRST', '1') != '0'     # 0: the first self-attention per sample (A/B runs)
+
+
 class _BevLayer(BaseTransformerLayer):
     """Post-norm layer ('self_attn','norm','cross_attn','norm','ffn','norm'); the loop follows
     encoder_unibev_detr_img.py:395-481 including its positional-encoding quirk q4: the
@@ -315,6 +318,7 @@ class _BevLayer(BaseTransformerLayer):
                 f'attention in operation_order {self.num_attn}'
         order = self.operation_order
         fuse_next = False                 # the previous op handed (out, identity, p) to this norm
+        shared = 0                        # > 0: the pending (out, identity) are ONE sample's rows for `shared` samples
         for op_i, layer in enumerate(order):
             # post-norm layers: `dropout(out) + identity` of an attention / FFN and the LayerNorm
             # that follows run as ONE kernel (functional.add_dropout_layernorm)
@@ -322,12 +326,31 @@ class _BevLayer(BaseTransformerLayer):
                      and query.is_cuda)
             if layer == 'self_attn':
                 ss, lsi = self._bev_shapes(bev_h, bev_w, query.device)
-                query = self.attentions[attn_index](
-                    query, query, query, identity if self.pre_norm else None, query_pos=bev_pos,
-                    key_pos=bev_pos, attn_mask=attn_masks[attn_index],
-                    key_padding_mask=query_key_padding_mask, reference_points=ref_2d,
-                    spatial_shapes=ss, level_start_index=lsi, bev_h=bev_h, bev_w=bev_w,
-                    return_parts=parts, pos_term=pos_term, **kwargs)
+                attn = self.attentions[attn_index]
+
+                def run_self(q, pos, ref):
+                    return attn(q, q, q, identity if self.pre_norm else None, query_pos=pos, key_pos=pos,
+                                attn_mask=attn_masks[attn_index], key_padding_mask=query_key_padding_mask,
+                                reference_points=ref, spatial_shapes=ss, level_start_index=lsi, bev_h=bev_h,
+                                bev_w=bev_w, return_parts=parts, pos_term=pos_term, **kwargs)
+                # The first layer's queries are ONE table for every sample (the reference repeats bev_query over the
+                # batch, encoder_unibev_detr_img.py:228-232; here a stride-0 expand): value / offset / logit
+                # projections, the sampling and output_proj of its self-attention are the same rows bs times.  They run
+                # for one sample; the samples part at the dropout of the fused add + LayerNorm, which reads the shared
+                # rows with a row period (ubv_add_dropout_layernorm_*: bcast_rows).  Same values, 1 / bs of the work.
+                bs = query.shape[0] if query.dim() == 3 else 1
+                one = (parts and _SHARE_FIRST and bs > 1 and query.stride(0) == 0 and attn_masks[attn_index] is None
+                       and query_key_padding_mask is None and (ref_2d is None or ref_2d.shape[0] == bs)
+                       and (pos_term is not None or bev_pos is None or bev_pos.shape[0] == 1
+                            or bev_pos.stride(0) == 0))      # (the positional term must be one table too)
+                out = None
+                if one:
+                    out = run_self(query[:1], None if bev_pos is None else bev_pos[:1],   # (unused under pos_term)
+                                   None if ref_2d is None else ref_2d[:1])
+                    if not (isinstance(out, tuple) and out[0].shape[0] == 1 and out[1].shape[0] == 1):
+                        out = None                             # (not the fused form: every sample on its own)
+                shared = bs if out is not None else 0
+                query = out if out is not None else run_self(query, bev_pos, ref_2d)
                 attn_index += 1
                 fuse_next = parts and isinstance(query, tuple)
                 if not fuse_next:
@@ -337,9 +360,9 @@ class _BevLayer(BaseTransformerLayer):
                 if fuse_next:
                     out, res, p = query
                     query = UF.add_dropout_layernorm(out, res, norm.weight, norm.bias, p,
-                                                     self.training, norm.eps)
+                                                     self.training, norm.eps, batch=shared)
                     identity = query
-                    fuse_next = False
+                    fuse_next, shared = False, 0
                 else:
                     query = norm(query)
                 norm_index += 1
