@@ -264,8 +264,8 @@ int ubv_bev_fuse_backward(const void* grad_out, const void* img, const void* pts
  *   bcast_rows  0, or the number of rows x and identity really hold: they REPEAT over the R rows (row r reads row
  *            r % bcast_rows; R % bcast_rows == 0) — the first encoder layer's self-attention, whose queries are one
  *            table for every sample (encoder_unibev_detr_img.py: bev_query.unsqueeze(1).repeat(1, bs, 1)); y, mean,
- *            rstd, the dropout mask, grad_x and grad_identity stay per row (the caller sums the gradients over the
- *            repeats).  C = 64, 128 or 256 channels per 16-byte-lane row only.
+ *            rstd and the dropout mask stay per row; the backward writes grad_x and grad_identity as [bcast_rows, C],
+ *            SUMMED over the repeats.  Rows of 16, 32 or 64 16-byte lanes only (f32: C = 64, 128, 256).
  *   C % 4 == 0, C <= 1024.
  */
 int64_t ubv_add_dropout_layernorm_backward_workspace(int C);

@@ -266,55 +266,72 @@ __global__ __launch_bounds__(256) void add_norm_bwd_rows_kernel(
 #pragma unroll
     for (int k = 0; k < 4; ++k) { g[i + k] = t4[k]; ag[i + k] = 0.0f; ab[i + k] = 0.0f; ax[i + k] = 0.0f; }
   }
-  for (long r0 = wave * G; r0 < R; r0 += nwaves * G) {
+  // period > 0 (x / identity are `period` rows shared by R / period samples): a lane group walks the SOURCE rows and,
+  // per source row, the samples' rows r + b period — x and identity are read once, and grad_x / grad_identity
+  // [period, C] come out already summed over the samples (what the shared rows' producers need)
+  const long Rs = period > 0 ? period : R;
+  const int nrep = period > 0 ? (int)(R / period) : 1;
+  for (long r0 = wave * G; r0 < Rs; r0 += nwaves * G) {
     const long r = r0 + sub;
-    const bool ok = r < R;
-    const long rr = ok ? r : 0;
-    const float mu = mean[rr], rs = rstd[rr];
-    const long rs_ = period > 0 ? (long)((unsigned)rr % (unsigned)period) : rr;      // source row of x / identity
-    float xv[VEC], iv[VEC], go[VEC], xh[VEC], dxh[VEC], keep[VEC];
-    vec_io<T, VEC>::load(x + rs_ * C + c, xv);
+    const bool ok = r < Rs;
+    const long rsrc = ok ? r : 0;
+    float xv[VEC], iv[VEC], dxs[VEC], dss[VEC];
+    vec_io<T, VEC>::load(x + rsrc * C + c, xv);
 #pragma unroll
     for (int i = 0; i < VEC; i += 4) {
       float t4[4];
-      load4<S>(identity + rs_ * C + c + i, t4);
+      load4<S>(identity + rsrc * C + c + i, t4);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) iv[i + k] = t4[k];
-      load4<S>(gy + rr * C + c + i, t4);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) go[i + k] = ok ? t4[k] : 0.0f;
+      for (int k = 0; k < 4; ++k) { iv[i + k] = t4[k]; dxs[i + k] = 0.0f; dss[i + k] = 0.0f; }
     }
-    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll 1
+    for (int b = 0; b < nrep; ++b) {
+      const long rr = rsrc + (long)b * Rs;
+      const float mu = mean[rr], rs = rstd[rr];
+      float go[VEC], xh[VEC], dxh[VEC], keep[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      keep[i] = 1.0f;
-      if (thresh != 0u) keep[i] = (drop_hash(seed, (uint64_t)(rr * C + c + i)) >= thresh) ? scale : 0.0f;
-      const float s = iv[i] + xv[i] * keep[i];
-      xh[i] = (s - mu) * rs;
-      dxh[i] = go[i] * g[i];
-      s1 += dxh[i];
-      s2 = fmaf(dxh[i], xh[i], s2);
-      ag[i] = fmaf(go[i], xh[i], ag[i]);
-      ab[i] += go[i];
+      for (int i = 0; i < VEC; i += 4) {
+        float t4[4];
+        load4<S>(gy + rr * C + c + i, t4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) go[i + k] = ok ? t4[k] : 0.0f;
+      }
+      float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        keep[i] = 1.0f;
+        if (thresh != 0u) keep[i] = (drop_hash(seed, (uint64_t)(rr * C + c + i)) >= thresh) ? scale : 0.0f;
+        const float s = iv[i] + xv[i] * keep[i];
+        xh[i] = (s - mu) * rs;
+        dxh[i] = go[i] * g[i];
+        s1 += dxh[i];
+        s2 = fmaf(dxh[i], xh[i], s2);
+        ag[i] = fmaf(go[i], xh[i], ag[i]);
+        ab[i] += go[i];
+      }
+      s1 = row_sum<LPR>(s1) / (float)C;
+      s2 = row_sum<LPR>(s2) / (float)C;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float ds = rs * (dxh[i] - s1 - xh[i] * s2);
+        dss[i] += ds;
+        dxs[i] = fmaf(ds, keep[i], dxs[i]);
+      }
     }
-    s1 = row_sum<LPR>(s1) / (float)C;
-    s2 = row_sum<LPR>(s2) / (float)C;
     if (ok) {
-      float dx[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; i += 4) {
         float ds[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          ds[k] = rs * (dxh[i + k] - s1 - xh[i + k] * s2);
-          dx[i + k] = ds[k] * keep[i + k];
+          ds[k] = dss[i + k];
           // column sums of grad_x AS STORED (rounded to T): the bias gradient of the Linear that
           // produced x, which would otherwise re-read grad_x
-          ax[i + k] += elem<T>::to_float(elem<T>::from_float(dx[i + k]));
+          ax[i + k] += elem<T>::to_float(elem<T>::from_float(dxs[i + k]));
         }
         store4<S>(gid + r * C + c + i, ds);
       }
-      vec_io<T, VEC>::store(gx + r * C + c, dx);
+      vec_io<T, VEC>::store(gx + r * C + c, dxs);
     }
   }
 #pragma unroll

@@ -536,8 +536,8 @@ class _AddDropoutNorm(Function):
             x2, id2, g, mean, rstd = ctx.saved_tensors
             R, C = ctx.rows, x2.shape[1]
             gy = grad_y.reshape(R, C).to(id2.dtype).contiguous()
-            gx = torch.empty(R, C, dtype=x2.dtype, device=x2.device)
-            gid = torch.empty(R, C, dtype=id2.dtype, device=x2.device)
+            gx = torch.empty_like(x2)            # (shared rows: [period, C], summed over the samples by the kernel)
+            gid = torch.empty_like(id2)
             dg, db = zeros_f32(C, x2.device), zeros_f32(C, x2.device)
             dxs = zeros_f32(C, x2.device)
             check(lib().ubv_add_dropout_layernorm_backward(_p(gy), _p(x2), _p(id2), _p(g), _p(mean),
@@ -546,13 +546,6 @@ class _AddDropoutNorm(Function):
                                                            _p(ctx.seed_base), _dt(x2), _dt(id2),
                                                            _p(_ordered_ws(C, x2.device)), _stream()),
                   'add_dropout_layernorm_backward')
-            if ctx.period:                       # one sample's rows were shared: their gradients add up over the samples
-                n = R // ctx.period
-                gx, gid = gx.view(n, ctx.period, C), gid.view(n, ctx.period, C)
-                sx, si = gx[0] + gx[1], gid[0] + gid[1]
-                for b_ in range(2, n):
-                    sx, si = sx + gx[b_], si + gid[b_]
-                gx, gid = sx, si
             gx = gx.view(ctx.shape)
             # column sums of grad_x ride along: if x came straight out of a Linear, its backward takes
             # them as the bias gradient instead of reducing grad_x again (linear._Linear.backward)
