@@ -752,6 +752,10 @@ def main():
                        'sampling_params': ('spread' if args.params == 'spread' else
                                            "init: the reference's init_weights (zero offset weights, compass-grid bias); "
                                            "`spread` sub-record: scattered offsets"),
+                       'first_layer_self_attention': ('one query table for the batch: computed once per step and shared by '
+                                                      'the samples (same values as per-sample; UBV_SHARE_FIRST=0 '
+                                                      'computes it per sample)')
+                       if os.environ.get('UBV_SHARE_FIRST', '1') != '0' else 'per sample',
                        'step': 'fwd + bwd (HIP graphs) + flat-gradient all-reduce + clip + AdamW'
                                if main_rec['hip_graphs'] else 'fwd + bwd + flat-gradient all-reduce + clip + AdamW',
                        'optimizer': 'flat-buffer clip + AdamW kernels' if args.flat_optimizer else 'torch clip_grad_norm_ + fused AdamW',
