@@ -103,8 +103,10 @@ def parse():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP graphs')
     ap.add_argument('--torch-optimizer', dest='flat_optimizer', action='store_false',
                     help='torch clip_grad_norm_ + fused AdamW instead of the flat-buffer kernels')
-    ap.add_argument('--single-stream', action='store_true',
-                    help='both encoders on one stream (default: image and point-cloud encoders on two)')
+    ap.add_argument('--single-stream', action='store_true', help='(the default since round 4: kept for old command lines)')
+    ap.add_argument('--two-streams', action='store_true',
+                    help='image and point-cloud encoders on two HIP streams: faster and NOT reproducible (gradients of the '
+                         'side branch 1e-2 off in a fraction of the steps, modules/transformer.py) - experiments only')
     ap.add_argument('--no-extras', action='store_true', help='skip the gemm / voxel records')
     ap.add_argument('--eval-mode', action='store_true', help='dropout / modality dropout off')
     ap.add_argument('--launcher', default='auto', choices=['auto', 'spawn', 'none'],
@@ -227,12 +229,16 @@ def sampling_ops(workload, bs, esize, visible_pairs):
     """op name -> (map tag in the library's kernel names, fwd bytes, bwd bytes) per launch."""
     kw, img_hw, pts_hw, _ = WORKLOADS[workload]
     C, H, Nq = kw['embed_dims'], 8, 200 * 200
-    ops = {'self_attn': ('Nc=1 map=200x200', k1_bytes(bs, Nq, Nq, C, H, 4, esize, False),
+    ops = {'self_attn': (f'Nc=1 map=200x200 Nq={Nq} B={bs}', k1_bytes(bs, Nq, Nq, C, H, 4, esize, False),
                          k1_bytes(bs, Nq, Nq, C, H, 4, esize, True))}
+    if bs > 1:      # the first layer's self-attention runs once for the batch (modules/encoders.py, DESIGN 3.6d)
+        ops['self_attn (first layer, one sample for the batch)'] = (
+            f'Nc=1 map=200x200 Nq={Nq} B=1', k1_bytes(1, Nq, Nq, C, H, 4, esize, False),
+            k1_bytes(1, Nq, Nq, C, H, 4, esize, True))
     mods = kw.get('modalities', 'LC')
     if 'L' in mods:
         S = pts_hw[0] * pts_hw[1]
-        ops['sca_pts'] = (f'Nc=1 map={pts_hw[0]}x{pts_hw[1]}', k1_bytes(bs, S, Nq, C, H, 8, esize, False),
+        ops['sca_pts'] = (f'Nc=1 map={pts_hw[0]}x{pts_hw[1]} Nq={Nq} B={bs}', k1_bytes(bs, S, Nq, C, H, 8, esize, False),
                           k1_bytes(bs, S, Nq, C, H, 8, esize, True))
     if 'C' in mods:
         fh, fw = img_hw[0] // 32, img_hw[1] // 32
@@ -242,7 +248,7 @@ def sampling_ops(workload, bs, esize, visible_pairs):
         pairs = visible_pairs
         fwd = bs * S6 * C * esize + pairs * H * 8 * 3 * 4 + pairs * C * esize
         bwd = bs * S6 * C * 2 * esize + 2 * pairs * H * 8 * 3 * 4 + pairs * C * esize
-        ops['sca_img'] = (f'Nc=6 map={fh}x{fw}', fwd, bwd)
+        ops['sca_img'] = (f'Nc=6 map={fh}x{fw} Nq={Nq} B={bs}', fwd, bwd)
     return ops
 
 
@@ -255,13 +261,14 @@ def op_roofline(prof, ops, prof_ops=None):
     prof_ops = prof_ops or prof
     for op, (tag, fb, bb) in ops.items():
         for direction, scope, nbytes in (('fwd', 'bev_lift_fwd<', fb), ('bwd', 'bev_lift_bwd_op<', bb)):
-            hit = [(k, r) for k, r in prof_ops.items() if k.startswith(scope) and tag in k]
+            # (tag ends with the batch: the first layer's self-attention, computed once for the batch, is its own row)
+            hit = [(k, r) for k, r in prof_ops.items() if k.startswith(scope) and k.endswith(tag)]
             if not hit:
                 continue
             us = sum(r['avg_us'] for _, r in hit)
             launches = hit[0][1]['launches']
             kern = {k.split('<')[0]: round(r['avg_us'], 1) for k, r in prof.items()
-                    if tag in k and k.startswith('bev_lift_' + direction) and not k.startswith('bev_lift_bwd_op')}
+                    if k.endswith(tag) and k.startswith('bev_lift_' + direction) and not k.startswith('bev_lift_bwd_op')}
             gbs = nbytes / (us * 1e-6) / 1e9
             out.append({'op': op, 'pass': direction, 'launches': launches, 'avg_us': us,
                         'compulsory_bytes_per_launch': float(nbytes), 'achieved_GBps': gbs,
@@ -398,8 +405,8 @@ def run_mode(args, name, head, world, rank, device, want_ops):
     # ---- per-op roofline: the same step, eager, HIP events on the launch stream around every
     # sampling kernel / op (events cannot be read back from inside a captured graph)
     if want_ops and not args.no_kernel_timing:
-        # (one stream: a kernel's duration is its own, not its share of a chip it splits with the other
-        #  encoder's kernels — the timed steps above run the two encoders on two streams)
+        # (one stream, also when the timed steps ran with --two-streams: a kernel's duration is its own, not its
+        #  share of a chip it splits with the other encoder's kernels)
         from unibev_amd.modules import transformer as _tr
         two = _tr._TWO_STREAMS[0]
         _tr.set_two_streams(False)
@@ -693,9 +700,8 @@ def main():
     # everything runs on one non-default stream: HIP-graph capture needs the gradient accumulation of
     # every parameter pinned to the capturing stream (graph_step.GraphedStep.capture)
     torch.cuda.set_stream(torch.cuda.Stream(device))
-    if args.single_stream:
-        from unibev_amd.modules import transformer as _tr
-        _tr.set_two_streams(False)
+    from unibev_amd.modules import transformer as _tr
+    _tr.set_two_streams(bool(args.two_streams) and not args.single_stream)
     from unibev_amd import dp
     dp.init_distributed('nccl', device)                       # RCCL over xGMI (no-op for N = 1)
 

@@ -211,3 +211,53 @@ def test_split_backward_graphs_equal_the_single_backward():
         torch.testing.assert_close(replayed, two.grads.flat, rtol=1e-4, atol=1e-5 * scale)
     two.close()
     torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+def test_training_step_gradients_are_reproducible_eagerly_and_replayed():
+    """The default (one-stream) step at BASELINE's shapes: forward + backward twice eagerly and three HIP-graph replays give
+    the same BEV features bit for bit and gradients within 5e-5 normwise of each other for every tensor (the only
+    run-to-run freedom is the f32 summation order of the binned sampling records: 6e-6 measured).  This is the property
+    the two-stream mode — off by default, modules/transformer.py — does not have (1e-2, tools/ab/grad_repro*.py)."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    from _util import encoder_case, t, tq
+    from unibev_amd import build_transformer, synthetic as syn
+    from unibev_amd.graph_step import GraphedStep
+    from unibev_amd.modules import transformer as TR
+    assert not TR._TWO_STREAMS[0]
+    dev = 'cuda'
+    torch.cuda.set_stream(torch.cuda.Stream())
+    cfg, sd, inp, g = encoder_case('fullsize_smooth')
+    model = build_transformer(json.loads(json.dumps(cfg))).to(dev).eval()
+    model.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    model.forced_flags = (1, 1)
+    nq, bs = inp['bev_h'] * inp['bev_w'], inp['bs']
+    cot = t(syn.seeded_array('cot:fullsize_smooth', (nq, bs, cfg['embed_dims']), 5) / nq ** 0.5, device=dev)
+    img = [t(x, device=dev).requires_grad_() for x in inp['img']]
+    pts = [t(x, device=dev).requires_grad_() for x in inp['pts']]
+    bev_q, bev_pos = tq(inp['bev_q'], device=dev, grad=True), t(inp['bev_pos'], device=dev)
+    params = [p for n, p in model.named_parameters() if not n.startswith('decoder') and not n.startswith('reference_points')]
+    fwd = lambda: model.encode(img, pts, bev_q, inp['bev_h'], inp['bev_w'], bev_pos=bev_pos, img_metas=inp['metas'])  # noqa: E731
+    gs = GraphedStep(model, fwd, cot, params, inputs=img + pts + [bev_q])
+
+    def snapshot(out):
+        torch.cuda.synchronize()
+        return out.detach().clone(), [v.clone() for v in gs.grads.views]
+
+    runs = []
+    for _ in range(2):
+        gs._clear_grads()
+        runs.append(snapshot(gs._fwd_bwd()))
+    gs.capture()
+    for _ in range(3):
+        model.forced_flags = (1, 1)
+        gs.step()
+        runs.append(snapshot(gs.out))
+    out0, g0 = runs[0]
+    for out, grads in runs[1:]:
+        assert torch.equal(out, out0)
+        for a, b in zip(grads, g0):
+            nb = float(b.norm())
+            assert float((a - b).norm()) <= 5e-5 * nb + 1e-20
+    gs.close()

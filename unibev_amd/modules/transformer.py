@@ -58,9 +58,17 @@ class ModalityProjectionModule(BaseModule):
 
 import os as _os
 
-# Image and point-cloud encoders on two HIP streams (UBV_TWO_STREAMS=0 or set_two_streams(False): one).
-# Measured at bs = 2, L+C CNW: 95.8 -> 106.3 samples/s in fp32, 173.9 -> 197.3 in bf16.
-_TWO_STREAMS = [_os.environ.get('UBV_TWO_STREAMS', '1') != '0']
+# Image and point-cloud encoders on two HIP streams: OFF by default since round 4, session 9 (UBV_TWO_STREAMS=1 or
+# set_two_streams(True) turns it on for experiments).  It was the default from round 2 on (95.8 -> 106.3 samples/s then,
+# 128.9 -> 141.1 at the end of round 4) and it is NOT SAFE: tools/ab/grad_repro.py / grad_repro_graph.py compare the
+# gradients of the full-size fixture with a one-stream run of the same process.  One stream reproduces to 6e-6 (f32
+# summation order of the binned records).  Two streams: eagerly, a fraction of the backward passes came out with the
+# side branch's last layer and the caller's branch's first layer 1e-2 off (the forward bit-identical every time);
+# replayed as a HIP graph — where nothing but the captured dependencies orders the two branches — the FORWARD itself
+# was off by 1e-3 in a third of the replays, and the gradients with it.  Workspaces, arenas and saved tensors are per
+# stream, the crossing tensors were recorded on both streams, the two backward passes were chained through the
+# autograd engine (eager: clean 12 / 12; graph: still 1 in 3 wrong): the race is not found, so the overlap is not used.
+_TWO_STREAMS = [_os.environ.get('UBV_TWO_STREAMS', '0') == '1']
 _SIDE_STREAMS = {}
 
 
