@@ -1,0 +1,43 @@
+"""One lifting op (forward) repeated on a side stream while GEMMs run on the current stream: do its outputs stay the same?
+   python tools/ab/lift_concurrent.py [pts|self] [iters]"""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import bench_lift as BL
+from unibev_amd import functional as UF
+dev = 'cuda'
+name = sys.argv[1] if len(sys.argv) > 1 else 'pts'
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+value, offlog, ref, vis0, count, gout, geom, is_grid, center = BL.instance(name, 2, torch.float32, dev, True, (256, 704), 32)
+B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh = geom
+def lift():
+    return UF.bev_lift(value, offlog, ref, Nc, (fh, fw), H, P, vis0=vis0, count=count, query_grid=(qh, qw), ref_is_grid=is_grid)
+ref_out = lift().clone()
+torch.cuda.synchronize()
+x = torch.randn(80000, 256, device=dev); w = torch.randn(256, 256, device=dev)
+hi, lo, _, _ = UF.split_weight(w)
+main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+xb = x.bfloat16(); wb = w.bfloat16().contiguous(); gy = torch.randn(80000, 256, device=dev)
+gam = torch.ones(256, device=dev); bet = torch.zeros(256, device=dev)
+for mode in ('alone', 'beside gemm_nt', 'beside gemm_nt bf16', 'beside wgrad', 'beside add_norm', 'beside torch.mm'):
+    outs = []
+    side.wait_stream(main)
+    for i in range(iters):
+        with torch.cuda.stream(side):
+            outs.append(lift())
+        if mode == 'beside gemm_nt':
+            for _ in range(3): UF.gemm_nt(x, hi, lo)
+        elif mode == 'beside gemm_nt bf16':
+            for _ in range(3): UF.gemm_nt(xb, wb, None)
+        elif mode == 'beside wgrad':
+            for _ in range(2): UF.gemm_wgrad(gy, x)
+        elif mode == 'beside add_norm':
+            for _ in range(3): UF.add_dropout_layernorm(x, gy, gam, bet, 0.1, True)
+        elif mode == 'beside torch.mm':
+            for _ in range(3): torch.mm(x, w)
+        elif mode == 'beside add':
+            for _ in range(6): x + 1.0
+    torch.cuda.synchronize()
+    bad = sum(not torch.equal(o, ref_out) for o in outs)
+    worst = max(float((o - ref_out).norm() / ref_out.norm()) for o in outs)
+    print(f'{name} {mode:16s}: {bad} of {iters} outputs differ, worst {worst:.1e}')
