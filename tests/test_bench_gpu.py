@@ -38,7 +38,8 @@ def test_bench_json_contract(force_ddp):
     assert all(x['value'] > d['value'] for x in d['lowp'])
     assert d['config']['rccl_ranks'] == 1
     ops = {(o['op'], o['pass']) for o in d['roofline_ops']}
-    assert ops == {(o, p) for o in ('self_attn', 'sca_pts', 'sca_img') for p in ('fwd', 'bwd')}
+    shared = 'self_attn (first layer, one sample for the batch)'       # its own row at per-GPU batch > 1
+    assert ops == {(o, p) for o in ('self_attn', 'sca_pts', 'sca_img', shared) for p in ('fwd', 'bwd')}
     if force_ddp == '0':
         assert d['gemm'] and d['voxel']['voxels'] > 10000 and d['voxel']['points_per_s'] > 0
 
@@ -51,7 +52,7 @@ def test_bench_other_workloads(workload, ops):
     d = _run({}, '--workload', workload, '--dtype', 'fp32', '--no-extras', '--no-parity')
     assert d['value'] > 0 and d['dtype'] == 'fp32' and d['n_gpus'] == 1 and 'lowp' not in d
     assert {'C': 'unibev_nus_C', 'L': 'unibev_nus_L', 'LC_cat128': 'unibev_nus_LC_cat_128'}[workload] in d['config']['workload']
-    assert {o['op'] for o in d['roofline_ops']} == ops
+    assert {o['op'] for o in d['roofline_ops']} == ops | {'self_attn (first layer, one sample for the batch)'}
     assert all(0 < o['frac'] < 1 and o['pass'] in ('fwd', 'bwd') for o in d['roofline_ops'])
     assert d['roofline']['bound'] == 'hbm' and d['config']['step'].startswith('fwd + bwd (HIP graphs)')
 
