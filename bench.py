@@ -103,10 +103,9 @@ def parse():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP graphs')
     ap.add_argument('--torch-optimizer', dest='flat_optimizer', action='store_false',
                     help='torch clip_grad_norm_ + fused AdamW instead of the flat-buffer kernels')
-    ap.add_argument('--single-stream', action='store_true', help='(the default since round 4: kept for old command lines)')
-    ap.add_argument('--two-streams', action='store_true',
-                    help='image and point-cloud encoders on two HIP streams: faster and NOT reproducible (gradients of the '
-                         'side branch 1e-2 off in a fraction of the steps, modules/transformer.py) - experiments only')
+    ap.add_argument('--single-stream', action='store_true',
+                    help='both encoders on one stream (default: image and point-cloud encoders on two)')
+    ap.add_argument('--two-streams', action='store_true', help='(the default; kept for command lines of round 4)')
     ap.add_argument('--no-extras', action='store_true', help='skip the gemm / voxel records')
     ap.add_argument('--eval-mode', action='store_true', help='dropout / modality dropout off')
     ap.add_argument('--launcher', default='auto', choices=['auto', 'spawn', 'none'],
@@ -405,8 +404,8 @@ def run_mode(args, name, head, world, rank, device, want_ops):
     # ---- per-op roofline: the same step, eager, HIP events on the launch stream around every
     # sampling kernel / op (events cannot be read back from inside a captured graph)
     if want_ops and not args.no_kernel_timing:
-        # (one stream, also when the timed steps ran with --two-streams: a kernel's duration is its own, not its
-        #  share of a chip it splits with the other encoder's kernels)
+        # (one stream: a kernel's duration is its own, not its share of a chip it splits with the other
+        #  encoder's kernels — the timed steps above run the two encoders on two streams)
         from unibev_amd.modules import transformer as _tr
         two = _tr._TWO_STREAMS[0]
         _tr.set_two_streams(False)
@@ -700,8 +699,9 @@ def main():
     # everything runs on one non-default stream: HIP-graph capture needs the gradient accumulation of
     # every parameter pinned to the capturing stream (graph_step.GraphedStep.capture)
     torch.cuda.set_stream(torch.cuda.Stream(device))
-    from unibev_amd.modules import transformer as _tr
-    _tr.set_two_streams(bool(args.two_streams) and not args.single_stream)
+    if args.single_stream:
+        from unibev_amd.modules import transformer as _tr
+        _tr.set_two_streams(False)
     from unibev_amd import dp
     dp.init_distributed('nccl', device)                       # RCCL over xGMI (no-op for N = 1)
 

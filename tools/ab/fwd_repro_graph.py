@@ -22,7 +22,7 @@ def fwd():
         return model.encode(gi, gp, gq, inp['bev_h'], inp['bev_w'], bev_pos=bev_pos, img_metas=inp['metas'], return_parts=True)
 TR.set_two_streams(False)
 ref = [x.clone() for x in fwd()]
-TR.set_two_streams(os.environ.get('UBV_TWO_STREAMS', '0') == '1')
+TR.set_two_streams(os.environ.get('UBV_TWO_STREAMS', '1') != '0')
 for _ in range(3):
     fwd()
 torch.cuda.synchronize()

@@ -48,7 +48,7 @@ def run():
 from unibev_amd.modules import transformer as TR
 TR.set_two_streams(False)
 ref = run()          # one stream: the reference (reproducible to ~6e-6)
-TR.set_two_streams(os.environ.get('UBV_TWO_STREAMS', '0') == '1')
+TR.set_two_streams(os.environ.get('UBV_TWO_STREAMS', '1') != '0')
 runs = [run() for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3)]
 for i, r in enumerate(runs):
     d = {k: float((r[k] - ref[k]).norm() / ref[k].norm().clamp_min(1e-30)) for k in ref if k in r}

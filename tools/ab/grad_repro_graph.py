@@ -33,7 +33,7 @@ def grads_of(gs):
 TR.set_two_streams(False)
 one = GraphedStep(model, fwd, cot, params, inputs=gi + gp + [gq])
 one._clear_grads(); ref_out = one._fwd_bwd().detach().clone(); ref = grads_of(one)
-TR.set_two_streams(os.environ.get('UBV_TWO_STREAMS', '0') == '1')
+TR.set_two_streams(os.environ.get('UBV_TWO_STREAMS', '1') != '0')
 two = GraphedStep(model, fwd, cot, params, inputs=gi + gp + [gq])
 two.capture()
 for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):

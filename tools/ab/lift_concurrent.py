@@ -10,13 +10,17 @@ name = sys.argv[1] if len(sys.argv) > 1 else 'pts'
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 value, offlog, ref, vis0, count, gout, geom, is_grid, center = BL.instance(name, 2, torch.float32, dev, True, (256, 704), 32)
 B, Nc, fh, fw, H, Dh, Nq, P, Z, qw, qh = geom
+print('ref contiguous:', ref.is_contiguous(), ref.dtype, tuple(ref.shape), tuple(ref.stride()), '| offlog', offlog.is_contiguous(), offlog.dtype, '| value', value.is_contiguous())
+if os.environ.get('UBV_REF_CONTIG') == '1':
+    ref = ref.float().contiguous()
 def lift():
     return UF.bev_lift(value, offlog, ref, Nc, (fh, fw), H, P, vis0=vis0, count=count, query_grid=(qh, qw), ref_is_grid=is_grid)
 ref_out = lift().clone()
 torch.cuda.synchronize()
 x = torch.randn(80000, 256, device=dev); w = torch.randn(256, 256, device=dev)
 hi, lo, _, _ = UF.split_weight(w)
-main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+prio = int(os.environ.get('UBV_SIDE_PRIORITY', '0'))
+main, side = torch.cuda.current_stream(), torch.cuda.Stream(priority=prio)
 xb = x.bfloat16(); wb = w.bfloat16().contiguous(); gy = torch.randn(80000, 256, device=dev)
 gam = torch.ones(256, device=dev); bet = torch.zeros(256, device=dev)
 for mode in ('alone', 'beside gemm_nt', 'beside gemm_nt bf16', 'beside wgrad', 'beside add_norm', 'beside torch.mm'):

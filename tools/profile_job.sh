@@ -12,9 +12,9 @@ B="python $ROOT/bench.py"
 (cd $ROOT && $B --cpu-baseline-plan > $OUT/bench.json 2> $OUT/bench.err)
 (cd $ROOT && $B --workload LC_cat128 --no-cpu-baseline --no-extras > $OUT/bench_cat128.json 2> $OUT/bench_cat128.err)
 for w in C L; do (cd $ROOT && $B --workload $w --no-cpu-baseline --no-extras > $OUT/bench_$w.json 2> $OUT/bench_$w.err); done
-# (the two-stream mode: faster, not reproducible, off by default - recorded for the comparison only)
-(cd $ROOT && $B --two-streams --no-cpu-baseline --no-extras --no-kernel-timing > $OUT/bench_two_streams.json 2>/dev/null)
-(cd $ROOT && python tools/ab/grad_repro.py 4 2>&1 | grep '^run' > $OUT/grad_repro_one_stream.txt; UBV_TWO_STREAMS=1 python tools/ab/grad_repro.py 6 2>&1 | grep '^run' > $OUT/grad_repro_two_streams.txt; UBV_TWO_STREAMS=1 python tools/ab/grad_repro_graph.py 6 2>&1 | grep '^replay' > $OUT/grad_repro_graph_two_streams.txt; UBV_TWO_STREAMS=0 python tools/ab/grad_repro_graph.py 4 2>&1 | grep '^replay' > $OUT/grad_repro_graph_one_stream.txt)
+(cd $ROOT && $B --single-stream --no-cpu-baseline --no-extras --no-kernel-timing > $OUT/bench_single_stream.json 2>/dev/null)
+# reproducibility of the step's gradients against a one-stream run of the same process, both modes, eager and replayed
+(cd $ROOT && UBV_TWO_STREAMS=0 python tools/ab/grad_repro.py 4 2>&1 | grep '^run' > $OUT/grad_repro_one_stream.txt; UBV_TWO_STREAMS=1 python tools/ab/grad_repro.py 12 2>&1 | grep '^run' > $OUT/grad_repro_two_streams.txt; UBV_TWO_STREAMS=1 python tools/ab/grad_repro_graph.py 24 2>&1 | grep '^replay' > $OUT/grad_repro_graph_two_streams.txt; UBV_TWO_STREAMS=0 python tools/ab/grad_repro_graph.py 4 2>&1 | grep '^replay' > $OUT/grad_repro_graph_one_stream.txt; UBV_TWO_STREAMS=1 python tools/ab/fwd_repro_graph.py 24 2>&1 | tail -1 > $OUT/fwd_repro_graph_two_streams.txt; python tools/ab/lift_concurrent.py pts 40 2>&1 | grep -v '^/opt' > $OUT/lift_concurrent.txt)
 # 3. rocprofv3 kernel summary of the default bench command (what roofline.achieved must agree with)
 rocprofv3 --kernel-trace -d /tmp/prof_cmd -o cmd -- $B --no-cpu-baseline > $OUT/bench_profiled.json 2>/dev/null
 python $ROOT/tools/db_table.py /tmp/prof_cmd/cmd_results.db 1 80 > $OUT/bench_command_kernel_totals.txt

@@ -58,17 +58,18 @@ class ModalityProjectionModule(BaseModule):
 
 import os as _os
 
-# Image and point-cloud encoders on two HIP streams: OFF by default since round 4, session 9 (UBV_TWO_STREAMS=1 or
-# set_two_streams(True) turns it on for experiments).  It was the default from round 2 on (95.8 -> 106.3 samples/s then,
-# 128.9 -> 141.1 at the end of round 4) and it is NOT SAFE: tools/ab/grad_repro.py / grad_repro_graph.py compare the
-# gradients of the full-size fixture with a one-stream run of the same process.  One stream reproduces to 6e-6 (f32
-# summation order of the binned records).  Two streams: eagerly, a fraction of the backward passes came out with the
-# side branch's last layer and the caller's branch's first layer 1e-2 off (the forward bit-identical every time);
-# replayed as a HIP graph — where nothing but the captured dependencies orders the two branches — the FORWARD itself
-# was off by 1e-3 in a third of the replays, and the gradients with it.  Workspaces, arenas and saved tensors are per
-# stream, the crossing tensors were recorded on both streams, the two backward passes were chained through the
-# autograd engine (eager: clean 12 / 12; graph: still 1 in 3 wrong): the race is not found, so the overlap is not used.
-_TWO_STREAMS = [_os.environ.get('UBV_TWO_STREAMS', '0') == '1']
+# Image and point-cloud encoders on two HIP streams (UBV_TWO_STREAMS=0 or set_two_streams(False): one).
+# Measured at bs = 2, L+C CNW: 95.8 -> 106.3 samples/s in fp32 (round 2), 131.0 -> 143.5 (round 4).
+# Round 4 found the mode NOT reproducible as built in rounds 2 - 4 — gradients of the side branch 1e-2 off in part of the
+# eager steps, the forward 1e-3 off in most HIP-graph replays, against 6e-6 for one stream — and traced it to the
+# instruction level (profiles/r04_two_stream_race.txt): PACKED f32 VALU instructions (v_pk_fma_f32 / v_pk_add_f32 /
+# v_pk_mul_f32, which clang's SLP vectoriser forms from pairs of scalar f32 operations) return wrong results in a wave
+# while MFMA instructions of another kernel's wave run on the same SIMD — here: a lifting kernel's coordinate arithmetic
+# beside the other encoder's GEMM.  The library is therefore built with -fno-slp-vectorize (csrc/Makefile: no packed
+# f32 arithmetic in any kernel; not slower), after which the two-stream step reproduces like the one-stream step
+# (tools/ab/grad_repro*.py, fwd_repro_graph.py: 0 of 60 replays / 30 eager runs differ;
+# tests/test_bench_gpu.py::test_training_step_gradients_are_reproducible_eagerly_and_replayed runs both modes).
+_TWO_STREAMS = [_os.environ.get('UBV_TWO_STREAMS', '1') != '0']
 _SIDE_STREAMS = {}
 
 
