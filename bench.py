@@ -127,7 +127,9 @@ def parse():
     ap.add_argument('--exchange', default='auto', choices=['auto', 'split', 'single'],
                     help="gradient exchange: 'split' = the backward is two HIP graphs cut at the first encoder layers and the "
                          "upper layers' segment of the flat gradient buffer is all-reduced beside the second graph; 'single' = "
-                         "one graph, one message after it; 'auto' = split when there is a process group (N > 1)")
+                         "one graph, one message after it; 'auto' = single.  (split puts RCCL's reduction kernels beside the "
+                         "lower backward's MFMA kernels; RCCL is not built by this repository and its f32 sums may use the "
+                         "packed instructions that go wrong there - DESIGN section 5/6 - so it is opt-in until checked on N > 1)")
     ap.add_argument('--no-ieee-gemm', action='store_true', help='skip the `ieee_gemm` sub-record (f32 step on library IEEE GEMMs)')
     ap.add_argument('--fp32-stream', action='store_true',
                     help='keep the encoder residual stream in f32 under autocast (default: the '
@@ -306,7 +308,7 @@ def run_mode(args, name, head, world, rank, device, want_ops):
     s = 2 if kw.get('fusion_method') == 'cat' else 1
     C = kw['embed_dims']
     cot = torch.randn(200 * 200, args.bs, C * s, device=device) / 200.0
-    split = args.exchange == 'split' or (args.exchange == 'auto' and dist.is_initialized())
+    split = args.exchange == 'split'
     tr = head.transformer
     encs = [getattr(tr, n) for n in ('img_bev_encoder', 'pts_bev_encoder') if getattr(tr, n, None) is not None]
     cut = encs if split else None
