@@ -565,11 +565,20 @@ int ubv_spconv_gather_mma(const void* feats, const int32_t* nbr, int64_t ld, int
  *   ubv_sumsq_f32     out[0] = sum x[i]^2 (deterministic two-stage reduction; workspace of
  *                     ubv_sumsq_workspace() bytes)
  *   ubv_adamw_flat    *step += 1 (device-side int64), then AdamW on p / m / v [n] from g [n]; when `sumsq` is given
- *                     the gradient is first scaled by min(1, max_norm / (sqrt(*sumsq) + 1e-6)) — nothing read back. */
+ *                     the gradient is first scaled by min(1, max_norm / (sqrt(*sumsq) + 1e-6)) — nothing read back.
+ *   ubv_adamw_flat_groups   the same step with torch.optim param_groups (what mmcv's DefaultOptimizerConstructor makes
+ *                     of the config's paramwise_cfg = dict(custom_keys = {'img_backbone': dict(lr_mult = 0.1)}),
+ *                     ...cnw_256_modality_dropout.py:455-462): range k of the buffers is [group_end[k-1], group_end[k])
+ *                     with its own lr and weight decay (HOST arrays of n_groups entries, ends ascending, the last one
+ *                     = n, at most ubv_adamw_flat_max_groups() ranges); one step counter and one clip coefficient. */
 int64_t ubv_sumsq_workspace(void);
 int ubv_sumsq_f32(const float* x, int64_t n, float* out, void* workspace, void* stream);
 int ubv_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int64_t* step, const float* sumsq, float max_norm, void* stream);
+int ubv_adamw_flat_max_groups(void);
+int ubv_adamw_flat_groups(float* p, const float* g, float* m, float* v, int64_t n, int n_groups, const int64_t* group_end,
+                          const float* group_lr, const float* group_weight_decay, float beta1, float beta2, float eps,
+                          int64_t* step, const float* sumsq, float max_norm, void* stream);
 
 /* ---- GridMask (the device-side image augmentation) --------------------------
  * Reference: models/utils/grid_mask.py:70-123 (GridMask.forward; built at models/detectors/unibev_detector.py:75):

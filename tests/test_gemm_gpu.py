@@ -171,6 +171,36 @@ def test_flat_adamw_matches_torch_adamw_with_clipping(max_norm):
     assert all(p.data_ptr() >= opt.flat.data_ptr() for p in mine)      # parameters live in the flat buffer
 
 
+def test_flat_adamw_parameter_groups_match_torch_param_groups():
+    """ubv_adamw_flat_groups: runs of parameters with their own lr / weight decay (the reference's paramwise_cfg,
+    config :455-462) against torch.optim.AdamW with the same param_groups; range boundaries fall inside a 16-byte
+    load (odd sizes), one clip coefficient over all groups."""
+    from unibev_amd.dp import FlatGradients
+    from unibev_amd.optim import FlatAdamW, paramwise_groups
+    torch.manual_seed(4)
+    names = ['img_backbone.conv.weight', 'img_backbone.conv.bias', 'head.fc.weight', 'head.fc.bias', 'img_backbone.tail']
+    shapes = [(37, 9), (5,), (64, 33), (3,), (1,)]
+    mine = [torch.nn.Parameter(torch.randn(*s, device=DEV)) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    cfg = dict(custom_keys={'img_backbone': dict(lr_mult=0.1), 'fc.bias': dict(decay_mult=0.0)})
+    fg = FlatGradients(mine)
+    fg.attach()
+    opt = FlatAdamW(paramwise_groups(zip(names, mine), 3e-3, 0.05, **cfg), fg, lr=3e-3, weight_decay=0.05,
+                    max_grad_norm=0.5)
+    assert len(opt.ranges) == 4
+    topt = torch.optim.AdamW(paramwise_groups(zip(names, ref), 3e-3, 0.05, **cfg), lr=3e-3, weight_decay=0.05)
+    for it in range(5):
+        gs = [torch.randn(*s, device=DEV) * (0.1 + it) for s in shapes]
+        for p, r, g in zip(mine, ref, gs):
+            p.grad.copy_(g)
+            r.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_(ref, 0.5)
+        topt.step()
+        opt.step()
+        for p, r in zip(mine, ref):
+            torch.testing.assert_close(p.detach(), r.detach(), rtol=2e-6, atol=2e-7)
+
+
 def test_split_weights_batched_matches_the_per_weight_kernel():
     from unibev_amd import functional as UF
     g = torch.Generator(device='cpu').manual_seed(5)

@@ -66,6 +66,9 @@ SIGNATURES = {
     'ubv_sumsq_workspace': (c_int64, []),
     'ubv_sumsq_f32': (c_int, [_P, c_int64, _P, _P, _P]),
     'ubv_adamw_flat': (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, _P, _P, c_float, _P]),
+    'ubv_adamw_flat_max_groups': (c_int, []),
+    'ubv_adamw_flat_groups': (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P, _P, c_float, c_float, c_float, _P, _P,
+                                      c_float, _P]),
     'ubv_spconv_table_slots': (c_int64, [c_int64]),
     'ubv_spconv_wgrad_splits': (c_int, [c_int64, c_int]),
     'ubv_spconv_wgrad': (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

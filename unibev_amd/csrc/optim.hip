@@ -55,9 +55,19 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const double* __restri
   if (threadIdx.x == 0) out[0] = (float)red[0];
 }
 
+// Parameter groups (torch.optim param_groups; mmcv's paramwise_cfg lr_mult / decay_mult make them): consecutive
+// element ranges of the flat buffers with their own learning rate and weight decay.  end[k] is the first element
+// past range k; the clip coefficient and the step counter are shared, as in one torch optimizer.
+constexpr int kMaxAdamGroups = 16;
+struct AdamGroups {
+  int count;
+  long end[kMaxAdamGroups];
+  float lr[kMaxAdamGroups], wd[kMaxAdamGroups];
+};
+
 __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                         float* __restrict__ m, float* __restrict__ v, long n, float lr,
-                                                         float b1, float b2, float eps, float wd,
+                                                         float* __restrict__ m, float* __restrict__ v, long n,
+                                                         const AdamGroups grp, float b1, float b2, float eps,
                                                          const long long* __restrict__ step, const float* __restrict__ sumsq,
                                                          float max_norm) {
   const float t = (float)(*step);
@@ -67,10 +77,12 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
     const float c = max_norm / (sqrtf(*sumsq) + 1e-6f);
     clip = c < 1.0f ? c : 1.0f;
   }
-  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2), decay = 1.0f - lr * wd;
+  const float inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
   const long stride = (long)gridDim.x * 256 * 4;
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
     const int cnt = (i + 3 < n) ? 4 : (int)(n - i);
+    int gi = 0;
+    while (gi + 1 < grp.count && i >= grp.end[gi]) ++gi;      // the range of element i; a boundary may fall inside the four
     float pv[4], gv[4], mv[4], vv[4];
     if (cnt == 4) {
       const float4 a = *reinterpret_cast<const float4*>(p + i), b = *reinterpret_cast<const float4*>(g + i);
@@ -81,6 +93,8 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
       for (int k = 0; k < cnt; ++k) { pv[k] = p[i + k]; gv[k] = g[i + k]; mv[k] = m[i + k]; vv[k] = v[i + k]; }
     }
     for (int k = 0; k < cnt; ++k) {
+      while (gi + 1 < grp.count && i + k >= grp.end[gi]) ++gi;
+      const float lr = grp.lr[gi], step_size = lr / bc1, decay = 1.0f - lr * grp.wd[gi];
       const float gk = gv[k] * clip;
       pv[k] *= decay;
       mv[k] = b1 * mv[k] + (1.0f - b1) * gk;
@@ -116,9 +130,48 @@ extern "C" int ubv_sumsq_f32(const float* x, int64_t n, float* out, void* worksp
   return UBV_OK;
 }
 
+static int adamw_run(float* p, const float* g, float* m, float* v, int64_t n, const ubv::AdamGroups& grp, float beta1,
+                     float beta2, float eps, int64_t* step, const float* sumsq, float max_norm, void* stream);
+
 extern "C" int ubv_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                               float beta2, float eps, float weight_decay, int64_t* step, const float* sumsq,
                               float max_norm, void* stream) {
+  ubv::AdamGroups grp{};
+  grp.count = 1;
+  grp.end[0] = (long)n;
+  grp.lr[0] = lr;
+  grp.wd[0] = weight_decay;
+  return adamw_run(p, g, m, v, n, grp, beta1, beta2, eps, step, sumsq, max_norm, stream);
+}
+
+extern "C" int ubv_adamw_flat_max_groups(void) { return ubv::kMaxAdamGroups; }
+
+extern "C" int ubv_adamw_flat_groups(float* p, const float* g, float* m, float* v, int64_t n, int n_groups,
+                                     const int64_t* group_end, const float* group_lr, const float* group_weight_decay,
+                                     float beta1, float beta2, float eps, int64_t* step, const float* sumsq,
+                                     float max_norm, void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(group_end && group_lr && group_weight_decay && n_groups >= 1, "adamw_flat_groups: bad arguments");
+  if (n_groups > kMaxAdamGroups) {
+    set_error("adamw_flat_groups: %d groups (ranges of one lr / weight decay), at most %d", n_groups, kMaxAdamGroups);
+    return UBV_ERR_UNSUPPORTED;
+  }
+  AdamGroups grp{};
+  grp.count = n_groups;
+  int64_t prev = 0;
+  for (int k = 0; k < n_groups; ++k) {
+    UBV_CHECK_ARG(group_end[k] >= prev && group_end[k] <= n, "adamw_flat_groups: ends must ascend inside [0, n]");
+    prev = group_end[k];
+    grp.end[k] = (long)group_end[k];
+    grp.lr[k] = group_lr[k];
+    grp.wd[k] = group_weight_decay[k];
+  }
+  UBV_CHECK_ARG(prev == n, "adamw_flat_groups: the last range must end at n");
+  return adamw_run(p, g, m, v, n, grp, beta1, beta2, eps, step, sumsq, max_norm, stream);
+}
+
+static int adamw_run(float* p, const float* g, float* m, float* v, int64_t n, const ubv::AdamGroups& grp, float beta1,
+                     float beta2, float eps, int64_t* step, const float* sumsq, float max_norm, void* stream) {
   using namespace ubv;
   UBV_CHECK_ARG(p && g && m && v && step && n >= 0, "adamw_flat: bad arguments");
   UBV_CHECK_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
@@ -130,8 +183,8 @@ extern "C" int ubv_adamw_flat(float* p, const float* g, float* m, float* v, int6
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, (long)n, lr, beta1, beta2,
-                       eps, weight_decay, (const long long*)step, sumsq, max_norm);
+    hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, (long)n, grp, beta1, beta2,
+                       eps, (const long long*)step, sumsq, max_norm);
   }
   UBV_CHECK_LAUNCH("adamw_flat");
   return UBV_OK;

@@ -8,13 +8,20 @@ multi-tensor launches over ~200 tensors (0.4 ms per step at the encoder's 13.9 M
 The parameters are re-pointed at views of the flat buffer (``p.data``); the gradients come from a
 ``dp.FlatGradients`` (the buffer the gradient all-reduce already uses).
 
-Restrictions, enforced loudly: ONE parameter group (one lr / weight decay — what the encoder-side parameters of the
-shipped configs share; the configs' ``paramwise_cfg`` lr_mult = 0.1 applies to ``img_backbone`` only, which is outside
-this optimizer's parameter list), and EVERY parameter must receive a gradient in every step: ``torch.optim.AdamW`` skips
+Parameter groups: ``params`` is a list of tensors (one lr / weight decay) or torch-style groups
+``[{'params': [...], 'lr': ..., 'weight_decay': ...}, ...]``; ``paramwise_groups`` makes them from the reference's
+``paramwise_cfg = dict(custom_keys = {'img_backbone': dict(lr_mult = 0.1)})`` (config :455-462) the way mmcv's
+``DefaultOptimizerConstructor`` does.  The groups stay ONE pass over the flat buffers: runs of consecutive parameters with
+the same (lr, weight decay) become ranges of ``ubv_adamw_flat_groups`` (one step counter, one clip coefficient over all
+groups, as in one torch optimizer).
+
+Restriction, enforced loudly: EVERY parameter must receive a gradient in every step: ``torch.optim.AdamW`` skips
 a parameter whose grad is None (no decay, no moment update), a flat pass cannot, so ``step`` raises when the gradient
 collection reports parameters without a gradient (freeze them with ``requires_grad_(False)`` and leave them out, or
 use the torch optimizer: ``bench.py --torch-optimizer``).
 """
+import ctypes
+
 import torch
 
 from . import functional as UF
@@ -22,14 +29,73 @@ from . import linear as UL
 from ._lib import lib, check
 
 
+def paramwise_groups(named_params, lr, weight_decay, custom_keys=None, bias_lr_mult=1.0, bias_decay_mult=1.0,
+                     norm_decay_mult=1.0, norm_names=()):
+    """torch-style parameter groups, one per parameter, from mmcv's ``paramwise_cfg`` (mmcv
+    ``DefaultOptimizerConstructor.add_params``; the reference's configs use ``custom_keys`` only, :455-462): a
+    parameter whose name contains a custom key takes that key's ``lr_mult`` / ``decay_mult`` — the LONGEST matching
+    key wins, ties in alphabetical order; otherwise ``bias_lr_mult`` / ``bias_decay_mult`` apply to parameters named
+    ``bias`` and ``norm_decay_mult`` to parameters of the modules listed in ``norm_names`` (name prefixes of the
+    normalisation layers: the caller knows its modules, this function sees names only).  Frozen parameters are left
+    out, like the constructor leaves them without a step."""
+    keys = sorted(sorted((custom_keys or {}).keys()), key=len, reverse=True)
+    groups = []
+    for name, p in named_params:
+        if not p.requires_grad:
+            continue
+        g = {'params': [p], 'lr': float(lr), 'weight_decay': float(weight_decay)}
+        for k in keys:
+            if k in name:
+                g['lr'] = float(lr) * float(custom_keys[k].get('lr_mult', 1.0))
+                g['weight_decay'] = float(weight_decay) * float(custom_keys[k].get('decay_mult', 1.0))
+                break
+        else:
+            is_norm = any(name.startswith(n + '.') for n in norm_names)
+            if name.endswith('.bias') or name == 'bias':
+                g['lr'] = float(lr) * float(bias_lr_mult)
+                if not is_norm:
+                    g['weight_decay'] = float(weight_decay) * float(bias_decay_mult)
+            if is_norm:
+                g['weight_decay'] = float(weight_decay) * float(norm_decay_mult)
+        groups.append(g)
+    return groups
+
+
+def group_ranges(groups, lr, weight_decay):
+    """(parameters in order, [(end element, lr, weight decay), ...]): runs of consecutive parameters with one
+    (lr, weight decay) merged into one range of the flat buffers."""
+    params, ranges, o = [], [], 0
+    for g in groups:
+        glr, gwd = float(g.get('lr', lr)), float(g.get('weight_decay', weight_decay))
+        for p in g['params']:
+            params.append(p)
+            o += p.numel()
+            if ranges and ranges[-1][1:] == (glr, gwd):
+                ranges[-1] = (o, glr, gwd)
+            else:
+                ranges.append((o, glr, gwd))
+    return params, ranges
+
+
 class FlatAdamW:
     def __init__(self, params, grads, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None):
-        self.params = list(params)
+        params = list(params)
+        if params and isinstance(params[0], dict):
+            self.params, self.ranges = group_ranges(params, lr, weight_decay)
+        else:
+            self.params, self.ranges = params, [(sum(p.numel() for p in params), float(lr), float(weight_decay))]
         assert [id(p) for p in self.params] == [id(p) for p in grads.params], 'same parameters, same order'
         assert all(p.dtype == torch.float32 and p.is_cuda for p in self.params)
+        if len(self.ranges) > int(lib().ubv_adamw_flat_max_groups()):
+            raise ValueError(f'FlatAdamW: {len(self.ranges)} runs of parameters with their own lr / weight decay, at most '
+                             f'{int(lib().ubv_adamw_flat_max_groups())}: order the parameters group by group')
         self.grads = grads
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), \
             float(weight_decay)
+        k = len(self.ranges)
+        self._ends = (ctypes.c_int64 * k)(*[r[0] for r in self.ranges])
+        self._lrs = (ctypes.c_float * k)(*[r[1] for r in self.ranges])
+        self._wds = (ctypes.c_float * k)(*[r[2] for r in self.ranges])
         self.max_grad_norm = None if max_grad_norm is None else float(max_grad_norm)
         dev = self.params[0].device
         n = grads.flat.numel()
@@ -61,9 +127,10 @@ class FlatAdamW:
             if self.max_grad_norm is not None:
                 check(lib().ubv_sumsq_f32(UF._p(g), g.numel(), UF._p(self.sumsq), UF._p(self._ws), st), 'sumsq_f32')
                 sq = self.sumsq
-            check(lib().ubv_adamw_flat(UF._p(self.flat), UF._p(g), UF._p(self.exp_avg), UF._p(self.exp_avg_sq),
-                                       g.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                                       UF._p(self.step_count), UF._p(sq), self.max_grad_norm or 0.0, st), 'adamw_flat')
+            check(lib().ubv_adamw_flat_groups(UF._p(self.flat), UF._p(g), UF._p(self.exp_avg), UF._p(self.exp_avg_sq),
+                                              g.numel(), len(self.ranges), self._ends, self._lrs, self._wds,
+                                              self.betas[0], self.betas[1], self.eps, UF._p(self.step_count),
+                                              UF._p(sq), self.max_grad_norm or 0.0, st), 'adamw_flat_groups')
         UL.mark_weights_changed()                       # the 16-bit / split weight copies are stale
 
     def grad_norm(self):
