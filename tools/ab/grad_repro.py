@@ -1,4 +1,5 @@
-"""Run-to-run reproducibility of the product's own gradients (full-size smooth fixture): python tools/ab/grad_repro.py [runs]"""
+"""Run-to-run reproducibility of the product's own gradients (full-size smooth fixture): python tools/ab/grad_repro.py [runs]
+UBV_REPRO_DTYPE=bf16|fp16 runs the passes under autocast (the one-stream reference too)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', 'golden')):
@@ -34,12 +35,14 @@ if os.environ.get('UBV_WATCH', '0') == '1':
                 _watch(a, f'{en[:3]}.L{li}.a{ai}.out')
             for fi, f in enumerate(layer.ffns):
                 _watch(f, f'{en[:3]}.L{li}.ffn.out')
+ADT = {'bf16': torch.bfloat16, 'fp16': torch.float16}.get(os.environ.get('UBV_REPRO_DTYPE', ''))
 def run():
     INTER.clear()
     for x in gi + gp + [gq] + [p for _, p in named]:
         x.grad = None
-    fused = model.encode(gi, gp, gq, inp['bev_h'], inp['bev_w'], bev_pos=bev_pos, img_metas=inp['metas'])
-    (fused * cot).sum().backward()
+    with torch.autocast('cuda', dtype=ADT or torch.bfloat16, enabled=ADT is not None):
+        fused = model.encode(gi, gp, gq, inp['bev_h'], inp['bev_w'], bev_pos=bev_pos, img_metas=inp['metas'])
+    (fused.float() * cot).sum().backward()
     torch.cuda.synchronize()
     out = {'fused': fused.detach().clone(), 'img feats': gi[0].grad.clone(), 'pts feats': gp[0].grad.clone(), 'bev queries': gq.grad.clone()}
     out.update({k: p.grad.clone() for k, p in named if p.grad is not None})
