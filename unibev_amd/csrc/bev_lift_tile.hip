@@ -12,7 +12,7 @@
 //   window = the pixel box of the block's footprints (at most 16x16) of the head's value slice, copied into LDS with
 //            whole 128-byte lines; only the rows / columns of the box are fetched (a 16x16 window per 8x8 tile would
 //            move 4x the map);
-//   corner = 8 ds_read_b128 + 16 v_pk_fma_f32 per lane, all arithmetic plain f32 (no operand splitting), no cross-lane
+//   corner = 8 ds_read_b128 + 32 v_fma_f32 per lane (no packed f32 instructions: Makefile), all arithmetic plain f32 (no operand splitting), no cross-lane
 //            traffic; a lane whose corner falls outside the window fetches that row from global memory itself (the
 //            window is a cache, never an approximation);
 //   output = forward: the 4 lanes of a query add their rows with DPP quad permutes and store 32 bytes each;
