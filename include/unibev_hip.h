@@ -169,6 +169,11 @@ int64_t ubv_bev_lift_backward_workspace(int B, int Nc, int fh, int fw, int H, in
  * `nonzero()` index lists of spatial_cross_attention_img.py:141-152 (six host syncs there). */
 int64_t ubv_visible_lists_elems(int Nc, int Nq);
 int ubv_compact_visible(const uint8_t* vis0, int Nc, int Nq, int32_t* lists, void* stream);
+/* The same lists for queries that are a BEV grid qgrid_w wide (Nq = qgrid_w x rows, both multiples of 8): the visible
+ * queries of a camera come TILE BY TILE (8 x 8 tiles of the grid, row-major inside a tile) instead of ascending, so a
+ * batch of consecutive entries is a compact patch of the ground and of the camera's map (fewer touched pixel blocks
+ * per batch in the CAMERA backward).  qgrid_w = 0, or a grid that is not whole tiles: ascending order. */
+int ubv_compact_visible_grid(const uint8_t* vis0, int Nc, int Nq, int qgrid_w, int32_t* lists, void* stream);
 
 int ubv_bev_lift_backward(const void* value, const void* offsets, int64_t off_stride,
                           const void* logits, int64_t log_stride, int offlog_dtype,

@@ -471,3 +471,40 @@ def test_lift_backward_repeatable_and_independent_of_kernel_concurrency(plan):
                     torch.testing.assert_close(v.grad.float(), base[1].float(), rtol=2.0 ** -7, atol=1e-3)
     finally:
         os.environ.pop('UBV_LIFT_TWO_STREAM', None)
+
+
+def test_visible_lists_tile_by_tile_hold_the_same_queries_and_gradients():
+    """ubv_compact_visible_grid: with the width of a BEV query grid of whole 8x8 tiles the per-camera lists come tile
+    by tile (row-major inside a tile) — the same queries as the ascending lists, in the order of the tile-major walk —
+    and the CAMERA backward that walks them gives the same gradients (a different order of its f32 partial sums);
+    a grid that is not whole tiles keeps the ascending order."""
+    from unibev_amd.functional import bev_lift, compact_visible
+    case = (2, 6, 8, 22, 8, 32, 64, 64, 8, 4)
+    B, Nc, fh, fw, H, Dh, qh, qw, P, Z = case
+    value, offlog, ref, vis0, count, gout = make_case(case, 31, True)
+    v0 = t(vis0, device=DEV)
+    Nq = qh * qw
+    asc, tiled = compact_visible(v0).cpu().numpy(), compact_visible(v0, qw).cpu().numpy()
+    assert np.array_equal(asc[Nc * Nq:], tiled[Nc * Nq:])                       # the counts
+    q = np.arange(Nq)
+    rank = ((q // qw // 8) * (qw // 8) + (q % qw) // 8) * 64 + (q // qw % 8) * 8 + q % 8     # position in the walk
+    for c in range(Nc):
+        n = int(asc[Nc * Nq + c])
+        a, b = asc[c * Nq:c * Nq + n], tiled[c * Nq:c * Nq + n]
+        assert np.array_equal(a, np.flatnonzero(vis0[c]))
+        assert np.array_equal(np.sort(b), a)
+        assert np.all(np.diff(rank[b]) > 0)
+    odd = compact_visible(v0[:, :60 * 60].contiguous(), 60).cpu().numpy()       # 60 is not a multiple of 8: ascending
+    for c in range(Nc):
+        n = int(odd[Nc * 3600 + c])
+        assert np.all(np.diff(odd[c * 3600:c * 3600 + n]) > 0)
+    grads = []
+    for lists in (compact_visible(v0), compact_visible(v0, qw)):
+        v = t(value, torch.float32, DEV).requires_grad_()
+        ol = t(offlog, torch.float32, DEV).requires_grad_()
+        out = bev_lift(v, ol, t(ref, torch.float32, DEV), Nc, (fh, fw), H, P, vis0=v0, count=t(count, device=DEV),
+                       query_grid=(qh, qw), visible_lists=lists)
+        out.backward(t(gout, torch.float32, DEV))
+        grads.append((v.grad.clone(), ol.grad.clone()))
+    assert torch.equal(grads[0][1], grads[1][1])                                # the query side does not walk the lists
+    torch.testing.assert_close(grads[0][0], grads[1][0], rtol=1e-5, atol=1e-5 * float(grads[0][0].abs().max()))

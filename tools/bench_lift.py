@@ -77,7 +77,7 @@ def main():
             offlog = offlog.to(dtype)        # what the sampling_offsets Linear emits under autocast
         value.requires_grad_()
         offlog.requires_grad_()
-        lists = UF.compact_visible(vis0) if vis0 is not None else None
+        lists = UF.compact_visible(vis0, qw) if vis0 is not None else None
         for it in range(a.iters + 3):
             if it == 3:
                 UF.kernel_profile(True)

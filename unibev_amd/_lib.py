@@ -34,6 +34,7 @@ SIGNATURES = {
                                       _P, c_int64, _P, c_int64] + [c_int] * 13 + [_P, _P, c_int64, _P]),
     'ubv_visible_lists_elems': (c_int64, [c_int, c_int]),
     'ubv_compact_visible': (c_int, [_P, c_int, c_int, _P, _P]),
+    'ubv_compact_visible_grid': (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     'ubv_bev_lift_backward_workspace': (c_int64, [c_int] * 11),
     'ubv_bev_lift_supported': (c_int, [c_int] * 4),
     'ubv_point_sampling': (c_int, [_P, _P, _P, _P, ctypes.POINTER(c_float), c_float, c_float,

@@ -518,10 +518,21 @@ __global__ __launch_bounds__(256) void lift_ovf_scatter_kernel(const LiftArgs a,
 //          band of full rows (the whole 8x22 map in one band), the points are a share of the
 //          camera's compacted visible-query list; the shares of one camera write partial maps
 //          ("slabs") that slab_reduce_kernel sums.
+// Width of the query grid when the visible lists can be walked tile by tile (whole 8x8 tiles), else 0 (ascending
+// order).  UBV_CAM_TILED=0 keeps the ascending order (A/B runs).
+static inline int visible_tile_width(int Nq, int qw) {
+  static const int tiled = getenv("UBV_CAM_TILED") ? atoi(getenv("UBV_CAM_TILED")) : 1;
+  if (!tiled || qw <= 0 || qw % 8 != 0 || Nq % qw != 0 || (Nq / qw) % 8 != 0) return 0;
+  return qw;
+}
+
 // Ordered compaction of each camera's visible queries (vis0[cam, q] != 0): list[cam, 0..n) holds the
-// query indices in ascending order.  One 1024-thread block per camera.
+// query indices in ascending order — or, when the queries are a qw-wide BEV grid of whole 8x8 tiles (qw > 0), in
+// TILE-MAJOR order (tile by tile, row-major inside a tile): a batch of 32 list entries is then half a tile, a patch
+// of the ground a few metres across that lands on a few neighbouring pixels of the camera's map, where 32 entries
+// of one grid row are a 16 m line that crosses it.  One 1024-thread block per camera.
 __global__ __launch_bounds__(1024) void compact_visible_kernel(const uint8_t* __restrict__ vis0,
-                                                               int Nq, int* __restrict__ list,
+                                                               int Nq, int qw, int* __restrict__ list,
                                                                int* __restrict__ n_out) {
   __shared__ int wave_cnt[16];
   __shared__ int base_s;
@@ -529,8 +540,13 @@ __global__ __launch_bounds__(1024) void compact_visible_kernel(const uint8_t* __
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (threadIdx.x == 0) base_s = 0;
   __syncthreads();
+  const int tiles_x = qw >> 3;
   for (int q0 = 0; q0 < Nq; q0 += 1024) {
-    const int q = q0 + threadIdx.x;
+    int q = q0 + threadIdx.x;
+    if (qw > 0 && q < Nq) {                               // position q0 + tid of the tile-major walk -> query index
+      const int tile = q >> 6, in = q & 63, ty = tile / tiles_x, tx = tile - ty * tiles_x;
+      q = (ty * 8 + (in >> 3)) * qw + tx * 8 + (in & 7);
+    }
     const bool v = q < Nq && (vis0 == nullptr || vis0[(long)cam * Nq + q] != 0);
     const unsigned long long m = __ballot(v);
     const int rank = __popcll(m & ((1ull << lane) - 1ull));
@@ -1440,7 +1456,7 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     }
   } else {
     if (!a.ext_list)
-      hipLaunchKernelGGL(compact_visible_kernel, dim3(a.Nc), dim3(1024), 0, st, a.vis0, a.Nq,
+      hipLaunchKernelGGL(compact_visible_kernel, dim3(a.Nc), dim3(1024), 0, st, a.vis0, a.Nq, visible_tile_width(a.Nq, a.qw),
                          a.cam_list, a.cam_n);
     constexpr int RB = 6;
     const bool rb3 = sizeof(T) == 4 && t.tile_h * a.fw <= 96;      // f32, half-height bands: 3 row blocks
@@ -1877,9 +1893,13 @@ extern "C" int64_t ubv_bev_lift_backward_workspace(int B, int Nc, int fh, int fw
 extern "C" int64_t ubv_visible_lists_elems(int Nc, int Nq) { return (int64_t)Nc * Nq + Nc; }
 
 extern "C" int ubv_compact_visible(const uint8_t* vis0, int Nc, int Nq, int32_t* lists, void* stream) {
-  UBV_CHECK_ARG(lists != nullptr && Nc > 0 && Nq > 0, "compact_visible: bad arguments");
+  return ubv_compact_visible_grid(vis0, Nc, Nq, 0, lists, stream);
+}
+
+extern "C" int ubv_compact_visible_grid(const uint8_t* vis0, int Nc, int Nq, int qw, int32_t* lists, void* stream) {
+  UBV_CHECK_ARG(lists != nullptr && Nc > 0 && Nq > 0 && qw >= 0, "compact_visible: bad arguments");
   hipLaunchKernelGGL(ubv::compact_visible_kernel, dim3(Nc), dim3(1024), 0, ubv::as_stream(stream), vis0, Nq,
-                     lists, lists + (size_t)Nc * Nq);
+                     ubv::visible_tile_width(Nq, qw), lists, lists + (size_t)Nc * Nq);
   UBV_CHECK_LAUNCH("compact_visible");
   return UBV_OK;
 }

@@ -297,15 +297,17 @@ class _BevLift(Function):
 
 
 @torch.no_grad()
-def compact_visible(vis0):
-    """Per-camera ordered lists of the visible queries (``ubv_compact_visible``): int32
+def compact_visible(vis0, grid_w=0):
+    """Per-camera ordered lists of the visible queries (``ubv_compact_visible_grid``): int32
     [Nc*Nq + Nc], list of camera c at [c*Nq, c*Nq + n_c), the counts n_c at the end.  They depend on
-    the visibility alone: one compaction per forward pass serves every layer's backward."""
+    the visibility alone: one compaction per forward pass serves every layer's backward.
+    ``grid_w``: width of the BEV query grid — the lists then come tile by tile (8 x 8 tiles) instead of
+    ascending, which keeps a batch of entries on neighbouring pixels of the camera's map."""
     with _need_cuda(vis0):
         Nc, Nq = vis0.shape
         lists = torch.empty(int(lib().ubv_visible_lists_elems(Nc, Nq)), dtype=torch.int32,
                             device=vis0.device)
-        check(lib().ubv_compact_visible(_p(vis0.contiguous()), Nc, Nq, _p(lists), _stream()),
+        check(lib().ubv_compact_visible_grid(_p(vis0.contiguous()), Nc, Nq, int(grid_w), _p(lists), _stream()),
               'compact_visible')
         return lists
 

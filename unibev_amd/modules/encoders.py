@@ -217,7 +217,7 @@ class ImgEncoder(_EncoderBase):
         ref_2d = self._cached(('2d', bev_h, bev_w, bs, dev, dt),
                               lambda: reference_points_2d(bev_h, bev_w, bs, dev, dt))
         cam, mask, vis0, count = self._project(*axes, self.pc_range, kwargs['img_metas'], dev, True)
-        lists = UF.compact_visible(vis0)        # once per pass; every layer's backward walks them
+        lists = UF.compact_visible(vis0, bev_w)  # once per pass; every layer's backward walks them (tile by tile)
         bev_query = bev_query.permute(1, 0, 2)
         if bev_pos is not None:
             bev_pos = bev_pos.permute(1, 0, 2)
