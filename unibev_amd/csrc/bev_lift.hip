@@ -534,6 +534,10 @@ static inline int visible_tile_width(int Nq, int qw) {
 __global__ __launch_bounds__(1024) void compact_visible_kernel(const uint8_t* __restrict__ vis0,
                                                                int Nq, int qw, int* __restrict__ list,
                                                                int* __restrict__ n_out) {
+  // FOUR walk positions per thread and step (Nq % 4 == 0, checked by the callers' plans: a BEV grid of whole tiles, or
+  // any list whose length is a multiple of 4; else one position per thread): the four are consecutive queries in either
+  // order — one 4-byte read of vis0 — and the block walks 40 000 queries in 10 steps of (wave scan, two barriers)
+  // instead of 40 (the kernel is one block per camera: its time is the length of that chain, 38 -> 14 us).
   __shared__ int wave_cnt[16];
   __shared__ int base_s;
   const int cam = blockIdx.x;
@@ -541,20 +545,38 @@ __global__ __launch_bounds__(1024) void compact_visible_kernel(const uint8_t* __
   if (threadIdx.x == 0) base_s = 0;
   __syncthreads();
   const int tiles_x = qw >> 3;
-  for (int q0 = 0; q0 < Nq; q0 += 1024) {
-    int q = q0 + threadIdx.x;
-    if (qw > 0 && q < Nq) {                               // position q0 + tid of the tile-major walk -> query index
-      const int tile = q >> 6, in = q & 63, ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const bool four = (Nq & 3) == 0 && (vis0 == nullptr || (((uintptr_t)vis0) & 3) == 0);
+  const int per = four ? 4 : 1;
+  for (int q0 = 0; q0 < Nq; q0 += 1024 * per) {
+    const int pos = q0 + (int)threadIdx.x * per;
+    int q = pos;
+    if (qw > 0 && pos < Nq) {                              // position of the tile-major walk -> query index
+      const int tile = pos >> 6, in = pos & 63, ty = tile / tiles_x, tx = tile - ty * tiles_x;
       q = (ty * 8 + (in >> 3)) * qw + tx * 8 + (in & 7);
     }
-    const bool v = q < Nq && (vis0 == nullptr || vis0[(long)cam * Nq + q] != 0);
-    const unsigned long long m = __ballot(v);
-    const int rank = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_cnt[wv] = __popcll(m);
+    unsigned bits = 0u;                                     // bit j: query q + j is visible
+    if (pos < Nq) {
+      if (vis0 == nullptr) bits = four ? 0xfu : 1u;
+      else if (four) {
+        const uint32_t v4 = *reinterpret_cast<const uint32_t*>(vis0 + (long)cam * Nq + q);
+        bits = ((v4 & 0xffu) != 0u) | (((v4 >> 8) & 0xffu) != 0u) << 1 | (((v4 >> 16) & 0xffu) != 0u) << 2 | ((v4 >> 24) != 0u) << 3;
+      } else bits = vis0[(long)cam * Nq + q] != 0;
+    }
+    const int cnt = __popc(bits);
+    int incl = cnt;                                         // inclusive scan over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += up;
+    }
+    if (lane == 63) wave_cnt[wv] = incl;
     __syncthreads();
-    int off = base_s;
+    int off = base_s + incl - cnt;
     for (int w = 0; w < wv; ++w) off += wave_cnt[w];
-    if (v) list[(long)cam * Nq + off + rank] = q;
+    int* dst = list + (long)cam * Nq + off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (bits & (1u << j)) *dst++ = q + j;
     __syncthreads();
     if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wave_cnt[w]; base_s += t; }
     __syncthreads();
