@@ -134,6 +134,8 @@ class _EncoderBase(TransformerLayerSequence):
                     layer_kwargs['bev_pos'] = self._sever(layer_kwargs['bev_pos'])
             if pos_terms is not None:
                 layer_kwargs['pos_term'] = pos_terms[li]
+            if li == 1:
+                layer_kwargs.pop('query_table', None)      # only the first layer's queries are the table itself
             output = layer(bev_query, key, value, *args, **layer_kwargs)
             bev_query = output
             if self.return_intermediate:
@@ -218,10 +220,11 @@ class ImgEncoder(_EncoderBase):
                               lambda: reference_points_2d(bev_h, bev_w, bs, dev, dt))
         cam, mask, vis0, count = self._project(*axes, self.pc_range, kwargs['img_metas'], dev, True)
         lists = UF.compact_visible(vis0, bev_w)  # once per pass; every layer's backward walks them (tile by tile)
+        table = getattr(bev_query, '_ubv_table', None)    # the un-expanded query table (transformer._encode)
         bev_query = bev_query.permute(1, 0, 2)
         if bev_pos is not None:
             bev_pos = bev_pos.permute(1, 0, 2)
-        layer_kwargs = dict(kwargs, bev_pos=bev_pos, ref_2d=ref_2d, ref_3d=ref_3d, bev_h=bev_h,
+        layer_kwargs = dict(kwargs, query_table=table, bev_pos=bev_pos, ref_2d=ref_2d, ref_3d=ref_3d, bev_h=bev_h,
                             bev_w=bev_w, spatial_shapes=spatial_shapes,
                             level_start_index=level_start_index, reference_points_cam=cam,
                             bev_mask=mask, cam_vis0=vis0, cam_count=count, cam_lists=lists,
@@ -261,10 +264,11 @@ class PtsEncoder(_EncoderBase):
                               lambda: reference_points_2d(bev_h, bev_w, bs, dev, dt))
         lidar = self._cached(('lidar', bev_h, bev_w, Z, D, bs, dev, dt),
                              lambda: self.point_sampling(ref_3d)[0].contiguous())
+        table = getattr(bev_query, '_ubv_table', None)    # the un-expanded query table (transformer._encode)
         bev_query = bev_query.permute(1, 0, 2)
         if bev_pos is not None:
             bev_pos = bev_pos.permute(1, 0, 2)
-        layer_kwargs = dict(kwargs, bev_pos=bev_pos, ref_2d=ref_2d, ref_3d=ref_3d, bev_h=bev_h,
+        layer_kwargs = dict(kwargs, query_table=table, bev_pos=bev_pos, ref_2d=ref_2d, ref_3d=ref_3d, bev_h=bev_h,
                             bev_w=bev_w, spatial_shapes=spatial_shapes,
                             level_start_index=level_start_index, reference_points_lidar=lidar,
                             query_grid=(bev_h, bev_w), ref_is_grid=True)
@@ -304,7 +308,7 @@ class _BevLayer(BaseTransformerLayer):
     def forward(self, query, key=None, value=None, bev_pos=None, query_pos=None, key_pos=None,
                 attn_masks=None, query_key_padding_mask=None, key_padding_mask=None, ref_2d=None,
                 ref_3d=None, bev_h=None, bev_w=None, mask=None, spatial_shapes=None,
-                level_start_index=None, pos_term=None, **kwargs):
+                level_start_index=None, pos_term=None, query_table=None, **kwargs):
         norm_index = attn_index = ffn_index = 0
         identity = query
         if attn_masks is None:
@@ -345,7 +349,13 @@ class _BevLayer(BaseTransformerLayer):
                             or bev_pos.stride(0) == 0))      # (the positional term must be one table too)
                 out = None
                 if one:
-                    out = run_self(query[:1], None if bev_pos is None else bev_pos[:1],   # (unused under pos_term)
+                    # the table itself when the caller handed it over (transformer._encode): a slice of the expanded
+                    # queries would send its gradient through a zero-filled [bs, Nq, C] tensor and a sum over the batch
+                    q1 = query[:1]
+                    if query_table is not None and query_table.shape == query.shape[1:] and \
+                            query_table.dtype == query.dtype:
+                        q1 = query_table.unsqueeze(0)
+                    out = run_self(q1, None if bev_pos is None else bev_pos[:1],   # (unused under pos_term)
                                    None if ref_2d is None else ref_2d[:1])
                     if not (isinstance(out, tuple) and out[0].shape[0] == 1 and out[1].shape[0] == 1):
                         out = None                             # (not the fused form: every sample on its own)

@@ -69,6 +69,7 @@ import os as _os
 # f32 arithmetic in any kernel; not slower), after which the two-stream step reproduces like the one-stream step
 # (tools/ab/grad_repro*.py, fwd_repro_graph.py: 0 of 60 replays / 30 eager runs differ;
 # tests/test_bench_gpu.py::test_training_step_gradients_are_reproducible_eagerly_and_replayed runs both modes).
+_QUERY_TABLE = os.environ.get('UBV_QUERY_TABLE', '1') != '0'
 _TWO_STREAMS = [_os.environ.get('UBV_TWO_STREAMS', '1') != '0']
 _SIDE_STREAMS = {}
 
@@ -388,6 +389,14 @@ class UniBEVTransformer(BaseModule):
             q_pts = bev_queries[1].unsqueeze(1).expand(-1, bs, -1)
         else:
             q_img = q_pts = bev_queries.unsqueeze(1).expand(-1, bs, -1)
+        # the encoders' first layer computes its self-attention once for the batch and takes the table
+        # itself for that: the attribute rides on the expanded view (a Python attribute, not part of the graph)
+        if not _QUERY_TABLE:
+            pass                                            # (UBV_QUERY_TABLE=0: A/B runs)
+        elif self.dual_queries:
+            q_img._ubv_table, q_pts._ubv_table = bev_queries[0], bev_queries[1]
+        else:
+            q_img._ubv_table = bev_queries
         img_bev_embed = pts_bev_embed = None
 
         def run_img():
