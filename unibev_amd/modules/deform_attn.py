@@ -184,6 +184,21 @@ class _DeformAttnBase(BaseModule):
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
         return _store_value(value)
 
+    def project_value_chained(self, value, chain, key_padding_mask=None):
+        """``project_value`` of a tensor that EVERY layer of the encoder projects (the camera / LiDAR features).
+        ``chain``: a dict the encoder hands to all its layers for one pass.  Layer k projects the pass-through alias
+        layer k - 1 left there (``linear.linear_pass``: the same values), so the layers' input gradients arrive as a
+        chain — each Linear's dX GEMM takes the later layers' sum as its accumulator input — instead of three
+        tensors that autograd adds with two element-wise kernels over the feature map."""
+        if chain is None or key_padding_mask is not None or not (value.is_cuda and torch.is_grad_enabled()
+                                                                 and value.requires_grad):
+            return self.project_value(value, key_padding_mask)
+        prev = chain.get('alias')
+        src = prev if prev is not None and prev.shape == value.shape and prev.dtype == value.dtype else value
+        out, alias = self.project_value(src, passthru=True)
+        chain['alias'] = alias
+        return out
+
     def k1(self, value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
         bs, num_value = value.shape[:2]
         return UF.MultiScaleDeformableAttnFunction.apply(
@@ -323,7 +338,7 @@ class _MSDeformableAttention3D(_DeformAttnBase):
         bs, num_value, _ = value.shape
         hw = static_hw(spatial_shapes)
         assert sum(h * w for h, w in hw) == num_value
-        value = self.project_value(value, key_padding_mask)
+        value = self.project_value_chained(value, kwargs.get('value_chain'), key_padding_mask)
         H, L, P = self.num_heads, self.num_levels, self.num_points
         if reference_points.shape[-1] != 2:
             if reference_points.shape[-1] == 4:

@@ -124,8 +124,12 @@ class _EncoderBase(TransformerLayerSequence):
         self._cuts = []
         cut = int(getattr(self, 'cut_after', 0) or 0)
         pos_terms = self._fold_pos_terms(layer_kwargs.pop('bev_pos_base', None), bev_query)
+        # every layer's cross-attention projects the same features: their input gradients form a chain
+        # (deform_attn.project_value_chained); a severed graph starts a new one
+        layer_kwargs['value_chain'] = {} if _VALUE_CHAIN else None
         for li, layer in enumerate(self.layers):
             if cut and li == cut:
+                layer_kwargs['value_chain'] = {} if _VALUE_CHAIN else None
                 same = value is key
                 bev_query = self._sever(bev_query)
                 key = self._sever(key)
@@ -275,6 +279,7 @@ class PtsEncoder(_EncoderBase):
         return self._run_layers(bev_query, key, value, args, layer_kwargs)
 
 
+_VALUE_CHAIN = os.environ.get('UBV_VALUE_CHAIN', '1') != '0'      # 0: the layers' feature-map gradients added by autograd (A/B runs)
 _SHARE_FIRST = os.environ.get('UBV_SHARE_FIRST', '1') != '0'     # 0: the first self-attention per sample (A/B runs)
 
 

@@ -76,7 +76,7 @@ class SpatialCrossAttentionImg(BaseModule):
                 offlog, inp_residual = da.offsets_and_logits(query, passthru=True)
             else:
                 offlog = da.offsets_and_logits(query)
-            slots = UF.bev_lift(da.project_value(value), offlog,
+            slots = UF.bev_lift(da.project_value_chained(value, kwargs.get('value_chain')), offlog,
                                 reference_points_cam, num_cams, hw[0], da.num_heads, da.num_points,
                                 vis0=vis0, count=count, query_grid=kwargs.get('query_grid'),
                                 visible_lists=kwargs.get('cam_lists') if kwargs.get('cam_vis0') is not None else None)
@@ -145,7 +145,7 @@ class SpatialCrossAttentionPts(BaseModule):
             query=query, key=value, value=value, reference_points=reference_points_lidar,
             spatial_shapes=spatial_shapes, level_start_index=level_start_index,
             query_grid=kwargs.get('query_grid'), ref_is_grid=kwargs.get('ref_is_grid', False),
-            want_query_alias=want_alias)
+            want_query_alias=want_alias, value_chain=kwargs.get('value_chain'))
         if want_alias:
             queries, alias = queries
             if alias is not None:
