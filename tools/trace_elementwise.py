@@ -21,7 +21,11 @@ class Mode(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         out = func(*args, **(kwargs or {}))
         name = str(func)
-        big = [a for a in args if isinstance(a, torch.Tensor) and a.numel() >= int(os.environ.get('UBV_TRACE_MIN', 5_000_000))]
+        flat_args = [t for a in args for t in (a if isinstance(a, (list, tuple)) else [a])]       # (cat / stack take lists)
+        mn = int(os.environ.get('UBV_TRACE_MIN', 5_000_000))
+        big = [a for a in flat_args if isinstance(a, torch.Tensor) and a.numel() >= mn]
+        if not big and 'cat' in name and isinstance(out, torch.Tensor) and out.numel() >= mn // 8:
+            big = [out]
         gemm = any(k in name for k in ('aten.mm', 'aten.addmm', 'aten.bmm', 'aten.linear', 'aten.matmul'))
         if gemm:
             big = [a for a in args if isinstance(a, torch.Tensor)]
