@@ -315,9 +315,14 @@ class _Linear(Function):
             # d(row_bias) = sum over the batch of grad_out's row blocks (plain adds: the framework's outer-dimension
             # reduction is slow on this shape, see bricks._ExpandBatch)
             g3 = go2.reshape(-1, ctx.rb_rows, go2.shape[-1])
-            grb = g3[0] if g3.shape[0] == 1 else g3[0] + g3[1]
-            for i in range(2, g3.shape[0]):
-                grb = grb + g3[i]
+            if g3.shape[0] == 1:
+                grb = g3[0]
+            elif g3.dtype == torch.float32 and g3.is_cuda and g3.is_contiguous() and g3[0].numel() % 4 == 0:
+                grb = UF.linear_grad_reduce(None, g3)[1]    # (this library's slice sum: no packed f32, see _SelfAttnIn)
+            else:
+                grb = g3[0] + g3[1]
+                for i in range(2, g3.shape[0]):
+                    grb = grb + g3[i]
         gx = None
         if act is not None and act[0] == 'masked_in' and ctx.needs_input_grad[0]:
             assert grad_alias is None, 'linear_after_relu_dropout has no pass-through output'
@@ -469,9 +474,17 @@ class _SelfAttnIn(Function):
         grb = None
         if ctx.needs_input_grad[1]:
             g3 = gol2.view(-1, ctx.rows, gol2.shape[-1])
-            grb = g3[0] if g3.shape[0] == 1 else g3[0] + g3[1]
-            for i in range(2, g3.shape[0]):
-                grb = grb + g3[i]
+            if g3.shape[0] == 1:
+                grb = g3[0]
+            elif g3.dtype == torch.float32 and g3.is_cuda and g3.is_contiguous() and g3[0].numel() % 4 == 0:
+                # the sum over the samples by this library's slice reduction: the framework's f32 add kernel holds
+                # packed f32 FMAs, and this runs inside an encoder branch, beside the other stream's MFMA kernels
+                # (DESIGN section 5 "Two streams")
+                grb = UF.linear_grad_reduce(None, g3)[1]
+            else:
+                grb = g3[0] + g3[1]
+                for i in range(2, g3.shape[0]):
+                    grb = grb + g3[i]
         # weight gradients: two passes over x measured FASTER than the fused ubv_gemm_wgrad_dual (90 vs 113 us back to
         # back at M = 80 000: the kernel is bound by its tiles' MFMA / LDS work, which is the same either way, and
         # the 352-row product takes 85 slabs of 6 tiles where the two take 128 x 4 and 256 x 2); UBV_SELF_IN_WGRAD=dual
