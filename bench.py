@@ -23,14 +23,16 @@ under `lowp`.  Every mode's distance to the reference-recorded full-size vectors
 RUN (`parity`: {fixture: normwise distance}, bar, pass) — the same quantity tests/test_modules_gpu.py
 asserts; see DESIGN.md section 4.
 
-Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+Rank 0 prints ONE JSON line on stdout, strict JSON of at most LINE_LIMIT bytes (`compact`): the contract fields,
   roofline      the dominant deformable-sampling OP of the headline run: compulsory bytes per launch
                 (SURVEY.md section 8(d)) / the op's duration, HIP events on the launch stream;
-  roofline_ops  the same for every sampling op, forward and backward, with its kernels;
-  lowp          the 16-bit runs (value, ms_per_step, their own dominant-op roofline);
-  gemm          the projection GEMMs: time, TFLOP/s against the dense MFMA peak, GB/s;
-  voxel         the LiDAR front end (voxelize + VFE mean + dense scatter): points/s, bytes;
-  cpu_baseline  the oracle (CPU port of the reference path) timed on this host (N = 1 only).
+  roofline_ops  every sampling op, forward and backward, as [op, pass, us, frac, PMC traffic / algorithmic bytes];
+  phases        graph replay / exposed all-reduce / clip + AdamW milliseconds per step;
+  cpu_baseline  the oracle (CPU port of the reference path) timed on this host (N = 1 only);
+  and one number per sub-record (spread_value + its ops, ieee_gemm_value, lowp values + parity verdicts, the 256x256
+  projection GEMM, the voxel front end, the k1 operator).
+The LONG form of every record (per-kernel times, notes, the gemm table, the 16-bit runs' own roofline_ops ...) is written
+to --extras-file (bench_extras.json beside this script) and to one `#extras `-prefixed line on stderr.
 """
 import argparse
 import json
@@ -130,6 +132,8 @@ def parse():
                          "one graph, one message after it; 'auto' = single.  (split puts RCCL's reduction kernels beside the "
                          "lower backward's MFMA kernels; RCCL is not built by this repository and its f32 sums may use the "
                          "packed instructions that go wrong there - DESIGN section 5/6 - so it is opt-in until checked on N > 1)")
+    ap.add_argument('--extras-file', default=os.path.join(ROOT, 'bench_extras.json'),
+                    help="where the long form of the record goes ('' = nowhere); the final stdout line is the short form")
     ap.add_argument('--no-ieee-gemm', action='store_true', help='skip the `ieee_gemm` sub-record (f32 step on library IEEE GEMMs)')
     ap.add_argument('--fp32-stream', action='store_true',
                     help='keep the encoder residual stream in f32 under autocast (default: the '
@@ -683,6 +687,120 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+LINE_LIMIT = 6000          # bytes of the final stdout line (the driver keeps a 9 KB tail of stdout: VERDICT r4 item 1)
+
+
+def _r(x, nd=5):
+    """Round floats (recursively) so that the short line stays short; non-finite values become None (strict JSON)."""
+    if isinstance(x, float):
+        return float(f'{x:.{nd}g}') if np.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+def _ops_short(ops):
+    """roofline_ops as rows [op, pass, us, frac, traffic / algorithmic bytes] (None where no PMC pass covers the op)."""
+    rows = []
+    for o in ops or []:
+        tr = o.get('traffic')
+        rows.append([o['op'].split(' (')[0] + ('/shared' if '(' in o['op'] else ''), o['pass'], round(o['avg_us'], 1),
+                     round(o['frac'], 4), None if not tr else round(tr / o['compulsory_bytes_per_launch'], 2)])
+    return rows
+
+
+def compact(full):
+    """The ONE line the driver parses: the contract fields, `roofline` (dominant sampling op), `cpu_baseline`, `phases`,
+    every sampling op as a 5-number row, and one number per sub-record.  The long form (`full`) goes to the extras
+    file and to a prefixed stderr line."""
+    cfg = full['config']
+    par = cfg.get('parity') or {}
+    short_cfg = {'workload': cfg['workload'].split(':')[0], 'shapes': cfg['workload'].split(': ', 1)[-1],
+                 'per_gpu_batch': cfg['per_gpu_batch'], 'global_batch': cfg['global_batch'],
+                 'mode': cfg['mode'].split(' (')[0], 'parallelism': cfg['parallelism'], 'rccl_ranks': cfg['rccl_ranks'],
+                 'gemm_arithmetic': ('f32 storage, Linear = split-bf16 x3 MFMA, f32 accumulate' if full['dtype'] == 'fp32'
+                                     else cfg['gemm_arithmetic']),
+                 'sampling_params': cfg['sampling_params'].split(':')[0],
+                 'streams': 2 if cfg['streams'].startswith('image') else 1,
+                 'step': cfg['step'], 'gradient_exchange': cfg['gradient_exchange'].split(':')[0].split(' (')[0],
+                 'launcher': cfg['launcher'].split(' (')[0],
+                 'parity': {'bar': par.get('bar'), 'pass': par.get('pass'), 'distance': par.get('distance')} if par else None}
+    out = {k: full[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+                                'scaling', 'vs_baseline', 'dtype', 'data')}
+    out['config'] = short_cfg
+    rf = full.get('roofline')
+    if rf:
+        out['roofline'] = {k: rf.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel',
+                                                  'avg_launch_us', 'algorithmic_bytes_per_launch')}
+    else:
+        out['roofline'] = None
+    out['roofline_ops_cols'] = ['op', 'pass', 'us', 'frac_of_8TBps', 'pmc_traffic_over_algorithmic']
+    out['roofline_ops'] = _ops_short(full.get('roofline_ops'))
+    out['phases'] = full.get('phases')
+    out['ms_per_step_rank_min'] = full['ms_per_step_rank_min']
+    out['host_enqueue_ms_per_step'] = full['host_enqueue_ms_per_step']
+    if 'spread' in full:
+        out['spread_value'] = full['spread']['value']
+        out['spread_roofline_ops'] = _ops_short(full['spread'].get('roofline_ops'))
+    if 'ieee_gemm' in full:
+        ip = full['ieee_gemm'].get('parity') or {}
+        out['ieee_gemm_value'] = full['ieee_gemm']['value']
+        out['ieee_gemm_parity_worst'] = max(ip['distance'].values()) if ip.get('distance') else None
+    if 'lowp' in full:
+        out['lowp'] = {r['dtype']: {'value': r['value'], 'parity_pass': (r.get('parity') or {}).get('pass'),
+                                    'parity_worst': max(r['parity']['distance'].values()) if r.get('parity') else None}
+                       for r in full['lowp']}
+    if 'gemm' in full:
+        g = {(x['dtype'], x['N'], x['K']): x for x in full['gemm']}
+        x = g.get(('fp32', 256, 256))
+        if x:
+            out['gemm_256x256_f32'] = {'us': x['us'], 'hbm_frac': x['hbm_frac'], 'mfma_frac': x['mfma_frac'], 'wgrad_us': x['wgrad_us']}
+    if 'voxel' in full:
+        v = full['voxel']
+        out['voxel'] = {'us_per_cloud_batch2': v.get('us_per_cloud_batch2'), 'points_per_s': v['points_per_s'],
+                        'middle_encoder_fwd_bwd_ms': v['middle_encoder']['forward_backward_ms'],
+                        'middle_encoder_fwd_ms': v['middle_encoder']['forward_ms']}
+    if 'k1_operator' in full:
+        k = full['k1_operator']
+        out['k1_operator'] = {kk: k[kk] for kk in ('fwd_us', 'fwd_frac', 'bwd_planned_us', 'bwd_planned_frac')}
+    if 'cpu_baseline' in full:
+        c = full['cpu_baseline']
+        out['cpu_baseline'] = {k: c[k] for k in ('value', 'unit', 'cores', 'kind', 'sample')}
+    if 'cpu_baseline_plan' in full:
+        out['cpu_baseline_plan'] = {e['config'].split()[0] + ':' + e['pass']: e['samples_per_s']
+                                    for e in full['cpu_baseline_plan']['entries']}
+    out['extras'] = 'bench_extras.json (long form of every record; also the `#extras ` stderr line)'
+    return _r(out)
+
+
+def emit(full, extras_file):
+    """Write the long record to ``extras_file`` and to a prefixed STDERR line, then print the short line, the only line
+    on stdout.  The short
+    line is strict JSON (no NaN / Infinity) and bounded: if a future field pushes it over LINE_LIMIT the optional
+    summaries are dropped one by one instead of letting the contract fields fall out of the driver's tail."""
+    long_line = json.dumps(_r(full, 7), allow_nan=False)
+    if extras_file:
+        try:
+            with open(extras_file, 'w') as f:
+                f.write(long_line + '\n')
+        except OSError as e:
+            print(f'[bench] could not write {extras_file}: {e}', file=sys.stderr)
+    print('#extras ' + long_line, file=sys.stderr, flush=True)     # (stdout carries exactly one line)
+    short = compact(full)
+    line = json.dumps(short, allow_nan=False)
+    for k in ('cpu_baseline_plan', 'spread_roofline_ops', 'k1_operator', 'voxel', 'gemm_256x256_f32', 'lowp', 'roofline_ops'):
+        if len(line) <= LINE_LIMIT:
+            break
+        short.pop(k, None)
+        short['dropped_for_length'] = short.get('dropped_for_length', []) + [k]
+        line = json.dumps(short, allow_nan=False)
+    assert len(line) <= LINE_LIMIT, len(line)
+    json.loads(line)
+    print(line, flush=True)
+
+
 def main():
     args = parse()
     torchrun = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
@@ -739,7 +857,7 @@ def main():
 
     if rank == 0:
         main_rec = recs[0]
-        out = {
+        full = {
             'metric': 'nuScenes samples/sec BEV-encoder fwd+bwd', 'value': main_rec['value'],
             'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': main_rec['ms_per_step'],
@@ -766,6 +884,7 @@ def main():
                        if os.environ.get('UBV_SHARE_FIRST', '1') != '0' else 'per sample',
                        'step': 'fwd + bwd (HIP graphs) + flat-gradient all-reduce + clip + AdamW'
                                if main_rec['hip_graphs'] else 'fwd + bwd + flat-gradient all-reduce + clip + AdamW',
+                       'gradient_exchange': main_rec['gradient_exchange'],
                        'optimizer': 'flat-buffer clip + AdamW kernels' if args.flat_optimizer else 'torch clip_grad_norm_ + fused AdamW',
                        'streams': 'image / point-cloud encoders on 2 HIP streams' if _two_streams() else '1 stream',
                        'launcher': 'self (bench.py -> torch.distributed.run)' if os.environ.get('UBV_BENCH_CHILD') == '1'
@@ -778,21 +897,21 @@ def main():
             'grid_overflow': main_rec.get('grid_overflow'),
         }
         if spread is not None:
-            out['spread'] = spread
+            full['spread'] = spread
         if ieee is not None:
-            out['ieee_gemm'] = ieee
+            full['ieee_gemm'] = ieee
         if len(recs) > 1:
-            out['lowp'] = recs[1:]
+            full['lowp'] = recs[1:]
         if world == 1 and not args.no_extras:
-            out['gemm'] = gemm_record(device, args.bs)
-            out['voxel'] = voxel_record(device)
-            out['k1_operator'] = k1_record(device, args.bs)
+            full['gemm'] = gemm_record(device, args.bs)
+            full['voxel'] = voxel_record(device)
+            full['k1_operator'] = k1_record(device, args.bs)
         # ---- CPU baseline: the oracle's forward on this host ------------------------------
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args, tcfg, head)
+            full['cpu_baseline'] = cpu_baseline(args, tcfg, head)
         if world == 1 and args.cpu_baseline_plan:
-            out['cpu_baseline_plan'] = cpu_baseline_plan()
-        print(json.dumps(out), flush=True)
+            full['cpu_baseline_plan'] = cpu_baseline_plan()
+        emit(full, args.extras_file)
     if dist.is_initialized():
         dist.destroy_process_group()
 

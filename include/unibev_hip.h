@@ -40,6 +40,18 @@ const char* ubv_last_error(void);
 /* Name of the gfx target the kernels were compiled for ("gfx950"). */
 const char* ubv_arch(void);
 
+/* Test aid (no reference counterpart): launches a kernel that writes `pattern` to 64 KB of LDS in 2048 blocks, so that
+ * the LDS a following kernel is handed holds those bits (e.g. 0x7fc00000, a NaN) instead of whatever ran before.  Used by
+ * tests/test_lift_gpu.py to show that no kernel consumes LDS it did not fill. */
+int ubv_debug_fill_lds(uint32_t pattern, void* stream);
+
+/* Test aid (no reference counterpart): a synthetic co-runner for the two-stream hazard study (tools/ab/lift_concurrent.py,
+ * profiles/r05_pk_mfma_hazard.txt).  kind 0 back-to-back bf16 MFMAs; 1 LDS stores + barriers + b128 reads + MFMAs (the
+ * skeleton of ubv_gemm_nt without global memory); 2 the same without MFMAs; 3 streaming reads of src[n_floats];
+ * 4 ds_read_b64_tr_b16 loop; 5 scalar-f32 VALU loop.  blocks x 256 threads, lds_bytes of dynamic LDS (>= 40 KB). */
+int ubv_debug_aggressor(int kind, int iters, int blocks, int lds_bytes, const float* src, int64_t n_floats, float* sink,
+                        void* stream);
+
 /* Optional per-kernel timing: while enabled, every kernel of the sampling family is bracketed by
  * HIP events on its launch stream.  ubv_profile_read() synchronises on them and writes one line per
  * kernel name: "name<TAB>launches<TAB>total_ms<TAB>algorithmic_bytes_per_launch\n"; returns the

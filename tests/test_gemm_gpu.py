@@ -201,6 +201,51 @@ def test_flat_adamw_parameter_groups_match_torch_param_groups():
             torch.testing.assert_close(p.detach(), r.detach(), rtol=2e-6, atol=2e-7)
 
 
+def test_flat_adamw_follows_a_learning_rate_schedule():
+    """A scheduler changes lr every iteration (the reference: linear warm-up + CosineAnnealing, config :463-469).  Both
+    ways of driving it — mmcv's LrUpdaterHook writing ``group['lr']`` from ``group['initial_lr']``, and ``opt.lr = x`` —
+    must reach the kernel in the NEXT step (the per-range arrays were filled once at construction)."""
+    import math
+    from unibev_amd.dp import FlatGradients
+    from unibev_amd.optim import FlatAdamW, paramwise_groups
+    torch.manual_seed(6)
+    names = ['img_backbone.w', 'head.w', 'head.b']
+    shapes = [(19, 7), (33, 5), (11,)]
+    mine = [torch.nn.Parameter(torch.randn(*s, device=DEV)) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    cfg = dict(custom_keys={'img_backbone': dict(lr_mult=0.1)})
+    fg = FlatGradients(mine)
+    fg.attach()
+    opt = FlatAdamW(paramwise_groups(zip(names, mine), 2e-3, 0.05, **cfg), fg, lr=2e-3, weight_decay=0.05)
+    topt = torch.optim.AdamW(paramwise_groups(zip(names, ref), 2e-3, 0.05, **cfg), lr=2e-3, weight_decay=0.05)
+    for g in topt.param_groups:
+        g.setdefault('initial_lr', g['lr'])
+    assert [g['initial_lr'] for g in opt.param_groups] == [2e-4, 2e-3]
+    for it in range(8):
+        factor = (it + 1) / 4 if it < 4 else 0.5 * (1 + math.cos(math.pi * (it - 4) / 4))     # warm-up, then cosine
+        for g in topt.param_groups:
+            g['lr'] = g['initial_lr'] * factor
+        if it % 2:
+            for g in opt.param_groups:
+                g['lr'] = g['initial_lr'] * factor
+        else:
+            opt.lr = 2e-3 * factor
+            if it == 4:
+                opt.weight_decay = 0.02
+        if it >= 4:
+            for g in topt.param_groups:
+                g['weight_decay'] = 0.02
+        assert [g['lr'] for g in opt.param_groups] == pytest.approx([2e-4 * factor, 2e-3 * factor])
+        gs = [torch.randn(*s, device=DEV) for s in shapes]
+        for p, r, g in zip(mine, ref, gs):
+            p.grad.copy_(g)
+            r.grad = g.clone()
+        topt.step()
+        opt.step()
+        for p, r in zip(mine, ref):
+            torch.testing.assert_close(p.detach(), r.detach(), rtol=2e-6, atol=2e-7)
+
+
 def test_split_weights_batched_matches_the_per_weight_kernel():
     from unibev_amd import functional as UF
     g = torch.Generator(device='cpu').manual_seed(5)

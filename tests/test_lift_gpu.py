@@ -508,3 +508,39 @@ def test_visible_lists_tile_by_tile_hold_the_same_queries_and_gradients():
         grads.append((v.grad.clone(), ol.grad.clone()))
     assert torch.equal(grads[0][1], grads[1][1])                                # the query side does not walk the lists
     torch.testing.assert_close(grads[0][0], grads[1][0], rtol=1e-5, atol=1e-5 * float(grads[0][0].abs().max()))
+
+
+@pytest.mark.parametrize('P,Z', [(4, 1), (8, 4)])
+def test_tile_plan_with_every_point_off_the_map_over_poisoned_lds(P, Z):
+    """a (tile, head) whose sampling points ALL fall outside the map has an empty pixel box, loads no window,
+    and its weightless corners are read from window pixel (0, 0) and multiplied by 0 — NaN if the LDS left behind by an
+    earlier kernel holds NaN bits.  Half of the tiles get offsets far off the map, the LDS of every CU is filled with
+    NaNs first: outputs and gradients stay finite and equal the fp64 oracle (exactly 0 for the off-map queries)."""
+    from unibev_amd import functional as UF
+    from unibev_amd._lib import lib, check
+    B, fh, fw, H, Dh, qh, qw = 1, 24, 24, 8, 32, 32, 32
+    rs = np.random.RandomState(5)
+    Nq, C = qh * qw, H * Dh
+    value = rs.standard_normal((B, fh * fw, C))
+    offs = rs.standard_normal((B, qh, qw, H * P * 2)) * 1.5
+    offs[:, :, :16] = 1000.0 + 50.0 * rs.standard_normal((B, qh, 16, H * P * 2))        # left half: far off the map
+    offlog = np.concatenate([offs.reshape(B, Nq, -1), rs.standard_normal((B, Nq, H * P))], -1)
+    ref = grid_ref(B, qh, qw, Z)
+    gout = rs.standard_normal((B, Nq, C))
+    v64, ol64 = t(value).requires_grad_(), t(offlog).requires_grad_()
+    o_ref = oracle_lift(v64, ol64, t(ref).double(), None, None, 1, fh, fw, H, P)
+    o_ref.backward(t(gout))
+    v = t(value, torch.float32, DEV).requires_grad_()
+    ol = t(offlog, torch.float32, DEV).requires_grad_()
+    nan_bits = 0x7fc00000
+    for _ in range(2):
+        check(lib().ubv_debug_fill_lds(nan_bits, UF._stream()), 'debug_fill_lds')
+    out = UF.bev_lift(v, ol, t(ref, torch.float32, DEV), 1, (fh, fw), H, P, query_grid=(qh, qw))
+    check(lib().ubv_debug_fill_lds(nan_bits, UF._stream()), 'debug_fill_lds')
+    out.backward(t(gout, torch.float32, DEV))
+    assert torch.isfinite(out).all() and torch.isfinite(ol.grad).all() and torch.isfinite(v.grad).all()
+    off_map = out.detach().view(B, qh, qw, C)[:, :, :16]
+    assert float(off_map.abs().max()) == 0.0
+    np.testing.assert_allclose(out.detach().cpu().numpy(), o_ref.detach().numpy(), rtol=3e-5, atol=3e-5)
+    np.testing.assert_allclose(v.grad.cpu().numpy(), v64.grad.numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(ol.grad.cpu().numpy(), ol64.grad.numpy(), rtol=2e-4, atol=5e-4)

@@ -32,7 +32,11 @@ def test_bias_and_norm_multipliers():
     named = _named([('fc.weight', (2, 2)), ('fc.bias', (2,)), ('norm.weight', (2,)), ('norm.bias', (2,))])
     groups = paramwise_groups(named, 1.0, 0.1, bias_lr_mult=2.0, bias_decay_mult=0.5, norm_decay_mult=0.0,
                               norm_names=('norm',))
-    assert [(g['lr'], g['weight_decay']) for g in groups] == [(1.0, 0.1), (2.0, 0.05), (1.0, 0.0), (2.0, 0.0)]
+    # (mmcv: bias_lr_mult / bias_decay_mult skip a normalisation layer's bias, which takes norm_decay_mult only)
+    assert [(g['lr'], g['weight_decay']) for g in groups] == [(1.0, 0.1), (2.0, 0.05), (1.0, 0.0), (1.0, 0.0)]
+    import pytest
+    with pytest.raises(ValueError, match='dwconv_decay_mult'):
+        paramwise_groups(named, 1.0, 0.1, dwconv_decay_mult=0.5)
 
 
 def test_runs_of_one_setting_merge_into_one_range():

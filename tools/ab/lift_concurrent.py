@@ -23,7 +23,18 @@ prio = int(os.environ.get('UBV_SIDE_PRIORITY', '0'))
 main, side = torch.cuda.current_stream(), torch.cuda.Stream(priority=prio)
 xb = x.bfloat16(); wb = w.bfloat16().contiguous(); gy = torch.randn(80000, 256, device=dev)
 gam = torch.ones(256, device=dev); bet = torch.zeros(256, device=dev)
-for mode in ('alone', 'beside gemm_nt', 'beside gemm_nt bf16', 'beside wgrad', 'beside add_norm', 'beside torch.mm'):
+from unibev_amd._lib import lib, check
+sink = torch.zeros(16, device=dev)
+SYN = {'beside syn mfma loop': 0, 'beside syn lds+barrier+mfma': 1, 'beside syn lds+barrier': 2, 'beside syn global reads': 3,
+       'beside syn ds_read_tr': 4, 'beside syn valu loop': 5}
+def syn(kind):
+    # (blocks x 256 threads, 60 KB of LDS: ubv_gemm_nt's launch geometry, 2 blocks per CU)
+    check(lib().ubv_debug_aggressor(kind, 20000 if kind != 4 else 4000, 512, 61440, UF._p(x), x.numel(), UF._p(sink), UF._stream()), 'dbg')
+modes = ('alone', 'beside gemm_nt', 'beside gemm_nt bf16', 'beside wgrad', 'beside add_norm', 'beside torch.mm') + tuple(SYN)
+if os.environ.get('UBV_MODES'):
+    modes = tuple(m.strip() for m in os.environ['UBV_MODES'].split(','))
+print('library:', os.environ.get('UBV_LIB_PATH', 'in-tree default'))
+for mode in modes:
     outs = []
     side.wait_stream(main)
     for i in range(iters):
@@ -39,6 +50,8 @@ for mode in ('alone', 'beside gemm_nt', 'beside gemm_nt bf16', 'beside wgrad', '
             for _ in range(3): UF.add_dropout_layernorm(x, gy, gam, bet, 0.1, True)
         elif mode == 'beside torch.mm':
             for _ in range(3): torch.mm(x, w)
+        elif mode in SYN:
+            syn(SYN[mode])
         elif mode == 'beside add':
             for _ in range(6): x + 1.0
     torch.cuda.synchronize()

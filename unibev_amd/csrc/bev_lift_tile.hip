@@ -173,6 +173,9 @@ __device__ __forceinline__ void tile_fill(const LiftArgs& a, const WinGeom& g, c
   for (int i = 0; i < 8; ++i)
     if (2 * i < t.rows)
       *reinterpret_cast<uint4*>(win + (2 * i + dyl) * kTWinRow + dx * kWinRowB + piece * 16) = v[i];
+  // an EMPTY box (every point of the tile off the map) loads nothing, and the no-miss paths read a weightless corner
+  // from pixel (0, 0) and multiply by 0: stale LDS bits there may be NaN / Inf — make the pixel a finite one
+  if (t.rows == 0 && tid < 8) *reinterpret_cast<uint4*>(win + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
 }
 

@@ -86,6 +86,115 @@ extern "C" int64_t ubv_profile_read(char* out, int64_t capacity) {
   return (int64_t)text.size() + 1;
 }
 
+// ---- test aid: fill the LDS of every CU with a bit pattern ---------------------------------------------
+namespace ubv {
+__global__ __launch_bounds__(256) void fill_lds_kernel(unsigned pattern, int words, unsigned* sink) {
+  extern __shared__ unsigned lds_words[];
+  for (int i = threadIdx.x; i < words; i += 256) lds_words[i] = pattern;
+  __syncthreads();
+  // (a read the compiler cannot drop keeps the stores)
+  if (sink != nullptr && lds_words[(threadIdx.x * 7) % words] != pattern) sink[0] = 1u;
+}
+}  // namespace ubv
+
+extern "C" int ubv_debug_fill_lds(uint32_t pattern, void* stream) {
+  // 2048 blocks x 64 KB: 8 waves of blocks over 256 CUs x 160 KB, every allocation slot is written at least once
+  constexpr int kBytes = 64 * 1024;
+  hipLaunchKernelGGL(ubv::fill_lds_kernel, dim3(2048), dim3(256), kBytes, (hipStream_t)stream, pattern, kBytes / 4,
+                     (unsigned*)nullptr);
+  UBV_CHECK_LAUNCH("debug_fill_lds");
+  return UBV_OK;
+}
+
+// ---- test aid: synthetic "aggressor" kernels for the two-stream hazard study (tools/ab/lift_concurrent.py) ----------
+// kind 0: back-to-back v_mfma_f32_32x32x16_bf16, nothing else        3: streaming global loads (a copy's read half)
+//      1: gemm-like skeleton: LDS stores + barrier + b128 reads + MFMAs   4: ds_read_b64_tr_b16 loop
+//      2: the same LDS traffic and barriers WITHOUT the MFMAs             5: plain VALU loop
+namespace ubv {
+typedef __attribute__((ext_vector_type(8))) __bf16 dbg_bf8;
+typedef __attribute__((ext_vector_type(16))) float dbg_f16v;
+typedef __attribute__((ext_vector_type(4))) float dbg_f4;
+typedef __attribute__((ext_vector_type(2))) int dbg_i2;
+template <int KIND>
+__global__ __launch_bounds__(256) void aggressor_kernel(const float* __restrict__ src, float* sink, int iters, long n4) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char albs[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  dbg_f16v c0 = {}, c1 = {};
+  dbg_f4 av = {1.0f + lane, 2.0f, 3.0f, 4.0f}, bv = {0.5f, 0.25f, 0.125f, lane * 0.01f};
+  float acc = 0.0f;
+  if constexpr (KIND == 0) {
+    for (int i = 0; i < iters; ++i) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dbg_bf8, av), __builtin_bit_cast(dbg_bf8, bv), c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dbg_bf8, bv), __builtin_bit_cast(dbg_bf8, av), c1, 0, 0, 0);
+    }
+  } else if constexpr (KIND == 1 || KIND == 2) {
+    dbg_f4* rows = reinterpret_cast<dbg_f4*>(albs);                 // [256 + 4] x 16 B per "chunk", 80-byte pitch like gemm_nt
+    for (int i = 0; i < iters / 8; ++i) {
+      __syncthreads();
+      *reinterpret_cast<dbg_f4*>(albs + tid * 80) = av;
+      *reinterpret_cast<dbg_f4*>(albs + 20480 + tid * 80) = bv;
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const dbg_f4 a = *reinterpret_cast<const dbg_f4*>(albs + ((tid + 32 * k) & 255) * 80);
+        const dbg_f4 b = *reinterpret_cast<const dbg_f4*>(albs + 20480 + ((tid + 64 * k) & 255) * 80);
+        if constexpr (KIND == 1) {
+          c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dbg_bf8, a), __builtin_bit_cast(dbg_bf8, b), c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dbg_bf8, b), __builtin_bit_cast(dbg_bf8, a), c1, 0, 0, 0);
+        } else {
+          acc += a[0] * b[1] + a[2] * b[3];
+        }
+      }
+      av[0] += 1.0f;
+    }
+    (void)rows;
+  } else if constexpr (KIND == 3) {
+    const dbg_f4* p = reinterpret_cast<const dbg_f4*>(src);
+    for (long i = (long)blockIdx.x * 256 + tid; i < n4; i += (long)gridDim.x * 256) {
+      const dbg_f4 v = p[i];
+      acc += v[0] + v[1] + v[2] + v[3];
+    }
+  } else if constexpr (KIND == 4) {
+    *reinterpret_cast<dbg_f4*>(albs + tid * 16) = av;
+    __syncthreads();
+    for (int i = 0; i < iters; ++i) {
+      dbg_i2 r;
+      const unsigned a = (unsigned)(((tid + i) & 255) * 16);
+      asm volatile("ds_read_b64_tr_b16 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(a));
+      acc += (float)(r[0] & 0xff) + (float)(r[1] & 0xff);
+    }
+  } else {
+    float x = lane * 0.001f, y = 1.0f + lane * 1e-6f;
+    for (int i = 0; i < iters * 16; ++i) x = __builtin_fmaf(x, y, y);
+    acc = x;
+  }
+  float s = acc;
+  for (int k = 0; k < 16; ++k) s += c0[k] + c1[k];
+  if (s == 123.456f) sink[0] = s;
+}
+}  // namespace ubv
+
+extern "C" int ubv_debug_aggressor(int kind, int iters, int blocks, int lds_bytes, const float* src, int64_t n_floats,
+                                   float* sink, void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(kind >= 0 && kind <= 5 && blocks > 0 && lds_bytes >= 40960 && lds_bytes <= 160 * 1024 && sink != nullptr,
+                "debug_aggressor: bad arguments");
+  UBV_CHECK_ARG(kind != 3 || (src != nullptr && n_floats >= 4), "debug_aggressor: kind 3 needs a source buffer");
+  const dim3 g(blocks), b(256);
+  hipStream_t st = (hipStream_t)stream;
+  const long n4 = n_floats / 4;
+  switch (kind) {
+    case 0: hipLaunchKernelGGL(aggressor_kernel<0>, g, b, lds_bytes, st, src, sink, iters, n4); break;
+    case 1: hipLaunchKernelGGL(aggressor_kernel<1>, g, b, lds_bytes, st, src, sink, iters, n4); break;
+    case 2: hipLaunchKernelGGL(aggressor_kernel<2>, g, b, lds_bytes, st, src, sink, iters, n4); break;
+    case 3: hipLaunchKernelGGL(aggressor_kernel<3>, g, b, lds_bytes, st, src, sink, iters, n4); break;
+    case 4: hipLaunchKernelGGL(aggressor_kernel<4>, g, b, lds_bytes, st, src, sink, iters, n4); break;
+    default: hipLaunchKernelGGL(aggressor_kernel<5>, g, b, lds_bytes, st, src, sink, iters, n4); break;
+  }
+  UBV_CHECK_LAUNCH("debug_aggressor");
+  return UBV_OK;
+}
+
 extern "C" int ubv_version(void) { return 100; }   // 0.1.0
 extern "C" const char* ubv_last_error(void) { return ubv::g_err; }
 extern "C" const char* ubv_arch(void) { return "gfx950"; }

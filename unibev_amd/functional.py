@@ -1403,11 +1403,21 @@ class batched_bn_ticks:
     def __exit__(self, *exc):
         global _BN_TICKS
         ticks, _BN_TICKS = _BN_TICKS, self._outer
-        if ticks:
+        if ticks and exc[0] is None:          # (a pass that raised counted nothing: torch ticks per completed forward)
             if self._outer is not None:
                 self._outer.extend(ticks)
             else:
-                torch._foreach_add_(ticks, 1)
+                # a module that ran twice in the pass appears twice: one entry per tensor with its count (a multi-tensor
+                # launch updates duplicate entries from unsynchronised blocks and loses increments)
+                seen = {}
+                for tk in ticks:
+                    ent = seen.setdefault(id(tk), [tk, 0])
+                    ent[1] += 1
+                by_n = {}
+                for tk, n in seen.values():
+                    by_n.setdefault(n, []).append(tk)
+                for n, group in by_n.items():
+                    torch._foreach_add_(group, n)
         return False
 
 

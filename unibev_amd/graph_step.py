@@ -100,13 +100,20 @@ class GraphedStep:
 
     def _order_params_for_split(self):
         """One traced forward: parameters used only above the cut go first (segment 0 of the flat buffer)."""
-        self.tr.forced_flags = self._combos()[0]
-        try:
-            out, cuts = self._trace()
-            up = self._reached([out.grad_fn])
-            low = self._reached([o.grad_fn for o, _ in cuts])
-        finally:
-            self.tr.forced_flags = None
+        # the partition must hold for EVERY modality combination that will be captured (a parameter above the cut under
+        # (1, 1) but below it under (0, 1) would make segment 0 incomplete in that graph): upper = used above the cut and
+        # never below it in any combination; every combination must cut somewhere
+        up, low, cuts = set(), set(), True
+        for flags in self._combos():
+            self.tr.forced_flags = flags
+            try:
+                out, c = self._trace()
+                up |= self._reached([out.grad_fn])
+                low |= self._reached([o.grad_fn for o, _ in c])
+                cuts = cuts and bool(c)
+                del out, c
+            finally:
+                self.tr.forced_flags = None
         mixed = up & low
         upper = [i for i in range(len(self.params)) if i in up]
         rest = [i for i in range(len(self.params)) if i not in up]

@@ -30,14 +30,20 @@ from ._lib import lib, check
 
 
 def paramwise_groups(named_params, lr, weight_decay, custom_keys=None, bias_lr_mult=1.0, bias_decay_mult=1.0,
-                     norm_decay_mult=1.0, norm_names=()):
+                     norm_decay_mult=1.0, norm_names=(), **unsupported):
     """torch-style parameter groups, one per parameter, from mmcv's ``paramwise_cfg`` (mmcv
     ``DefaultOptimizerConstructor.add_params``; the reference's configs use ``custom_keys`` only, :455-462): a
     parameter whose name contains a custom key takes that key's ``lr_mult`` / ``decay_mult`` — the LONGEST matching
     key wins, ties in alphabetical order; otherwise ``bias_lr_mult`` / ``bias_decay_mult`` apply to parameters named
     ``bias`` and ``norm_decay_mult`` to parameters of the modules listed in ``norm_names`` (name prefixes of the
-    normalisation layers: the caller knows its modules, this function sees names only).  Frozen parameters are left
-    out, like the constructor leaves them without a step."""
+    normalisation layers: the caller knows its modules, this function sees names only).  As in the constructor,
+    ``bias_lr_mult`` does NOT apply to a normalisation layer's bias, and a normalisation layer's parameters take
+    ``norm_decay_mult`` only.  Frozen parameters are left out, like the constructor leaves them without a step.
+    ``dwconv_decay_mult`` / ``dcn_offset_lr_mult`` (depth-wise convolutions, DCN offset convolutions: module types this
+    function cannot see from names) are rejected instead of ignored; no shipped config sets them."""
+    if unsupported:
+        raise ValueError(f'paramwise_groups: unsupported paramwise_cfg keys {sorted(unsupported)} (supported: custom_keys, '
+                         f'bias_lr_mult, bias_decay_mult, norm_decay_mult)')
     keys = sorted(sorted((custom_keys or {}).keys()), key=len, reverse=True)
     groups = []
     for name, p in named_params:
@@ -51,10 +57,9 @@ def paramwise_groups(named_params, lr, weight_decay, custom_keys=None, bias_lr_m
                 break
         else:
             is_norm = any(name.startswith(n + '.') for n in norm_names)
-            if name.endswith('.bias') or name == 'bias':
+            if (name.endswith('.bias') or name == 'bias') and not is_norm:
                 g['lr'] = float(lr) * float(bias_lr_mult)
-                if not is_norm:
-                    g['weight_decay'] = float(weight_decay) * float(bias_decay_mult)
+                g['weight_decay'] = float(weight_decay) * float(bias_decay_mult)
             if is_norm:
                 g['weight_decay'] = float(weight_decay) * float(norm_decay_mult)
         groups.append(g)
@@ -90,12 +95,16 @@ class FlatAdamW:
             raise ValueError(f'FlatAdamW: {len(self.ranges)} runs of parameters with their own lr / weight decay, at most '
                              f'{int(lib().ubv_adamw_flat_max_groups())}: order the parameters group by group')
         self.grads = grads
-        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), \
-            float(weight_decay)
+        self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
+        self._base = self._initial = (float(lr), float(weight_decay))
         k = len(self.ranges)
         self._ends = (ctypes.c_int64 * k)(*[r[0] for r in self.ranges])
-        self._lrs = (ctypes.c_float * k)(*[r[1] for r in self.ranges])
-        self._wds = (ctypes.c_float * k)(*[r[2] for r in self.ranges])
+        self._lrs, self._wds = (ctypes.c_float * k)(), (ctypes.c_float * k)()
+        # torch-style mutable settings, one dict per range of the flat buffers, READ AT EVERY STEP: a scheduler writes
+        # ``group['lr']`` (mmcv's LrUpdaterHook computes it from ``group['initial_lr']``; the reference's schedule is
+        # linear warm-up + CosineAnnealing, a new lr every iteration: config :463-469) or ``opt.lr = x`` (below)
+        self.param_groups = [{'lr': r[1], 'initial_lr': r[1], 'weight_decay': r[2], 'initial_weight_decay': r[2],
+                              'range': (0 if i == 0 else self.ranges[i - 1][0], r[0])} for i, r in enumerate(self.ranges)]
         self.max_grad_norm = None if max_grad_norm is None else float(max_grad_norm)
         dev = self.params[0].device
         n = grads.flat.numel()
@@ -112,6 +121,30 @@ class FlatAdamW:
         self._ws = torch.empty(int(lib().ubv_sumsq_workspace()), dtype=torch.uint8, device=dev)
         UL.mark_weights_changed()                       # cached low-precision copies point at the old storage
 
+    @property
+    def lr(self):
+        """The base learning rate.  Assigning scales every group: ``group['lr'] = x * initial_lr / initial base lr`` (the
+        groups keep their ``lr_mult``)."""
+        return self._base[0]
+
+    @lr.setter
+    def lr(self, x):
+        b0 = self.param_groups[0]['initial_lr'] if not self._initial[0] else self._initial[0]
+        for g in self.param_groups:
+            g['lr'] = float(x) * (g['initial_lr'] / b0 if b0 else 1.0)
+        self._base = (float(x), self._base[1])
+
+    @property
+    def weight_decay(self):
+        return self._base[1]
+
+    @weight_decay.setter
+    def weight_decay(self, x):
+        b0 = self._initial[1]
+        for g in self.param_groups:
+            g['weight_decay'] = float(x) * (g['initial_weight_decay'] / b0 if b0 else 1.0)
+        self._base = (self._base[0], float(x))
+
     @torch.no_grad()
     def step(self):
         """One update from ``grads.flat`` (the parameters' ``.grad`` views).  Nothing is read back."""
@@ -121,6 +154,8 @@ class FlatAdamW:
             raise RuntimeError(f'FlatAdamW: {len(self.grads.missing)} parameter(s) received no gradient in this step '
                                f'(shapes {names} ...): torch.optim.AdamW would skip them, the flat pass would decay '
                                f'them.  Exclude them (requires_grad_(False)) or use the torch optimizer.')
+        for i, grp in enumerate(self.param_groups):     # (k <= 16 floats: the host arrays are by-value kernel arguments)
+            self._lrs[i], self._wds[i] = float(grp['lr']), float(grp['weight_decay'])
         with UF._need_cuda(self.flat, g):
             st = UF._stream()
             sq = None
