@@ -48,9 +48,15 @@ int ubv_debug_fill_lds(uint32_t pattern, void* stream);
 /* Test aid (no reference counterpart): a synthetic co-runner for the two-stream hazard study (tools/ab/lift_concurrent.py,
  * profiles/r05_pk_mfma_hazard.txt).  kind 0 back-to-back bf16 MFMAs; 1 LDS stores + barriers + b128 reads + MFMAs (the
  * skeleton of ubv_gemm_nt without global memory); 2 the same without MFMAs; 3 streaming reads of src[n_floats];
- * 4 ds_read_b64_tr_b16 loop; 5 scalar-f32 VALU loop.  blocks x 256 threads, lds_bytes of dynamic LDS (>= 40 KB). */
+ * 4 ds_read_b64_tr_b16 loop; 5 scalar-f32 VALU loop; 6 v_cvt_pk_bf16_f32 loop; 7 MFMAs on 8 independent accumulators;
+ * 8 streaming copy of src's first half onto its second; 9 v_pk_fma_f32 loop; 10 v_pk_fma_f32 between MFMAs; 11 scalar v_fma_f32
+ * between MFMAs.  blocks x 256 threads, lds_bytes of dynamic LDS (>= 40 KB). */
 int ubv_debug_aggressor(int kind, int iters, int blocks, int lds_bytes, const float* src, int64_t n_floats, float* sink,
                         void* stream);
+
+/* Test aid: shader-clock stamps of the weight-stationary GEMM's tile loop (csrc/gemm_ws.hip, launches made with
+ * UBV_WS_ABL=16): out_host [2 blocks][16 tiles][8 stamps]. */
+int ubv_debug_ws_timing(uint64_t* out_host);
 
 /* Optional per-kernel timing: while enabled, every kernel of the sampling family is bracketed by
  * HIP events on its launch stream.  ubv_profile_read() synchronises on them and writes one line per

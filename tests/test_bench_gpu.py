@@ -34,9 +34,11 @@ def _run(extra_env, *flags, extras=False):
                               '--no-cpu-baseline', '--extras-file', xf, *flags], env=env, capture_output=True, text=True,
                              timeout=600, cwd=ROOT)
         assert out.returncode == 0, out.stderr[-2000:]
-        # stdout carries exactly ONE line (the long record goes to the extras file and a prefixed stderr line)
-        lines = [l for l in out.stdout.splitlines() if l.strip()]
-        assert len(lines) == 1 and lines[0].startswith('{'), out.stdout[-2000:]
+        # stdout carries exactly ONE JSON line, and it is the LAST line (RCCL may print its banner before it); the long
+        # record goes to the extras file and a prefixed stderr line
+        nonempty = [l for l in out.stdout.splitlines() if l.strip()]
+        lines = [l for l in nonempty if l.startswith('{')]
+        assert len(lines) == 1 and nonempty[-1] is lines[0], out.stdout[-2000:]
         d = _strict(lines[0])
         if extras:
             full = json.load(open(xf))

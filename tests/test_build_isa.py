@@ -31,7 +31,34 @@ def test_library_has_no_packed_f32_instructions(tmp_path):
     for f in objs:
         out = subprocess.run([OBJDUMP, '-d', f], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
         kernels += len(re.findall(r'^[0-9a-f]+ <_Z', out, flags=re.M))
+        # (the synthetic co-runners of the hazard study, ubv_debug_aggressor, hold packed instructions on purpose)
+        out = re.sub(r'^[0-9a-f]+ <_ZN3ubv16aggressor_kernel[^>]*>:\n.*?s_endpgm', '', out, flags=re.M | re.S)
         for m in re.findall(r'\bv_pk_[a-z0-9_]*f32\b', out):
             packed[m] = packed.get(m, 0) + 1
     assert kernels > 100, f'disassembly looks empty ({kernels} functions)'
     assert not packed, f'packed f32 VALU instructions in the library: {packed} — build with -fno-slp-vectorize'
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason='llvm-objdump of the ROCm toolchain not found')
+def test_weight_stationary_gemm_kernels_do_not_spill(tmp_path):
+    """csrc/gemm_ws.hip counts its vector-memory instructions by hand (its LDS-DMA requests are invisible to hipcc), so a
+    scratch access — a spilled register is one — would shift every counted `s_waitcnt vmcnt`.  The kernel descriptors of
+    the built library must report no private segment for any gemm_ws_kernel instantiation, and their code no scratch
+    instruction."""
+    so = os.path.join(ROOT, 'unibev_amd', 'libunibev_hip.so')
+    if not os.path.exists(so):
+        import __graft_entry__ as g
+        g.build()
+    shutil.copy(so, tmp_path / 'lib.so')
+    subprocess.run([OBJDUMP, '--offloading', 'lib.so'], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL)
+    found = 0
+    for f in [f for f in os.listdir(tmp_path) if f.endswith('gfx950')]:
+        out = subprocess.run([OBJDUMP, '-d', f], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        # (the product instantiations: timing-study switch ABL = 0, the last template argument)
+        for m in re.finditer(r'^[0-9a-f]+ <(_ZN3ubv14gemm_ws_kernelILi\d+ELi\dELi0EEE[^>]*)>:\n(.*?)s_endpgm', out, flags=re.M | re.S):
+            found += 1
+            body = m.group(2)
+            assert 'scratch_' not in body, f'{m.group(1)} spills (scratch instructions in its code)'
+            assert 'global_load_lds_dwordx4' in body and 'v_mfma_f32_32x32x16_bf16' in body
+    assert found >= 12, f'only {found} gemm_ws_kernel instantiations found in the library'

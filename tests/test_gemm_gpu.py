@@ -368,3 +368,52 @@ def test_self_attn_in_fused_gemm_matches_separate_linears():
     torch.testing.assert_close(rb.grad, rr.grad.float(), **tol(rr.grad, 2e-4))
     for got, ref in zip((wv, bv, wo, bo, wa, ba), pr):
         torch.testing.assert_close(got.grad, ref.grad.float(), **tol(ref.grad, 2e-4))
+
+
+@pytest.mark.parametrize('M', [1, 31, 32, 33, 4099, 20000])
+@pytest.mark.parametrize('N,K', [(256, 256), (512, 256), (192, 256), (128, 256), (256, 192), (256, 128), (768, 96), (256, 64),
+                                 (192, 192), (128, 64)])
+def test_gemm_ws_weight_stationary_kernel(M, N, K):
+    """The weight-stationary persistent kernel (csrc/gemm_ws.hip: every f32 Linear with K <= 256 and N in {128, 192, 256 k})
+    against f64: plain, bias + residual (also in place), the row-periodic term (ubv_gemm_nt_rowbias) and the masked form
+    (ubv_gemm_nt_act mode 2); row counts around the 32-row tile, fewer tiles than blocks, several column groups."""
+    from unibev_amd.functional import gemm_nt, gemm_nt_act, split_weight
+    g = torch.Generator(device='cpu').manual_seed(M * 7 + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    wh, wl, _, _ = split_weight(w.to(DEV), transposed=False)
+    ref = x.double() @ w.double().t()
+    scale = max(float(ref.abs().max()), 1.0)
+    xd = x.to(DEV)
+    y = gemm_nt(xd, wh, wl)
+    assert float((y.cpu().double() - ref).abs().max()) < 3e-5 * scale
+    y = gemm_nt(xd, wh, wl, bias=b.to(DEV), residual=r.to(DEV))
+    assert float((y.cpu().double() - (ref + b.double() + r.double())).abs().max()) < 3e-5 * scale
+    acc = r.to(DEV).clone()
+    y = gemm_nt(xd, wh, wl, residual=acc, out=acc)
+    assert y.data_ptr() == acc.data_ptr()
+    assert float((acc.cpu().double() - (ref + r.double())).abs().max()) < 3e-5 * scale
+    # row-periodic term: R[m % period] (period divides M), through a view with a wider row stride
+    for period in {1, M} | ({M // 7} if M % 7 == 0 and M > 7 else set()):
+        wide = torch.randn(period, N + 32, generator=g)
+        rb = wide.to(DEV)[:, 16:16 + N]
+        y = gemm_nt(xd, wh, wl, bias=b.to(DEV), row_bias=rb)
+        want = ref + b.double() + wide[:, 16:16 + N].double().repeat(M // period, 1)
+        assert float((y.cpu().double() - want).abs().max()) < 3e-5 * scale
+    # masked gradient form: (x @ w^T) / (1 - p) where mask != 0
+    mask = (torch.rand(M, N, generator=g) < 0.6).float() * torch.rand(M, N, generator=g).clamp_min(0.1)
+    y = gemm_nt_act(xd, wh, wl, act=2, mask=mask.to(DEV), p=0.25)
+    want = torch.where(mask != 0, ref / 0.75, torch.zeros_like(ref))
+    assert float((y.cpu().double() - want).abs().max()) < 3e-5 * scale / 0.75
+    # FFN activation in the epilogue: dropout(relu(x @ w^T + b)) with the keep mask of the separate kernel for the seed
+    from unibev_amd.functional import relu_dropout_raw
+    for p in (0.0, 0.3):
+        y = gemm_nt_act(xd, wh, wl, bias=b.to(DEV), act=1, p=p, seed=1234 + M)
+        want = relu_dropout_raw(gemm_nt(xd, wh, wl, bias=b.to(DEV)), p, 1234 + M)
+        assert torch.equal(y, want)
+        if p == 0.0:
+            assert float((y.cpu().double() - torch.relu(ref + b.double())).abs().max()) < 3e-5 * scale
+        else:
+            assert 0.2 < float((y == 0).float().mean()) - float((want if p == 0 else torch.relu(ref + b.double()) == 0).float().mean()) < 0.4

@@ -1,0 +1,10 @@
+#!/bin/bash
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/r5d
+mkdir -p $OUT
+cd $ROOT
+M="alone,beside gemm_nt,beside gemm_nt (other build),beside syn pk_fma loop,beside syn mfma + pk_fma"
+(UBV_LIB_PATH=$ROOT/unibev_amd/libunibev_hip_slp.so UBV_OTHER_LIB=$ROOT/unibev_amd/libunibev_hip.so UBV_MODES="$M" timeout 600 python tools/ab/lift_concurrent.py pts 40 2>&1 | grep -v '^/opt' > $OUT/lift_concurrent_slp_victim.txt)
+(UBV_OTHER_LIB=$ROOT/unibev_amd/libunibev_hip_slp.so UBV_MODES="$M" timeout 600 python tools/ab/lift_concurrent.py pts 40 2>&1 | grep -v '^/opt' > $OUT/lift_concurrent_noslp_victim.txt)
+cat $OUT/lift_concurrent_slp_victim.txt $OUT/lift_concurrent_noslp_victim.txt
+timeout 900 python -m pytest tests/test_bench_gpu.py -q -m gpu -x 2>&1 | tail -3

@@ -24,12 +24,29 @@ main, side = torch.cuda.current_stream(), torch.cuda.Stream(priority=prio)
 xb = x.bfloat16(); wb = w.bfloat16().contiguous(); gy = torch.randn(80000, 256, device=dev)
 gam = torch.ones(256, device=dev); bet = torch.zeros(256, device=dev)
 from unibev_amd._lib import lib, check
+# the OTHER build of the library (UBV_OTHER_LIB), called through its C ABI directly: the co-runner's GEMM from a build
+# with / without packed f32 instructions beside a victim from the build UBV_LIB_PATH names
+import ctypes
+other = None
+if os.environ.get('UBV_OTHER_LIB'):
+    other = ctypes.CDLL(os.environ['UBV_OTHER_LIB'])
+    other.ubv_gemm_nt.restype = ctypes.c_int
+    other.ubv_gemm_nt.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_int, ctypes.c_void_p]
+    yo = torch.empty(80000, 256, device=dev)
+def other_gemm():
+    rc = other.ubv_gemm_nt(x.data_ptr(), 256, hi.data_ptr(), lo.data_ptr(), 256, None, None, yo.data_ptr(), 256, 80000, 256, 256, 0,
+                           UF._stream())
+    assert rc == 0
 sink = torch.zeros(16, device=dev)
+xs = torch.randn(2 * 80000 * 256, device=dev)        # (kind 8 copies its first half onto its second)
 SYN = {'beside syn mfma loop': 0, 'beside syn lds+barrier+mfma': 1, 'beside syn lds+barrier': 2, 'beside syn global reads': 3,
-       'beside syn ds_read_tr': 4, 'beside syn valu loop': 5}
+       'beside syn ds_read_tr': 4, 'beside syn valu loop': 5, 'beside syn cvt_pk_bf16 loop': 6,
+       'beside syn mfma 8 accumulators': 7, 'beside syn copy': 8, 'beside syn pk_fma loop': 9, 'beside syn mfma + pk_fma': 10, 'beside syn mfma + scalar fma': 11}
 def syn(kind):
     # (blocks x 256 threads, 60 KB of LDS: ubv_gemm_nt's launch geometry, 2 blocks per CU)
-    check(lib().ubv_debug_aggressor(kind, 20000 if kind != 4 else 4000, 512, 61440, UF._p(x), x.numel(), UF._p(sink), UF._stream()), 'dbg')
+    check(lib().ubv_debug_aggressor(kind, 20000 if kind != 4 else 4000, 512, 61440, UF._p(xs), xs.numel(), UF._p(sink), UF._stream()), 'dbg')
 modes = ('alone', 'beside gemm_nt', 'beside gemm_nt bf16', 'beside wgrad', 'beside add_norm', 'beside torch.mm') + tuple(SYN)
 if os.environ.get('UBV_MODES'):
     modes = tuple(m.strip() for m in os.environ['UBV_MODES'].split(','))
@@ -50,6 +67,8 @@ for mode in modes:
             for _ in range(3): UF.add_dropout_layernorm(x, gy, gam, bet, 0.1, True)
         elif mode == 'beside torch.mm':
             for _ in range(3): torch.mm(x, w)
+        elif mode == 'beside gemm_nt (other build)':
+            for _ in range(3): other_gemm()
         elif mode in SYN:
             syn(SYN[mode])
         elif mode == 'beside add':

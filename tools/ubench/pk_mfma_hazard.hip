@@ -41,9 +41,10 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
   } while (0)
 
 // ---------------------------------------------------------------------------------------------- aggressors
-enum { A_NONE = 0, A_VALU, A_MFMA_32_BF16, A_MFMA_32_F16, A_MFMA_32_F32, A_MFMA_16_BF16, A_LIB_GEMM, A_COUNT };
+enum { A_NONE = 0, A_VALU, A_MFMA_32_BF16, A_MFMA_32_F16, A_MFMA_32_F32, A_MFMA_16_BF16, A_MFMA_PLUS_PK, A_MFMA_PLUS_VALU, A_LIB_GEMM, A_COUNT };
 static const char* kAggName[A_COUNT] = {"nothing", "valu v_fma_f32 loop", "v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x16_f16",
-                                        "v_mfma_f32_32x32x2_f32", "v_mfma_f32_16x16x32_bf16", "libunibev ubv_gemm_nt f32"};
+                                        "v_mfma_f32_32x32x2_f32", "v_mfma_f32_16x16x32_bf16", "mfma bf16 + v_pk_fma_f32 mixed",
+                                        "mfma bf16 + v_fma_f32 mixed", "libunibev ubv_gemm_nt f32"};
 
 template <int KIND>
 __global__ __launch_bounds__(256) void aggressor(float* sink, int iters) {
@@ -80,6 +81,23 @@ __global__ __launch_bounds__(256) void aggressor(float* sink, int iters) {
     float s = 0.f;
     for (int k = 0; k < 16; ++k) s += c0[k] + c1[k];
     if (s == 123.456f) sink[0] = s;
+  } else if constexpr (KIND == A_MFMA_PLUS_PK || KIND == A_MFMA_PLUS_VALU) {
+    // ONE wave stream that alternates an MFMA with four VALU instructions (packed f32 / scalar f32): what a GEMM's main
+    // loop looks like (operand conversion between the matrix instructions) and what the pure loops above do not have
+    f16v c0 = {};
+    f4 av = {1.0f + lane, 2.0f, 3.0f, 4.0f}, bv = {0.5f, 0.25f, 0.125f, lane * 0.01f};
+    f2 x = {1.0f + lane * 0.001f, 2.0f - lane * 0.001f};
+    const f2 a = {0.9990234375f, 1.0009765625f}, b = {0.001953125f, -0.0009765625f};
+    for (int i = 0; i < iters; ++i) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, av), __builtin_bit_cast(bf8, bv), c0, 0, 0, 0);
+      for (int k = 0; k < 4; ++k) {
+        if constexpr (KIND == A_MFMA_PLUS_PK) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
+        else { asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[0]) : "v"(a[0]), "v"(b[0])); asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[1]) : "v"(a[1]), "v"(b[1])); }
+      }
+    }
+    float s = x[0] + x[1];
+    for (int k = 0; k < 16; ++k) s += c0[k];
+    if (s == 123.456f) sink[0] = s;
   } else if constexpr (KIND == A_MFMA_16_BF16) {
     f4 c0 = {}, c1 = {};
     f4 av = {1.0f + lane, 2.0f, 3.0f, 4.0f}, bv = {0.5f, 0.25f, 0.125f, lane * 0.01f};
@@ -93,9 +111,9 @@ __global__ __launch_bounds__(256) void aggressor(float* sink, int iters) {
 }
 
 // ---------------------------------------------------------------------------------------------- victims
-enum { V_PK_FMA = 0, V_PK_ADD, V_PK_MUL, V_PK_FMA_OPSEL, V_COORDS, V_COUNT };
+enum { V_PK_FMA = 0, V_PK_ADD, V_PK_MUL, V_PK_FMA_OPSEL, V_COORDS, V_AXPY_LDS, V_COUNT };
 static const char* kVicName[V_COUNT] = {"v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32", "v_pk_fma_f32 op_sel_hi:[0,1,1]",
-                                        "coords (compiler-packed)"};
+                                        "coords (compiler-packed)", "axpy from LDS (compiler-packed)"};
 
 __device__ __forceinline__ float sfma(float a, float b, float c) {
   float d;
@@ -117,7 +135,7 @@ __device__ __forceinline__ float smul(float a, float b) {
 // packed result differs from the scalar one, wrong[1] = one example (lane id | block << 8), wrong[2..3] bits
 template <int KIND>
 __global__ __launch_bounds__(256) void victim(unsigned* wrong, int len, int reps, float fw, float fh) {
-  __shared__ float lds_pad[1024];                         // (an LDS allocation like the lifting kernels': co-residency)
+  __shared__ __attribute__((aligned(16))) float lds_pad[1024];                         // (an LDS allocation like the lifting kernels': co-residency)
   lds_pad[threadIdx.x] = (float)threadIdx.x;
   __syncthreads();
   const int t = blockIdx.x * 256 + threadIdx.x;
@@ -128,7 +146,33 @@ __global__ __launch_bounds__(256) void victim(unsigned* wrong, int len, int reps
     f2 x = {s0, s1};
     float y0 = s0, y1 = s1;
     const f2 a = {0.9990234375f, 1.0009765625f}, b = {0.001953125f * s1, -0.0009765625f * s0};
-    if constexpr (KIND == V_COORDS) {
+    if constexpr (KIND == V_AXPY_LDS) {
+      // the lifting kernels' accumulation (bev_lift_tile.hip tile_axpy32): acc[32] += c * (32 floats read from LDS with
+      // ds_read_b128), 4 corners x 2 points — the SLP vectoriser turns the FMAs into v_pk_fma_f32 ... op_sel_hi:[0,1,1]
+      float acc[32], ref[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) { acc[k] = 0.0f; ref[k] = 0.0f; }
+      for (int i = 0; i < len; ++i) {
+        const float c = s0 * 0.125f + (float)i * 0.03125f;
+        const float* p = lds_pad + ((threadIdx.x * 36 + i * 4) & 991);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const f4 v = *reinterpret_cast<const f4*>(p + 4 * q - ((reinterpret_cast<uintptr_t>(p) >> 2) & 3));
+          acc[4 * q] = __builtin_fmaf(c, v[0], acc[4 * q]);
+          acc[4 * q + 1] = __builtin_fmaf(c, v[1], acc[4 * q + 1]);
+          acc[4 * q + 2] = __builtin_fmaf(c, v[2], acc[4 * q + 2]);
+          acc[4 * q + 3] = __builtin_fmaf(c, v[3], acc[4 * q + 3]);
+          ref[4 * q] = sfma(c, v[0], ref[4 * q]);
+          ref[4 * q + 1] = sfma(c, v[1], ref[4 * q + 1]);
+          ref[4 * q + 2] = sfma(c, v[2], ref[4 * q + 2]);
+          ref[4 * q + 3] = sfma(c, v[3], ref[4 * q + 3]);
+        }
+      }
+      unsigned d = 0;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) d |= __float_as_uint(acc[k]) ^ __float_as_uint(ref[k]);
+      x[0] = __uint_as_float(d); y0 = 0.0f; x[1] = 0.0f; y1 = 0.0f;
+    } else if constexpr (KIND == V_COORDS) {
       // the lifting kernels' arithmetic (bev_lift_tile.hip tile_points): lx = ref + off / W; rx = lx * W - 0.5
       f2 ref = {s0 * 0.25f, s1 * 0.25f};
       const f2 wh = {fw, fh};
@@ -258,6 +302,8 @@ int main(int argc, char** argv) {
           case A_MFMA_32_F16: launch_aggr<A_MFMA_32_F16>(sa, sink, iters, agg_blocks); break;
           case A_MFMA_32_F32: launch_aggr<A_MFMA_32_F32>(sa, sink, iters / 4, agg_blocks); break;
           case A_MFMA_16_BF16: launch_aggr<A_MFMA_16_BF16>(sa, sink, iters, agg_blocks); break;
+          case A_MFMA_PLUS_PK: launch_aggr<A_MFMA_PLUS_PK>(sa, sink, iters, agg_blocks); break;
+          case A_MFMA_PLUS_VALU: launch_aggr<A_MFMA_PLUS_VALU>(sa, sink, iters, agg_blocks); break;
           case A_LIB_GEMM:
             for (int g = 0; g < 24; ++g)
               if (gemm_nt(gx, K, gwh, gwl, K, nullptr, nullptr, gy, N, M, N, K, 0, sa) != 0) { fprintf(stderr, "gemm_nt failed\n"); exit(2); }
@@ -273,6 +319,7 @@ int main(int argc, char** argv) {
             case V_PK_MUL: launch_vic<V_PK_MUL>(sv, wrong, vic_blocks, 64, 24); break;
             case V_PK_FMA_OPSEL: launch_vic<V_PK_FMA_OPSEL>(sv, wrong, vic_blocks, 64, 24); break;
             case V_COORDS: launch_vic<V_COORDS>(sv, wrong, vic_blocks, 16, 24); break;
+            case V_AXPY_LDS: launch_vic<V_AXPY_LDS>(sv, wrong, vic_blocks, 16, 12); break;
           }
         }
         CK(hipEventRecord(v1, sv));

@@ -110,6 +110,8 @@ extern "C" int ubv_debug_fill_lds(uint32_t pattern, void* stream) {
 // kind 0: back-to-back v_mfma_f32_32x32x16_bf16, nothing else        3: streaming global loads (a copy's read half)
 //      1: gemm-like skeleton: LDS stores + barrier + b128 reads + MFMAs   4: ds_read_b64_tr_b16 loop
 //      2: the same LDS traffic and barriers WITHOUT the MFMAs             5: plain VALU loop
+//      6: v_cvt_pk_bf16_f32 loop    7: MFMAs on 8 independent accumulators    8: streaming copy (src's first half -> second half)
+//      9: v_pk_fma_f32 loop         10: v_pk_fma_f32 between MFMAs   11: scalar v_fma_f32 between MFMAs
 namespace ubv {
 typedef __attribute__((ext_vector_type(8))) __bf16 dbg_bf8;
 typedef __attribute__((ext_vector_type(16))) float dbg_f16v;
@@ -163,6 +165,51 @@ __global__ __launch_bounds__(256) void aggressor_kernel(const float* __restrict_
       asm volatile("ds_read_b64_tr_b16 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(a));
       acc += (float)(r[0] & 0xff) + (float)(r[1] & 0xff);
     }
+  } else if constexpr (KIND == 6) {
+    // v_cvt_pk_bf16_f32 loop (the f32 -> bf16 split every GEMM of this library runs on its operands)
+    float x = 1.0f + lane * 0.001f, y = 0.5f + lane * 0.002f;
+    unsigned r = 0;
+    for (int i = 0; i < iters * 8; ++i) {
+      unsigned t;
+      asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(t) : "v"(x), "v"(y));
+      r ^= t;
+      x += 1.0f;
+    }
+    acc = (float)(r & 0xff);
+  } else if constexpr (KIND == 7) {
+    // 8 INDEPENDENT accumulators: no dependency stalls between the MFMAs, the matrix pipe never idles
+    dbg_f16v c[8] = {};
+    for (int i = 0; i < iters / 4; ++i) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        c[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dbg_bf8, av), __builtin_bit_cast(dbg_bf8, bv), c[k], 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c0 += c[k];
+  } else if constexpr (KIND == 8) {
+    // streaming copy: 16-byte loads and stores
+    const dbg_f4* p = reinterpret_cast<const dbg_f4*>(src);
+    dbg_f4* q = reinterpret_cast<dbg_f4*>(const_cast<float*>(src)) + n4;          // second half of the buffer
+    for (long i = (long)blockIdx.x * 256 + tid; i < n4; i += (long)gridDim.x * 256) q[i] = p[i];
+  } else if constexpr (KIND == 9 || KIND == 10 || KIND == 11) {
+    // 9: v_pk_fma_f32 loop; 10: the same between MFMAs (a kernel that holds BOTH, like an SLP-built GEMM epilogue)
+    typedef float dbg_f2 __attribute__((ext_vector_type(2)));
+    dbg_f2 x = {1.0f + lane * 0.001f, 2.0f - lane * 0.001f};
+    const dbg_f2 a = {0.9990234375f, 1.0009765625f}, b = {0.001953125f, -0.0009765625f};
+    for (int i = 0; i < iters; ++i) {
+      if constexpr (KIND >= 10)
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dbg_bf8, av), __builtin_bit_cast(dbg_bf8, bv), c0, 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if constexpr (KIND == 11) {                       // the same arithmetic as two scalar FMAs: no packed instruction
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[0]) : "v"(a[0]), "v"(b[0]));
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[1]) : "v"(a[1]), "v"(b[1]));
+        } else {
+          asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
+        }
+      }
+    }
+    acc = x[0] + x[1];
   } else {
     float x = lane * 0.001f, y = 1.0f + lane * 1e-6f;
     for (int i = 0; i < iters * 16; ++i) x = __builtin_fmaf(x, y, y);
@@ -177,18 +224,24 @@ __global__ __launch_bounds__(256) void aggressor_kernel(const float* __restrict_
 extern "C" int ubv_debug_aggressor(int kind, int iters, int blocks, int lds_bytes, const float* src, int64_t n_floats,
                                    float* sink, void* stream) {
   using namespace ubv;
-  UBV_CHECK_ARG(kind >= 0 && kind <= 5 && blocks > 0 && lds_bytes >= 40960 && lds_bytes <= 160 * 1024 && sink != nullptr,
+  UBV_CHECK_ARG(kind >= 0 && kind <= 11 && blocks > 0 && lds_bytes >= 40960 && lds_bytes <= 160 * 1024 && sink != nullptr,
                 "debug_aggressor: bad arguments");
-  UBV_CHECK_ARG(kind != 3 || (src != nullptr && n_floats >= 4), "debug_aggressor: kind 3 needs a source buffer");
+  UBV_CHECK_ARG((kind != 3 && kind != 8) || (src != nullptr && n_floats >= 4), "debug_aggressor: kind 3 needs a source buffer");
   const dim3 g(blocks), b(256);
   hipStream_t st = (hipStream_t)stream;
-  const long n4 = n_floats / 4;
+  const long n4 = kind == 8 ? n_floats / 8 : n_floats / 4;
   switch (kind) {
     case 0: hipLaunchKernelGGL(aggressor_kernel<0>, g, b, lds_bytes, st, src, sink, iters, n4); break;
     case 1: hipLaunchKernelGGL(aggressor_kernel<1>, g, b, lds_bytes, st, src, sink, iters, n4); break;
     case 2: hipLaunchKernelGGL(aggressor_kernel<2>, g, b, lds_bytes, st, src, sink, iters, n4); break;
     case 3: hipLaunchKernelGGL(aggressor_kernel<3>, g, b, lds_bytes, st, src, sink, iters, n4); break;
     case 4: hipLaunchKernelGGL(aggressor_kernel<4>, g, b, lds_bytes, st, src, sink, iters, n4); break;
+    case 6: hipLaunchKernelGGL(aggressor_kernel<6>, g, b, lds_bytes, st, src, sink, iters, n4); break;
+    case 7: hipLaunchKernelGGL(aggressor_kernel<7>, g, b, lds_bytes, st, src, sink, iters, n4); break;
+    case 8: hipLaunchKernelGGL(aggressor_kernel<8>, g, b, lds_bytes, st, src, sink, iters, n4); break;
+    case 9: hipLaunchKernelGGL(aggressor_kernel<9>, g, b, lds_bytes, st, src, sink, iters, n4); break;
+    case 10: hipLaunchKernelGGL(aggressor_kernel<10>, g, b, lds_bytes, st, src, sink, iters, n4); break;
+    case 11: hipLaunchKernelGGL(aggressor_kernel<11>, g, b, lds_bytes, st, src, sink, iters, n4); break;
     default: hipLaunchKernelGGL(aggressor_kernel<5>, g, b, lds_bytes, st, src, sink, iters, n4); break;
   }
   UBV_CHECK_LAUNCH("debug_aggressor");

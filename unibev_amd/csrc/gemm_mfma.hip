@@ -23,6 +23,7 @@
 // row: bias / residual / store are 16-byte (8-byte for 16-bit outputs) vectors.
 #include <type_traits>
 
+#include "gemm_act.h"
 #include "ubv_common.h"
 
 namespace ubv {
@@ -32,18 +33,6 @@ typedef __attribute__((ext_vector_type(8))) _Float16 gf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float gf32x16_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t gu32x4_t;   // staging registers: native vectors (a HIP
 typedef __attribute__((ext_vector_type(4))) float gf32x4_t;      // uint4 / float4 struct copy ended up in scratch)
-
-// Optional epilogue of the FFN GEMMs (ubv_gemm_nt_act): mode 1 y = dropout(relu(acc + bias)) with the
-// keep mask of ubv_relu_dropout_forward (hash of seed and the element's index in the [M, N] output);
-// mode 2 y = acc * scale where mask[m][n] != 0, else 0 — the backward of that activation applied to the
-// input gradient of the NEXT Linear (mask = the activation's saved output).
-struct GemmAct { int mode; const void* mask; uint32_t thresh; float scale; uint64_t seed; const uint64_t* seed_dev;
-                 long res_period, res_ld;      // res_period > 0: R is a ROW-PERIODIC term, R[(m % res_period) * res_ld + n]
-                 // "dual" form (ubv_gemm_nt_dual; the fused value_proj | offsets | logits GEMM of the BEV self-attention
-                 // and its input gradient): X's columns k >= k_split come from a second matrix, Y's columns n >= n_split
-                 // go to a second matrix (the row-periodic term then applies to those only); N need not fill the last
-                 // column tile
-                 const void* x2; long ldx2; int k_split; void* y2; long ldy2; int n_split; };
 
 constexpr int kGemmBM = 128;
 #ifndef UBV_GEMM_XD
@@ -563,6 +552,10 @@ static int gemm_nt_run(const void* x, int64_t ldx, const void* w_hi, const void*
   }
   hipStream_t st = as_stream(stream);
   int rc;
+  if (dtype == UBV_F32 && gemm_ws_try(x, ldx, w_hi, w_lo, ldw, bias, residual, y, ldy, M, N, K, act, st)) {
+    UBV_CHECK_LAUNCH(who);
+    return UBV_OK;
+  }
   if (dtype == UBV_F32) rc = gemm_nt_launch<true, false, false>(x, ldx, w_hi, w_lo, ldw, bias, residual, y, ldy, M, N, K, act, st);
   else if (dtype == UBV_F16) rc = gemm_nt_launch<false, true, true>(x, ldx, w_hi, nullptr, ldw, bias, residual, y, ldy, M, N, K, act, st);
   else rc = gemm_nt_launch<false, false, true>(x, ldx, w_hi, nullptr, ldw, bias, residual, y, ldy, M, N, K, act, st);
