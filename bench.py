@@ -798,6 +798,14 @@ def emit(full, extras_file):
         line = json.dumps(short, allow_nan=False)
     assert len(line) <= LINE_LIMIT, len(line)
     json.loads(line)
+    # C-level stdout first (RCCL prints its version banner through printf: unflushed, it would land AFTER the line — at
+    # process exit — and the last line of stdout would not be the JSON)
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
     print(line, flush=True)
 
 
