@@ -129,9 +129,14 @@ def parse():
     ap.add_argument('--exchange', default='auto', choices=['auto', 'split', 'single'],
                     help="gradient exchange: 'split' = the backward is two HIP graphs cut at the first encoder layers and the "
                          "upper layers' segment of the flat gradient buffer is all-reduced beside the second graph; 'single' = "
-                         "one graph, one message after it; 'auto' = single.  (split puts RCCL's reduction kernels beside the "
-                         "lower backward's MFMA kernels; RCCL is not built by this repository and its f32 sums may use the "
-                         "packed instructions that go wrong there - DESIGN section 5/6 - so it is opt-in until checked on N > 1)")
+                         "one graph, one message after it; 'auto' = split for N > 1, single for one GPU.  The overlapped "
+                         "segments are SUM all-reduces on RCCL's ring (dp.init_distributed pins NCCL_ALGO=Ring: the ring "
+                         "FuncSum kernels hold no packed f32 instruction, profiles/r04_rccl_packed_f32_functions.txt) and are "
+                         "divided by the world size when waited for")
+    ap.add_argument('--lr', type=float, default=2e-4, help='AdamW learning rate (0: the step runs, the parameters stay put)')
+    ap.add_argument('--grad-checksum', action='store_true',
+                    help='add order-independent checksums of the flat gradient buffer after the last step (`grad_checksum`) to '
+                         'the line: tests compare the exchange modes with them')
     ap.add_argument('--extras-file', default=os.path.join(ROOT, 'bench_extras.json'),
                     help="where the long form of the record goes ('' = nowhere); the final stdout line is the short form")
     ap.add_argument('--no-ieee-gemm', action='store_true', help='skip the `ieee_gemm` sub-record (f32 step on library IEEE GEMMs)')
@@ -308,11 +313,11 @@ def run_mode(args, name, head, world, rank, device, want_ops):
     params = [p for p in head.parameters() if p.requires_grad]
     for p in params:
         p.grad = None
-    opt = None if args.flat_optimizer else torch.optim.AdamW(params, lr=2e-4, weight_decay=0.01, fused=True)
+    opt = None if args.flat_optimizer else torch.optim.AdamW(params, lr=args.lr, weight_decay=0.01, fused=True)
     s = 2 if kw.get('fusion_method') == 'cat' else 1
     C = kw['embed_dims']
     cot = torch.randn(200 * 200, args.bs, C * s, device=device) / 200.0
-    split = args.exchange == 'split'
+    split = args.exchange == 'split' or (args.exchange == 'auto' and world > 1)
     tr = head.transformer
     encs = [getattr(tr, n) for n in ('img_bev_encoder', 'pts_bev_encoder') if getattr(tr, n, None) is not None]
     cut = encs if split else None
@@ -324,7 +329,7 @@ def run_mode(args, name, head, world, rank, device, want_ops):
     if args.flat_optimizer:
         # clip (max_norm 35) + AdamW as two streaming passes over the flat parameter / gradient / moment buffers
         from unibev_amd.optim import FlatAdamW
-        opt = FlatAdamW(params, gs.grads, lr=2e-4, weight_decay=0.01, max_grad_norm=35.0)
+        opt = FlatAdamW(params, gs.grads, lr=args.lr, weight_decay=0.01, max_grad_norm=35.0)
 
         def finish():
             opt.step()
@@ -397,10 +402,14 @@ def run_mode(args, name, head, world, rank, device, want_ops):
         launch_dt += time.perf_counter() - t1
     torch.cuda.synchronize()
     launch_dt /= min(args.steps, 10)
+    checksum = None
+    if args.grad_checksum:                         # (the last step's exchanged gradients; the parameter order is the mode's own)
+        f = gs.grads.flat.double()
+        checksum = {'l2': float(f.square().sum().sqrt()), 'sum': float(f.sum()), 'abs': float(f.abs().sum()), 'n': int(f.numel())}
     nsteps_run = args.warmup + 1 + args.steps + min(args.steps, 10) * (2 if graphed else 1)       # (profilers divide by this)
     rec = {'dtype': name, 'value': world * args.bs * args.steps / dt, 'ms_per_step': 1e3 * dt / args.steps,
            'ms_per_step_rank_min': 1e3 * dt_min / args.steps, 'ms_per_step_rank_max': 1e3 * dt / args.steps,
-           'phases': phases,
+           'phases': phases, 'grad_checksum': checksum,
            'host_enqueue_ms_per_step': 1e3 * launch_dt, 'host_loop_ms_per_step': 1e3 * host_dt / args.steps,
            'hip_graphs': graphed, 'steps_run': nsteps_run,
            'gradient_exchange': ('split: 2 HIP graphs, segment 0 (%d of %d bytes) all-reduced beside the second graph'
@@ -739,6 +748,8 @@ def compact(full):
     out['roofline_ops_cols'] = ['op', 'pass', 'us', 'frac_of_8TBps', 'pmc_traffic_over_algorithmic']
     out['roofline_ops'] = _ops_short(full.get('roofline_ops'))
     out['phases'] = full.get('phases')
+    if full.get('grad_checksum'):
+        out['grad_checksum'] = full['grad_checksum']
     out['ms_per_step_rank_min'] = full['ms_per_step_rank_min']
     out['host_enqueue_ms_per_step'] = full['host_enqueue_ms_per_step']
     if 'spread' in full:
@@ -772,7 +783,10 @@ def compact(full):
         out['cpu_baseline_plan'] = {e['config'].split()[0] + ':' + e['pass']: e['samples_per_s']
                                     for e in full['cpu_baseline_plan']['entries']}
     out['extras'] = 'bench_extras.json (long form of every record; also the `#extras ` stderr line)'
-    return _r(out)
+    out = _r(out)
+    if full.get('grad_checksum'):                 # (compared between runs to 1e-5: not rounded)
+        out['grad_checksum'] = full['grad_checksum']
+    return out
 
 
 def emit(full, extras_file):
@@ -870,7 +884,7 @@ def main():
             'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': main_rec['ms_per_step'],
             'ms_per_step_rank_min': main_rec['ms_per_step_rank_min'], 'ms_per_step_rank_max': main_rec['ms_per_step_rank_max'],
-            'phases': main_rec['phases'],
+            'phases': main_rec['phases'], 'grad_checksum': main_rec.get('grad_checksum'),
             'host_enqueue_ms_per_step': main_rec['host_enqueue_ms_per_step'],
             'host_loop_ms_per_step': main_rec['host_loop_ms_per_step'],
             'higher_is_better': True, 'scaling': 'weak',

@@ -111,6 +111,33 @@ def test_bench_launches_its_own_ranks():
     assert d['config']['step'].startswith('fwd + bwd (HIP graphs)')
 
 
+def test_overlapped_exchange_gives_the_gradients_of_the_single_message():
+    """``--exchange split`` (two HIP graphs, segment 0 of the flat gradient buffer all-reduced on RCCL's stream beside the
+    second graph: what ``auto`` selects for N > 1) against ``--exchange single`` through the same launcher, one rank WITH an
+    RCCL process group (or two on a two-GPU box), dropout off and learning rate 0 (every step then computes the same
+    gradients; with updates a 1e-7 difference grows through AdamW's normalised steps): order-independent checksums of
+    the exchanged gradients after the last step agree to 1e-5, the line says which mode ran and carries the per-phase times."""
+    import torch
+    n = 2 if torch.cuda.device_count() >= 2 else 1
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    got = {}
+    for mode in ('single', 'split'):
+        flags = ['--gpus', str(n), '--launcher', 'spawn', '--dtype', 'fp32', '--no-extras', '--no-parity', '--no-kernel-timing',
+                 '--eval-mode', '--params', 'init', '--no-ieee-gemm', '--exchange', mode, '--grad-checksum', '--lr', '0',
+                 '--extras-file', '']
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1',
+                              '--no-cpu-baseline', *flags], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-3000:]
+        d = _strict([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+        assert d['config']['gradient_exchange'].startswith(mode) and d['config']['rccl_ranks'] == n
+        assert d['phases'] and d['phases']['gradient_bytes'] > 5e7
+        got[mode] = d['grad_checksum']
+    assert got['single']['n'] == got['split']['n']
+    for k in ('l2', 'abs'):
+        assert abs(got['split'][k] - got['single'][k]) <= 1e-5 * abs(got['single'][k]), (k, got)
+    assert abs(got['split']['sum'] - got['single']['sum']) <= 1e-5 * got['single']['abs'], got
+
+
 def test_bench_refuses_a_mismatched_world_and_a_silent_eager_fallback():
     env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29543')
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1'],

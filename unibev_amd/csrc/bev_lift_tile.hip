@@ -22,6 +22,8 @@
 // Measured at bs = 2 on the 200x200 (P = 4) / 180x180 (P = 8) maps, us: forward 81 -> 71 / 115 -> 92; query gradient
 // (+ bins) 108 + 37 -> 78 (+ bins) / 157 + 65 -> 112 (+ bins).  profiles/r04_tile_*.txt.
 
+#include <string.h>
+
 #include "bev_lift_core.h"
 
 namespace ubv {
@@ -137,12 +139,16 @@ __device__ __forceinline__ float tile_dot32(const float* __restrict__ p, const f
 
 // Window of a block from its box: origin (clamped into the map like win_origin) and the rows / columns worth loading.
 struct TileWin { int rows, cols; };
-__device__ __forceinline__ TileWin tile_window(const LiftArgs& a, const int4 bb, WinGeom& g) {
+__device__ __forceinline__ TileWin tile_window(const LiftArgs& a, const int4 bb, WinGeom& g, int max_box) {
   g.wx0 = min(max(bb.x, 0), max(a.fw - kWin, 0));
   g.wy0 = min(max(bb.y, 0), max(a.fh - kWin, 0));
   TileWin t;
   t.cols = min(max(bb.z - g.wx0 + 1, 0), min(kWin, a.fw));
   t.rows = min(max(bb.w - g.wy0 + 1, 0), min(kWin, a.fh));
+  // a box beyond `max_box` pixels is not copied: every lane then fetches its corners from global memory itself (the
+  // window is a cache) — with offsets scattered by several pixels per query the copy of a 16 x 16 window costs a
+  // 4-point block more than the 1 024 corner rows it serves (block-uniform)
+  if (t.cols * t.rows > max_box) { t.cols = 0; t.rows = 0; }
   return t;
 }
 
@@ -188,7 +194,7 @@ __device__ __forceinline__ int tile_row(int xc, int yc, const WinGeom& g, const 
 // ------------------------------------------------------------------------------------------------
 // Forward.  Two barriers (block box, window fill).
 template <int P>
-__global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, int chunk) {
+__global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, int chunk, int max_box) {
   extern __shared__ __attribute__((aligned(16))) unsigned char win[];
   constexpr int PW = P / 4;
   WinGeom g;
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, in
   if (!valid) q = 0;
   const long bq = (long)b * a.Nq + q;
   const int4 bb = tile_points<P, false>(a, bq, valid, h, pp, wv, lane, rx, ry, rw);
-  const TileWin tw = tile_window(a, bb, g);
+  const TileWin tw = tile_window(a, bb, g, max_box);
   tile_fill(a, g, tw, h, win);
   const float* vb = (const float*)a.value + (long)g.b * a.fh * a.fw * rowi + h * 32;      // wave-uniform
 
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, in
 // same fixed-capacity buckets + overflow list; see there): ranks inside the wave through LDS counters on an 8x8 torus
 // of tile slots, one returning global atomic per occupied slot.  The caller zeroes the counters.
 template <int P, bool BINS>
-__global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs a, int chunk, int tiles_x, int tiles) {
+__global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs a, int chunk, int tiles_x, int tiles, int max_box) {
   extern __shared__ __attribute__((aligned(16))) unsigned char win[];
   // per wave: a 4x4 torus of tile slots — occupant tile, local count, global base (a wave's 16 queries x 4 points
   // reach a handful of tiles; two tiles that collide on the torus take the direct global path)
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
   }
   float rx[PW], ry[PW], rw[PW];
   const int4 bb = tile_points<P, true>(a, bq, valid, h, pp, wv, lane, rx, ry, rw);
-  const TileWin tw = tile_window(a, bb, g);
+  const TileWin tw = tile_window(a, bb, g, max_box);
   tile_fill(a, g, tw, h, win);
   const float* vb = (const float*)a.value + (long)g.b * a.fh * a.fw * rowi + h * 32;      // wave-uniform
 
@@ -391,11 +397,24 @@ bool tile_ok(const LiftArgs& a, int Dh, int P, int dtype) {
          a.vis0 == nullptr && a.count == nullptr && a.fh >= 1 && a.fw >= 1;
 }
 
+// largest pixel box a block copies into LDS (UBV_TILE_MAXBOX_FWD / _BWD, one value or "P4,P8"; 256 = always)
+static int tile_max_box(const char* env, int P, int dflt4, int dflt8) {
+  const char* e = getenv(env);
+  int v4 = dflt4, v8 = dflt8;
+  if (e != nullptr) {
+    v4 = v8 = atoi(e);
+    const char* c = strchr(e, ',');
+    if (c != nullptr) v8 = atoi(c + 1);
+  }
+  return P == 4 ? v4 : v8;
+}
+
 void tile_fwd_launch(const LiftArgs& a, int P, hipStream_t st) {
   const long units = (long)a.total_tiles * a.H;
   const int chunk = (int)((units + 7) / 8);
-  if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4>), dim3(8 * chunk), dim3(256), kTWinLds, st, a, chunk);
-  else hipLaunchKernelGGL((lift_tile_fwd_kernel<8>), dim3(8 * chunk), dim3(256), kTWinLds, st, a, chunk);
+  static const int mb4 = tile_max_box("UBV_TILE_MAXBOX_FWD", 4, 256, 256), mb8 = tile_max_box("UBV_TILE_MAXBOX_FWD", 8, 256, 256);
+  if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4>), dim3(8 * chunk), dim3(256), kTWinLds, st, a, chunk, mb4);
+  else hipLaunchKernelGGL((lift_tile_fwd_kernel<8>), dim3(8 * chunk), dim3(256), kTWinLds, st, a, chunk, mb8);
 }
 
 // bins: the points are binned here (the caller zeroed a.bin_cnt / a.ovf_n and launches no lift_bin_kernel)
@@ -403,12 +422,13 @@ void tile_bwd_query_launch(const LiftArgs& a, int P, bool bins, int tiles_x, int
   const long units = (long)a.total_tiles * a.H;
   const int chunk = (int)((units + 7) / 8);
   const dim3 grid(8 * chunk), blk(256);
+  static const int mb4 = tile_max_box("UBV_TILE_MAXBOX_BWD", 4, 256, 256), mb8 = tile_max_box("UBV_TILE_MAXBOX_BWD", 8, 256, 256);
   if (P == 4) {
-    if (bins) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles);
-    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4, false>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles);
+    if (bins) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb4);
+    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4, false>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb4);
   } else {
-    if (bins) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<8, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles);
-    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<8, false>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles);
+    if (bins) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<8, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb8);
+    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<8, false>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb8);
   }
 }
 

@@ -25,6 +25,13 @@ def init_distributed(backend=None, device=None):
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         kw = {}
+        if backend == 'nccl':
+            # RING all-reduce for every collective of this process (a user's own NCCL_ALGO wins).  The gradient segments
+            # that overlap the rest of the backward (FlatGradients.start_segment) are SUM all-reduces, and of RCCL's
+            # reduction kernels only the ring FuncSum variants hold no packed f32 instruction
+            # (profiles/r04_rccl_packed_f32_functions.txt; why that matters: profiles/r05_pk_mfma_hazard.txt).  On one
+            # node's point-to-point xGMI links the ring is also the bandwidth-optimal algorithm for 18 - 56 MB messages.
+            os.environ.setdefault('NCCL_ALGO', 'Ring')
         if backend == 'nccl' and device is not None:
             kw['device_id'] = device
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
