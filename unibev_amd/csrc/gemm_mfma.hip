@@ -642,6 +642,9 @@ namespace ubv {
 // slab_sum_kernel — one read of dY and X instead of the strided-batched library GEMM + a separate
 // column-sum pass.
 constexpr int kWgTile = 128, kWgMC = 64;
+#ifndef UBV_WGRAD_SPREAD
+#define UBV_WGRAD_SPREAD 0
+#endif
 constexpr int kWgCS = kWgMC * 16 + 16;                    // halves per column group (64 rows x 16 + 32 B)
 constexpr int kWgPlane = 8 * kWgCS;                       // halves per operand plane (128 columns)
 
@@ -767,10 +770,8 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
   // every load of the NEXT chunk (vmcnt 14 .. 0) before the first MFMA of the current one: the prefetch ran in series
   // with the arithmetic.
   uint32_t ymask = 0u, xmask = 0u;
-  auto load_chunk = [&](long mc) {
-    ymask = 0u; xmask = 0u;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
+  auto load_piece = [&](long mc, int i) __attribute__((always_inline)) {
+    {
       const long m = mc + sr + (256 / TPR) * i;
       long mm = m < my_end ? m : my_end - 1;
       mm = mm > 0 ? mm : 0;                               // (an offset with no pair in this slab: row 0, dropped)
@@ -798,6 +799,11 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
       ymask |= (m < my_end && yok) ? (1u << i) : 0u;
       xmask |= (xrow_ok && xok) ? (1u << i) : 0u;
     }
+  };
+  auto load_chunk = [&](long mc) __attribute__((always_inline)) {
+    ymask = 0u; xmask = 0u;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) load_piece(mc, i);
   };
   auto split_store = [&](uint16_t* th, uint16_t* tl, int o, const gf32x4_t v) {
     const uint32_t h0 = cvt_pk_bf16(v.x, v.y), h1 = cvt_pk_bf16(v.z, v.w);
@@ -836,8 +842,15 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
     __syncthreads();
     store_chunk();
     __syncthreads();
-    if (mc + kWgMC < mend) {
-      load_chunk(mc + kWgMC);
+    // UBV_WGRAD_SPREAD=1 (compile time; round-5 experiment, measured neutral: 70.4 vs 71.2 us hot, 66.3 vs 66.2 cold at
+    // 256 x 256, job r5s): the next chunk's 2 NI loads of dense operands issued BETWEEN the MFMA groups of this chunk, NI / 2
+    // per K step, instead of one burst in front of them — what took the weight-stationary forward GEMM's tile from 5 700 to
+    // 4 400 cycles (csrc/gemm_ws.hip) does nothing here: this kernel's time is its transposing LDS reads and barriers.
+    constexpr bool SPREAD = !GATHER && UBV_WGRAD_SPREAD;
+    const bool more = mc + kWgMC < mend;
+    if (more) {
+      if constexpr (SPREAD) { ymask = 0u; xmask = 0u; }
+      else load_chunk(mc + kWgMC);
       if (mc + 2 * kWgMC < mend) load_idx(mc + 2 * kWgMC);
     }
 #pragma unroll
@@ -871,6 +884,15 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
           accb[j] = gemm_mma<F16>(ones, bh[j], accb[j]);
           if constexpr (SPLIT) accb[j] = gemm_mma<F16>(ones, bl[j], accb[j]);
         }
+      }
+      if constexpr (SPREAD) {
+        constexpr int PER = NI / (kWgMC / 16);            // pieces per K step
+        __builtin_amdgcn_sched_barrier(0x7);              // (ALU may cross; MFMA, LDS and vector-memory instructions not)
+        if (more) {
+#pragma unroll
+          for (int q = 0; q < PER; ++q) load_piece(mc + kWgMC, (ks / 16) * PER + q);
+        }
+        __builtin_amdgcn_sched_barrier(0x7);
       }
     }
   }

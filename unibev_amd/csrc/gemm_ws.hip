@@ -389,7 +389,11 @@ bool gemm_ws_try(const void* X, long ldx, const void* Wh, const void* Wl, long l
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
     cus = p.multiProcessorCount;
   }
-  int per_group = cus / a.ncg;                                        // blocks per column group
+  // UBV_WS_CUS: CUs a launch may occupy (default all: a persistent block holds its CU's registers and LDS until the
+  // kernel ends, so a kernel of another stream runs beside it only on CUs left out here)
+  static const int cu_cap = getenv("UBV_WS_CUS") ? atoi(getenv("UBV_WS_CUS")) : 0;
+  const int use_cus = cu_cap > 0 && cu_cap < cus ? cu_cap : cus;
+  int per_group = use_cus / a.ncg;                                    // blocks per column group
   per_group = per_group / 8 * 8;                                      // ... a multiple of 8: one XCD's slots per sequence step
   if (per_group < 8) per_group = 8;
   while (per_group > 8 && per_group - 8 >= a.tiles) per_group -= 8;   // (tiny M: no idle blocks)
