@@ -548,12 +548,21 @@ def k1_record(device, bs):
     plain = torch.as_tensor([[Hq, Wq]], dtype=torch.long, device=device)      # no host copy attached: atomic kernel
 
     def timed(fn, n=10):
+        """Device time per call: n calls captured in one HIP graph and replayed (the eager python loop of an autograd
+        Function is host-bound below ~100 us per call: rounds 3 - 4 reported that as the operator's forward)."""
         for _ in range(3):
             fn()
+        torch.cuda.synchronize()
+        from unibev_amd import dp as _dp
+        _dp.drain_watchdog()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode='thread_local'):
+            for _ in range(n):
+                fn()
+        g.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(n):
-            fn()
+        g.replay()
         e1.record()
         torch.cuda.synchronize()
         return 1e3 * e0.elapsed_time(e1) / n
@@ -562,14 +571,19 @@ def k1_record(device, bs):
         v.grad = loc.grad = aw.grad = None
         UF.ms_deform_attn(v, shapes, ls, loc, aw).backward(go)
 
+    sg = shapes_tensor([(Hq, Wq)], device, query_grid=(Hq, Wq))      # + the query-grid hint: the TILE plan
     with torch.no_grad():
         f_us = timed(lambda: UF.ms_deform_attn(v, ss, ls, loc, aw))
-    fb_planned, fb_atomic = timed(lambda: fwd_bwd(ss)), timed(lambda: fwd_bwd(plain))
+        fg_us = timed(lambda: UF.ms_deform_attn(v, sg, ls, loc, aw))
+    fb_planned, fb_atomic, fb_grid = timed(lambda: fwd_bwd(ss)), timed(lambda: fwd_bwd(plain)), timed(lambda: fwd_bwd(sg))
     fb, bb = k1_bytes(B, S, Nq, H * Dh, H, P, 4, False), k1_bytes(B, S, Nq, H * Dh, H, P, 4, True)
     return {'shape': f'B={B} S=Nq={S} H={H} Dh={Dh} P={P} f32', 'fwd_us': f_us, 'fwd_frac': fb / f_us / 1e3 / HBM_PEAK_GBS,
             'bwd_planned_us': fb_planned - f_us, 'bwd_planned_frac': bb / (fb_planned - f_us) / 1e3 / HBM_PEAK_GBS,
             'bwd_atomic_us': fb_atomic - f_us, 'bwd_atomic_frac': bb / (fb_atomic - f_us) / 1e3 / HBM_PEAK_GBS,
-            'note': 'backward = (forward + backward) - forward, eager launches; bytes: SURVEY.md section 8(d) k1 formulas'}
+            'grid_fwd_us': fg_us, 'grid_fwd_frac': fb / fg_us / 1e3 / HBM_PEAK_GBS,
+            'grid_bwd_us': fb_grid - fg_us, 'grid_bwd_frac': bb / (fb_grid - fg_us) / 1e3 / HBM_PEAK_GBS,
+            'note': 'backward = (forward + backward) - forward, device time of graph replays; bytes: SURVEY.md section 8(d) k1 formulas; '
+                    'grid_*: the same operator with the query-grid hint (ubv_ms_deform_attn_forward_grid / _backward_grid)'}
 
 
 def voxel_record(device):
@@ -775,7 +789,8 @@ def compact(full):
                         'middle_encoder_fwd_ms': v['middle_encoder']['forward_ms']}
     if 'k1_operator' in full:
         k = full['k1_operator']
-        out['k1_operator'] = {kk: k[kk] for kk in ('fwd_us', 'fwd_frac', 'bwd_planned_us', 'bwd_planned_frac')}
+        out['k1_operator'] = {kk: k[kk] for kk in ('fwd_us', 'fwd_frac', 'bwd_planned_us', 'bwd_planned_frac', 'grid_fwd_us',
+                                                   'grid_fwd_frac', 'grid_bwd_us', 'grid_bwd_frac') if kk in k}
     if 'cpu_baseline' in full:
         c = full['cpu_baseline']
         out['cpu_baseline'] = {k: c[k] for k in ('value', 'unit', 'cores', 'kind', 'sample')}

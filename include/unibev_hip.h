@@ -117,6 +117,30 @@ int ubv_ms_deform_attn_backward_planned(const void* value, const int64_t* spatia
                                         int S, int H, int Dh, int L, int Nq, int P, int dtype, int fh, int fw,
                                         void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The operator with a QUERY-GRID hint (round 5): the caller states that the Nq queries are a qgrid_h x qgrid_w grid in
+ * row-major order — true at the reference's BEV call sites (models/modules/spatial_cross_attention_pts.py:439-442: the
+ * queries are the bev_h x bev_w BEV grid; the encoder's self-attention likewise) — and that the single level is fh x fw.
+ * mmcv's signature cannot say either; with them the operator runs on the TILE plan of the fused lifting kernels
+ * (csrc/bev_lift_tile.hip: block = 8x8 query tile x head, one lane per sampling point, the tile's pixel box of the value
+ * map in LDS; backward: d(locations), d(weights) from the same block, grad_value by owner tiles, no f32 atomics).
+ * Covered: f32, L == 1, H == 8, Dh == 32, P in {4, 8}, qgrid_h * qgrid_w == Nq (ubv_ms_deform_attn_grid_supported).
+ * forward_grid falls back to ubv_ms_deform_attn_forward for anything else; backward_grid returns UBV_ERR_UNSUPPORTED and
+ * the caller takes ubv_ms_deform_attn_backward[_planned].  grad_value is WRITTEN; workspace:
+ * ubv_ms_deform_attn_backward_grid_workspace(...) bytes. */
+int ubv_ms_deform_attn_grid_supported(int H, int Dh, int L, int P, int dtype, int fh, int fw, int Nq, int qgrid_h,
+                                      int qgrid_w);
+int ubv_ms_deform_attn_forward_grid(const void* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                                    const float* sampling_loc, const float* attn_weight, void* out, int B, int S, int H,
+                                    int Dh, int L, int Nq, int P, int dtype, int fh, int fw, int qgrid_h, int qgrid_w,
+                                    void* stream);
+int64_t ubv_ms_deform_attn_backward_grid_workspace(int B, int fh, int fw, int H, int Dh, int Nq, int P, int dtype,
+                                                   int qgrid_h, int qgrid_w);
+int ubv_ms_deform_attn_backward_grid(const void* value, const float* sampling_loc, const float* attn_weight,
+                                     const void* grad_out, float* grad_value, float* grad_sampling_loc,
+                                     float* grad_attn_weight, int B, int S, int H, int Dh, int L, int Nq, int P, int dtype,
+                                     int fh, int fw, int qgrid_h, int qgrid_w, void* workspace, int64_t workspace_bytes,
+                                     void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused BEV query lifting (one level): offsets -> locations, logits -> softmax, sampling,
  * per-camera accumulation and the camera mean, in one kernel; nothing but the GEMM outputs is

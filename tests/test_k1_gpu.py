@@ -225,3 +225,53 @@ def test_k1_full_size_gradients_vs_c_oracle(dtype, tol):
     idx = np.arange(0, Nq, 97)
     assert rel(l.grad.cpu().numpy()[:, idx], gl[:, idx]) < max(tol, 2e-4)
     assert rel(w.grad.cpu().numpy()[:, idx], gw[:, idx]) < max(tol, 2e-4)
+
+
+@pytest.mark.parametrize('B,fh,fw,qh,qw,P,sig', [
+    (2, 37, 41, 40, 45, 8, 0.04),      # partial edge tiles of the query grid and of the pixel grid
+    (1, 50, 50, 50, 50, 4, 0.02),
+    (2, 16, 16, 19, 13, 4, 0.6),       # locations far outside the map, boxes larger than the window
+    (1, 180, 180, 200, 200, 8, 0.01),  # the SCA-pts instance's size
+])
+def test_k1_with_query_grid_hint_equals_the_plain_operator(B, fh, fw, qh, qw, P, sig):
+    """``ubv_ms_deform_attn_forward_grid`` / ``_backward_grid`` (the operator on the TILE plan: the caller states that its
+    queries are a qh x qw grid) against the plain operator on the same explicit locations / weights — forward to f32
+    round-off, grad_value / grad_loc / grad_weight likewise (the owner tiles sum in another order than the atomics) —
+    and against the fp64 oracle at the small sizes."""
+    from unibev_amd import functional as UF
+    from unibev_amd.modules.deform_attn import index_tensor, shapes_tensor
+    from oracle import unibev_ref as R
+    H, Dh = 8, 32
+    Nq, S = qh * qw, fh * fw
+    g = torch.Generator(device='cpu').manual_seed(B * 100 + P + qh)
+    ys, xs = torch.meshgrid(torch.arange(qh), torch.arange(qw), indexing='ij')
+    ref = torch.stack(((xs + 0.5) / qw, (ys + 0.5) / qh), -1).view(1, Nq, 1, 1, 1, 2)
+    loc0 = ref + sig * torch.randn(B, Nq, H, 1, P, 2, generator=g)
+    aw0 = torch.softmax(torch.randn(B, Nq, H, 1, P, generator=g), -1)
+    v0 = torch.randn(B, S, H, Dh, generator=g)
+    go = torch.randn(B, Nq, H * Dh, generator=g).to(DEV)
+    ls = index_tensor([0], DEV)
+    outs = {}
+    for name, ss in (('plain', shapes_tensor([(fh, fw)], DEV)), ('grid', shapes_tensor([(fh, fw)], DEV, query_grid=(qh, qw)))):
+        v, loc, aw = (x.clone().to(DEV).requires_grad_() for x in (v0, loc0, aw0))
+        UF.kernel_profile(True)
+        out = UF.ms_deform_attn(v, ss, ls, loc, aw)
+        out.backward(go)
+        torch.cuda.synchronize()
+        kernels = set(UF.kernel_profile())
+        UF.kernel_profile(False)
+        assert any(k.startswith('k1_tile_') for k in kernels) == (name == 'grid'), kernels
+        outs[name] = (out.detach(), v.grad, loc.grad, aw.grad)
+    for a, b, what in zip(outs['grid'], outs['plain'], ('out', 'grad_value', 'grad_loc', 'grad_weight')):
+        scale = max(float(b.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) < 3e-5 * scale + 1e-6, (what, float((a - b).abs().max()), scale)
+    if Nq <= 2500:
+        v64, l64, w64 = (x.double().requires_grad_() for x in (v0, loc0, aw0))
+        o64 = R.msda(v64, [(fh, fw)], l64, w64)
+        o64.backward(go.cpu().double())
+        for a, b, what in zip(outs['grid'], (o64.detach(), v64.grad, l64.grad, w64.grad), ('out', 'gv', 'gloc', 'gw')):
+            a, b = a.cpu().double().numpy(), b.numpy()
+            bad = np.abs(a - b) > 2e-4 * np.abs(b) + 2e-4 * max(float(np.abs(b).max()), 1.0)
+            # d / d(location) jumps where a sample sits on a pixel boundary: f32 and f64 may floor() a location that
+            # close to an integer to different sides — a handful of the 10^5 points, never the other tensors
+            assert bad.mean() <= (2e-5 if what == 'gloc' else 0.0), (what, int(bad.sum()), bad.size)

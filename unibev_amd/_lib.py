@@ -30,6 +30,10 @@ SIGNATURES = {
     'ubv_ms_deform_attn_backward': (c_int, [_P] * 9 + [c_int] * 9 + [_P]),
     'ubv_ms_deform_attn_backward_workspace': (c_int64, [c_int] * 8),
     'ubv_ms_deform_attn_backward_planned': (c_int, [_P] * 9 + [c_int] * 10 + [_P, c_int64, _P]),
+    'ubv_ms_deform_attn_grid_supported': (c_int, [c_int] * 10),
+    'ubv_ms_deform_attn_forward_grid': (c_int, [_P] * 6 + [c_int] * 12 + [_P]),
+    'ubv_ms_deform_attn_backward_grid_workspace': (c_int64, [c_int] * 10),
+    'ubv_ms_deform_attn_backward_grid': (c_int, [_P] * 7 + [c_int] * 12 + [_P, c_int64, _P]),
     'ubv_bev_lift_forward_workspace': (c_int64, [c_int] * 8),
     'ubv_bev_lift_forward': (c_int, [_P, _P, c_int64, _P, c_int64, c_int, _P, _P, _P, _P]
                              + [c_int] * 12 + [_P, c_int64, _P]),

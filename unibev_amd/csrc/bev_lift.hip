@@ -1892,6 +1892,77 @@ int k1_grid_value(const float* loc, const float* aw, const void* gout, float* gv
   return UBV_OK;
 }
 
+// ---- the k1 OPERATOR on the TILE plan: explicit sampling locations / attention weights, queries on a
+// qh x qw grid (the caller says so: the mmcv operator's signature has no such notion).  Forward = lift_tile_fwd_kernel<P, K1>;
+// backward = lift_tile_bwd_query_kernel<P, bins, K1> (d locations, d weights, records) + the owner tiles.
+static void k1_tile_args(LiftArgs& a, int B, int fh, int fw, int H, int Nq, int qh, int qw) {
+  a = LiftArgs{};
+  a.B = B; a.Nc = 1; a.fh = fh; a.fw = fw; a.H = H; a.Nq = Nq; a.Z = 1; a.qw = qw; a.qh = qh;
+  a.tiles_x = (qw + 7) / 8;
+  a.tiles_per_sample = a.tiles_x * ((qh + 7) / 8);
+  a.total_tiles = B * a.tiles_per_sample;
+  a.chunk = (a.total_tiles + 7) / 8;
+  // (mg_tps / mg_tx = 0: plain divisions in the tile decode)
+}
+bool k1_tile_ok(int H, int Dh, int P, int dtype, int fh, int fw, int Nq, int qh, int qw) {
+  if (qh <= 0 || qw <= 0 || (long)qh * qw != Nq || fh < 1 || fw < 1) return false;
+  LiftArgs a;
+  k1_tile_args(a, 1, fh, fw, H, Nq, qh, qw);
+  return tile_ok(a, Dh, P, dtype) && (long)fh * fw * H * Dh < (1L << 30) && (long)Nq * H * Dh < (1L << 30);
+}
+int k1_tile_forward(const void* value, const float* loc, const float* aw, void* out, int B, int fh, int fw, int H, int Nq,
+                    int P, int qh, int qw, hipStream_t st) {
+  LiftArgs a;
+  k1_tile_args(a, B, fh, fw, H, Nq, qh, qw);
+  a.value = value; a.offsets = loc; a.off_stride = (long)H * P * 2; a.logits = aw; a.log_stride = (long)H * P; a.out = out;
+  ProfScope ps("k1_tile_fwd", st, 0.0);
+  tile_fwd_launch(a, P, st, true);
+  return UBV_OK;
+}
+int64_t k1_tile_workspace(int B, int fh, int fw, int H, int Nq, int P, int qh, int qw) {
+  LiftArgs a; TileArgs t{};
+  k1_tile_args(a, B, fh, fw, H, Nq, qh, qw);
+  (void)plan_backward(a, 32, P, UBV_F32, 2, t);
+  return (int64_t)grid_ws(a, t, P).total;
+}
+int k1_tile_backward(const void* value, const float* loc, const float* aw, const void* gout, float* gvalue, float* gloc,
+                     float* gaw, int B, int fh, int fw, int H, int Nq, int P, int qh, int qw, void* ws, int64_t ws_bytes,
+                     hipStream_t st) {
+  LiftArgs a; TileArgs t{};
+  k1_tile_args(a, B, fh, fw, H, Nq, qh, qw);
+  if (plan_backward(a, 32, P, UBV_F32, 2, t) != kPlanGrid) { set_error("ms_deform_attn_backward_grid: no owner-tile plan for this shape"); return UBV_ERR_UNSUPPORTED; }
+  const GridWs w = grid_ws(a, t, P);
+  if (ws == nullptr || ws_bytes < (int64_t)w.total) {
+    set_error("ms_deform_attn_backward_grid: workspace of %lld bytes needed, got %lld", (long long)w.total, (long long)ws_bytes);
+    return UBV_ERR_INVALID;
+  }
+  a.value = value; a.offsets = loc; a.off_stride = (long)H * P * 2; a.logits = aw; a.log_stride = (long)H * P;
+  a.gout = gout; a.gvalue = gvalue; a.goff = gloc; a.goff_stride = (long)H * P * 2; a.glog = gaw; a.glog_stride = (long)H * P;
+  a.bin_cnt = (int*)ws;
+  a.ovf_n = a.bin_cnt + (size_t)B * H * t.tiles_x * t.tiles_y;
+  a.bins = (float4*)((char*)ws + w.bins_off);
+  a.ovf_rec = (float4*)((char*)ws + w.ovf_rec_off);
+  a.ovf_tile = (int*)((char*)ws + w.ovf_tile_off);
+  a.cap = t.cap;
+  a.ovf_cap = (int)min(w.ovf_cap, (long)INT_MAX);
+  a.ovf_after = 1;                                        // owner tiles store plainly, the overflow list is added afterwards
+  if (hipMemsetAsync(ws, 0, w.cnt_bytes, st) != hipSuccess) { set_error("ms_deform_attn_backward_grid: memset failed"); return UBV_ERR_LAUNCH; }
+  const int tiles = t.tiles_x * t.tiles_y;
+  {
+    ProfScope ps("k1_tile_bwd_query", st, 0.0);
+    tile_bwd_query_launch(a, P, true, t.tiles_x, tiles, st, true);
+  }
+  constexpr int RB = 2;
+  const size_t lds = (size_t)t.waves * TileLds<float, 32, RB>::kWords * sizeof(uint16_t);
+  {
+    ProfScope ps("k1_tile_bwd_value", st, 0.0);
+    if (P == 4) hipLaunchKernelGGL((lift_bwd_value_kernel<float, 32, 4, RB>), dim3(8 * t.chunk), dim3(64 * t.waves), lds, st, a, t);
+    else hipLaunchKernelGGL((lift_bwd_value_kernel<float, 32, 8, RB>), dim3(8 * t.chunk), dim3(64 * t.waves), lds, st, a, t);
+  }
+  hipLaunchKernelGGL((lift_ovf_scatter_kernel<float, 32>), dim3(256), dim3(256), 0, st, a, t.tiles_x, tiles);
+  return UBV_OK;
+}
+
 }  // namespace ubv
 
 extern "C" int64_t ubv_bev_lift_backward_workspace(int B, int Nc, int fh, int fw, int H, int Dh,

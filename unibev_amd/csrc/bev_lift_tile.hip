@@ -61,7 +61,9 @@ __device__ __forceinline__ int wave_max_i32(int v) { return -wave_min_i32(-v); }
 // The sampling points of this lane — lane = (query, slot pp of 4), points pp + 4 j — as pixel coordinates and softmax
 // weights (0 for a query outside the grid), and the pixel box of the block's corners: those with a non-zero bilinear
 // weight (forward), every corner inside the map (BWD: a corner of weight 0 still has a derivative).  One barrier.
-template <int P, bool BWD>
+// K1: the mmcv operator's inputs — a.offsets holds the sampling LOCATIONS [B, Nq, H, P, 2] (normalised), a.logits the
+// attention WEIGHTS [B, Nq, H, P] (already normalised: no softmax), no reference points.
+template <int P, bool BWD, bool K1 = false>
 __device__ __forceinline__ int4 tile_points(const LiftArgs& a, long bq, bool valid, int h, int pp, int wv, int lane,
                                             float (&rx)[P / 4], float (&ry)[P / 4], float (&rw)[P / 4]) {
   constexpr int PW = P / 4;
@@ -69,20 +71,21 @@ __device__ __forceinline__ int4 tile_points(const LiftArgs& a, long bq, bool val
   const float fwf = (float)a.fw, fhf = (float)a.fh;
   const float* __restrict__ offp = (const float*)a.offsets + bq * a.off_stride + h * 2 * P;
   const float* __restrict__ lgp = (const float*)a.logits + bq * a.log_stride + h * P;
-  const float* __restrict__ rp = a.ref + bq * a.Z * 2;
+  const float* __restrict__ rp = K1 ? nullptr : a.ref + bq * a.Z * 2;
   float2 off[PW], ref[PW];
   float lg[PW];
 #pragma unroll
   for (int j = 0; j < PW; ++j) {
     const int p = pp + 4 * j;
     off[j] = *reinterpret_cast<const float2*>(offp + 2 * p);
-    ref[j] = *reinterpret_cast<const float2*>(rp + (p % a.Z) * 2);
+    if constexpr (!K1) ref[j] = *reinterpret_cast<const float2*>(rp + (p % a.Z) * 2);
+    else ref[j] = make_float2(0.0f, 0.0f);
     lg[j] = lgp[p];
   }
   int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1;
 #pragma unroll
   for (int j = 0; j < PW; ++j) {
-    const float lx = ref[j].x + off[j].x / fwf, ly = ref[j].y + off[j].y / fhf;
+    const float lx = K1 ? off[j].x : ref[j].x + off[j].x / fwf, ly = K1 ? off[j].y : ref[j].y + off[j].y / fhf;
     rx[j] = lx * fwf - 0.5f; ry[j] = ly * fhf - 0.5f;
     const Footprint f = footprint_px(rx[j], ry[j], a.fh, a.fw);
 #pragma unroll
@@ -95,6 +98,14 @@ __device__ __forceinline__ int4 tile_points(const LiftArgs& a, long bq, bool val
   }
   x0 = wave_min_i32(x0); y0 = wave_min_i32(y0); x1 = wave_max_i32(x1); y1 = wave_max_i32(y1);
   if (lane == 0) wbox[wv] = make_int4(x0, y0, x1, y1);
+  if constexpr (K1) {                                     // weights as given
+#pragma unroll
+    for (int j = 0; j < PW; ++j) rw[j] = valid ? lg[j] : 0.0f;
+    __syncthreads();
+    const int4 c0 = wbox[0], c1 = wbox[1], c2 = wbox[2], c3 = wbox[3];
+    return make_int4(min(min(c0.x, c1.x), min(c2.x, c3.x)), min(min(c0.y, c1.y), min(c2.y, c3.y)),
+                     max(max(c0.z, c1.z), max(c2.z, c3.z)), max(max(c0.w, c1.w), max(c2.w, c3.w)));
+  }
   // softmax of the query's P logits: the quad holds them
   float m = lg[0];
 #pragma unroll
@@ -193,7 +204,7 @@ __device__ __forceinline__ int tile_row(int xc, int yc, const WinGeom& g, const 
 
 // ------------------------------------------------------------------------------------------------
 // Forward.  Two barriers (block box, window fill).
-template <int P>
+template <int P, bool K1 = false>
 __global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, int chunk, int max_box) {
   extern __shared__ __attribute__((aligned(16))) unsigned char win[];
   constexpr int PW = P / 4;
@@ -208,7 +219,7 @@ __global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, in
   const bool valid = lift_query(a, g.tile, li, b, q);
   if (!valid) q = 0;
   const long bq = (long)b * a.Nq + q;
-  const int4 bb = tile_points<P, false>(a, bq, valid, h, pp, wv, lane, rx, ry, rw);
+  const int4 bb = tile_points<P, false, K1>(a, bq, valid, h, pp, wv, lane, rx, ry, rw);
   const TileWin tw = tile_window(a, bb, g, max_box);
   tile_fill(a, g, tw, h, win);
   const float* vb = (const float*)a.value + (long)g.b * a.fh * a.fw * rowi + h * 32;      // wave-uniform
@@ -259,7 +270,7 @@ __global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, in
 // tile that holds one of its corners of non-zero coefficient (what lift_bin_kernel<MODE 0> does, same record format,
 // same fixed-capacity buckets + overflow list; see there): ranks inside the wave through LDS counters on an 8x8 torus
 // of tile slots, one returning global atomic per occupied slot.  The caller zeroes the counters.
-template <int P, bool BINS>
+template <int P, bool BINS, bool K1 = false>
 __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs a, int chunk, int tiles_x, int tiles, int max_box) {
   extern __shared__ __attribute__((aligned(16))) unsigned char win[];
   // per wave: a 4x4 torus of tile slots — occupant tile, local count, global base (a wave's 16 queries x 4 points
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
     }
   }
   float rx[PW], ry[PW], rw[PW];
-  const int4 bb = tile_points<P, true>(a, bq, valid, h, pp, wv, lane, rx, ry, rw);
+  const int4 bb = tile_points<P, true, K1>(a, bq, valid, h, pp, wv, lane, rx, ry, rw);
   const TileWin tw = tile_window(a, bb, g, max_box);
   tile_fill(a, g, tw, h, win);
   const float* vb = (const float*)a.value + (long)g.b * a.fh * a.fw * rowi + h * 32;      // wave-uniform
@@ -382,9 +393,15 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
       const int p = pp + 4 * j;
-      glog[p] = rw[j] * (gw[j] - sp);
-      // d loc = w * g * W; d off = d loc / W (the reference's rounding)
-      *reinterpret_cast<float2*>(goff + 2 * p) = make_float2((rw[j] * gx[j] * fwf) / fwf, (rw[j] * gy[j] * fhf) / fhf);
+      if constexpr (K1) {
+        // the operator's gradients: d(weight) = the interpolated dot, d(location) = w * g * (W, H)
+        glog[p] = gw[j];
+        *reinterpret_cast<float2*>(goff + 2 * p) = make_float2(rw[j] * gx[j] * fwf, rw[j] * gy[j] * fhf);
+      } else {
+        glog[p] = rw[j] * (gw[j] - sp);
+        // d loc = w * g * W; d off = d loc / W (the reference's rounding)
+        *reinterpret_cast<float2*>(goff + 2 * p) = make_float2((rw[j] * gx[j] * fwf) / fwf, (rw[j] * gy[j] * fhf) / fhf);
+      }
     }
   }
 }
@@ -409,20 +426,30 @@ static int tile_max_box(const char* env, int P, int dflt4, int dflt8) {
   return P == 4 ? v4 : v8;
 }
 
-void tile_fwd_launch(const LiftArgs& a, int P, hipStream_t st) {
+void tile_fwd_launch(const LiftArgs& a, int P, hipStream_t st, bool k1) {
   const long units = (long)a.total_tiles * a.H;
   const int chunk = (int)((units + 7) / 8);
   static const int mb4 = tile_max_box("UBV_TILE_MAXBOX_FWD", 4, 256, 256), mb8 = tile_max_box("UBV_TILE_MAXBOX_FWD", 8, 256, 256);
+  if (k1) {
+    if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4, true>), dim3(8 * chunk), dim3(256), kTWinLds, st, a, chunk, mb4);
+    else hipLaunchKernelGGL((lift_tile_fwd_kernel<8, true>), dim3(8 * chunk), dim3(256), kTWinLds, st, a, chunk, mb8);
+    return;
+  }
   if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4>), dim3(8 * chunk), dim3(256), kTWinLds, st, a, chunk, mb4);
   else hipLaunchKernelGGL((lift_tile_fwd_kernel<8>), dim3(8 * chunk), dim3(256), kTWinLds, st, a, chunk, mb8);
 }
 
 // bins: the points are binned here (the caller zeroed a.bin_cnt / a.ovf_n and launches no lift_bin_kernel)
-void tile_bwd_query_launch(const LiftArgs& a, int P, bool bins, int tiles_x, int tiles, hipStream_t st) {
+void tile_bwd_query_launch(const LiftArgs& a, int P, bool bins, int tiles_x, int tiles, hipStream_t st, bool k1) {
   const long units = (long)a.total_tiles * a.H;
   const int chunk = (int)((units + 7) / 8);
   const dim3 grid(8 * chunk), blk(256);
   static const int mb4 = tile_max_box("UBV_TILE_MAXBOX_BWD", 4, 256, 256), mb8 = tile_max_box("UBV_TILE_MAXBOX_BWD", 8, 256, 256);
+  if (k1) {                                               // (the operator's backward always bins)
+    if (P == 4) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4, true, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb4);
+    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<8, true, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb8);
+    return;
+  }
   if (P == 4) {
     if (bins) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb4);
     else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4, false>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb4);

@@ -355,3 +355,56 @@ extern "C" int ubv_ms_deform_attn_backward(const void* value, const int64_t* spa
                 grad_value, grad_sampling_loc, grad_attn_weight, B, S, H, Dh, L, Nq, P};
   return ubv::k1_dispatch(a, dtype, true, stream);
 }
+
+// The operator with a QUERY-GRID hint: the Nq queries are a qgrid_h x qgrid_w grid in row-major order (BEV queries —
+// what the reference's call sites spatial_cross_attention_pts.py:439-442 and the encoder's self-attention pass) and the
+// single level is fh x fw.  f32, 8 heads of 32 channels, 4 or 8 points: the TILE plan of csrc/bev_lift_tile.hip (one lane
+// per sampling point, the tile's pixel box in LDS; backward: owner tiles, no f32 atomics).  Any other shape: the plain
+// operator (forward) / UBV_ERR_UNSUPPORTED (backward: the caller takes ubv_ms_deform_attn_backward[_planned]).
+extern "C" int ubv_ms_deform_attn_grid_supported(int H, int Dh, int L, int P, int dtype, int fh, int fw, int Nq, int qgrid_h,
+                                                 int qgrid_w) {
+  return (L == 1 && ubv::k1_tile_ok(H, Dh, P, dtype, fh, fw, Nq, qgrid_h, qgrid_w)) ? 1 : 0;
+}
+
+extern "C" int ubv_ms_deform_attn_forward_grid(const void* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                                               const float* sampling_loc, const float* attn_weight, void* out, int B, int S,
+                                               int H, int Dh, int L, int Nq, int P, int dtype, int fh, int fw, int qgrid_h,
+                                               int qgrid_w, void* stream) {
+  using namespace ubv;
+  if (L == 1 && (long)fh * fw == S && Nq > 0 && k1_tile_ok(H, Dh, P, dtype, fh, fw, Nq, qgrid_h, qgrid_w)) {
+    UBV_CHECK_ARG(value && sampling_loc && attn_weight && out, "ms_deform_attn_forward_grid: null pointer");
+    const int rc = k1_tile_forward(value, sampling_loc, attn_weight, out, B, fh, fw, H, Nq, P, qgrid_h, qgrid_w, as_stream(stream));
+    if (rc != UBV_OK) return rc;
+    UBV_CHECK_LAUNCH("ms_deform_attn_forward_grid");
+    return UBV_OK;
+  }
+  return ubv_ms_deform_attn_forward(value, spatial_shapes, level_start, sampling_loc, attn_weight, out, B, S, H, Dh, L, Nq, P,
+                                    dtype, 64, stream);
+}
+
+extern "C" int64_t ubv_ms_deform_attn_backward_grid_workspace(int B, int fh, int fw, int H, int Dh, int Nq, int P, int dtype,
+                                                              int qgrid_h, int qgrid_w) {
+  if (B <= 0 || !ubv::k1_tile_ok(H, Dh, P, dtype, fh, fw, Nq, qgrid_h, qgrid_w)) return 0;
+  return ubv::k1_tile_workspace(B, fh, fw, H, Nq, P, qgrid_h, qgrid_w);
+}
+
+extern "C" int ubv_ms_deform_attn_backward_grid(const void* value, const float* sampling_loc, const float* attn_weight,
+                                                const void* grad_out, float* grad_value, float* grad_sampling_loc,
+                                                float* grad_attn_weight, int B, int S, int H, int Dh, int L, int Nq, int P,
+                                                int dtype, int fh, int fw, int qgrid_h, int qgrid_w, void* workspace,
+                                                int64_t workspace_bytes, void* stream) {
+  using namespace ubv;
+  if (L != 1 || (long)fh * fw != S || !k1_tile_ok(H, Dh, P, dtype, fh, fw, Nq, qgrid_h, qgrid_w)) {
+    set_error("ms_deform_attn_backward_grid: f32, one level of fh x fw = S pixels, 8 heads of 32 channels, P in {4, 8}, "
+              "queries = qgrid_h x qgrid_w (got L=%d S=%d %dx%d H=%d Dh=%d P=%d Nq=%d grid %dx%d)", L, S, fh, fw, H, Dh, P, Nq,
+              qgrid_h, qgrid_w);
+    return UBV_ERR_UNSUPPORTED;
+  }
+  UBV_CHECK_ARG(value && sampling_loc && attn_weight && grad_out && grad_value && grad_sampling_loc && grad_attn_weight,
+                "ms_deform_attn_backward_grid: null pointer");
+  const int rc = k1_tile_backward(value, sampling_loc, attn_weight, grad_out, grad_value, grad_sampling_loc, grad_attn_weight,
+                                  B, fh, fw, H, Nq, P, qgrid_h, qgrid_w, workspace, workspace_bytes, as_stream(stream));
+  if (rc != UBV_OK) return rc;
+  UBV_CHECK_LAUNCH("ms_deform_attn_backward_grid");
+  return UBV_OK;
+}

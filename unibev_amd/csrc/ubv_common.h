@@ -212,6 +212,14 @@ bool k1_grid_ok(int H, int Dh, int P, int dtype, int fh, int fw);
 int64_t k1_grid_workspace(int B, int fh, int fw, int H, int Dh, int Nq, int P, int dtype);
 int k1_grid_value(const float* loc, const float* aw, const void* gout, float* gvalue, int B, int fh, int fw, int H,
                   int Dh, int Nq, int P, int dtype, void* ws, int64_t ws_bytes, hipStream_t st);
+// the k1 operator on the TILE plan (bev_lift_tile.hip) when its queries are a qh x qw grid in row-major order
+bool k1_tile_ok(int H, int Dh, int P, int dtype, int fh, int fw, int Nq, int qh, int qw);
+int k1_tile_forward(const void* value, const float* loc, const float* aw, void* out, int B, int fh, int fw, int H, int Nq,
+                    int P, int qh, int qw, hipStream_t st);
+int64_t k1_tile_workspace(int B, int fh, int fw, int H, int Nq, int P, int qh, int qw);
+int k1_tile_backward(const void* value, const float* loc, const float* aw, const void* gout, float* gvalue, float* gloc,
+                     float* gaw, int B, int fh, int fw, int H, int Nq, int P, int qh, int qw, void* ws, int64_t ws_bytes,
+                     hipStream_t st);
 
 // RAII pair of HIP events around one kernel launch (a no-op unless ubv_profile_enable(1)).
 class ProfScope {

@@ -156,11 +156,25 @@ class MultiScaleDeformableAttnFunction(Function):
             loc = sampling_locations.float().contiguous()
             aw = attention_weights.float().contiguous()
             out = torch.empty(B, Nq, H * Dh, dtype=value.dtype, device=value.device)
-            with _timed('k1_fwd'):
-                check(lib().ubv_ms_deform_attn_forward(_p(value), _p(ss), _p(ls), _p(loc), _p(aw),
-                                                       _p(out), B, S, H, Dh, L, Nq, P, _dt(value),
-                                                       int(im2col_step), _stream()),
-                      'ms_deform_attn_forward')
+            # query-grid hint (deform_attn.shapes_tensor(..., query_grid=(qh, qw))): BEV queries in row-major order and a
+            # host-known level shape -> the TILE plan (ubv_ms_deform_attn_forward_grid / _backward_grid)
+            hw = getattr(value_spatial_shapes, '_ubv_hw', None)
+            qg = getattr(value_spatial_shapes, '_ubv_qgrid', None)
+            ctx.grid = None
+            if qg is not None and hw is not None and len(hw) == 1 and _K1_PLAN[0] and \
+                    lib().ubv_ms_deform_attn_grid_supported(H, Dh, L, P, _dt(value), int(hw[0][0]), int(hw[0][1]), Nq,
+                                                            int(qg[0]), int(qg[1])) and hw[0][0] * hw[0][1] == S:
+                ctx.grid = (int(hw[0][0]), int(hw[0][1]), int(qg[0]), int(qg[1]))
+                with _timed('k1_fwd_grid'):
+                    check(lib().ubv_ms_deform_attn_forward_grid(_p(value), _p(ss), _p(ls), _p(loc), _p(aw), _p(out), B, S, H,
+                                                                Dh, L, Nq, P, _dt(value), *ctx.grid, _stream()),
+                          'ms_deform_attn_forward_grid')
+            else:
+                with _timed('k1_fwd'):
+                    check(lib().ubv_ms_deform_attn_forward(_p(value), _p(ss), _p(ls), _p(loc), _p(aw),
+                                                           _p(out), B, S, H, Dh, L, Nq, P, _dt(value),
+                                                           int(im2col_step), _stream()),
+                          'ms_deform_attn_forward')
             ctx.save_for_backward(value, ss, ls, loc, aw)
             # host copy of the shapes when the producer attached one (deform_attn.shapes_tensor): lets the backward
             # plan owner tiles without reading the device tensor back
@@ -179,6 +193,16 @@ class MultiScaleDeformableAttnFunction(Function):
             go = grad_output.to(value.dtype).contiguous()
             gloc = torch.empty_like(loc)
             gaw = torch.empty_like(aw)
+            if ctx.grid is not None:                   # the TILE plan: one block computes d(loc), d(weight) and the records
+                fh, fw, qh, qw = ctx.grid
+                nws = int(lib().ubv_ms_deform_attn_backward_grid_workspace(B, fh, fw, H, Dh, Nq, P, _dt(value), qh, qw))
+                gv = torch.empty(value.shape, dtype=torch.float32, device=value.device)
+                ws = _workspace(nws, value.device)
+                with _timed('k1_bwd_grid'):
+                    check(lib().ubv_ms_deform_attn_backward_grid(
+                        _p(value), _p(loc), _p(aw), _p(go), _p(gv), _p(gloc), _p(gaw), B, S, H, Dh, L, Nq, P, _dt(value),
+                        fh, fw, qh, qw, _p(ws), nws, _stream()), 'ms_deform_attn_backward_grid')
+                return (gv.to(value.dtype), None, None, gloc.to(ctx.in_dtypes[0]), gaw.to(ctx.in_dtypes[1]), None)
             # one level with host-known shape: grad_value on the GRID owner-tile plan — sampling points binned by
             # owner tile, every pixel stored once, no f32 atomics (ubv_ms_deform_attn_backward_planned)
             if L == 1 and ctx.hw is not None and len(ctx.hw) == 1 and _K1_PLAN[0]:

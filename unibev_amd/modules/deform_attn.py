@@ -71,15 +71,19 @@ def static_hw(spatial_shapes):
 _SHAPE_TENSORS = {}
 
 
-def shapes_tensor(hw, device):
+def shapes_tensor(hw, device, query_grid=None):
     """(L, 2) int64 device tensor carrying its own host copy.  Cached per (shapes, device): the
     upload happens once, so a later forward pass issues no host-to-device copy (none is allowed
-    while a HIP graph is being captured)."""
-    key = (tuple(tuple(int(v) for v in r) for r in hw), str(device))
+    while a HIP graph is being captured).  ``query_grid`` = (qh, qw): the queries the operator will be called with are
+    that grid in row-major order (BEV queries) — ``functional.ms_deform_attn`` then takes the TILE plan
+    (``ubv_ms_deform_attn_forward_grid``)."""
+    key = (tuple(tuple(int(v) for v in r) for r in hw), str(device), None if query_grid is None else tuple(query_grid))
     t = _SHAPE_TENSORS.get(key)
     if t is None:
         t = torch.as_tensor(hw, dtype=torch.long, device=device)
         t._ubv_hw = [tuple(int(v) for v in r) for r in hw]
+        if query_grid is not None:
+            t._ubv_qgrid = (int(query_grid[0]), int(query_grid[1]))
         if len(_SHAPE_TENSORS) > 64:
             _SHAPE_TENSORS.clear()
         _SHAPE_TENSORS[key] = t
