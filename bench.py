@@ -868,7 +868,18 @@ def main():
     head.train(not args.eval_mode)
     names = ['fp32', 'bf16', 'fp16'] if args.dtype == 'all' else [args.dtype]
     set_sampling_params(head, 'spread' if args.params == 'spread' else 'init')
-    recs = [run_mode(args, n, head, world, rank, device, want_ops=True) for n in names]
+    try:
+        recs = [run_mode(args, n, head, world, rank, device, want_ops=True) for n in names]
+    except Exception as e:
+        # `auto` chose the overlapped (split) exchange for N > 1, a path the builder could only exercise with one rank: if
+        # it fails the same way on every rank, the run falls back to one message after the backward and says so
+        if not (args.exchange == 'auto' and world > 1):
+            raise
+        print(f'[bench] overlapped gradient exchange failed ({type(e).__name__}: {e}); falling back to --exchange single',
+              file=sys.stderr, flush=True)
+        args.exchange = 'single'
+        torch.cuda.synchronize()
+        recs = [run_mode(args, n, head, world, rank, device, want_ops=True) for n in names]
     spread = ieee = None
     if args.params == 'both':
         # second operating point of the headline precision: offsets scattered per query (trained-looking)
