@@ -1290,7 +1290,7 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     }
     static const int shared_env = getenv("UBV_LIFT_SHARED") ? atoi(getenv("UBV_LIFT_SHARED")) : 1;
     if (tile_ok(a, DH, P, sizeof(T) == 4 ? UBV_F32 : UBV_BF16)) {   // one lane per (query, point), LDS window (bev_lift_tile.hip)
-      tile_fwd_launch(a, P, st);
+      tile_fwd_launch(a, P, st, false, DH);
       return;
     }
     if (shared_env && win_ok<T, DH, P>(a)) {   // BEV-grid queries: corners served from an LDS window (bev_lift_win.inl)
@@ -1384,7 +1384,7 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     auto run_query = [&]() {
       {
         ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes);
-        if (tile) tile_bwd_query_launch(aq, P, true, t.tiles_x, tiles, st);
+        if (tile) tile_bwd_query_launch(aq, P, true, t.tiles_x, tiles, st, false, DH);
         else if (win_ok<T, DH, P>(a)) {
           constexpr int HG = 128 / (DH * (int)sizeof(T));
           const int chunk = (int)(((long)a.total_tiles * (a.H / HG) + 7) / 8);
@@ -1908,7 +1908,7 @@ bool k1_tile_ok(int H, int Dh, int P, int dtype, int fh, int fw, int Nq, int qh,
   if (qh <= 0 || qw <= 0 || (long)qh * qw != Nq || fh < 1 || fw < 1) return false;
   LiftArgs a;
   k1_tile_args(a, 1, fh, fw, H, Nq, qh, qw);
-  return tile_ok(a, Dh, P, dtype) && (long)fh * fw * H * Dh < (1L << 30) && (long)Nq * H * Dh < (1L << 30);
+  return Dh == 32 && tile_ok(a, Dh, P, dtype) && (long)fh * fw * H * Dh < (1L << 30) && (long)Nq * H * Dh < (1L << 30);
 }
 int k1_tile_forward(const void* value, const float* loc, const float* aw, void* out, int B, int fh, int fw, int H, int Nq,
                     int P, int qh, int qw, hipStream_t st) {

@@ -35,12 +35,15 @@ namespace ubv {
 constexpr int kTWinRow = kWin * kWinRowB + 64;
 constexpr int kTWinLds = kWin * kTWinRow;
 
-// (tile, head) of this block with H = 8 heads (tile_ok): head fastest, XCD x owns a contiguous range of units
+// (tile, 128-byte line of heads) of this block with H = 8 heads (tile_ok): HPB heads share a line (Dh = 32: one head,
+// Dh = 16: two); line fastest, XCD x owns a contiguous range of units
+template <int HPB>
 __device__ __forceinline__ bool tile_decode8(const LiftArgs& a, int chunk, WinGeom& g) {
+  constexpr int UPT = 8 / HPB;                            // units per tile
   const int v = xcd_remap(blockIdx.x, chunk);
-  const int item = v >> 3;
+  const int item = v / UPT;
   if (item >= a.total_tiles) return false;
-  g.hg = v & 7;
+  g.hg = v % UPT;
   g.b = div_mg(item, a.tiles_per_sample, a.mg_tps);
   g.tile = item;
   return true;
@@ -65,9 +68,8 @@ __device__ __forceinline__ int wave_max_i32(int v) { return -wave_min_i32(-v); }
 // attention WEIGHTS [B, Nq, H, P] (already normalised: no softmax), no reference points.
 template <int P, bool BWD, bool K1 = false>
 __device__ __forceinline__ int4 tile_points(const LiftArgs& a, long bq, bool valid, int h, int pp, int wv, int lane,
-                                            float (&rx)[P / 4], float (&ry)[P / 4], float (&rw)[P / 4]) {
+                                            float (&rx)[P / 4], float (&ry)[P / 4], float (&rw)[P / 4], int4* wbox) {
   constexpr int PW = P / 4;
-  __shared__ int4 wbox[4];
   const float fwf = (float)a.fw, fhf = (float)a.fh;
   const float* __restrict__ offp = (const float*)a.offsets + bq * a.off_stride + h * 2 * P;
   const float* __restrict__ lgp = (const float*)a.logits + bq * a.log_stride + h * P;
@@ -124,10 +126,11 @@ __device__ __forceinline__ int4 tile_points(const LiftArgs& a, long bq, bool val
                    max(max(b0.z, b1.z), max(b2.z, b3.z)), max(max(b0.w, b1.w), max(b2.w, b3.w)));
 }
 
-// acc[0..32) += c * (32 consecutive floats at p): LDS or global, 16-byte pieces
-__device__ __forceinline__ void tile_axpy32(const float* __restrict__ p, float c, float (&acc)[32]) {
+// acc[0..DH) += c * (DH consecutive floats at p): LDS or global, 16-byte pieces
+template <int DH>
+__device__ __forceinline__ void tile_axpy(const float* __restrict__ p, float c, float (&acc)[DH]) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < DH / 4; ++i) {
     const float4 v = reinterpret_cast<const float4*>(p)[i];
     acc[4 * i] = fmaf(c, v.x, acc[4 * i]);
     acc[4 * i + 1] = fmaf(c, v.y, acc[4 * i + 1]);
@@ -135,10 +138,11 @@ __device__ __forceinline__ void tile_axpy32(const float* __restrict__ p, float c
     acc[4 * i + 3] = fmaf(c, v.w, acc[4 * i + 3]);
   }
 }
-__device__ __forceinline__ float tile_dot32(const float* __restrict__ p, const float (&g)[32]) {
+template <int DH>
+__device__ __forceinline__ float tile_dot(const float* __restrict__ p, const float (&g)[DH]) {
   float d0 = 0.0f, d1 = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < DH / 4; ++i) {
     const float4 v = reinterpret_cast<const float4*>(p)[i];
     d0 = fmaf(g[4 * i], v.x, d0);
     d1 = fmaf(g[4 * i + 1], v.y, d1);
@@ -146,6 +150,10 @@ __device__ __forceinline__ float tile_dot32(const float* __restrict__ p, const f
     d1 = fmaf(g[4 * i + 3], v.w, d1);
   }
   return d0 + d1;
+}
+
+__device__ __forceinline__ int4 box_union(const int4 a, const int4 b) {
+  return make_int4(min(a.x, b.x), min(a.y, b.y), max(a.z, b.z), max(a.w, b.w));
 }
 
 // Window of a block from its box: origin (clamped into the map like win_origin) and the rows / columns worth loading.
@@ -165,13 +173,13 @@ __device__ __forceinline__ TileWin tile_window(const LiftArgs& a, const int4 bb,
 
 // Fills rows [0, rows) x columns [0, cols) of the window: 8 lanes per pixel (one 128-byte line per 8 lanes), 32
 // pixels = 2 window rows per pass, all passes' loads in flight before the first LDS store.  Ends with a barrier.
-__device__ __forceinline__ void tile_fill(const LiftArgs& a, const WinGeom& g, const TileWin t, int h,
+__device__ __forceinline__ void tile_fill(const LiftArgs& a, const WinGeom& g, const TileWin t, int line, int rowi,
                                           unsigned char* __restrict__ win) {
   const int tid = threadIdx.x, piece = tid & 7, pxl = tid >> 3;
   const int dx = pxl & 15, dyl = pxl >> 4;
   const int cdx = min(dx, max(t.cols - 1, 0));            // columns past the box re-read its last one (same line: free)
-  const int rowi = a.H * 32;
-  const float* vb = (const float*)a.value + (long)g.b * a.fh * a.fw * rowi + h * 32 + piece * 4;
+  // (rowi = floats per pixel over all heads; `line` = which 128-byte line of the pixel: HPB heads)
+  const float* vb = (const float*)a.value + (long)g.b * a.fh * a.fw * rowi + line * 32 + piece * 4;
   // element offset of this thread's pixel in pass 0, and the (uniform) step of a pass = 2 map rows; a pass whose second
   // row lies past the box re-reads its first one (dyl = 1 lanes step back one row)
   const unsigned off0 = (unsigned)(((g.wy0 + dyl) * a.fw + g.wx0 + cdx) * rowi);
@@ -203,64 +211,73 @@ __device__ __forceinline__ int tile_row(int xc, int yc, const WinGeom& g, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Forward.  Two barriers (block box, window fill).
-template <int P, bool K1 = false>
+// Forward.  Two barriers per head of the line (block box) + one (window fill).  DH = 16: the two heads of a 128-byte
+// line are one block's work — both boxes first, ONE window for their union, then the corners head by head.
+template <int P, int DH, bool K1 = false>
 __global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, int chunk, int max_box) {
   extern __shared__ __attribute__((aligned(16))) unsigned char win[];
-  constexpr int PW = P / 4;
+  __shared__ int4 wbox[32 / DH][4];
+  constexpr int PW = P / 4, HPB = 32 / DH;
   WinGeom g;
-  if (!tile_decode8(a, chunk, g)) return;
+  if (!tile_decode8<HPB>(a, chunk, g)) return;
   const int lane = threadIdx.x & 63, wv = wave_in_block();
-  const int h = g.hg;
-  constexpr int rowi = 8 * 32;
+  constexpr int rowi = 8 * DH;                            // floats per pixel / per query row (H = 8)
   const int li = wv * 16 + (lane >> 2), pp = lane & 3;
-  float rx[PW], ry[PW], rw[PW];
+  float rx[HPB][PW], ry[HPB][PW], rw[HPB][PW];
   int b, q;
   const bool valid = lift_query(a, g.tile, li, b, q);
   if (!valid) q = 0;
   const long bq = (long)b * a.Nq + q;
-  const int4 bb = tile_points<P, false, K1>(a, bq, valid, h, pp, wv, lane, rx, ry, rw);
+  int4 bb = make_int4(INT_MAX, INT_MAX, -1, -1);
+#pragma unroll
+  for (int hh = 0; hh < HPB; ++hh)
+    bb = box_union(bb, tile_points<P, false, K1>(a, bq, valid, g.hg * HPB + hh, pp, wv, lane, rx[hh], ry[hh], rw[hh], wbox[hh]));
   const TileWin tw = tile_window(a, bb, g, max_box);
-  tile_fill(a, g, tw, h, win);
-  const float* vb = (const float*)a.value + (long)g.b * a.fh * a.fw * rowi + h * 32;      // wave-uniform
-
-  float acc[32];
+  tile_fill(a, g, tw, g.hg, rowi, win);
 #pragma unroll
-  for (int i = 0; i < 32; ++i) acc[i] = 0.0f;
+  for (int hh = 0; hh < HPB; ++hh) {
+    const int h = g.hg * HPB + hh;
+    const float* vb = (const float*)a.value + (long)g.b * a.fh * a.fw * rowi + h * DH;      // wave-uniform
+    const unsigned char* wh = win + hh * (DH * 4);        // this head's part of a window pixel
+    float acc[DH];
 #pragma unroll
-  for (int j = 0; j < PW; ++j) {
-    const Footprint f = footprint_px(rx[j], ry[j], a.fh, a.fw);
-    float c[4];
-    int wr[4];
-    bool miss = false;
+    for (int i = 0; i < DH; ++i) acc[i] = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      c[k] = rw[j] * f.w[k];
-      wr[k] = tile_row(f.xc[k & 1], f.yc[k >> 1], g, tw);
-      miss = miss || (wr[k] < 0 && c[k] != 0.0f);
-    }
-    if (__ballot(miss) == 0ull) {
-      // the wave's corners are all in the window (or weightless: any row will do): straight-line code, the 32 LDS reads
-      // of the point in flight together
-#pragma unroll
-      for (int k = 0; k < 4; ++k) tile_axpy32(reinterpret_cast<const float*>(win + (unsigned)max(wr[k], 0)), c[k], acc);
-    } else {
+    for (int j = 0; j < PW; ++j) {
+      const Footprint f = footprint_px(rx[hh][j], ry[hh][j], a.fh, a.fw);
+      float c[4];
+      int wr[4];
+      bool miss = false;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (wr[k] >= 0) tile_axpy32(reinterpret_cast<const float*>(win + (unsigned)wr[k]), c[k], acc);
-        else if (c[k] != 0.0f) tile_axpy32(gather_ptr(vb, (unsigned)(f.idx[k] * rowi)), c[k], acc);
+        c[k] = rw[hh][j] * f.w[k];
+        wr[k] = tile_row(f.xc[k & 1], f.yc[k >> 1], g, tw);
+        miss = miss || (wr[k] < 0 && c[k] != 0.0f);
+      }
+      if (__ballot(miss) == 0ull) {
+        // the wave's corners are all in the window (or weightless: any row will do): straight-line code, the LDS reads
+        // of the point in flight together
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tile_axpy<DH>(reinterpret_cast<const float*>(wh + (unsigned)max(wr[k], 0)), c[k], acc);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (wr[k] >= 0) tile_axpy<DH>(reinterpret_cast<const float*>(wh + (unsigned)wr[k]), c[k], acc);
+          else if (c[k] != 0.0f) tile_axpy<DH>(gather_ptr(vb, (unsigned)(f.idx[k] * rowi)), c[k], acc);
+        }
       }
     }
-  }
 #pragma unroll
-  for (int i = 0; i < 32; ++i) acc[i] = add_xor<2>(add_xor<1>(acc[i]));
-  if (valid) {
-    float o[8];
+    for (int i = 0; i < DH; ++i) acc[i] = add_xor<2>(add_xor<1>(acc[i]));
+    if (valid) {
+      constexpr int Q = DH / 4;                           // floats per lane of the quad
+      float o[Q];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = pp == 0 ? acc[i] : pp == 1 ? acc[8 + i] : pp == 2 ? acc[16 + i] : acc[24 + i];
-    float4* dst = reinterpret_cast<float4*>((float*)a.out + bq * rowi + h * 32 + pp * 8);
-    dst[0] = make_float4(o[0], o[1], o[2], o[3]);
-    dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+      for (int i = 0; i < Q; ++i) o[i] = pp == 0 ? acc[i] : pp == 1 ? acc[Q + i] : pp == 2 ? acc[2 * Q + i] : acc[3 * Q + i];
+      float4* dst = reinterpret_cast<float4*>((float*)a.out + bq * rowi + h * DH + pp * Q);
+#pragma unroll
+      for (int i = 0; i < Q / 4; ++i) dst[i] = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+    }
   }
 }
 
@@ -270,45 +287,53 @@ __global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, in
 // tile that holds one of its corners of non-zero coefficient (what lift_bin_kernel<MODE 0> does, same record format,
 // same fixed-capacity buckets + overflow list; see there): ranks inside the wave through LDS counters on an 8x8 torus
 // of tile slots, one returning global atomic per occupied slot.  The caller zeroes the counters.
-template <int P, bool BINS, bool K1 = false>
+template <int P, int DH, bool BINS, bool K1 = false>
 __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs a, int chunk, int tiles_x, int tiles, int max_box) {
   extern __shared__ __attribute__((aligned(16))) unsigned char win[];
+  __shared__ int4 wbox[32 / DH][4];
   // per wave: a 4x4 torus of tile slots — occupant tile, local count, global base (a wave's 16 queries x 4 points
   // reach a handful of tiles; two tiles that collide on the torus take the direct global path)
   __shared__ volatile int slot_tile[4][16];
   __shared__ int slot_cnt[4][16], slot_base[4][16];
-  constexpr int PW = P / 4;
+  constexpr int PW = P / 4, HPB = 32 / DH;
   WinGeom g;
-  if (!tile_decode8(a, chunk, g)) return;
+  if (!tile_decode8<HPB>(a, chunk, g)) return;
   const int lane = threadIdx.x & 63, wv = wave_in_block();
-  const int h = g.hg;
-  constexpr int rowi = 8 * 32;
+  constexpr int rowi = 8 * DH;
   const int li = wv * 16 + (lane >> 2), pp = lane & 3;
   int b, q;
   const bool valid = lift_query(a, g.tile, li, b, q);
   if (!valid) q = 0;
   const long bq = (long)b * a.Nq + q;
   if (BINS && lane < 16) { slot_tile[wv][lane] = -1; slot_cnt[wv][lane] = 0; }
-  float go[32];
-  {
-    const float4* gp = reinterpret_cast<const float4*>((const float*)a.gout + bq * rowi + h * 32);
+  float rx[HPB][PW], ry[HPB][PW], rw[HPB][PW];
+  int4 bb = make_int4(INT_MAX, INT_MAX, -1, -1);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+  for (int hh = 0; hh < HPB; ++hh)
+    bb = box_union(bb, tile_points<P, true, K1>(a, bq, valid, g.hg * HPB + hh, pp, wv, lane, rx[hh], ry[hh], rw[hh], wbox[hh]));
+  const TileWin tw = tile_window(a, bb, g, max_box);
+  tile_fill(a, g, tw, g.hg, rowi, win);
+
+#pragma unroll
+  for (int hh = 0; hh < HPB; ++hh) {
+  const int h = g.hg * HPB + hh;
+  const unsigned char* wh = win + hh * (DH * 4);
+  float go[DH];
+  {
+    const float4* gp = reinterpret_cast<const float4*>((const float*)a.gout + bq * rowi + h * DH);
+#pragma unroll
+    for (int i = 0; i < DH / 4; ++i) {
       const float4 v = gp[i];
       go[4 * i] = v.x; go[4 * i + 1] = v.y; go[4 * i + 2] = v.z; go[4 * i + 3] = v.w;
     }
   }
-  float rx[PW], ry[PW], rw[PW];
-  const int4 bb = tile_points<P, true, K1>(a, bq, valid, h, pp, wv, lane, rx, ry, rw);
-  const TileWin tw = tile_window(a, bb, g, max_box);
-  tile_fill(a, g, tw, h, win);
-  const float* vb = (const float*)a.value + (long)g.b * a.fh * a.fw * rowi + h * 32;      // wave-uniform
+  const float* vb = (const float*)a.value + (long)g.b * a.fh * a.fw * rowi + h * DH;      // wave-uniform
 
   float gw[PW], gx[PW], gy[PW];
   float sp = 0.0f;
 #pragma unroll
   for (int j = 0; j < PW; ++j) {
-    const Footprint f = footprint_px(rx[j], ry[j], a.fh, a.fw);
+    const Footprint f = footprint_px(rx[hh][j], ry[hh][j], a.fh, a.fw);
     float d[4];
     int wr[4];
     bool miss = false;
@@ -319,13 +344,13 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
     }
     if (__ballot(miss) == 0ull) {          // all in the window (or masked out): straight-line code
 #pragma unroll
-      for (int k = 0; k < 4; ++k) d[k] = tile_dot32(reinterpret_cast<const float*>(win + (unsigned)max(wr[k], 0)), go) * f.m[k];
+      for (int k = 0; k < 4; ++k) d[k] = tile_dot<DH>(reinterpret_cast<const float*>(wh + (unsigned)max(wr[k], 0)), go) * f.m[k];
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         d[k] = 0.0f;
-        if (wr[k] >= 0) d[k] = tile_dot32(reinterpret_cast<const float*>(win + (unsigned)wr[k]), go);
-        else if (valid && f.m[k] != 0.0f) d[k] = tile_dot32(gather_ptr(vb, (unsigned)(f.idx[k] * rowi)), go);
+        if (wr[k] >= 0) d[k] = tile_dot<DH>(reinterpret_cast<const float*>(wh + (unsigned)wr[k]), go);
+        else if (valid && f.m[k] != 0.0f) d[k] = tile_dot<DH>(gather_ptr(vb, (unsigned)(f.idx[k] * rowi)), go);
         d[k] *= f.m[k];
       }
     }
@@ -333,14 +358,14 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
     gw[j] = hy * hx * d[0] + hy * f.lx * d[1] + f.ly * hx * d[2] + f.ly * f.lx * d[3];
     gx[j] = (d[1] - d[0]) * hy + (d[3] - d[2]) * f.ly;
     gy[j] = (d[2] - d[0]) * hx + (d[3] - d[1]) * f.lx;
-    sp = fmaf(rw[j], gw[j], sp);
+    sp = fmaf(rw[hh][j], gw[j], sp);
 
     if constexpr (BINS) {
       // one lane = one point: append it to the bucket of every tile that holds a corner of non-zero coefficient
       const int tile_base = (g.b * a.H + h) * tiles;
       int* __restrict__ cntp = a.bin_cnt + tile_base;
       float4* __restrict__ binp = a.bins + (long)tile_base * a.cap;
-      const float4 rec = make_float4(rx[j], ry[j], rw[j], __int_as_float(q));
+      const float4 rec = make_float4(rx[hh][j], ry[hh][j], rw[hh][j], __int_as_float(q));
       auto put = [&](int tile, int idx) {
         if (idx < a.cap) {
           binp[(long)tile * a.cap + idx] = rec;
@@ -353,7 +378,7 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
       bool nz[4], lead[4], local[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        nz[k] = rw[j] != 0.0f && f.w[k] != 0.0f;
+        nz[k] = rw[hh][j] != 0.0f && f.w[k] != 0.0f;
         const int tx = f.xc[k & 1] >> 3, ty = f.yc[k >> 1] >> 3;
         tk[k] = ty * tiles_x + tx;
         hs[k] = ((ty & 3) << 2) | (tx & 3);
@@ -396,22 +421,24 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
       if constexpr (K1) {
         // the operator's gradients: d(weight) = the interpolated dot, d(location) = w * g * (W, H)
         glog[p] = gw[j];
-        *reinterpret_cast<float2*>(goff + 2 * p) = make_float2(rw[j] * gx[j] * fwf, rw[j] * gy[j] * fhf);
+        *reinterpret_cast<float2*>(goff + 2 * p) = make_float2(rw[hh][j] * gx[j] * fwf, rw[hh][j] * gy[j] * fhf);
       } else {
-        glog[p] = rw[j] * (gw[j] - sp);
+        glog[p] = rw[hh][j] * (gw[j] - sp);
         // d loc = w * g * W; d off = d loc / W (the reference's rounding)
-        *reinterpret_cast<float2*>(goff + 2 * p) = make_float2((rw[j] * gx[j] * fwf) / fwf, (rw[j] * gy[j] * fhf) / fhf);
+        *reinterpret_cast<float2*>(goff + 2 * p) = make_float2((rw[hh][j] * gx[j] * fwf) / fwf, (rw[hh][j] * gy[j] * fhf) / fhf);
       }
     }
   }
+  }  // heads of the line
 }
 
-// f32 data, Dh = 32, one map per sample, grid-tiled queries, no visibility / count: the BEV self-attention and
-// SCA-pts instances.  UBV_LIFT_TILE=0 switches the plan off (A/B runs against the window / gather kernels).
+// f32 data, Dh = 32 or 16 (H = 8), one map per sample, grid-tiled queries, no visibility / count: the BEV self-attention
+// and SCA-pts instances.  UBV_LIFT_TILE=0 switches the plan off (A/B runs against the window / gather kernels).
 bool tile_ok(const LiftArgs& a, int Dh, int P, int dtype) {
   static const int env = getenv("UBV_LIFT_TILE") ? atoi(getenv("UBV_LIFT_TILE")) : 1;
-  return env != 0 && dtype == UBV_F32 && Dh == 32 && a.H == 8 && (P == 4 || P == 8) && a.ol16 == 0 && a.Nc == 1 && a.qw > 0 &&
-         a.vis0 == nullptr && a.count == nullptr && a.fh >= 1 && a.fw >= 1;
+  static const int env16 = getenv("UBV_LIFT_TILE16") ? atoi(getenv("UBV_LIFT_TILE16")) : 1;
+  return env != 0 && dtype == UBV_F32 && (Dh == 32 || (Dh == 16 && env16 != 0)) && a.H == 8 && (P == 4 || P == 8) && a.ol16 == 0 &&
+         a.Nc == 1 && a.qw > 0 && a.vis0 == nullptr && a.count == nullptr && a.fh >= 1 && a.fw >= 1;
 }
 
 // largest pixel box a block copies into LDS (UBV_TILE_MAXBOX_FWD / _BWD, one value or "P4,P8"; 256 = always)
@@ -426,37 +453,42 @@ static int tile_max_box(const char* env, int P, int dflt4, int dflt8) {
   return P == 4 ? v4 : v8;
 }
 
-void tile_fwd_launch(const LiftArgs& a, int P, hipStream_t st, bool k1) {
-  const long units = (long)a.total_tiles * a.H;
+void tile_fwd_launch(const LiftArgs& a, int P, hipStream_t st, bool k1, int Dh) {
+  const long units = (long)a.total_tiles * (Dh == 16 ? 4 : 8);         // (tile, 128-byte line of heads)
   const int chunk = (int)((units + 7) / 8);
   static const int mb4 = tile_max_box("UBV_TILE_MAXBOX_FWD", 4, 256, 256), mb8 = tile_max_box("UBV_TILE_MAXBOX_FWD", 8, 256, 256);
-  if (k1) {
-    if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4, true>), dim3(8 * chunk), dim3(256), kTWinLds, st, a, chunk, mb4);
-    else hipLaunchKernelGGL((lift_tile_fwd_kernel<8, true>), dim3(8 * chunk), dim3(256), kTWinLds, st, a, chunk, mb8);
-    return;
+  const dim3 grid(8 * chunk), blk(256);
+  if (k1) {                                               // (the operator's form: Dh = 32 only)
+    if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4, 32, true>), grid, blk, kTWinLds, st, a, chunk, mb4);
+    else hipLaunchKernelGGL((lift_tile_fwd_kernel<8, 32, true>), grid, blk, kTWinLds, st, a, chunk, mb8);
+  } else if (Dh == 16) {
+    if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4, 16>), grid, blk, kTWinLds, st, a, chunk, mb4);
+    else hipLaunchKernelGGL((lift_tile_fwd_kernel<8, 16>), grid, blk, kTWinLds, st, a, chunk, mb8);
+  } else {
+    if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4, 32>), grid, blk, kTWinLds, st, a, chunk, mb4);
+    else hipLaunchKernelGGL((lift_tile_fwd_kernel<8, 32>), grid, blk, kTWinLds, st, a, chunk, mb8);
   }
-  if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4>), dim3(8 * chunk), dim3(256), kTWinLds, st, a, chunk, mb4);
-  else hipLaunchKernelGGL((lift_tile_fwd_kernel<8>), dim3(8 * chunk), dim3(256), kTWinLds, st, a, chunk, mb8);
 }
 
 // bins: the points are binned here (the caller zeroed a.bin_cnt / a.ovf_n and launches no lift_bin_kernel)
-void tile_bwd_query_launch(const LiftArgs& a, int P, bool bins, int tiles_x, int tiles, hipStream_t st, bool k1) {
-  const long units = (long)a.total_tiles * a.H;
+void tile_bwd_query_launch(const LiftArgs& a, int P, bool bins, int tiles_x, int tiles, hipStream_t st, bool k1, int Dh) {
+  const long units = (long)a.total_tiles * (Dh == 16 ? 4 : 8);
   const int chunk = (int)((units + 7) / 8);
   const dim3 grid(8 * chunk), blk(256);
   static const int mb4 = tile_max_box("UBV_TILE_MAXBOX_BWD", 4, 256, 256), mb8 = tile_max_box("UBV_TILE_MAXBOX_BWD", 8, 256, 256);
-  if (k1) {                                               // (the operator's backward always bins)
-    if (P == 4) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4, true, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb4);
-    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<8, true, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb8);
+  if (k1) {                                               // (the operator's backward always bins; Dh = 32 only)
+    if (P == 4) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4, 32, true, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb4);
+    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<8, 32, true, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb8);
     return;
   }
-  if (P == 4) {
-    if (bins) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb4);
-    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4, false>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb4);
-  } else {
-    if (bins) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<8, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb8);
-    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<8, false>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb8);
-  }
+#define UBV_TILE_BWD(PV, DHV, MB)                                                                                           \
+  do {                                                                                                                      \
+    if (bins) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<PV, DHV, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, MB); \
+    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<PV, DHV, false>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, MB);     \
+  } while (0)
+  if (Dh == 16) { if (P == 4) UBV_TILE_BWD(4, 16, mb4); else UBV_TILE_BWD(8, 16, mb8); }
+  else { if (P == 4) UBV_TILE_BWD(4, 32, mb4); else UBV_TILE_BWD(8, 32, mb8); }
+#undef UBV_TILE_BWD
 }
 
 }  // namespace ubv
