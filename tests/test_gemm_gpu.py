@@ -418,3 +418,41 @@ def test_gemm_ws_weight_stationary_kernel(M, N, K):
         elif M >= 4099:                                     # about p of the positive entries are dropped
             pos = (ref + b.double()) > 1e-3
             assert 0.27 < float((y.cpu()[pos] == 0).float().mean()) < 0.33
+
+
+@pytest.mark.parametrize('form', ['plain', 'residual', 'masked', 'relu_dropout'])
+def test_gemm_ws_results_do_not_depend_on_memory_latency(form):
+    """The weight-stationary GEMM counts its vector-memory instructions by hand (`s_waitcnt vmcnt(N)` in front of the LDS
+    reads of DMA-filled tiles).  A count that is too high would read a tile before it landed — only when the memory system
+    is slow enough.  So: 30 launches at the step's size while a second stream saturates HBM with 1 GB copies, every output
+    bitwise equal to the launch made alone."""
+    from unibev_amd.functional import gemm_nt, gemm_nt_act, split_weight
+    g = torch.Generator(device='cpu').manual_seed(9)
+    M, N, K = 80000, 256, 256
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    r = torch.randn(M, N, generator=g).to(DEV)
+    wh, wl, _, _ = split_weight(w, transposed=False)
+
+    def run():
+        if form == 'plain':
+            return gemm_nt(x, wh, wl, bias=b)
+        if form == 'residual':
+            return gemm_nt(x, wh, wl, bias=b, residual=r)
+        if form == 'masked':
+            return gemm_nt_act(x, wh, wl, act=2, mask=r, p=0.1)
+        return gemm_nt_act(x, wh, wl, bias=b, act=1, p=0.1, seed=77)
+    ref = run().clone()
+    torch.cuda.synchronize()
+    big_a = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=DEV)
+    big_b = torch.empty_like(big_a)
+    side = torch.cuda.Stream()
+    outs = []
+    for i in range(30):
+        with torch.cuda.stream(side):
+            big_b.copy_(big_a)
+            big_a.copy_(big_b)
+        outs.append(run())
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, ref) for o in outs)
