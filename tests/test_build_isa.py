@@ -1,10 +1,12 @@
 """The built library must hold NO packed f32 VALU instructions (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32).
 
-On gfx950 a packed f32 instruction of one wave returns wrong results while another kernel's MFMA instructions run on
-the same SIMD — two HIP streams are enough (DESIGN section 5 "Two streams", profiles/r04_two_stream_race.txt).  The
-library is built with -fno-slp-vectorize for that reason (unibev_amd/csrc/Makefile); this test reads the device code
-of the built .so back, so that a changed flag or a hand-written packed operation cannot return unnoticed.  CPU-only:
-it disassembles, nothing runs."""
+The SLP-vectorised build of the lifting kernels (390 packed f32 instructions in one of them) returned wrong results when
+it shared a SIMD with another stream's MFMA + VALU kernel — two HIP streams are enough — and the scalar build of the same
+source never does (DESIGN section 5 "Two streams", profiles/r04_two_stream_race.txt, profiles/r05_pk_mfma_hazard.txt;
+the packed instructions are necessary there, not sufficient in general).  The library is built with -fno-slp-vectorize for
+that reason (unibev_amd/csrc/Makefile); this test reads the device code of the built .so back, so that a changed flag, a
+vector-typed float expression (an ext_vector add compiles to v_pk_add_f32 without any vectoriser) or a hand-written packed
+operation cannot return unnoticed.  CPU-only: it disassembles, nothing runs."""
 import os
 import re
 import shutil
