@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs the SLP-vectorised build of the library first: make -C unibev_amd/csrc SLP=1 -j8)
 # round 5: hazard study, stage 2 — the REAL victim (lifting kernel built with the SLP vectoriser: packed f32) beside synthetic
 # co-runners, and the default (no packed f32) build as control; then the GPU tests
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs the SLP-vectorised build of the library first: make -C unibev_amd/csrc SLP=1 -j8)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/r5c
 mkdir -p $OUT
