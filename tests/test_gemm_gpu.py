@@ -92,6 +92,66 @@ def test_gemm_wgrad(M, N, K, dtype):
     assert float((gb.cpu().double() - refb).abs().max()) < 1e-5 * max(1.0, float(refb.abs().max())) * (1 if dtype == torch.float32 else 1)
 
 
+@pytest.fixture
+def wgrad_kernel():
+    """Selects the weight-gradient kernel for one test (ubv_debug_set_wgrad_ws) and restores the default."""
+    from unibev_amd._lib import lib
+    def choose(pw):
+        assert lib().ubv_debug_set_wgrad_ws(pw) == 0
+    yield choose
+    lib().ubv_debug_set_wgrad_ws(0)
+
+
+@pytest.mark.parametrize('pw', [4, 8])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('M,N,K', [(5000, 256, 256), (4099, 192, 256), (777, 96, 128), (9000, 512, 256), (300, 64, 40),
+                                   (12345, 256, 512), (64, 256, 256), (129, 128, 128), (40000, 256, 256)])
+def test_gemm_wgrad_wave_specialised_kernel(M, N, K, dtype, pw, wgrad_kernel):
+    """csrc/gemm_wgrad_ws.inl (4 MFMA waves + 4 or 8 producer waves, one block per CU, double-buffered operand planes)
+    against f64 with the 4-wave kernel's tolerances, and against the 4-wave kernel itself: same products, same order
+    inside a slab; the slabs differ (half as many), so the comparison is to f32 summation noise, not to the bit.
+    Ragged row counts (one chunk, a chunk + 1 row, slabs with an odd chunk count), partial tiles in N and K."""
+    from unibev_amd.functional import gemm_wgrad
+    if K == 40 and dtype == torch.float32:
+        K = 36
+    g = torch.Generator(device='cpu').manual_seed(M + N + pw)
+    gy = torch.randn(M, N, generator=g).to(dtype).to(DEV)
+    x = torch.randn(M, K, generator=g).to(dtype).to(DEV)
+    base_w, base_b = gemm_wgrad(gy, x)
+    wgrad_kernel(pw)
+    res = gemm_wgrad(gy, x)
+    assert res is not None
+    gw, gb = res
+    refw = gy.double().t() @ x.double()
+    refb = gy.double().sum(0)
+    tol = 3e-5 if dtype == torch.float32 else 2e-6
+    assert float((gw.double() - refw).abs().max()) < max(tol * float(refw.abs().max()), 1e-3 * tol * M ** 0.5 * 30)
+    assert float((gb.double() - refb).abs().max()) < 1e-5 * max(1.0, float(refb.abs().max()))
+    assert float((gw - base_w).abs().max()) <= 4e-6 * float(refw.abs().max()) + 1e-6 * M ** 0.5
+    assert float((gb - base_b).abs().max()) <= 4e-6 * max(1.0, float(refb.abs().max()))
+
+
+@pytest.mark.parametrize('pw', [4, 8])
+def test_gemm_wgrad_dual_wave_specialised_kernel(pw, wgrad_kernel):
+    """ubv_gemm_wgrad_dual (grad_out in two matrices, the fused value_proj | offsets | logits Linear) on the
+    wave-specialised kernel against the product of the concatenated matrix in f64."""
+    from unibev_amd.functional import gemm_wgrad_dual
+    g = torch.Generator(device='cpu').manual_seed(11)
+    M, N1, N2, K = 7001, 256, 96, 256
+    g1 = torch.randn(M, N1, generator=g).to(DEV)
+    g2 = torch.randn(M, N2, generator=g).to(DEV)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    wgrad_kernel(pw)
+    res = gemm_wgrad_dual(g1, g2, x)
+    assert res is not None
+    gw, gb = res
+    gy = torch.cat([g1, g2], 1).double()
+    refw, refb = gy.t() @ x.double(), gy.sum(0)
+    assert gw.shape == (N1 + N2, K)
+    assert float((gw.double() - refw).abs().max()) < 3e-5 * float(refw.abs().max())
+    assert float((gb.double() - refb).abs().max()) < 1e-5 * float(refb.abs().max())
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('p', [0.0, 0.1])
 def test_ffn_activation_in_gemm_epilogues(dtype, p, monkeypatch):

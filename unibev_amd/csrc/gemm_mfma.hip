@@ -959,12 +959,43 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
   }
 }
 
+#include "gemm_wgrad_ws.inl"
+
+// Which weight-gradient kernel runs: 0 (default) the 4-wave kernel, two blocks per CU; 4 / 8 the wave-specialised one with
+// that many producer waves, one block per CU.  Measured (profiles/r05_wgrad_ws.txt): alone the wave-specialised kernel is
+// 8 - 10 % faster (80 000 x 256 x 256 cold: 65.7 -> 58.8 us), in the one-stream step + 1.6 %, in the two-stream step — the
+// default — - 0.6 %: a 133 KB block owns its CU and the other stream's kernels lose the co-residency they had.
+// UBV_WGRAD_WS=0 / 1 and UBV_WGRAD_PW=4 / 8 set the start value, ubv_debug_set_wgrad_ws changes it (tests).
+static int g_wgrad_ws = -1;
+static int wgrad_ws_mode() {
+  if (g_wgrad_ws < 0) {
+    const int on = getenv("UBV_WGRAD_WS") ? atoi(getenv("UBV_WGRAD_WS")) : 0;
+    const int pw = getenv("UBV_WGRAD_PW") ? atoi(getenv("UBV_WGRAD_PW")) : 8;
+    g_wgrad_ws = on == 0 ? 0 : (pw == 4 ? 4 : 8);
+  }
+  return g_wgrad_ws;
+}
+static bool wgrad_ws_on() { return wgrad_ws_mode() != 0; }
+
+template <typename Kern> static void wgrad_ws_lds(Kern kern, size_t lds) {
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
 }  // namespace ubv
+
+extern "C" int ubv_debug_set_wgrad_ws(int producer_waves) {
+  using namespace ubv;
+  UBV_CHECK_ARG(producer_waves == 0 || producer_waves == 4 || producer_waves == 8,
+                "set_wgrad_ws: 0 (4-wave kernel), 4 or 8 producer waves, got %d", producer_waves);
+  g_wgrad_ws = producer_waves;
+  return UBV_OK;
+}
 
 extern "C" int ubv_gemm_wgrad_splits(int64_t M, int N, int K) {
   const int tiles = ((N + ubv::kWgTile - 1) / ubv::kWgTile) * ((K + ubv::kWgTile - 1) / ubv::kWgTile);
-  static const int blocks_env = getenv("UBV_WGRAD_BLOCKS") ? atoi(getenv("UBV_WGRAD_BLOCKS")) : 512;   // study knob
-  long s = (blocks_env + tiles - 1) / tiles;              // two blocks per CU
+  static const int blocks_env = getenv("UBV_WGRAD_BLOCKS") ? atoi(getenv("UBV_WGRAD_BLOCKS")) : 0;   // study knob
+  const int blocks = blocks_env > 0 ? blocks_env : (ubv::wgrad_ws_on() ? 256 : 512);
+  long s = (blocks + tiles - 1) / tiles;                  // one 8-wave / two 4-wave blocks per CU
   const long max_s = (M + 255) / 256;                     // at least 256 rows per split
   if (s > max_s) s = max_s;
   if (s > 256) s = 256;
@@ -1007,6 +1038,25 @@ static int gemm_wgrad_run(const void* grad_out, const void* grad_out2, int n_spl
   const dim3 grid((unsigned)((splits + 7) / 8 * 8 * tiles)), blk(256);
   const size_t lds = (size_t)(dtype == UBV_F32 ? 4 : 2) * kWgPlane * sizeof(uint16_t);
   hipStream_t st = as_stream(stream);
+  if (wgrad_ws_on()) {
+    rps = (rps + 2 * kWgMC - 1) / (2 * kWgMC) * (2 * kWgMC);   // an even number of chunks per slab
+    static const int abl = getenv("UBV_WGRAD_ABL") ? atoi(getenv("UBV_WGRAD_ABL")) : 0;   // timing study (wrong results)
+    if (dtype == UBV_F32 && abl != 0) {
+#define UBV_WG_ABL(A) { wgrad_ws_lds(gemm_wgrad_ws_kernel<true, false, false, A>, 2 * lds); \
+      hipLaunchKernelGGL((gemm_wgrad_ws_kernel<true, false, false, A>), grid, dim3(512), 2 * lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps, (const int32_t*)nullptr, 0L, (const int32_t*)nullptr, (const int32_t*)nullptr, grad_out2, n_split, 1, 7); }
+      if (abl == 1) UBV_WG_ABL(1) else if (abl == 2) UBV_WG_ABL(2) else if (abl == 3) UBV_WG_ABL(3)
+      else if (abl == 4) UBV_WG_ABL(4) else if (abl == 5) UBV_WG_ABL(5) else if (abl == 6) UBV_WG_ABL(6) else UBV_WG_ABL(7)
+#undef UBV_WG_ABL
+    } else {
+    const int pw = wgrad_ws_mode();                     // producer waves: 4 or 8
+#define UBV_WG_GO(S, H, P) { wgrad_ws_lds(gemm_wgrad_ws_kernel<S, H, false, 0, P>, 2 * lds); \
+      hipLaunchKernelGGL((gemm_wgrad_ws_kernel<S, H, false, 0, P>), grid, dim3(256 + 64 * P), 2 * lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps, (const int32_t*)nullptr, 0L, (const int32_t*)nullptr, (const int32_t*)nullptr, grad_out2, n_split, 1, 7); }
+    if (dtype == UBV_F32) { if (pw == 8) UBV_WG_GO(true, false, 8) else UBV_WG_GO(true, false, 4) }
+    else if (dtype == UBV_F16) { if (pw == 8) UBV_WG_GO(false, true, 8) else UBV_WG_GO(false, true, 4) }
+    else { if (pw == 8) UBV_WG_GO(false, false, 8) else UBV_WG_GO(false, false, 4) }
+#undef UBV_WG_GO
+    }
+  } else
   if (dtype == UBV_F32)
     hipLaunchKernelGGL((gemm_wgrad_kernel<true, false, false>), grid, blk, lds, st, grad_out, x, partials, (long)M, N, K, tiles_k, tiles, splits, (int)rps, (const int32_t*)nullptr, 0L, (const int32_t*)nullptr, (const int32_t*)nullptr, grad_out2, n_split, 1, 7);
   else if (dtype == UBV_F16)
@@ -1025,7 +1075,8 @@ static int gemm_wgrad_run(const void* grad_out, const void* grad_out2, int n_spl
 // 128 x 128 tile per offset, split-K over the rows.  partials [splits, kvol, Cout*Cin + Cout] f32 scratch;
 // grad_w [kvol, Cout*Cin + Cout] f32, WRITTEN (the last Cout entries of each block are unused).
 extern "C" int ubv_spconv_wgrad_splits(int64_t rows, int kvol) {
-  long s = (768 + kvol - 1) / kvol;
+  static const int blocks_env = getenv("UBV_SPCONV_WGRAD_BLOCKS") ? atoi(getenv("UBV_SPCONV_WGRAD_BLOCKS")) : 768;   // study knob
+  long s = (blocks_env + kvol - 1) / kvol;
   const long max_s = (rows + 255) / 256;
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -1079,6 +1130,17 @@ static int spconv_wgrad_run(const void* grad_out, const void* feats, const int32
   const dim3 grid((unsigned)((splits + 7) / 8 * 8 * ptiles)), blk(256);
   const size_t lds = (size_t)(dtype == UBV_F32 ? 4 : 2) * kWgPlane * sizeof(uint16_t);
   hipStream_t st = as_stream(stream);
+  static const int ws_env = getenv("UBV_SPCONV_WGRAD_WS") ? atoi(getenv("UBV_SPCONV_WGRAD_WS")) : 1;
+  if (wgrad_ws_on() && ws_env != 0 && out_rows != nullptr && counts != nullptr) {   // (pair lists: see load_idx)
+    rps = (rps + 2 * kWgMC - 1) / (2 * kWgMC) * (2 * kWgMC);
+    const int pw = wgrad_ws_mode();
+#define UBV_WG_GO(S, H, P) { wgrad_ws_lds(gemm_wgrad_ws_kernel<S, H, true, 0, P>, 2 * lds); \
+      hipLaunchKernelGGL((gemm_wgrad_ws_kernel<S, H, true, 0, P>), grid, dim3(256 + 64 * P), 2 * lds, st, grad_out, feats, partials, (long)rows, Cout, Cin, 1, ptiles, splits, (int)rps, nbr, (long)ld, out_rows, counts, (const void*)nullptr, 0, kvol, cwsh); }
+    if (dtype == UBV_F32) { if (pw == 8) UBV_WG_GO(true, false, 8) else UBV_WG_GO(true, false, 4) }
+    else if (dtype == UBV_F16) { if (pw == 8) UBV_WG_GO(false, true, 8) else UBV_WG_GO(false, true, 4) }
+    else { if (pw == 8) UBV_WG_GO(false, false, 8) else UBV_WG_GO(false, false, 4) }
+#undef UBV_WG_GO
+  } else
   if (dtype == UBV_F32)
     hipLaunchKernelGGL((gemm_wgrad_kernel<true, false, true>), grid, blk, lds, st, grad_out, feats, partials, (long)rows, Cout, Cin, 1, ptiles, splits, (int)rps, nbr, (long)ld, out_rows, counts, (const void*)nullptr, 0, kvol, cwsh);
   else if (dtype == UBV_F16)
