@@ -58,11 +58,12 @@ int ubv_debug_aggressor(int kind, int iters, int blocks, int lds_bytes, const fl
  * UBV_WS_ABL=16): out_host [2 blocks][16 tiles][8 stamps]. */
 int ubv_debug_ws_timing(uint64_t* out_host);
 
-/* Study / test aid: which weight-gradient kernel ubv_gemm_wgrad* and ubv_spconv_wgrad_pairs launch from now on.
- * 0 (the default; also UBV_WGRAD_WS=0): the 4-wave kernel, two blocks per CU.  4 or 8: the wave-specialised kernel
- * (csrc/gemm_wgrad_ws.inl: that many producer waves + 4 MFMA waves, one block per CU).  Same results either way;
- * ubv_gemm_wgrad_splits follows the choice, so ask it again after a change.  Not thread-safe. */
-int ubv_debug_set_wgrad_ws(int producer_waves);
+/* Study / test aid: which weight-gradient kernel ubv_gemm_wgrad* (`dense`) and ubv_spconv_wgrad_pairs (`sparse`) launch
+ * from now on.  0: the 4-wave kernel, two blocks per CU.  4 or 8: the wave-specialised kernel (csrc/gemm_wgrad_ws.inl:
+ * that many producer waves + 4 MFMA waves, one block per CU).  -1: leave as it is.  Start values: dense 0
+ * (UBV_WGRAD_WS=1 with UBV_WGRAD_PW=4|8 changes it), sparse 8 (UBV_SPCONV_WGRAD_WS=0|4|8).  Same results either way;
+ * ubv_gemm_wgrad_splits follows `dense`, so ask it again after a change.  Not thread-safe. */
+int ubv_debug_set_wgrad_ws(int dense, int sparse);
 
 /* Optional per-kernel timing: while enabled, every kernel of the sampling family is bracketed by
  * HIP events on its launch stream.  ubv_profile_read() synchronises on them and writes one line per

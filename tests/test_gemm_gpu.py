@@ -97,9 +97,9 @@ def wgrad_kernel():
     """Selects the weight-gradient kernel for one test (ubv_debug_set_wgrad_ws) and restores the default."""
     from unibev_amd._lib import lib
     def choose(pw):
-        assert lib().ubv_debug_set_wgrad_ws(pw) == 0
+        assert lib().ubv_debug_set_wgrad_ws(pw, -1) == 0
     yield choose
-    lib().ubv_debug_set_wgrad_ws(0)
+    lib().ubv_debug_set_wgrad_ws(0, -1)
 
 
 @pytest.mark.parametrize('pw', [4, 8])

@@ -24,7 +24,7 @@ SIGNATURES = {
     'ubv_debug_fill_lds': (c_int, [ctypes.c_uint32, _P]),
     'ubv_debug_aggressor': (c_int, [c_int, c_int, c_int, c_int, _P, c_int64, _P, _P]),
     'ubv_debug_ws_timing': (c_int, [_P]),
-    'ubv_debug_set_wgrad_ws': (c_int, [c_int]),
+    'ubv_debug_set_wgrad_ws': (c_int, [c_int, c_int]),
     'ubv_profile_enable': (c_int, [c_int]),
     'ubv_profile_read': (c_int64, [c_char_p, c_int64]),
     'ubv_ms_deform_attn_forward': (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 9 + [_P]),

@@ -976,6 +976,17 @@ static int wgrad_ws_mode() {
   return g_wgrad_ws;
 }
 static bool wgrad_ws_on() { return wgrad_ws_mode() != 0; }
+// The sparse convolutions' weight gradient (ubv_spconv_wgrad_pairs) runs in the LiDAR front end, outside the two-stream
+// region, where the wave-specialised kernel's gain is not paid back: 8 producer waves by default (middle encoder
+// 10.25 -> 9.96 ms); UBV_SPCONV_WGRAD_WS=0 / 4 / 8.
+static int g_spwg_ws = -1;
+static int spwg_ws_mode() {
+  if (g_spwg_ws < 0) {
+    const int v = getenv("UBV_SPCONV_WGRAD_WS") ? atoi(getenv("UBV_SPCONV_WGRAD_WS")) : 8;
+    g_spwg_ws = v == 0 ? 0 : (v == 4 ? 4 : 8);
+  }
+  return g_spwg_ws;
+}
 
 template <typename Kern> static void wgrad_ws_lds(Kern kern, size_t lds) {
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -983,11 +994,13 @@ template <typename Kern> static void wgrad_ws_lds(Kern kern, size_t lds) {
 
 }  // namespace ubv
 
-extern "C" int ubv_debug_set_wgrad_ws(int producer_waves) {
+extern "C" int ubv_debug_set_wgrad_ws(int dense, int sparse) {
   using namespace ubv;
-  UBV_CHECK_ARG(producer_waves == 0 || producer_waves == 4 || producer_waves == 8,
-                "set_wgrad_ws: 0 (4-wave kernel), 4 or 8 producer waves, got %d", producer_waves);
-  g_wgrad_ws = producer_waves;
+  auto ok = [](int v) { return v == -1 || v == 0 || v == 4 || v == 8; };
+  UBV_CHECK_ARG(ok(dense) && ok(sparse), "set_wgrad_ws: -1 (keep), 0 (4-wave kernel), 4 or 8 producer waves, got %d, %d",
+                dense, sparse);
+  if (dense >= 0) g_wgrad_ws = dense;
+  if (sparse >= 0) g_spwg_ws = sparse;
   return UBV_OK;
 }
 
@@ -1130,10 +1143,9 @@ static int spconv_wgrad_run(const void* grad_out, const void* feats, const int32
   const dim3 grid((unsigned)((splits + 7) / 8 * 8 * ptiles)), blk(256);
   const size_t lds = (size_t)(dtype == UBV_F32 ? 4 : 2) * kWgPlane * sizeof(uint16_t);
   hipStream_t st = as_stream(stream);
-  static const int ws_env = getenv("UBV_SPCONV_WGRAD_WS") ? atoi(getenv("UBV_SPCONV_WGRAD_WS")) : 1;
-  if (wgrad_ws_on() && ws_env != 0 && out_rows != nullptr && counts != nullptr) {   // (pair lists: see load_idx)
+  if (spwg_ws_mode() != 0 && out_rows != nullptr && counts != nullptr) {   // (pair lists: see load_idx)
     rps = (rps + 2 * kWgMC - 1) / (2 * kWgMC) * (2 * kWgMC);
-    const int pw = wgrad_ws_mode();
+    const int pw = spwg_ws_mode();
 #define UBV_WG_GO(S, H, P) { wgrad_ws_lds(gemm_wgrad_ws_kernel<S, H, true, 0, P>, 2 * lds); \
       hipLaunchKernelGGL((gemm_wgrad_ws_kernel<S, H, true, 0, P>), grid, dim3(256 + 64 * P), 2 * lds, st, grad_out, feats, partials, (long)rows, Cout, Cin, 1, ptiles, splits, (int)rps, nbr, (long)ld, out_rows, counts, (const void*)nullptr, 0, kvol, cwsh); }
     if (dtype == UBV_F32) { if (pw == 8) UBV_WG_GO(true, false, 8) else UBV_WG_GO(true, false, 4) }
