@@ -421,7 +421,8 @@ class UniBEVTransformer(BaseModule):
             side = _side_stream(dev)
             # the image encoder stays on the caller's stream, the point-cloud encoder gets the side stream: two
             # active streams (three — caller idle + one per encoder — measured the same, and a fourth stream of
-            # any kind, e.g. RCCL's, then falls back to the single-stream time)
+            # any kind, e.g. RCCL's, then falls back to the single-stream time; round 5, tools/ab/job_r5p1.sh: the
+            # encoders swapped between the streams 149.8 -> 148.9 samples/s, a high-priority side stream -> 115)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 pts_bev_embed = run_pts()
