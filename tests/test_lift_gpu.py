@@ -454,14 +454,22 @@ def test_lift_backward_repeatable_and_independent_of_kernel_concurrency(plan):
     ol = t(offlog, dt, DEV).requires_grad_()
     r = t(ref, torch.float32, DEV)
     go = t(gout, dt, DEV)
-    base = None
+    base = first = None
     try:
         for two in ('0', '1'):
             os.environ['UBV_LIFT_TWO_STREAM'] = two
-            for _ in range(250):
+            for it in range(250):
                 v.grad = ol.grad = None
                 bev_lift(v, ol, r, Nc, (fh, fw), H, P, **kw).backward(go)
                 if base is None:
+                    base = first = (ol.grad.clone(), v.grad.clone())
+                    continue
+                if plan == 'grid' and two == '1' and it == 0:
+                    # Since round 5 the one-stream GRID backward of 16-bit maps is the TILE query kernel (it also bins, so
+                    # there is no separate chain to put on a side stream); the two-stream diagnostic keeps the shared-footprint
+                    # kernel + lift_bin_kernel.  Two kernels, two orders of the same f32 sums: equal to the rounding of the
+                    # 16-bit result, each bit-identical to itself from then on.
+                    torch.testing.assert_close(ol.grad.float(), first[0].float(), rtol=2.0 ** -6, atol=2e-3)
                     base = (ol.grad.clone(), v.grad.clone())
                     continue
                 assert torch.equal(ol.grad, base[0]), two

@@ -1289,8 +1289,9 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
       }
     }
     static const int shared_env = getenv("UBV_LIFT_SHARED") ? atoi(getenv("UBV_LIFT_SHARED")) : 1;
-    if (tile_ok(a, DH, P, sizeof(T) == 4 ? UBV_F32 : UBV_BF16)) {   // one lane per (query, point), LDS window (bev_lift_tile.hip)
-      tile_fwd_launch(a, P, st, false, DH);
+    constexpr int DT = sizeof(T) == 4 ? UBV_F32 : std::is_same<T, f16_t>::value ? UBV_F16 : UBV_BF16;
+    if (tile_ok(a, DH, P, DT)) {                 // one lane per (query, point), LDS window (bev_lift_tile.hip)
+      tile_fwd_launch(a, P, st, false, DH, DT);
       return;
     }
     if (shared_env && win_ok<T, DH, P>(a)) {   // BEV-grid queries: corners served from an LDS window (bev_lift_win.inl)
@@ -1376,15 +1377,17 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     // order: the scheduler's placement of the window fill changed), the gather kernel does not care.  Without
     // ovf_after the caller's memset zeroed the counters and the order is bins -> overflow -> query -> owner tiles.
     // TILE plan (bev_lift_tile.hip): the query-gradient kernel also bins its points — no lift_bin_kernel
-    const bool tile = tile_ok(a, DH, P, sizeof(T) == 4 ? UBV_F32 : UBV_BF16) && a.ovf_after && !two;
-    const bool qfirst = a.ovf_after && !win_ok<T, DH, P>(a) && !tile;
+    // (16-bit grad_value, !ovf_after: the TILE query kernel — which bins — then has to run before the overflow pass)
+    constexpr int DT = sizeof(T) == 4 ? UBV_F32 : std::is_same<T, f16_t>::value ? UBV_F16 : UBV_BF16;
+    const bool tile = tile_ok(a, DH, P, DT, true) && !two;
+    const bool qfirst = (a.ovf_after && !win_ok<T, DH, P>(a) && !tile) || (tile && !a.ovf_after);
     if (a.ovf_after && !qfirst) (void)hipMemsetAsync(a.bin_cnt, 0, (size_t)a.cnt_words * sizeof(int), st);
     LiftArgs aq = a;
     if (!qfirst) aq.cnt_words = 0;
     auto run_query = [&]() {
       {
         ProfScope ps(name("bev_lift_bwd_query"), st, q_bytes);
-        if (tile) tile_bwd_query_launch(aq, P, true, t.tiles_x, tiles, st, false, DH);
+        if (tile) tile_bwd_query_launch(aq, P, true, t.tiles_x, tiles, st, false, DH, DT);
         else if (win_ok<T, DH, P>(a)) {
           constexpr int HG = 128 / (DH * (int)sizeof(T));
           const int chunk = (int)(((long)a.total_tiles * (a.H / HG) + 7) / 8);
@@ -1908,7 +1911,7 @@ bool k1_tile_ok(int H, int Dh, int P, int dtype, int fh, int fw, int Nq, int qh,
   if (qh <= 0 || qw <= 0 || (long)qh * qw != Nq || fh < 1 || fw < 1) return false;
   LiftArgs a;
   k1_tile_args(a, 1, fh, fw, H, Nq, qh, qw);
-  return Dh == 32 && tile_ok(a, Dh, P, dtype) && (long)fh * fw * H * Dh < (1L << 30) && (long)Nq * H * Dh < (1L << 30);
+  return Dh == 32 && dtype == UBV_F32 && tile_ok(a, Dh, P, dtype) && (long)fh * fw * H * Dh < (1L << 30) && (long)Nq * H * Dh < (1L << 30);
 }
 int k1_tile_forward(const void* value, const float* loc, const float* aw, void* out, int B, int fh, int fw, int H, int Nq,
                     int P, int qh, int qw, hipStream_t st) {

@@ -257,8 +257,9 @@ __device__ __forceinline__ int win_row(int xc, int yc, const WinGeom& g) {
 
 
 // ---- TILE plan (bev_lift_tile.hip): f32 GRID instances, one lane per query ----
-bool tile_ok(const LiftArgs& a, int Dh, int P, int dtype);
-void tile_fwd_launch(const LiftArgs& a, int P, hipStream_t st, bool k1 = false, int Dh = 32);
-void tile_bwd_query_launch(const LiftArgs& a, int P, bool bins, int tiles_x, int tiles, hipStream_t st, bool k1 = false, int Dh = 32);
+bool tile_ok(const LiftArgs& a, int Dh, int P, int dtype, bool bwd = false);
+void tile_fwd_launch(const LiftArgs& a, int P, hipStream_t st, bool k1 = false, int Dh = 32, int dtype = 0);
+void tile_bwd_query_launch(const LiftArgs& a, int P, bool bins, int tiles_x, int tiles, hipStream_t st, bool k1 = false, int Dh = 32,
+                           int dtype = 0);
 
 }  // namespace ubv

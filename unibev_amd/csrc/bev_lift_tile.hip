@@ -24,6 +24,8 @@
 
 #include <string.h>
 
+#include <type_traits>
+
 #include "bev_lift_core.h"
 
 namespace ubv {
@@ -66,23 +68,40 @@ __device__ __forceinline__ int wave_max_i32(int v) { return -wave_min_i32(-v); }
 // weight (forward), every corner inside the map (BWD: a corner of weight 0 still has a derivative).  One barrier.
 // K1: the mmcv operator's inputs — a.offsets holds the sampling LOCATIONS [B, Nq, H, P, 2] (normalised), a.logits the
 // attention WEIGHTS [B, Nq, H, P] (already normalised: no softmax), no reference points.
-template <int P, bool BWD, bool K1 = false>
+// TO: the element type of offsets / logits — float, or the value's 16-bit type (LiftArgs.ol16)
+template <typename TO> __device__ __forceinline__ float2 tile_load2(const TO* p) {
+  if constexpr (sizeof(TO) == 4) return *reinterpret_cast<const float2*>(p);
+  else {
+    TO v[2];
+    *reinterpret_cast<uint32_t*>(v) = *reinterpret_cast<const uint32_t*>(p);
+    return make_float2(elem<TO>::to_float(v[0]), elem<TO>::to_float(v[1]));
+  }
+}
+template <typename TO> __device__ __forceinline__ void tile_store2(TO* p, float x, float y) {
+  if constexpr (sizeof(TO) == 4) *reinterpret_cast<float2*>(p) = make_float2(x, y);
+  else {
+    TO v[2] = {elem<TO>::from_float(x), elem<TO>::from_float(y)};
+    *reinterpret_cast<uint32_t*>(p) = *reinterpret_cast<const uint32_t*>(v);
+  }
+}
+
+template <int P, bool BWD, bool K1 = false, typename TO = float>
 __device__ __forceinline__ int4 tile_points(const LiftArgs& a, long bq, bool valid, int h, int pp, int wv, int lane,
                                             float (&rx)[P / 4], float (&ry)[P / 4], float (&rw)[P / 4], int4* wbox) {
   constexpr int PW = P / 4;
   const float fwf = (float)a.fw, fhf = (float)a.fh;
-  const float* __restrict__ offp = (const float*)a.offsets + bq * a.off_stride + h * 2 * P;
-  const float* __restrict__ lgp = (const float*)a.logits + bq * a.log_stride + h * P;
+  const TO* __restrict__ offp = (const TO*)a.offsets + bq * a.off_stride + h * 2 * P;
+  const TO* __restrict__ lgp = (const TO*)a.logits + bq * a.log_stride + h * P;
   const float* __restrict__ rp = K1 ? nullptr : a.ref + bq * a.Z * 2;
   float2 off[PW], ref[PW];
   float lg[PW];
 #pragma unroll
   for (int j = 0; j < PW; ++j) {
     const int p = pp + 4 * j;
-    off[j] = *reinterpret_cast<const float2*>(offp + 2 * p);
+    off[j] = tile_load2<TO>(offp + 2 * p);
     if constexpr (!K1) ref[j] = *reinterpret_cast<const float2*>(rp + (p % a.Z) * 2);
     else ref[j] = make_float2(0.0f, 0.0f);
-    lg[j] = lgp[p];
+    lg[j] = elem<TO>::to_float(lgp[p]);
   }
   int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1;
 #pragma unroll
@@ -126,28 +145,33 @@ __device__ __forceinline__ int4 tile_points(const LiftArgs& a, long bq, bool val
                    max(max(b0.z, b1.z), max(b2.z, b3.z)), max(max(b0.w, b1.w), max(b2.w, b3.w)));
 }
 
-// acc[0..DH) += c * (DH consecutive floats at p): LDS or global, 16-byte pieces
-template <int DH>
-__device__ __forceinline__ void tile_axpy(const float* __restrict__ p, float c, float (&acc)[DH]) {
+// acc[0..DH) += c * (DH consecutive elements at p): LDS or global, 16-byte pieces
+template <typename T, int DH>
+__device__ __forceinline__ void tile_axpy(const T* __restrict__ p, float c, float (&acc)[DH]) {
+  constexpr int V = 16 / (int)sizeof(T);                  // elements per 16-byte piece
 #pragma unroll
-  for (int i = 0; i < DH / 4; ++i) {
-    const float4 v = reinterpret_cast<const float4*>(p)[i];
-    acc[4 * i] = fmaf(c, v.x, acc[4 * i]);
-    acc[4 * i + 1] = fmaf(c, v.y, acc[4 * i + 1]);
-    acc[4 * i + 2] = fmaf(c, v.z, acc[4 * i + 2]);
-    acc[4 * i + 3] = fmaf(c, v.w, acc[4 * i + 3]);
+  for (int i = 0; i < DH / V; ++i) {
+    float v[V];
+    vec_io<T, V>::load(p + V * i, v);
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[V * i + e] = fmaf(c, v[e], acc[V * i + e]);
   }
 }
-template <int DH>
-__device__ __forceinline__ float tile_dot(const float* __restrict__ p, const float (&g)[DH]) {
+template <typename T, int DH>
+__device__ __forceinline__ float tile_dot(const T* __restrict__ p, const float (&g)[DH]) {
+  constexpr int V = 16 / (int)sizeof(T);
   float d0 = 0.0f, d1 = 0.0f;
 #pragma unroll
-  for (int i = 0; i < DH / 4; ++i) {
-    const float4 v = reinterpret_cast<const float4*>(p)[i];
-    d0 = fmaf(g[4 * i], v.x, d0);
-    d1 = fmaf(g[4 * i + 1], v.y, d1);
-    d0 = fmaf(g[4 * i + 2], v.z, d0);
-    d1 = fmaf(g[4 * i + 3], v.w, d1);
+  for (int i = 0; i < DH / V; ++i) {
+    float v[V];
+    vec_io<T, V>::load(p + V * i, v);
+#pragma unroll
+    for (int e = 0; e < V; e += 4) {
+      d0 = fmaf(g[V * i + e], v[e], d0);
+      d1 = fmaf(g[V * i + e + 1], v[e + 1], d1);
+      d0 = fmaf(g[V * i + e + 2], v[e + 2], d0);
+      d1 = fmaf(g[V * i + e + 3], v[e + 3], d1);
+    }
   }
   return d0 + d1;
 }
@@ -178,7 +202,8 @@ __device__ __forceinline__ void tile_fill(const LiftArgs& a, const WinGeom& g, c
   const int tid = threadIdx.x, piece = tid & 7, pxl = tid >> 3;
   const int dx = pxl & 15, dyl = pxl >> 4;
   const int cdx = min(dx, max(t.cols - 1, 0));            // columns past the box re-read its last one (same line: free)
-  // (rowi = floats per pixel over all heads; `line` = which 128-byte line of the pixel: HPB heads)
+  // (rowi = DWORDS per pixel over all heads — 16-bit maps: half their element count; `line` = which 128-byte line of
+  //  the pixel: HPB heads)
   const float* vb = (const float*)a.value + (long)g.b * a.fh * a.fw * rowi + line * 32 + piece * 4;
   // element offset of this thread's pixel in pass 0, and the (uniform) step of a pass = 2 map rows; a pass whose second
   // row lies past the box re-reads its first one (dyl = 1 lanes step back one row)
@@ -213,15 +238,17 @@ __device__ __forceinline__ int tile_row(int xc, int yc, const WinGeom& g, const 
 // ------------------------------------------------------------------------------------------------
 // Forward.  Two barriers per head of the line (block box) + one (window fill).  DH = 16: the two heads of a 128-byte
 // line are one block's work — both boxes first, ONE window for their union, then the corners head by head.
-template <int P, int DH, bool K1 = false>
+template <int P, int DH, bool K1 = false, typename T = float, bool OL16 = false>
 __global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, int chunk, int max_box) {
   extern __shared__ __attribute__((aligned(16))) unsigned char win[];
-  __shared__ int4 wbox[32 / DH][4];
-  constexpr int PW = P / 4, HPB = 32 / DH;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int PW = P / 4, HPB = 128 / (DH * ES);        // heads per 128-byte line
+  __shared__ int4 wbox[HPB][4];
+  using TO = std::conditional_t<OL16, T, float>;
   WinGeom g;
   if (!tile_decode8<HPB>(a, chunk, g)) return;
   const int lane = threadIdx.x & 63, wv = wave_in_block();
-  constexpr int rowi = 8 * DH;                            // floats per pixel / per query row (H = 8)
+  constexpr int rowi = 8 * DH;                            // elements per pixel / per query row (H = 8)
   const int li = wv * 16 + (lane >> 2), pp = lane & 3;
   float rx[HPB][PW], ry[HPB][PW], rw[HPB][PW];
   int b, q;
@@ -231,14 +258,14 @@ __global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, in
   int4 bb = make_int4(INT_MAX, INT_MAX, -1, -1);
 #pragma unroll
   for (int hh = 0; hh < HPB; ++hh)
-    bb = box_union(bb, tile_points<P, false, K1>(a, bq, valid, g.hg * HPB + hh, pp, wv, lane, rx[hh], ry[hh], rw[hh], wbox[hh]));
+    bb = box_union(bb, tile_points<P, false, K1, TO>(a, bq, valid, g.hg * HPB + hh, pp, wv, lane, rx[hh], ry[hh], rw[hh], wbox[hh]));
   const TileWin tw = tile_window(a, bb, g, max_box);
-  tile_fill(a, g, tw, g.hg, rowi, win);
+  tile_fill(a, g, tw, g.hg, rowi * ES / 4, win);
 #pragma unroll
   for (int hh = 0; hh < HPB; ++hh) {
     const int h = g.hg * HPB + hh;
-    const float* vb = (const float*)a.value + (long)g.b * a.fh * a.fw * rowi + h * DH;      // wave-uniform
-    const unsigned char* wh = win + hh * (DH * 4);        // this head's part of a window pixel
+    const T* vb = (const T*)a.value + (long)g.b * a.fh * a.fw * rowi + h * DH;      // wave-uniform
+    const unsigned char* wh = win + hh * (DH * ES);       // this head's part of a window pixel
     float acc[DH];
 #pragma unroll
     for (int i = 0; i < DH; ++i) acc[i] = 0.0f;
@@ -258,25 +285,23 @@ __global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, in
         // the wave's corners are all in the window (or weightless: any row will do): straight-line code, the LDS reads
         // of the point in flight together
 #pragma unroll
-        for (int k = 0; k < 4; ++k) tile_axpy<DH>(reinterpret_cast<const float*>(wh + (unsigned)max(wr[k], 0)), c[k], acc);
+        for (int k = 0; k < 4; ++k) tile_axpy<T, DH>(reinterpret_cast<const T*>(wh + (unsigned)max(wr[k], 0)), c[k], acc);
       } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          if (wr[k] >= 0) tile_axpy<DH>(reinterpret_cast<const float*>(wh + (unsigned)wr[k]), c[k], acc);
-          else if (c[k] != 0.0f) tile_axpy<DH>(gather_ptr(vb, (unsigned)(f.idx[k] * rowi)), c[k], acc);
+          if (wr[k] >= 0) tile_axpy<T, DH>(reinterpret_cast<const T*>(wh + (unsigned)wr[k]), c[k], acc);
+          else if (c[k] != 0.0f) tile_axpy<T, DH>(gather_ptr(vb, (unsigned)(f.idx[k] * rowi)), c[k], acc);
         }
       }
     }
 #pragma unroll
     for (int i = 0; i < DH; ++i) acc[i] = add_xor<2>(add_xor<1>(acc[i]));
     if (valid) {
-      constexpr int Q = DH / 4;                           // floats per lane of the quad
+      constexpr int Q = DH / 4;                           // elements per lane of the quad
       float o[Q];
 #pragma unroll
       for (int i = 0; i < Q; ++i) o[i] = pp == 0 ? acc[i] : pp == 1 ? acc[Q + i] : pp == 2 ? acc[2 * Q + i] : acc[3 * Q + i];
-      float4* dst = reinterpret_cast<float4*>((float*)a.out + bq * rowi + h * DH + pp * Q);
-#pragma unroll
-      for (int i = 0; i < Q / 4; ++i) dst[i] = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+      vec_io<T, Q>::store((T*)a.out + bq * rowi + h * DH + pp * Q, o);
     }
   }
 }
@@ -287,15 +312,17 @@ __global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, in
 // tile that holds one of its corners of non-zero coefficient (what lift_bin_kernel<MODE 0> does, same record format,
 // same fixed-capacity buckets + overflow list; see there): ranks inside the wave through LDS counters on an 8x8 torus
 // of tile slots, one returning global atomic per occupied slot.  The caller zeroes the counters.
-template <int P, int DH, bool BINS, bool K1 = false>
+template <int P, int DH, bool BINS, bool K1 = false, typename T = float, bool OL16 = false>
 __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs a, int chunk, int tiles_x, int tiles, int max_box) {
   extern __shared__ __attribute__((aligned(16))) unsigned char win[];
-  __shared__ int4 wbox[32 / DH][4];
+  constexpr int ES = (int)sizeof(T);
+  __shared__ int4 wbox[128 / (DH * ES)][4];
+  using TO = std::conditional_t<OL16, T, float>;
   // per wave: a 4x4 torus of tile slots — occupant tile, local count, global base (a wave's 16 queries x 4 points
   // reach a handful of tiles; two tiles that collide on the torus take the direct global path)
   __shared__ volatile int slot_tile[4][16];
   __shared__ int slot_cnt[4][16], slot_base[4][16];
-  constexpr int PW = P / 4, HPB = 32 / DH;
+  constexpr int PW = P / 4, HPB = 128 / (DH * ES);
   WinGeom g;
   if (!tile_decode8<HPB>(a, chunk, g)) return;
   const int lane = threadIdx.x & 63, wv = wave_in_block();
@@ -310,24 +337,27 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
   int4 bb = make_int4(INT_MAX, INT_MAX, -1, -1);
 #pragma unroll
   for (int hh = 0; hh < HPB; ++hh)
-    bb = box_union(bb, tile_points<P, true, K1>(a, bq, valid, g.hg * HPB + hh, pp, wv, lane, rx[hh], ry[hh], rw[hh], wbox[hh]));
+    bb = box_union(bb, tile_points<P, true, K1, TO>(a, bq, valid, g.hg * HPB + hh, pp, wv, lane, rx[hh], ry[hh], rw[hh], wbox[hh]));
   const TileWin tw = tile_window(a, bb, g, max_box);
-  tile_fill(a, g, tw, g.hg, rowi, win);
+  tile_fill(a, g, tw, g.hg, rowi * ES / 4, win);
 
 #pragma unroll
   for (int hh = 0; hh < HPB; ++hh) {
   const int h = g.hg * HPB + hh;
-  const unsigned char* wh = win + hh * (DH * 4);
+  const unsigned char* wh = win + hh * (DH * ES);
   float go[DH];
   {
-    const float4* gp = reinterpret_cast<const float4*>((const float*)a.gout + bq * rowi + h * DH);
+    constexpr int V = 16 / ES;
+    const T* gp = (const T*)a.gout + bq * rowi + h * DH;
 #pragma unroll
-    for (int i = 0; i < DH / 4; ++i) {
-      const float4 v = gp[i];
-      go[4 * i] = v.x; go[4 * i + 1] = v.y; go[4 * i + 2] = v.z; go[4 * i + 3] = v.w;
+    for (int i = 0; i < DH / V; ++i) {
+      float v[V];
+      vec_io<T, V>::load(gp + V * i, v);
+#pragma unroll
+      for (int e = 0; e < V; ++e) go[V * i + e] = v[e];
     }
   }
-  const float* vb = (const float*)a.value + (long)g.b * a.fh * a.fw * rowi + h * DH;      // wave-uniform
+  const T* vb = (const T*)a.value + (long)g.b * a.fh * a.fw * rowi + h * DH;      // wave-uniform
 
   float gw[PW], gx[PW], gy[PW];
   float sp = 0.0f;
@@ -344,13 +374,13 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
     }
     if (__ballot(miss) == 0ull) {          // all in the window (or masked out): straight-line code
 #pragma unroll
-      for (int k = 0; k < 4; ++k) d[k] = tile_dot<DH>(reinterpret_cast<const float*>(wh + (unsigned)max(wr[k], 0)), go) * f.m[k];
+      for (int k = 0; k < 4; ++k) d[k] = tile_dot<T, DH>(reinterpret_cast<const T*>(wh + (unsigned)max(wr[k], 0)), go) * f.m[k];
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         d[k] = 0.0f;
-        if (wr[k] >= 0) d[k] = tile_dot<DH>(reinterpret_cast<const float*>(wh + (unsigned)wr[k]), go);
-        else if (valid && f.m[k] != 0.0f) d[k] = tile_dot<DH>(gather_ptr(vb, (unsigned)(f.idx[k] * rowi)), go);
+        if (wr[k] >= 0) d[k] = tile_dot<T, DH>(reinterpret_cast<const T*>(wh + (unsigned)wr[k]), go);
+        else if (valid && f.m[k] != 0.0f) d[k] = tile_dot<T, DH>(gather_ptr(vb, (unsigned)(f.idx[k] * rowi)), go);
         d[k] *= f.m[k];
       }
     }
@@ -413,31 +443,39 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
   sp = add_xor<2>(add_xor<1>(sp));
   if (valid) {
     const float fwf = (float)a.fw, fhf = (float)a.fh;
-    float* __restrict__ glog = (float*)a.glog + bq * a.glog_stride + h * P;
-    float* __restrict__ goff = (float*)a.goff + bq * a.goff_stride + h * 2 * P;
+    TO* __restrict__ glog = (TO*)a.glog + bq * a.glog_stride + h * P;
+    TO* __restrict__ goff = (TO*)a.goff + bq * a.goff_stride + h * 2 * P;
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
       const int p = pp + 4 * j;
       if constexpr (K1) {
         // the operator's gradients: d(weight) = the interpolated dot, d(location) = w * g * (W, H)
-        glog[p] = gw[j];
-        *reinterpret_cast<float2*>(goff + 2 * p) = make_float2(rw[hh][j] * gx[j] * fwf, rw[hh][j] * gy[j] * fhf);
+        glog[p] = elem<TO>::from_float(gw[j]);
+        tile_store2<TO>(goff + 2 * p, rw[hh][j] * gx[j] * fwf, rw[hh][j] * gy[j] * fhf);
       } else {
-        glog[p] = rw[hh][j] * (gw[j] - sp);
+        glog[p] = elem<TO>::from_float(rw[hh][j] * (gw[j] - sp));
         // d loc = w * g * W; d off = d loc / W (the reference's rounding)
-        *reinterpret_cast<float2*>(goff + 2 * p) = make_float2((rw[hh][j] * gx[j] * fwf) / fwf, (rw[hh][j] * gy[j] * fhf) / fhf);
+        tile_store2<TO>(goff + 2 * p, (rw[hh][j] * gx[j] * fwf) / fwf, (rw[hh][j] * gy[j] * fhf) / fhf);
       }
     }
   }
   }  // heads of the line
 }
 
-// f32 data, Dh = 32 or 16 (H = 8), one map per sample, grid-tiled queries, no visibility / count: the BEV self-attention
-// and SCA-pts instances.  UBV_LIFT_TILE=0 switches the plan off (A/B runs against the window / gather kernels).
-bool tile_ok(const LiftArgs& a, int Dh, int P, int dtype) {
+// Dh = 32 or 16 (H = 8), one map per sample, grid-tiled queries, no visibility / count: the BEV self-attention and
+// SCA-pts instances.  f32 maps; since round 5 also 16-bit maps (a 128-byte line then holds two heads of 32 channels or
+// four of 16; offsets / logits f32 or in the map's type) — for the BACKWARD only by default: measured at bs = 2 (job
+// r5t1, bf16 / fp16, us) the query-gradient + binning kernel takes the self-attention backward 159 -> 145 / 138 and
+// SCA-pts' 265 -> 260 / 250, but the forward loses to the window / shared-footprint kernels (43 -> 56 / 49, 76 -> 95 /
+// 80: every element of a corner costs a lane an unpack instruction on top of its FMA, where those kernels spread a
+// corner over 8 lanes).  UBV_LIFT_TILE=0 switches the plan off (A/B runs against the window / gather kernels),
+// UBV_LIFT_TILE16=0 keeps Dh = 16 off it, UBV_LIFT_TILE_LP=0 / 1 / 2: 16-bit maps never / backward only / both ways.
+bool tile_ok(const LiftArgs& a, int Dh, int P, int dtype, bool bwd) {
   static const int env = getenv("UBV_LIFT_TILE") ? atoi(getenv("UBV_LIFT_TILE")) : 1;
   static const int env16 = getenv("UBV_LIFT_TILE16") ? atoi(getenv("UBV_LIFT_TILE16")) : 1;
-  return env != 0 && dtype == UBV_F32 && (Dh == 32 || (Dh == 16 && env16 != 0)) && a.H == 8 && (P == 4 || P == 8) && a.ol16 == 0 &&
+  static const int envlp = getenv("UBV_LIFT_TILE_LP") ? atoi(getenv("UBV_LIFT_TILE_LP")) : 1;
+  const bool type_ok = dtype == UBV_F32 ? a.ol16 == 0 : (envlp >= 2 || (envlp == 1 && bwd));
+  return env != 0 && type_ok && (Dh == 32 || (Dh == 16 && env16 != 0)) && a.H == 8 && (P == 4 || P == 8) &&
          a.Nc == 1 && a.qw > 0 && a.vis0 == nullptr && a.count == nullptr && a.fh >= 1 && a.fw >= 1;
 }
 
@@ -453,42 +491,74 @@ static int tile_max_box(const char* env, int P, int dflt4, int dflt8) {
   return P == 4 ? v4 : v8;
 }
 
-void tile_fwd_launch(const LiftArgs& a, int P, hipStream_t st, bool k1, int Dh) {
-  const long units = (long)a.total_tiles * (Dh == 16 ? 4 : 8);         // (tile, 128-byte line of heads)
-  const int chunk = (int)((units + 7) / 8);
-  static const int mb4 = tile_max_box("UBV_TILE_MAXBOX_FWD", 4, 256, 256), mb8 = tile_max_box("UBV_TILE_MAXBOX_FWD", 8, 256, 256);
+// (tile, 128-byte line of heads) units of a launch: 8 heads of Dh elements of `es` bytes
+static long tile_units(const LiftArgs& a, int Dh, int es) { return (long)a.total_tiles * (8 * Dh * es / 128); }
+
+template <typename T, bool OL16>
+static void tile_fwd_launch_t(const LiftArgs& a, int P, hipStream_t st, int Dh, int chunk, int mb4, int mb8) {
   const dim3 grid(8 * chunk), blk(256);
-  if (k1) {                                               // (the operator's form: Dh = 32 only)
-    if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4, 32, true>), grid, blk, kTWinLds, st, a, chunk, mb4);
-    else hipLaunchKernelGGL((lift_tile_fwd_kernel<8, 32, true>), grid, blk, kTWinLds, st, a, chunk, mb8);
-  } else if (Dh == 16) {
-    if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4, 16>), grid, blk, kTWinLds, st, a, chunk, mb4);
-    else hipLaunchKernelGGL((lift_tile_fwd_kernel<8, 16>), grid, blk, kTWinLds, st, a, chunk, mb8);
+  if (Dh == 16) {
+    if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4, 16, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, mb4);
+    else hipLaunchKernelGGL((lift_tile_fwd_kernel<8, 16, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, mb8);
   } else {
-    if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4, 32>), grid, blk, kTWinLds, st, a, chunk, mb4);
-    else hipLaunchKernelGGL((lift_tile_fwd_kernel<8, 32>), grid, blk, kTWinLds, st, a, chunk, mb8);
+    if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4, 32, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, mb4);
+    else hipLaunchKernelGGL((lift_tile_fwd_kernel<8, 32, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, mb8);
   }
 }
 
-// bins: the points are binned here (the caller zeroed a.bin_cnt / a.ovf_n and launches no lift_bin_kernel)
-void tile_bwd_query_launch(const LiftArgs& a, int P, bool bins, int tiles_x, int tiles, hipStream_t st, bool k1, int Dh) {
-  const long units = (long)a.total_tiles * (Dh == 16 ? 4 : 8);
+void tile_fwd_launch(const LiftArgs& a, int P, hipStream_t st, bool k1, int Dh, int dtype) {
+  const long units = tile_units(a, Dh, dtype == UBV_F32 ? 4 : 2);
   const int chunk = (int)((units + 7) / 8);
+  static const int mb4 = tile_max_box("UBV_TILE_MAXBOX_FWD", 4, 256, 256), mb8 = tile_max_box("UBV_TILE_MAXBOX_FWD", 8, 256, 256);
   const dim3 grid(8 * chunk), blk(256);
-  static const int mb4 = tile_max_box("UBV_TILE_MAXBOX_BWD", 4, 256, 256), mb8 = tile_max_box("UBV_TILE_MAXBOX_BWD", 8, 256, 256);
-  if (k1) {                                               // (the operator's backward always bins; Dh = 32 only)
-    if (P == 4) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4, 32, true, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb4);
-    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<8, 32, true, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb8);
-    return;
+  if (k1) {                                               // (the operator's form: f32, Dh = 32 only)
+    if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4, 32, true>), grid, blk, kTWinLds, st, a, chunk, mb4);
+    else hipLaunchKernelGGL((lift_tile_fwd_kernel<8, 32, true>), grid, blk, kTWinLds, st, a, chunk, mb8);
+  } else if (dtype == UBV_F32) {
+    tile_fwd_launch_t<float, false>(a, P, st, Dh, chunk, mb4, mb8);
+  } else if (dtype == UBV_F16) {
+    if (a.ol16) tile_fwd_launch_t<f16_t, true>(a, P, st, Dh, chunk, mb4, mb8);
+    else tile_fwd_launch_t<f16_t, false>(a, P, st, Dh, chunk, mb4, mb8);
+  } else {
+    if (a.ol16) tile_fwd_launch_t<bf16_t, true>(a, P, st, Dh, chunk, mb4, mb8);
+    else tile_fwd_launch_t<bf16_t, false>(a, P, st, Dh, chunk, mb4, mb8);
   }
+}
+
+template <typename T, bool OL16>
+static void tile_bwd_launch_t(const LiftArgs& a, int P, bool bins, int tiles_x, int tiles, hipStream_t st, int Dh, int chunk,
+                              int mb4, int mb8) {
+  const dim3 grid(8 * chunk), blk(256);
 #define UBV_TILE_BWD(PV, DHV, MB)                                                                                           \
   do {                                                                                                                      \
-    if (bins) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<PV, DHV, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, MB); \
-    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<PV, DHV, false>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, MB);     \
+    if (bins) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<PV, DHV, true, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, MB); \
+    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<PV, DHV, false, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, MB);     \
   } while (0)
   if (Dh == 16) { if (P == 4) UBV_TILE_BWD(4, 16, mb4); else UBV_TILE_BWD(8, 16, mb8); }
   else { if (P == 4) UBV_TILE_BWD(4, 32, mb4); else UBV_TILE_BWD(8, 32, mb8); }
 #undef UBV_TILE_BWD
+}
+
+// bins: the points are binned here (the caller zeroed a.bin_cnt / a.ovf_n and launches no lift_bin_kernel)
+void tile_bwd_query_launch(const LiftArgs& a, int P, bool bins, int tiles_x, int tiles, hipStream_t st, bool k1, int Dh,
+                           int dtype) {
+  const long units = tile_units(a, Dh, dtype == UBV_F32 ? 4 : 2);
+  const int chunk = (int)((units + 7) / 8);
+  const dim3 grid(8 * chunk), blk(256);
+  static const int mb4 = tile_max_box("UBV_TILE_MAXBOX_BWD", 4, 256, 256), mb8 = tile_max_box("UBV_TILE_MAXBOX_BWD", 8, 256, 256);
+  if (k1) {                                               // (the operator's backward always bins; f32, Dh = 32 only)
+    if (P == 4) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4, 32, true, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb4);
+    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<8, 32, true, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb8);
+    return;
+  }
+  if (dtype == UBV_F32) tile_bwd_launch_t<float, false>(a, P, bins, tiles_x, tiles, st, Dh, chunk, mb4, mb8);
+  else if (dtype == UBV_F16) {
+    if (a.ol16) tile_bwd_launch_t<f16_t, true>(a, P, bins, tiles_x, tiles, st, Dh, chunk, mb4, mb8);
+    else tile_bwd_launch_t<f16_t, false>(a, P, bins, tiles_x, tiles, st, Dh, chunk, mb4, mb8);
+  } else {
+    if (a.ol16) tile_bwd_launch_t<bf16_t, true>(a, P, bins, tiles_x, tiles, st, Dh, chunk, mb4, mb8);
+    else tile_bwd_launch_t<bf16_t, false>(a, P, bins, tiles_x, tiles, st, Dh, chunk, mb4, mb8);
+  }
 }
 
 }  // namespace ubv
