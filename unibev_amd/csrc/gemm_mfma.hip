@@ -1007,7 +1007,9 @@ extern "C" int ubv_debug_set_wgrad_ws(int dense, int sparse) {
 extern "C" int ubv_gemm_wgrad_splits(int64_t M, int N, int K) {
   const int tiles = ((N + ubv::kWgTile - 1) / ubv::kWgTile) * ((K + ubv::kWgTile - 1) / ubv::kWgTile);
   static const int blocks_env = getenv("UBV_WGRAD_BLOCKS") ? atoi(getenv("UBV_WGRAD_BLOCKS")) : 0;   // study knob
-  const int blocks = blocks_env > 0 ? blocks_env : (ubv::wgrad_ws_on() ? 256 : 512);
+  // one-tile products (C = 128 configurations: 128 x 128) take one block per CU: with two, a block's five chunks are
+  // as much prologue + 64 KB partial tile as product (cfg5 f32: 245.3 -> 247.8 samples/s, job r5c6)
+  const int blocks = blocks_env > 0 ? blocks_env : ((ubv::wgrad_ws_on() || tiles == 1) ? 256 : 512);
   long s = (blocks + tiles - 1) / tiles;                  // one 8-wave / two 4-wave blocks per CU
   const long max_s = (M + 255) / 256;                     // at least 256 rows per split
   if (s > max_s) s = max_s;
