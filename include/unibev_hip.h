@@ -61,7 +61,7 @@ int ubv_debug_ws_timing(uint64_t* out_host);
 /* Study / test aid: which weight-gradient kernel ubv_gemm_wgrad* (`dense`) and ubv_spconv_wgrad_pairs (`sparse`) launch
  * from now on.  0: the 4-wave kernel, two blocks per CU.  4 or 8: the wave-specialised kernel (csrc/gemm_wgrad_ws.inl:
  * that many producer waves + 4 MFMA waves, one block per CU).  -1: leave as it is.  Start values: dense 0
- * (UBV_WGRAD_WS=1 with UBV_WGRAD_PW=4|8 changes it), sparse 8 (UBV_SPCONV_WGRAD_WS=0|4|8).  Same results either way;
+ * (UBV_WGRAD_WS=1 with UBV_WGRAD_PW=4|8 changes it), sparse 0 (UBV_SPCONV_WGRAD_WS=0|4|8).  Same results either way;
  * ubv_gemm_wgrad_splits follows `dense`, so ask it again after a change.  Not thread-safe. */
 int ubv_debug_set_wgrad_ws(int dense, int sparse);
 

@@ -400,12 +400,11 @@ def test_weight_operand_kernel_equals_the_framework_composition(dtype):
                 assert lo is None and rlo is None
 
 
-@pytest.mark.parametrize('pw', [0, 4])
-def test_sparse_weight_gradient_on_the_other_kernels(pw):
-    """ubv_spconv_wgrad_pairs runs on csrc/gemm_wgrad_ws.inl with 8 producer waves by default (pair indices fetched two
-    chunks ahead of their rows, offsets packed into the 128-wide tile as in the 4-wave kernel) — what every test above
-    exercised.  Here the convolution and encoder tests are re-run on the 4-wave kernel (0) and on the 4-producer form
-    (ubv_debug_set_wgrad_ws)."""
+@pytest.mark.parametrize('pw', [4, 8])
+def test_sparse_weight_gradient_on_the_wave_specialised_kernel(pw):
+    """ubv_spconv_wgrad_pairs through csrc/gemm_wgrad_ws.inl (pair indices fetched two chunks ahead of their rows, offsets
+    packed into the 128-wide tile as in the 4-wave kernel, which is the default): the convolution and encoder tests
+    above, re-run with that kernel selected (ubv_debug_set_wgrad_ws)."""
     from unibev_amd._lib import lib
     assert lib().ubv_debug_set_wgrad_ws(-1, pw) == 0
     try:
@@ -414,4 +413,4 @@ def test_sparse_weight_gradient_on_the_other_kernels(pw):
         test_sparse_conv_forward_backward_vs_dense_oracle('subm', torch.bfloat16, 2e-2)
         test_sparse_encoder_vs_dense_oracle('basicblock')
     finally:
-        lib().ubv_debug_set_wgrad_ws(-1, 8)
+        lib().ubv_debug_set_wgrad_ws(-1, 0)

@@ -750,18 +750,34 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
   // chunk's rows go out without waiting for an index load — index -> row was two round trips in series per 64-row
   // chunk, with 48 MFMAs per wave to hide them behind (MFMA busy 18 % at 128 channels)
   int pix[GATHER ? NI : 1], piy[GATHER ? NI : 1];
+  // Round 5 (from csrc/gemm_wgrad_ws.inl): rows are counted from the slab's first row in 32 bits and an address is ONE
+  // v_mad_u64_u32 (row x pitch + base) — the 64-bit compares / selects / multiplies written here before were 22
+  // instructions per pair of loads, four of them quarter-rate multiplies.
+  constexpr int ES = SPLIT ? 4 : 2;                       // bytes per element
+  const long own_end = my_end > mbeg ? my_end : mbeg;
+  const int lim = (int)(own_end - mbeg) - 1;              // this thread's last row, relative (-1: none)
+  const bool second = SPLIT && n_split > 0 && n0 >= n_split;       // dual dY: block-uniform (n_split % 128 == 0)
+  const char* ybase = (const char*)(second ? dY2v : dYv);
+  const long yld = SPLIT && n_split > 0 ? (second ? N - n_split : n_split) : N;
+  const long ycol2 = (second && yok) ? ycol - n_split : ycol;
+  const char* ysl = ybase + ((GATHER ? 0L : mbeg * yld) + ycol2) * ES;
+  const char* xsl = (const char*)Xv + ((GATHER ? 0L : mbeg * (long)K) + xcol) * ES;
+  const uint32_t ypitch = (uint32_t)(yld * ES), xpitch = (uint32_t)((long)K * ES);
+  const int32_t* xlist = GATHER ? xidx + mbeg : nullptr;
+  const int32_t* ylist = (GATHER && yidx != nullptr) ? yidx + mbeg : nullptr;
   auto load_idx = [&](long mc) {
     if constexpr (GATHER) {
+      const int crel = (int)(mc - mbeg);
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        const long m = mc + sr + (256 / TPR) * i;
-        long mm = m < my_end ? m : my_end - 1;
-        mm = mm > 0 ? mm : 0;
+        int r = crel + sr + (256 / TPR) * i;
+        r = r < lim ? r : lim;
+        r = r > 0 ? r : 0;
         // (unconditional loads — a conditional one put a branch and a wait in front of the prefetch: 148 -> 221 us per
-        //  launch.  An offset with no pair in this slab reads entry 0 of its list, which ubv_spconv_pairs leaves
-        //  unwritten past the count: load_chunk never turns an index of a row past my_end into an address)
-        pix[i] = xidx[mm];
-        piy[i] = yidx != nullptr ? yidx[mm] : (int)mm;
+        //  launch.  An offset with no pair in this slab reads the slab's first entry of its list, which ubv_spconv_pairs
+        //  leaves unwritten past the count: load_chunk never turns an index of a row past my_end into an address)
+        pix[i] = xlist[r];
+        piy[i] = ylist != nullptr ? ylist[r] : (int)mbeg + r;
       }
     }
   };
@@ -772,31 +788,25 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
   uint32_t ymask = 0u, xmask = 0u;
   auto load_piece = [&](long mc, int i) __attribute__((always_inline)) {
     {
-      const long m = mc + sr + (256 / TPR) * i;
-      long mm = m < my_end ? m : my_end - 1;
-      mm = mm > 0 ? mm : 0;                               // (an offset with no pair in this slab: row 0, dropped)
-      long xm = mm, ym = mm;
-      bool xrow_ok = m < my_end;
+      const int rel = (int)(mc - mbeg) + sr + (256 / TPR) * i;
+      const bool ok = rel <= lim;
+      int r = rel < lim ? rel : lim;
+      r = r > 0 ? r : 0;                                   // (an offset with no pair in this slab: the slab's row 0, dropped)
+      int xr = r, yr = r;
+      bool xrow_ok = ok;
       if constexpr (GATHER) {
-        const int r = pix[i];
-        const bool in_list = xrow_ok;                      // m < my_end: only then are the indices defined
-        xrow_ok = xrow_ok && r >= 0;
-        xm = xrow_ok ? r : 0;
-        ym = (in_list && piy[i] >= 0) ? piy[i] : 0;
+        xrow_ok = ok && pix[i] >= 0;                       // rel <= lim: only then are the indices defined
+        xr = xrow_ok ? pix[i] : 0;
+        yr = (ok && piy[i] >= 0) ? piy[i] : 0;
       }
       if constexpr (SPLIT) {
-        if (n_split > 0) {
-          const bool second = n0 >= n_split;               // block-uniform (n_split % 128 == 0)
-          const float* yb = second ? (const float*)dY2v : (const float*)dYv;
-          fy[i] = *reinterpret_cast<const gf32x4_t*>(yb + ym * (long)(second ? N - n_split : n_split) + ((second && yok) ? ycol - n_split : ycol));
-        } else
-        fy[i] = *reinterpret_cast<const gf32x4_t*>((const float*)dYv + ym * N + ycol);
-        fx[i] = *reinterpret_cast<const gf32x4_t*>((const float*)Xv + xm * K + xcol);
+        fy[i] = *reinterpret_cast<const gf32x4_t*>(ysl + (uint64_t)(uint32_t)yr * ypitch);
+        fx[i] = *reinterpret_cast<const gf32x4_t*>(xsl + (uint64_t)(uint32_t)xr * xpitch);
       } else {
-        hy[i] = *reinterpret_cast<const gu32x4_t*>((const uint16_t*)dYv + ym * N + ycol);
-        hx[i] = *reinterpret_cast<const gu32x4_t*>((const uint16_t*)Xv + xm * K + xcol);
+        hy[i] = *reinterpret_cast<const gu32x4_t*>(ysl + (uint64_t)(uint32_t)yr * ypitch);
+        hx[i] = *reinterpret_cast<const gu32x4_t*>(xsl + (uint64_t)(uint32_t)xr * xpitch);
       }
-      ymask |= (m < my_end && yok) ? (1u << i) : 0u;
+      ymask |= (ok && yok) ? (1u << i) : 0u;
       xmask |= (xrow_ok && xok) ? (1u << i) : 0u;
     }
   };
@@ -812,11 +822,14 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
     *reinterpret_cast<uint2*>(th + o) = make_uint2(h0, h1);
     *reinterpret_cast<uint2*>(tl + o) = make_uint2(cvt_pk_bf16(r0, r1), cvt_pk_bf16(r2, r3));
   };
-  auto store_chunk = [&]() {
+  // masked = false: every piece of every lane of the wave is data (all chunks but a slab's last, whole tiles) — the
+  // four selects per piece, a fifth of the split's instructions, are skipped under a wave-uniform branch
+  auto store_pieces = [&](auto masked) __attribute__((always_inline)) {
+    constexpr bool MASKED = decltype(masked)::value;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int o = soff + (sr + (256 / TPR) * i) * 16;
-      const bool ky = (ymask >> i) & 1u, kx = (xmask >> i) & 1u;
+      const bool ky = !MASKED || ((ymask >> i) & 1u), kx = !MASKED || ((xmask >> i) & 1u);
       if constexpr (SPLIT) {
         split_store(ty_h, ty_l, o, ky ? fy[i] : gf32x4_t{0.f, 0.f, 0.f, 0.f});
         split_store(tx_h, tx_l, o, kx ? fx[i] : gf32x4_t{0.f, 0.f, 0.f, 0.f});
@@ -825,6 +838,11 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
         *reinterpret_cast<gu32x4_t*>(tx_h + o) = kx ? hx[i] : gu32x4_t{0u, 0u, 0u, 0u};
       }
     }
+  };
+  constexpr uint32_t ALLP = (1u << NI) - 1u;
+  auto store_chunk = [&]() {
+    if (__all(ymask == ALLP && xmask == ALLP)) store_pieces(std::false_type{});
+    else store_pieces(std::true_type{});
   };
 
   // fragment base of this lane inside an MFMA block whose first column group is c: group (lane >> 4) & 1
@@ -962,9 +980,11 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
 #include "gemm_wgrad_ws.inl"
 
 // Which weight-gradient kernel runs: 0 (default) the 4-wave kernel, two blocks per CU; 4 / 8 the wave-specialised one with
-// that many producer waves, one block per CU.  Measured (profiles/r05_wgrad_ws.txt): alone the wave-specialised kernel is
-// 8 - 10 % faster (80 000 x 256 x 256 cold: 65.7 -> 58.8 us), in the one-stream step + 1.6 %, in the two-stream step — the
-// default — - 0.6 %: a 133 KB block owns its CU and the other stream's kernels lose the co-residency they had.
+// that many producer waves, one block per CU.  Measured (profiles/r05_wgrad_ws.txt): alone the wave-specialised kernel was
+// 8 - 10 % faster than round 4's 4-wave kernel (80 000 x 256 x 256 cold: 65.7 -> 58.8 us), in the one-stream step + 1.6 %,
+// in the two-stream step — the default — - 0.6 %: a 133 KB block owns its CU and the other stream's kernels lose the
+// co-residency they had.  Its producer-side savings (32-bit row arithmetic, unmasked store path) then went into the
+// 4-wave kernel: 65 - 67 -> 62.4 us cold, 512 x 256 106 - 110 -> 97, two-stream step + 0.9 % (job r5a1).
 // UBV_WGRAD_WS=0 / 1 and UBV_WGRAD_PW=4 / 8 set the start value, ubv_debug_set_wgrad_ws changes it (tests).
 static int g_wgrad_ws = -1;
 static int wgrad_ws_mode() {
@@ -976,13 +996,14 @@ static int wgrad_ws_mode() {
   return g_wgrad_ws;
 }
 static bool wgrad_ws_on() { return wgrad_ws_mode() != 0; }
-// The sparse convolutions' weight gradient (ubv_spconv_wgrad_pairs) runs in the LiDAR front end, outside the two-stream
-// region, where the wave-specialised kernel's gain is not paid back: 8 producer waves by default (middle encoder
-// 10.25 -> 9.96 ms); UBV_SPCONV_WGRAD_WS=0 / 4 / 8.
+// The sparse convolutions' weight gradient (ubv_spconv_wgrad_pairs): same choice, its own switch
+// (UBV_SPCONV_WGRAD_WS=0 / 4 / 8, default 0).  It ran on the wave-specialised kernel for a few sessions (the LiDAR front
+// end is outside the two-stream region: middle encoder 10.25 -> 9.96 ms); since the 4-wave kernel took over that
+// kernel's row arithmetic and unmasked store path the two are level there too (10.01 - 10.10 vs 10.06 - 10.30 ms, job r5a2).
 static int g_spwg_ws = -1;
 static int spwg_ws_mode() {
   if (g_spwg_ws < 0) {
-    const int v = getenv("UBV_SPCONV_WGRAD_WS") ? atoi(getenv("UBV_SPCONV_WGRAD_WS")) : 8;
+    const int v = getenv("UBV_SPCONV_WGRAD_WS") ? atoi(getenv("UBV_SPCONV_WGRAD_WS")) : 0;
     g_spwg_ws = v == 0 ? 0 : (v == 4 ? 4 : 8);
   }
   return g_spwg_ws;
