@@ -64,3 +64,26 @@ def test_weight_stationary_gemm_kernels_do_not_spill(tmp_path):
             assert 'scratch_' not in body, f'{m.group(1)} spills (scratch instructions in its code)'
             assert 'global_load_lds_dwordx4' in body and 'v_mfma_f32_32x32x16_bf16' in body
     assert found >= 12, f'only {found} gemm_ws_kernel instantiations found in the library'
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason='llvm-objdump of the ROCm toolchain not found')
+def test_weight_gradient_kernels_keep_their_closures_in_registers(tmp_path):
+    """csrc/gemm_mfma.hip's weight-gradient kernels are built from nested lambdas; one arrangement of them (the chunk loop as
+    a lambda around the product lambda, two instantiations live) made hipcc keep a closure in scratch memory and re-read it
+    every chunk — no spill is reported for that.  No instantiation of gemm_wgrad_kernel / gemm_wgrad_ws_kernel may hold a
+    scratch instruction."""
+    so = os.path.join(ROOT, 'unibev_amd', 'libunibev_hip.so')
+    if not os.path.exists(so):
+        import __graft_entry__ as g
+        g.build()
+    shutil.copy(so, tmp_path / 'lib.so')
+    subprocess.run([OBJDUMP, '--offloading', 'lib.so'], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL)
+    found = 0
+    for f in [f for f in os.listdir(tmp_path) if f.endswith('gfx950')]:
+        out = subprocess.run([OBJDUMP, '-d', f], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        for m in re.finditer(r'^[0-9a-f]+ <(_ZN3ubv\d+gemm_wgrad(?:_ws)?_kernelI[^>]*)>:\n(.*?)s_endpgm', out, flags=re.M | re.S):
+            found += 1
+            assert 'scratch_' not in m.group(2), f'{m.group(1)} uses scratch memory'
+    assert found >= 12, f'only {found} weight-gradient kernels found in the library'
+

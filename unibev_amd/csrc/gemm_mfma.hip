@@ -864,6 +864,9 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
     // 256 x 256, job r5s): the next chunk's 2 NI loads of dense operands issued BETWEEN the MFMA groups of this chunk, NI / 2
     // per K step, instead of one burst in front of them — what took the weight-stationary forward GEMM's tile from 5 700 to
     // 4 400 cycles (csrc/gemm_ws.hip) does nothing here: this kernel's time is its transposing LDS reads and barriers.
+    // Also measured and dropped (job r5a1, second run): the wave-specialised kernel's consumer side — fragments of k step
+    // s + 1 read before the MFMAs of step s, the bias product as a compile-time variant — 210 -> 234 registers, two-stream
+    // step 151.4 -> 150.7 samples/s.
     constexpr bool SPREAD = !GATHER && UBV_WGRAD_SPREAD;
     const bool more = mc + kWgMC < mend;
     if (more) {
