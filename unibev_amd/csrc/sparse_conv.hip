@@ -463,16 +463,34 @@ __global__ __launch_bounds__(64 * NW) void spconv_gather_mma_kernel(const T* __r
   }
   // D[i][n]: this lane holds column n = lane & 31 (output channel within block j), rows (r & 3) + 8 (r >> 2) + 4 kg
   if (!wave_live) return;
+  // Round 5: the stores go through a wave-uniform base (this wave's first row) + a 32-bit element offset, and the row
+  // bound is tested once per wave — written as `out[orow * Cout + n]` under `if (orow < rows)` the epilogue was 1 570
+  // instructions for its 128 stores (a 64-bit multiply, compare and branch per store: 387 quarter-rate multiplies), ~5 %
+  // of the kernel's cycles at 128 channels.
+  T* __restrict__ ob = out + row0 * Cout;
+  const uint32_t lo = (uint32_t)(4 * kg * Cout + m);      // lane's offset inside the wave's 64 rows x Cout block (< 2^13)
+  const uint32_t uc = (uint32_t)Cout;
+  if (row0 + 32 * RB <= rows) {                           // every row of the wave exists (all waves but the last one)
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        if (j * 32 + m >= Cout) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          ob[lo + (uint32_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * uc + (uint32_t)(j * 32)] = elem<T>::from_float(acc[i][j][r]);
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < RB; ++i)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      const int n = j * 32 + m;
-      if (n >= Cout) continue;
+      if (j * 32 + m >= Cout) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const long orow = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-        if (orow < rows) out[orow * Cout + n] = elem<T>::from_float(acc[i][j][r]);
+        const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
+        if (row0 + rr + 4 * kg < rows) ob[lo + (uint32_t)rr * uc + (uint32_t)(j * 32)] = elem<T>::from_float(acc[i][j][r]);
       }
     }
 }
