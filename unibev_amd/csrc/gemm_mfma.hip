@@ -824,6 +824,9 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
   };
   // masked = false: every piece of every lane of the wave is data (all chunks but a slab's last, whole tiles) — the
   // four selects per piece, a fifth of the split's instructions, are skipped under a wave-uniform branch
+  // A thread whose columns lie past N / K (the 96 columns of a 128-wide tile: sampling_offsets | attention_weights, the last
+  // tile of the fused 352-wide product) holds zeros in its LDS slots from the start and skips its stores on the unmasked
+  // path — its column tail alone used to send the whole wave down the masked one in every chunk.
   auto store_pieces = [&](auto masked) __attribute__((always_inline)) {
     constexpr bool MASKED = decltype(masked)::value;
 #pragma unroll
@@ -831,19 +834,32 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const void* __restri
       const int o = soff + (sr + (256 / TPR) * i) * 16;
       const bool ky = !MASKED || ((ymask >> i) & 1u), kx = !MASKED || ((xmask >> i) & 1u);
       if constexpr (SPLIT) {
-        split_store(ty_h, ty_l, o, ky ? fy[i] : gf32x4_t{0.f, 0.f, 0.f, 0.f});
-        split_store(tx_h, tx_l, o, kx ? fx[i] : gf32x4_t{0.f, 0.f, 0.f, 0.f});
+        if (MASKED || yok) split_store(ty_h, ty_l, o, ky ? fy[i] : gf32x4_t{0.f, 0.f, 0.f, 0.f});
+        if (MASKED || xok) split_store(tx_h, tx_l, o, kx ? fx[i] : gf32x4_t{0.f, 0.f, 0.f, 0.f});
       } else {
-        *reinterpret_cast<gu32x4_t*>(ty_h + o) = ky ? hy[i] : gu32x4_t{0u, 0u, 0u, 0u};
-        *reinterpret_cast<gu32x4_t*>(tx_h + o) = kx ? hx[i] : gu32x4_t{0u, 0u, 0u, 0u};
+        if (MASKED || yok) *reinterpret_cast<gu32x4_t*>(ty_h + o) = ky ? hy[i] : gu32x4_t{0u, 0u, 0u, 0u};
+        if (MASKED || xok) *reinterpret_cast<gu32x4_t*>(tx_h + o) = kx ? hx[i] : gu32x4_t{0u, 0u, 0u, 0u};
       }
     }
   };
   constexpr uint32_t ALLP = (1u << NI) - 1u;
   auto store_chunk = [&]() {
-    if (__all(ymask == ALLP && xmask == ALLP)) store_pieces(std::false_type{});
+    if (__all((ymask == ALLP || !yok) && (xmask == ALLP || !xok))) store_pieces(std::false_type{});
     else store_pieces(std::true_type{});
   };
+  if (!yok || !xok) {                                     // the column tail's slots: zero, once (ordered by the loop's first barrier)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int o = soff + (sr + (256 / TPR) * i) * 16;
+      if constexpr (SPLIT) {
+        if (!yok) { *reinterpret_cast<uint2*>(ty_h + o) = make_uint2(0u, 0u); *reinterpret_cast<uint2*>(ty_l + o) = make_uint2(0u, 0u); }
+        if (!xok) { *reinterpret_cast<uint2*>(tx_h + o) = make_uint2(0u, 0u); *reinterpret_cast<uint2*>(tx_l + o) = make_uint2(0u, 0u); }
+      } else {
+        if (!yok) *reinterpret_cast<gu32x4_t*>(ty_h + o) = gu32x4_t{0u, 0u, 0u, 0u};
+        if (!xok) *reinterpret_cast<gu32x4_t*>(tx_h + o) = gu32x4_t{0u, 0u, 0u, 0u};
+      }
+    }
+  }
 
   // fragment base of this lane inside an MFMA block whose first column group is c: group (lane >> 4) & 1
   // selects c / c + 4, lane >> 5 the reduction half (rows 8 .. 15), lane & 15 the piece
