@@ -78,7 +78,7 @@ def parity_record(workload, names, device, fp32_stream):
         for n in names:
             dt = DTYPES[n]
             model.lowp_stream = not fp32_stream
-            with torch.no_grad(), torch.autocast('cuda', dtype=dt, enabled=dt != torch.float32):
+            with torch.no_grad(), value_storage(n), torch.autocast('cuda', dtype=dt, enabled=dt != torch.float32):
                 fused = model.encode(img, pts, t(inp['bev_q'], device=device), inp['bev_h'], inp['bev_w'],
                                      bev_pos=t(inp['bev_pos'], device=device), img_metas=inp['metas'])
             f = fused.float().cpu().numpy().reshape(-1)
@@ -97,8 +97,11 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--bs', type=int, default=2, help='samples per GPU (cfg4: 2)')
-    ap.add_argument('--dtype', default='all', choices=['all', 'bf16', 'fp16', 'fp32'],
-                    help="'all': fp32 headline + bf16 and fp16 sub-records")
+    ap.add_argument('--dtype', default='all', choices=['all', 'bf16', 'fp16', 'fp32', 'value-fp16'],
+                    help="'all': fp32 headline + value-fp16, bf16 and fp16 sub-records.  'value-fp16': the f32 step (f32 residual "
+                         "stream, offsets, logits, split-bf16 MFMA Linear layers) with ONLY the projected value maps and the "
+                         "sampled outputs stored in fp16 (deform_attn.set_value_storage): the sub-f32 mode that holds the 1e-3 "
+                         "bar at the operating point and on cfg5")
     ap.add_argument('--workload', default='LC_cnw', choices=['LC_cnw', 'C', 'L', 'LC_cat128'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
@@ -115,8 +118,19 @@ def parse():
                          "torch.distributed.run with N ranks; 'spawn': always (also N = 1: one rank with a process "
                          "group, the multi-GPU code path on a one-GPU box); 'none': never")
     ap.add_argument('--cpu-baseline-plan', action='store_true',
-                    help='BASELINE.md section 3 in full (forward of cfg1-cfg5, forward + backward of cfg2 / cfg3) through the '
-                         'oracle on this host, as `cpu_baseline_plan`; a few minutes of CPU time, not part of the default run')
+                    help='BASELINE.md section 3 with 1 warm-up + up to 5 timed passes per entry (forward of cfg1-cfg5, forward + '
+                         'backward of cfg2 / cfg3) through the oracle on this host, as `cpu_baseline_plan`; a few minutes of CPU '
+                         'time.  The DEFAULT run carries the same plan bounded to ~1 minute (1 warm-up + <= 2 timed passes per entry)')
+    ap.add_argument('--no-cpu-baseline-plan', action='store_true', help='skip `cpu_baseline_plan` altogether')
+    ap.add_argument('--cpu-baseline-child', type=int, default=0, metavar='THREADS',
+                    help='(internal) time the CPU baseline pass with THREADS torch threads and print the seconds per pass')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launcher + process group + gradient-exchange protocol on tiny CPU tensors (gloo when no GPU is '
+                         'visible): rank environment, one JSON line from rank 0, `rccl_ranks` == N; no kernels, no timing claim')
+    ap.add_argument('--allreduce-algo', default='auto', choices=['auto', 'default', 'ring'],
+                    help="RCCL all-reduce algorithm: 'default' = RCCL's own choice (direct on a fully connected xGMI node), "
+                         "'ring' = NCCL_ALGO=Ring, 'auto' = ring for --exchange split (its collectives run beside the "
+                         "backward's GEMMs: dp.init_distributed), default otherwise.  Recorded in config.collective")
     ap.add_argument('--allow-eager', action='store_true',
                     help='if HIP-graph capture fails, time eager launches instead of exiting non-zero')
     ap.add_argument('--no-parity', action='store_true',
@@ -129,8 +143,10 @@ def parse():
     ap.add_argument('--exchange', default='auto', choices=['auto', 'split', 'single'],
                     help="gradient exchange: 'split' = the backward is two HIP graphs cut at the first encoder layers and the "
                          "upper layers' segment of the flat gradient buffer is all-reduced beside the second graph; 'single' = "
-                         "one graph, one message after it; 'auto' = split for N > 1, single for one GPU.  The overlapped "
-                         "segments are SUM all-reduces on RCCL's ring (dp.init_distributed pins NCCL_ALGO=Ring: the ring "
+                         "one graph, one message after it; 'auto' = single (the overlapped exchange has only ever run with one "
+                         "rank: it stays opt-in until a multi-GPU box has executed it — a rank-local failure inside a split-mode "
+                         "collective would leave the other ranks waiting).  The overlapped "
+                         "segments are SUM all-reduces on RCCL's ring (--allreduce-algo: the ring "
                          "FuncSum kernels hold no packed f32 instruction, profiles/r04_rccl_packed_f32_functions.txt) and are "
                          "divided by the world size when waited for")
     ap.add_argument('--lr', type=float, default=2e-4, help='AdamW learning rate (0: the step runs, the parameters stay put)')
@@ -161,7 +177,23 @@ WORKLOADS = {
                   'unibev_nus_LC_cat_128_modality_dropout: L+C cat, 6x(25x45) img tokens '
                   '[800x1440/32], 200x200x128 BEV'),
 }
-DTYPES = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}
+DTYPES = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32, 'value-fp16': torch.float32}
+VALUE_STORAGE = {'value-fp16': torch.float16}     # modes that store only the projected value maps / sampled outputs in 16 bits
+
+
+class value_storage:
+    """``with value_storage(mode)``: deform_attn.set_value_storage for the modes of VALUE_STORAGE, restored on exit."""
+
+    def __init__(self, name):
+        self.st = VALUE_STORAGE.get(name)
+
+    def __enter__(self):
+        from unibev_amd.modules.deform_attn import set_value_storage
+        self.prev = set_value_storage(self.st)
+
+    def __exit__(self, *exc):
+        from unibev_amd.modules.deform_attn import set_value_storage
+        set_value_storage(self.prev)
 
 
 def build_head(workload, device):
@@ -303,6 +335,11 @@ def traffic_of(op_rec, dtype_name, workload, bs):
 
 def run_mode(args, name, head, world, rank, device, want_ops):
     """Warm up, capture, time K steps of one precision mode.  Returns the mode's record."""
+    with value_storage(name):
+        return _run_mode(args, name, head, world, rank, device, want_ops)
+
+
+def _run_mode(args, name, head, world, rank, device, want_ops):
     from unibev_amd import functional as UF
     from unibev_amd.graph_step import GraphedStep
     dtype = DTYPES[name]
@@ -317,7 +354,7 @@ def run_mode(args, name, head, world, rank, device, want_ops):
     s = 2 if kw.get('fusion_method') == 'cat' else 1
     C = kw['embed_dims']
     cot = torch.randn(200 * 200, args.bs, C * s, device=device) / 200.0
-    split = args.exchange == 'split' or (args.exchange == 'auto' and world > 1)
+    split = args.exchange == 'split'
     tr = head.transformer
     encs = [getattr(tr, n) for n in ('img_bev_encoder', 'pts_bev_encoder') if getattr(tr, n, None) is not None]
     cut = encs if split else None
@@ -415,7 +452,8 @@ def run_mode(args, name, head, world, rank, device, want_ops):
            'gradient_exchange': ('split: 2 HIP graphs, segment 0 (%d of %d bytes) all-reduced beside the second graph'
                                  % (gs.grads.segments[0].numel() * 4, gs.grads.flat.numel() * 4))
            if len(gs.grads.segments) == 2 else ('single message after the graph' + (f' ({gs.split_note})' if getattr(gs, 'split_note', None) else '')),
-           'residual_stream': 'f32' if (args.fp32_stream or name == 'fp32') else name}
+           'residual_stream': 'f32' if (args.fp32_stream or DTYPES[name] == torch.float32) else name,
+           'value_storage': 'fp16' if name in VALUE_STORAGE else ('f32' if name == 'fp32' else name)}
     # ---- per-op roofline: the same step, eager, HIP events on the launch stream around every
     # sampling kernel / op (events cannot be read back from inside a captured graph)
     if want_ops and not args.no_kernel_timing:
@@ -456,6 +494,7 @@ def run_mode(args, name, head, world, rank, device, want_ops):
                                               WORKLOADS[args.workload][1])
             pairs = args.bs * int(vis0.sum().item())         # rows of sample 0's visibility (quirk q1) per sample
         ops = op_roofline(prof, sampling_ops(args.workload, args.bs, 4 if name == 'fp32' else 2, pairs), prof_ops)
+        # (value-fp16: the op's operands are the fp16 value map, f32 offsets / logits, fp16 rows — priced at 2 bytes like the 16-bit modes)
         for o in ops:
             o['traffic'] = traffic_of(o, name, args.workload, args.bs)
         rec['roofline_ops'] = ops
@@ -693,10 +732,11 @@ def self_launch(args):
     torch.distributed.launch, tools/train_UniBEV.py:242-249)."""
     import socket
     import subprocess
-    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
-    have = torch.cuda.device_count()
-    if have < args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but only {have} GPU(s) are visible')
+    if not args.dry_run:
+        assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f'--gpus {args.gpus} but only {have} GPU(s) are visible')
     with socket.socket() as sock:
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
@@ -708,6 +748,78 @@ def self_launch(args):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
     return subprocess.call(cmd, env=env)
+
+
+def allreduce_algo(args):
+    """'ring' | 'default' for dp.init_distributed: the overlapped exchange asks for the ring (see --allreduce-algo)."""
+    if args.allreduce_algo != 'auto':
+        return args.allreduce_algo
+    return 'ring' if args.exchange == 'split' else 'default'
+
+
+def dry_run(args, rank, world, local):
+    """The N-rank protocol of this script without its kernels: process group from the launcher's environment (RCCL when
+    GPUs are visible, gloo on CPU), identical replicas of a small registry-built module, per-rank synthetic gradients,
+    the flat-buffer exchange in the selected mode (`single`: one averaged message; `split`: two segments, the first in
+    flight while the second is collected), barrier + max-over-ranks timing, and rank 0's single JSON line.  The averaged
+    gradients are checked against their closed form on every rank; a mismatch exits non-zero.  What a first multi-GPU
+    run can then still get wrong is RCCL / HIP-graph specific, not the launcher, the rank environment or the exchange
+    bookkeeping (tests/test_bench_dryrun.py drives this with world_size 2 on gloo)."""
+    from unibev_amd import dp
+    from unibev_amd.registry import build_feedforward_network
+    use_gpu = torch.cuda.is_available() and torch.cuda.device_count() >= world
+    if use_gpu:
+        torch.cuda.set_device(local)
+    device = torch.device('cuda', local) if use_gpu else torch.device('cpu')
+    dp.init_distributed('nccl' if use_gpu else 'gloo', device if use_gpu else None, algo=allreduce_algo(args))
+    torch.manual_seed(0)                                          # identical replicas
+    net = torch.nn.Sequential(build_feedforward_network(dict(type='FFN', embed_dims=32, feedforward_channels=64, ffn_drop=0.0)),
+                              torch.nn.LayerNorm(32)).to(device)
+    params = list(net.parameters())
+    split = args.exchange == 'split'
+    fg = dp.FlatGradients(params, first_segment=2 if split else None)
+    fg.attach()
+
+    def step(k):
+        grads = [torch.full_like(p, float((rank + 1) * (k + 1))) for p in params]     # what a backward would leave
+        if split:
+            fg.collect(0, 2, grads[:2])
+            fg.start_segment(0)
+            fg.collect(2, len(params), grads[2:])
+            fg.start_segment(1)
+            fg.finish_segments()
+        else:
+            fg.collect(grads=grads)
+            fg.all_reduce_mean()
+
+    for k in range(args.warmup):
+        step(k)
+    dp.barrier(device if use_gpu else None)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    dp.barrier(device if use_gpu else None)
+    dt = dp.max_over_ranks(time.perf_counter() - t0, device)
+    want = (args.steps) * (world + 1) / 2.0 if args.steps else 0.0              # mean over ranks of (rank + 1) * steps
+    ok = args.steps == 0 or bool(torch.allclose(fg.flat, torch.full_like(fg.flat, want)))
+    ok_all = dp.min_over_ranks(1.0 if ok else 0.0, device) == 1.0
+    if rank == 0:
+        line = {'metric': 'nuScenes samples/sec BEV-encoder fwd+bwd', 'value': None, 'unit': 'samples/s', 'n_gpus': world,
+                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / max(args.steps, 1),
+                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
+                'dry_run': True, 'exchange_ok': ok_all,
+                'config': {'workload': 'dry run: launcher + exchange protocol on a 32-channel FFN + LayerNorm, no kernels',
+                           'per_gpu_batch': args.bs, 'global_batch': world * args.bs, 'parallelism': f'dp{world}',
+                           'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
+                           'collective': dp.collective_info(),
+                           'gradient_exchange': 'split' if split else 'single',
+                           'launcher': 'self (bench.py -> torch.distributed.run)' if os.environ.get('UBV_BENCH_CHILD') == '1'
+                                       else ('torchrun' if 'LOCAL_RANK' in os.environ else 'single process')}}
+        print(json.dumps(line, allow_nan=False), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    if not ok_all:
+        raise SystemExit('dry run: the exchanged gradients differ from their closed form')
 
 
 LINE_LIMIT = 6000          # bytes of the final stdout line (the driver keeps a 9 KB tail of stdout: VERDICT r4 item 1)
@@ -745,6 +857,7 @@ def compact(full):
                  'mode': cfg['mode'].split(' (')[0], 'parallelism': cfg['parallelism'], 'rccl_ranks': cfg['rccl_ranks'],
                  'gemm_arithmetic': ('f32 storage, Linear = split-bf16 x3 MFMA, f32 accumulate' if full['dtype'] == 'fp32'
                                      else cfg['gemm_arithmetic']),
+                 'collective': cfg.get('collective'),
                  'sampling_params': cfg['sampling_params'].split(':')[0],
                  'streams': 2 if cfg['streams'].startswith('image') else 1,
                  'step': cfg['step'], 'gradient_exchange': cfg['gradient_exchange'].split(':')[0].split(' (')[0],
@@ -775,7 +888,8 @@ def compact(full):
         out['ieee_gemm_parity_worst'] = max(ip['distance'].values()) if ip.get('distance') else None
     if 'lowp' in full:
         out['lowp'] = {r['dtype']: {'value': r['value'], 'parity_pass': (r.get('parity') or {}).get('pass'),
-                                    'parity_worst': max(r['parity']['distance'].values()) if r.get('parity') else None}
+                                    'parity_worst': max(r['parity']['distance'].values()) if r.get('parity') else None,
+                                    'parity_distance': (r.get('parity') or {}).get('distance')}
                        for r in full['lowp']}
     if 'gemm' in full:
         g = {(x['dtype'], x['N'], x['K']): x for x in full['gemm']}
@@ -794,9 +908,13 @@ def compact(full):
     if 'cpu_baseline' in full:
         c = full['cpu_baseline']
         out['cpu_baseline'] = {k: c[k] for k in ('value', 'unit', 'cores', 'kind', 'sample')}
+        out['cpu_baseline']['host_cores'] = c.get('host_cores')
+        # samples/s at other thread counts (all host threads = BASELINE.md section 3's os.cpu_count()); None: timed out
+        out['cpu_baseline']['threads_scan'] = {n: v.get('samples_per_s') for n, v in (c.get('threads_scan') or {}).items()}
     if 'cpu_baseline_plan' in full:
         out['cpu_baseline_plan'] = {e['config'].split()[0] + ':' + e['pass']: e['samples_per_s']
                                     for e in full['cpu_baseline_plan']['entries']}
+        out['cpu_baseline_plan']['threads'] = full['cpu_baseline_plan']['cores']
     out['extras'] = 'bench_extras.json (long form of every record; also the `#extras ` stderr line)'
     out = _r(out)
     if full.get('grad_checksum'):                 # (compared between runs to 1e-5: not rounded)
@@ -840,6 +958,8 @@ def emit(full, extras_file):
 
 def main():
     args = parse()
+    if args.cpu_baseline_child > 0:
+        return cpu_baseline_child(args)
     torchrun = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
     if not torchrun and (args.launcher == 'spawn' or (args.launcher == 'auto' and args.gpus > 1)):
         raise SystemExit(self_launch(args))
@@ -850,6 +970,8 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with '
                          f'python -m torch.distributed.run --nproc-per-node {args.gpus} ... or drop the torchrun '
                          f'environment and let bench.py launch its own ranks')
+    if args.dry_run:
+        return dry_run(args, rank, world, local)
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
@@ -860,26 +982,15 @@ def main():
         from unibev_amd.modules import transformer as _tr
         _tr.set_two_streams(False)
     from unibev_amd import dp
-    dp.init_distributed('nccl', device)                       # RCCL over xGMI (no-op for N = 1)
+    dp.init_distributed('nccl', device, algo=allreduce_algo(args))   # RCCL over xGMI (no-op for N = 1)
 
     torch.manual_seed(0)          # identical replicas
     np.random.seed(rank)          # modality dropout is per process, as in the reference
     head, tcfg = build_head(args.workload, device)
     head.train(not args.eval_mode)
-    names = ['fp32', 'bf16', 'fp16'] if args.dtype == 'all' else [args.dtype]
+    names = ['fp32', 'value-fp16', 'bf16', 'fp16'] if args.dtype == 'all' else [args.dtype]
     set_sampling_params(head, 'spread' if args.params == 'spread' else 'init')
-    try:
-        recs = [run_mode(args, n, head, world, rank, device, want_ops=True) for n in names]
-    except Exception as e:
-        # `auto` chose the overlapped (split) exchange for N > 1, a path the builder could only exercise with one rank: if
-        # it fails the same way on every rank, the run falls back to one message after the backward and says so
-        if not (args.exchange == 'auto' and world > 1):
-            raise
-        print(f'[bench] overlapped gradient exchange failed ({type(e).__name__}: {e}); falling back to --exchange single',
-              file=sys.stderr, flush=True)
-        args.exchange = 'single'
-        torch.cuda.synchronize()
-        recs = [run_mode(args, n, head, world, rank, device, want_ops=True) for n in names]
+    recs = [run_mode(args, n, head, world, rank, device, want_ops=True) for n in names]
     spread = ieee = None
     if args.params == 'both':
         # second operating point of the headline precision: offsets scattered per query (trained-looking)
@@ -922,7 +1033,9 @@ def main():
                        'gemm_arithmetic': ('f32 storage; every Linear is a split-bf16 x3 MFMA product (x_hi w_hi + x_hi w_lo + '
                                            'x_lo w_hi, ~2^-17 per product) with f32 accumulation; sampling kernels plain f32; '
                                            'the IEEE-GEMM run of the same step rides along as `ieee_gemm`')
-                       if main_rec['dtype'] == 'fp32' else 'autocast ' + main_rec['dtype'],
+                       if main_rec['dtype'] == 'fp32' else
+                       ('as fp32 (split-bf16 x3 MFMA Linear layers, f32 stream); projected value maps and sampled outputs '
+                        'stored in fp16' if main_rec['dtype'] in VALUE_STORAGE else 'autocast ' + main_rec['dtype']),
                        'sampling_params': ('spread' if args.params == 'spread' else
                                            "init: the reference's init_weights (zero offset weights, compass-grid bias); "
                                            "`spread` sub-record: scattered offsets"),
@@ -939,6 +1052,7 @@ def main():
                                    else ('torchrun' if 'TORCHELASTIC_RUN_ID' in os.environ or 'LOCAL_RANK' in os.environ
                                          else 'single process'),
                        'parallelism': f'dp{world}', 'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
+                       'collective': dp.collective_info(),
                        'parity': main_rec.get('parity')},
             'roofline': main_rec.get('roofline'),
             'roofline_ops': main_rec.get('roofline_ops'),
@@ -957,21 +1071,18 @@ def main():
         # ---- CPU baseline: the oracle's forward on this host ------------------------------
         if world == 1 and not args.no_cpu_baseline:
             full['cpu_baseline'] = cpu_baseline(args, tcfg, head)
-        if world == 1 and args.cpu_baseline_plan:
-            full['cpu_baseline_plan'] = cpu_baseline_plan()
+        if world == 1 and not args.no_cpu_baseline and not args.no_cpu_baseline_plan:
+            # the default run carries the plan bounded to about a minute; --cpu-baseline-plan: the fuller protocol
+            full['cpu_baseline_plan'] = (cpu_baseline_plan() if args.cpu_baseline_plan else
+                                         cpu_baseline_plan(max_seconds=4.0, max_passes=2))
         emit(full, args.extras_file)
     if dist.is_initialized():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, tcfg, head):
-    """The oracle (CPU restatement of the reference path, oracle/unibev_ref.py) timed on the host:
-    forward only, fp32, bs = 1, eval mode; SURVEY.md section 8(d)'s protocol — 3 warm-up + 10 timed
-    passes, median — bounded to ~30 s of timed work (fewer passes on a slow host, stated)."""
+def _cpu_pass_fn(args, tcfg, head):
+    """The oracle's forward of the bench workload (bs = 1, fp32, eval) as a closure over CPU tensors."""
     from oracle import unibev_ref as R
-    # a 256-thread host oversubscribes torch's small CPU kernels (78.9 s/pass measured with all
-    # threads vs ~3 s with 16): the baseline uses at most 16 threads and says so
-    torch.set_num_threads(min(os.cpu_count() or 1, 16))
     sd = {k[len('transformer.'):]: v.detach().float().cpu() for k, v in head.state_dict().items()
           if k.startswith('transformer.')}
     img, pts, metas = synth_inputs(args.workload, 1, torch.float32, 'cpu', 0)
@@ -987,10 +1098,57 @@ def cpu_baseline(args, tcfg, head):
             return R.transformer_encode_fuse(sd, cfg, None if img is None else [x.detach() for x in img],
                                              None if pts is None else [x.detach() for x in pts],
                                              bev_q, 200, 200, pos, metas)
-    for _ in range(3):
+    return run
+
+
+def cpu_baseline_child(args):
+    """``--cpu-baseline-child T`` (run by cpu_baseline in a child process it can kill): one warm-up + one timed pass of
+    the oracle's forward with T torch threads; prints the seconds of the timed pass."""
+    torch.set_num_threads(args.cpu_baseline_child)
+    torch.manual_seed(0)
+    head, tcfg = build_head(args.workload, 'cpu')
+    head.eval()
+    run = _cpu_pass_fn(args, tcfg, head)
+    run()
+    t0 = time.perf_counter()
+    run()
+    print(f'cpu_pass_seconds {time.perf_counter() - t0:.4f}', flush=True)
+
+
+def cpu_thread_scan(args, counts, timeout_s):
+    """Seconds per pass at other thread counts, each in a child process that is killed after ``timeout_s`` (an
+    oversubscribed host does not come back from one pass in bounded time: 78.9 s measured with 256 threads)."""
+    import subprocess
+    out = {}
+    for n in counts:
+        cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-child', str(n), '--workload', args.workload]
+        env = dict(os.environ, OMP_NUM_THREADS=str(n), HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='')
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+            sec = [float(ln.split()[1]) for ln in r.stdout.splitlines() if ln.startswith('cpu_pass_seconds')]
+            out[str(n)] = ({'seconds_per_pass': sec[0], 'samples_per_s': 1.0 / sec[0]} if sec else
+                           {'error': (r.stderr or r.stdout).strip().splitlines()[-1][:160] if (r.stderr or r.stdout).strip() else f'rc {r.returncode}'})
+        except subprocess.TimeoutExpired:
+            out[str(n)] = {'timed_out_after_s': round(time.perf_counter() - t0, 1),
+                           'note': 'model build + warm-up + one pass did not finish: slower than the 16-thread figure'}
+    return out
+
+
+def cpu_baseline(args, tcfg, head):
+    """The oracle (CPU restatement of the reference path, oracle/unibev_ref.py) timed on the host:
+    forward only, fp32, bs = 1, eval mode; 2 warm-up + up to 6 timed passes, median, bounded to ~20 s of timed work
+    (fewer passes on a slow host, stated).  The headline figure uses 16 torch threads — all 256 hardware threads of the
+    GPU host oversubscribe torch's small CPU kernels — and ``threads_scan`` reports 64 threads and ALL host threads
+    (BASELINE.md section 3's ``os.cpu_count()``) beside it, each bounded by a time-out."""
+    # a 256-thread host oversubscribes torch's small CPU kernels (78.9 s/pass measured with all
+    # threads vs ~3 s with 16): the baseline uses at most 16 threads and says so
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    run = _cpu_pass_fn(args, tcfg, head)
+    for _ in range(2):
         run()
     times, spent = [], 0.0
-    while len(times) < 10 and spent < 30.0:
+    while len(times) < 6 and spent < 20.0:
         t0 = time.perf_counter()
         run()
         times.append(time.perf_counter() - t0)
@@ -1002,13 +1160,18 @@ def cpu_baseline(args, tcfg, head):
         cpu = [ln.split(':', 1)[1].strip() for ln in open('/proc/cpuinfo') if ln.startswith('model name')][0]
     except Exception:
         pass
+    ncpu = os.cpu_count() or 1
+    scan = {}
+    if ncpu > 16 and os.environ.get('UBV_CPU_SCAN', '1') != '0':
+        scan = cpu_thread_scan(args, [n for n in (64, ncpu) if 16 < n <= ncpu and (n == ncpu or n < ncpu)], 45.0)
+    best = max([1.0 / med] + [v['samples_per_s'] for v in scan.values() if 'samples_per_s' in v])
     return {'value': 1.0 / med, 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'cpu': cpu, 'host_cores': os.cpu_count(),
-            'sample': f'forward only, fp32, bs=1, eval: 3 warm-up + {len(times)} timed passes of the same '
+            'cpu': cpu, 'host_cores': ncpu, 'threads_scan': scan, 'best_samples_per_s': best,
+            'sample': f'forward only, fp32, bs=1, eval: 2 warm-up + {len(times)} timed passes of the same '
                       f'workload, median {med:.2f} s, through oracle/unibev_ref.py (torch CPU)'}
 
 
-def cpu_baseline_plan(threads=16, max_seconds=40.0):
+def cpu_baseline_plan(threads=16, max_seconds=40.0, max_passes=5):
     """the oracle's forward through ``fused_bev_embed`` for cfg1-cfg5 of BASELINE.json.configs
     (bs = 1, fp32, eval) and forward + backward for cfg2 / cfg3; 1 warm-up + up to 5 timed passes per entry (median),
     each entry bounded to ``max_seconds``.  ``threads`` torch CPU threads: all 256 hardware threads of the GPU host
@@ -1052,7 +1215,7 @@ def cpu_baseline_plan(threads=16, max_seconds=40.0):
         for backward in ((False, True) if with_bwd else (False,)):
             run(backward)
             times, spent = [], 0.0
-            while len(times) < 5 and spent < max_seconds:
+            while len(times) < max_passes and spent < max_seconds:
                 t0 = time.perf_counter()
                 run(backward)
                 times.append(time.perf_counter() - t0)
@@ -1066,7 +1229,8 @@ def cpu_baseline_plan(threads=16, max_seconds=40.0):
     except Exception:
         pass
     return {'kind': 'port', 'cores': torch.get_num_threads(), 'host_cores': os.cpu_count(), 'cpu': cpu,
-            'protocol': 'oracle/unibev_ref.py (torch CPU), fp32, bs = 1, eval, 1 warm-up + <= 5 timed passes, median', 'entries': out}
+            'protocol': f'oracle/unibev_ref.py (torch CPU), fp32, bs = 1, eval, 1 warm-up + <= {max_passes} timed passes '
+                        f'(each entry bounded to {max_seconds:g} s of timed work), median', 'entries': out}
 
 
 if __name__ == '__main__':

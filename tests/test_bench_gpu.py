@@ -61,8 +61,13 @@ def test_bench_json_contract(force_ddp):
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and 0 < r['frac'] < 1
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-4 * r['frac']      # (the line carries 5 significant digits)
     # the headline is the parity-grade precision; the 16-bit runs ride along with their own numbers
-    assert d['dtype'] == 'fp32' and list(d['lowp']) == ['bf16', 'fp16'] and [x['dtype'] for x in full['lowp']] == ['bf16', 'fp16']
-    assert all(x['value'] > d['value'] for x in d['lowp'].values())
+    modes = ['value-fp16', 'bf16', 'fp16']
+    assert d['dtype'] == 'fp32' and list(d['lowp']) == modes and [x['dtype'] for x in full['lowp']] == modes
+    assert all(d['lowp'][m]['value'] > d['value'] for m in ('bf16', 'fp16')) and d['lowp']['value-fp16']['value'] > 0
+    # the value-only fp16 mode holds the bar at the operating point (fullsize_init); every mode reports its distances
+    assert d['lowp']['value-fp16']['parity_distance']['fullsize_init'] < 1e-3
+    assert full['lowp'][0]['residual_stream'] == 'f32' and full['lowp'][0]['value_storage'] == 'fp16'
+    assert d['config']['collective'] is not None
     assert d['config']['rccl_ranks'] == 1 and d['config']['streams'] == 2
     assert d['spread_value'] > 0 and d['ieee_gemm_value'] > 0 and len(d['spread_roofline_ops']) == len(d['roofline_ops'])
     ops = {(o['op'], o['pass']) for o in full['roofline_ops']}
@@ -113,7 +118,7 @@ def test_bench_launches_its_own_ranks():
 
 def test_overlapped_exchange_gives_the_gradients_of_the_single_message():
     """``--exchange split`` (two HIP graphs, segment 0 of the flat gradient buffer all-reduced on RCCL's stream beside the
-    second graph: what ``auto`` selects for N > 1) against ``--exchange single`` through the same launcher, one rank WITH an
+    second graph: opt-in, ``auto`` = single) against ``--exchange single`` through the same launcher, one rank WITH an
     RCCL process group (or two on a two-GPU box), dropout off and learning rate 0 (every step then computes the same
     gradients; with updates a 1e-7 difference grows through AdamW's normalised steps): order-independent checksums of
     the exchanged gradients after the last step agree to 1e-5, the line says which mode ran and carries the per-phase times."""

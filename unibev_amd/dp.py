@@ -14,9 +14,18 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend=None, device=None):
+def init_distributed(backend=None, device=None, algo=None):
     """Initialise the default process group from the torchrun environment (RANK / WORLD_SIZE /
-    MASTER_ADDR / MASTER_PORT).  Returns (rank, world_size).  A single process needs no group."""
+    MASTER_ADDR / MASTER_PORT).  Returns (rank, world_size).  A single process needs no group.
+
+    ``algo``: all-reduce algorithm of the RCCL communicator — ``None`` / ``'default'`` leave the choice to RCCL
+    (an 8-GPU MI355X node is fully connected over xGMI: SURVEY.md section 5 prices the direct reduce-scatter +
+    all-gather at ~0.09 ms for the 55.6 MB gradient message against ~0.64 ms for a ring), ``'ring'`` pins
+    ``NCCL_ALGO=Ring`` — asked for ONLY by the overlapped exchange (``FlatGradients.start_segment``): of RCCL's SUM
+    reduction kernels the ring variants hold no packed f32 instruction (profiles/r04_rccl_packed_f32_functions.txt, one
+    RCCL build), and a collective that runs beside the backward's GEMMs is exactly where that matters
+    (profiles/r05_pk_mfma_hazard.txt).  A user's own NCCL_ALGO always wins; a difference is reported on stderr.  The pin
+    is applied before the communicator exists and only to single-node jobs."""
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if (world > 1 or force_ddp()) and not dist.is_initialized():
@@ -25,17 +34,32 @@ def init_distributed(backend=None, device=None):
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         kw = {}
-        if backend == 'nccl':
-            # RING all-reduce for every collective of this process (a user's own NCCL_ALGO wins).  The gradient segments
-            # that overlap the rest of the backward (FlatGradients.start_segment) are SUM all-reduces, and of RCCL's
-            # reduction kernels only the ring FuncSum variants hold no packed f32 instruction
-            # (profiles/r04_rccl_packed_f32_functions.txt; why that matters: profiles/r05_pk_mfma_hazard.txt).  On one
-            # node's point-to-point xGMI links the ring is also the bandwidth-optimal algorithm for 18 - 56 MB messages.
-            os.environ.setdefault('NCCL_ALGO', 'Ring')
+        if backend == 'nccl' and algo == 'ring':
+            one_node = int(os.environ.get('LOCAL_WORLD_SIZE', world)) == world
+            user = os.environ.get('NCCL_ALGO')
+            if user is not None and user.lower() != 'ring':
+                import sys
+                print(f'[dp] NCCL_ALGO={user} is set by the caller; the overlapped exchange was validated on Ring only',
+                      file=sys.stderr, flush=True)
+            elif one_node:
+                os.environ['NCCL_ALGO'] = 'Ring'
         if backend == 'nccl' and device is not None:
             kw['device_id'] = device
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world
+
+
+def collective_info():
+    """What the bench line records about the collective library: backend, RCCL version, NCCL_ALGO in effect."""
+    if not dist.is_initialized():
+        return {'backend': None, 'ranks': 1}
+    info = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(), 'NCCL_ALGO': os.environ.get('NCCL_ALGO', 'default')}
+    if info['backend'] == 'nccl':
+        try:
+            info['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                               # pragma: no cover
+            info['rccl_version'] = None
+    return info
 
 
 def force_ddp():
