@@ -180,6 +180,34 @@ __device__ __forceinline__ int4 box_union(const int4 a, const int4 b) {
   return make_int4(min(a.x, b.x), min(a.y, b.y), max(a.z, b.z), max(a.w, b.w));
 }
 
+// A box wider (taller) than the window — offsets scattered by several pixels per query, a trained layer's — cannot be
+// copied whole.  Anchoring the window at the box's smallest corner (round 4) then leaves the far side of the tile without
+// any margin: most waves had a corner outside and took the slow path.  The window is centred on the block's MEAN sampling
+// position instead (the sampling pattern of a head leans one way; the mean follows it), clamped into the box.  Only in
+// that case (block-uniform): one more barrier, three wave sums.  UBV_TILE_CENTER=0: the round-4 anchor (A/B runs).
+template <int HPB, int PW>
+__device__ __forceinline__ void tile_recentre(const LiftArgs& a, int4& bb, const float (&rx)[HPB][PW], const float (&ry)[HPB][PW],
+                                              bool valid, int wv, int lane, float (*cred)[4], int centre) {
+  const bool wide = bb.z - bb.x >= kWin, tall = bb.w - bb.y >= kWin;
+  if (!centre || !(wide || tall)) return;                 // block-uniform
+  float sx = 0.0f, sy = 0.0f, n = 0.0f;
+  const float xm = (float)(a.fw - 1), ym = (float)(a.fh - 1);
+#pragma unroll
+  for (int hh = 0; hh < HPB; ++hh)
+#pragma unroll
+    for (int j = 0; j < PW; ++j)
+      if (valid) { sx += fminf(fmaxf(rx[hh][j], 0.0f), xm); sy += fminf(fmaxf(ry[hh][j], 0.0f), ym); n += 1.0f; }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) { sx += __shfl_xor(sx, m, 64); sy += __shfl_xor(sy, m, 64); n += __shfl_xor(n, m, 64); }
+  if (lane == 0) { cred[wv][0] = sx; cred[wv][1] = sy; cred[wv][2] = n; }
+  __syncthreads();
+  const float tn = fmaxf(cred[0][2] + cred[1][2] + cred[2][2] + cred[3][2], 1.0f);
+  const int cx = (int)floorf((cred[0][0] + cred[1][0] + cred[2][0] + cred[3][0]) / tn) - (kWin / 2 - 1);
+  const int cy = (int)floorf((cred[0][1] + cred[1][1] + cred[2][1] + cred[3][1]) / tn) - (kWin / 2 - 1);
+  if (wide) bb.x = min(max(cx, bb.x), bb.z - (kWin - 1));
+  if (tall) bb.y = min(max(cy, bb.y), bb.w - (kWin - 1));
+}
+
 // Window of a block from its box: origin (clamped into the map like win_origin) and the rows / columns worth loading.
 struct TileWin { int rows, cols; };
 __device__ __forceinline__ TileWin tile_window(const LiftArgs& a, const int4 bb, WinGeom& g, int max_box) {
@@ -239,11 +267,12 @@ __device__ __forceinline__ int tile_row(int xc, int yc, const WinGeom& g, const 
 // Forward.  Two barriers per head of the line (block box) + one (window fill).  DH = 16: the two heads of a 128-byte
 // line are one block's work — both boxes first, ONE window for their union, then the corners head by head.
 template <int P, int DH, bool K1 = false, typename T = float, bool OL16 = false>
-__global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, int chunk, int max_box) {
+__global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, int chunk, int max_box, int centre) {
   extern __shared__ __attribute__((aligned(16))) unsigned char win[];
   constexpr int ES = (int)sizeof(T);
   constexpr int PW = P / 4, HPB = 128 / (DH * ES);        // heads per 128-byte line
   __shared__ int4 wbox[HPB][4];
+  __shared__ float cred[4][4];
   using TO = std::conditional_t<OL16, T, float>;
   WinGeom g;
   if (!tile_decode8<HPB>(a, chunk, g)) return;
@@ -259,6 +288,7 @@ __global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, in
 #pragma unroll
   for (int hh = 0; hh < HPB; ++hh)
     bb = box_union(bb, tile_points<P, false, K1, TO>(a, bq, valid, g.hg * HPB + hh, pp, wv, lane, rx[hh], ry[hh], rw[hh], wbox[hh]));
+  tile_recentre<HPB, PW>(a, bb, rx, ry, valid, wv, lane, cred, centre);
   const TileWin tw = tile_window(a, bb, g, max_box);
   tile_fill(a, g, tw, g.hg, rowi * ES / 4, win);
 #pragma unroll
@@ -287,10 +317,18 @@ __global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, in
 #pragma unroll
         for (int k = 0; k < 4; ++k) tile_axpy<T, DH>(reinterpret_cast<const T*>(wh + (unsigned)max(wr[k], 0)), c[k], acc);
       } else {
+        // some lane has a corner outside the window: the window's corners first, still straight-line (a corner outside
+        // contributes with weight 0), then each corner SLOT that any lane missed as one more pass in which only the
+        // missing lanes fetch their row from global memory (round 4 branched per lane and corner: 8 divergent bodies)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          tile_axpy<T, DH>(reinterpret_cast<const T*>(wh + (unsigned)max(wr[k], 0)), wr[k] >= 0 ? c[k] : 0.0f, acc);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          if (wr[k] >= 0) tile_axpy<T, DH>(reinterpret_cast<const T*>(wh + (unsigned)wr[k]), c[k], acc);
-          else if (c[k] != 0.0f) tile_axpy<T, DH>(gather_ptr(vb, (unsigned)(f.idx[k] * rowi)), c[k], acc);
+          const bool ms = wr[k] < 0 && c[k] != 0.0f;
+          if (__ballot(ms) != 0ull) {
+            if (ms) tile_axpy<T, DH>(gather_ptr(vb, (unsigned)(f.idx[k] * rowi)), c[k], acc);
+          }
         }
       }
     }
@@ -313,10 +351,11 @@ __global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, in
 // same fixed-capacity buckets + overflow list; see there): ranks inside the wave through LDS counters on an 8x8 torus
 // of tile slots, one returning global atomic per occupied slot.  The caller zeroes the counters.
 template <int P, int DH, bool BINS, bool K1 = false, typename T = float, bool OL16 = false>
-__global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs a, int chunk, int tiles_x, int tiles, int max_box) {
+__global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs a, int chunk, int tiles_x, int tiles, int max_box, int centre) {
   extern __shared__ __attribute__((aligned(16))) unsigned char win[];
   constexpr int ES = (int)sizeof(T);
   __shared__ int4 wbox[128 / (DH * ES)][4];
+  __shared__ float cred[4][4];
   using TO = std::conditional_t<OL16, T, float>;
   // per wave: a 4x4 torus of tile slots — occupant tile, local count, global base (a wave's 16 queries x 4 points
   // reach a handful of tiles; two tiles that collide on the torus take the direct global path)
@@ -338,6 +377,7 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
 #pragma unroll
   for (int hh = 0; hh < HPB; ++hh)
     bb = box_union(bb, tile_points<P, true, K1, TO>(a, bq, valid, g.hg * HPB + hh, pp, wv, lane, rx[hh], ry[hh], rw[hh], wbox[hh]));
+  tile_recentre<HPB, PW>(a, bb, rx, ry, valid, wv, lane, cred, centre);
   const TileWin tw = tile_window(a, bb, g, max_box);
   tile_fill(a, g, tw, g.hg, rowi * ES / 4, win);
 
@@ -376,13 +416,18 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
 #pragma unroll
       for (int k = 0; k < 4; ++k) d[k] = tile_dot<T, DH>(reinterpret_cast<const T*>(wh + (unsigned)max(wr[k], 0)), go) * f.m[k];
     } else {
+      // (as in the forward: the window's corners straight-line, then one pass per corner slot that some lane missed)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k] = tile_dot<T, DH>(reinterpret_cast<const T*>(wh + (unsigned)max(wr[k], 0)), go);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        d[k] = 0.0f;
-        if (wr[k] >= 0) d[k] = tile_dot<T, DH>(reinterpret_cast<const T*>(wh + (unsigned)wr[k]), go);
-        else if (valid && f.m[k] != 0.0f) d[k] = tile_dot<T, DH>(gather_ptr(vb, (unsigned)(f.idx[k] * rowi)), go);
-        d[k] *= f.m[k];
+        const bool ms = wr[k] < 0 && valid && f.m[k] != 0.0f;
+        if (__ballot(ms) != 0ull) {
+          if (ms) d[k] = tile_dot<T, DH>(gather_ptr(vb, (unsigned)(f.idx[k] * rowi)), go);
+        }
       }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k] = (wr[k] >= 0 || (valid && f.m[k] != 0.0f)) ? d[k] * f.m[k] : 0.0f;
     }
     const float hx = 1.0f - f.lx, hy = 1.0f - f.ly;
     gw[j] = hy * hx * d[0] + hy * f.lx * d[1] + f.ly * hx * d[2] + f.ly * f.lx * d[3];
@@ -491,6 +536,11 @@ static int tile_max_box(const char* env, int P, int dflt4, int dflt8) {
   return P == 4 ? v4 : v8;
 }
 
+static int tile_centre() {
+  static const int v = getenv("UBV_TILE_CENTER") ? atoi(getenv("UBV_TILE_CENTER")) : 1;
+  return v;
+}
+
 // (tile, 128-byte line of heads) units of a launch: 8 heads of Dh elements of `es` bytes
 static long tile_units(const LiftArgs& a, int Dh, int es) { return (long)a.total_tiles * (8 * Dh * es / 128); }
 
@@ -498,11 +548,11 @@ template <typename T, bool OL16>
 static void tile_fwd_launch_t(const LiftArgs& a, int P, hipStream_t st, int Dh, int chunk, int mb4, int mb8) {
   const dim3 grid(8 * chunk), blk(256);
   if (Dh == 16) {
-    if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4, 16, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, mb4);
-    else hipLaunchKernelGGL((lift_tile_fwd_kernel<8, 16, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, mb8);
+    if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4, 16, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, mb4, tile_centre());
+    else hipLaunchKernelGGL((lift_tile_fwd_kernel<8, 16, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, mb8, tile_centre());
   } else {
-    if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4, 32, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, mb4);
-    else hipLaunchKernelGGL((lift_tile_fwd_kernel<8, 32, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, mb8);
+    if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4, 32, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, mb4, tile_centre());
+    else hipLaunchKernelGGL((lift_tile_fwd_kernel<8, 32, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, mb8, tile_centre());
   }
 }
 
@@ -512,8 +562,8 @@ void tile_fwd_launch(const LiftArgs& a, int P, hipStream_t st, bool k1, int Dh, 
   static const int mb4 = tile_max_box("UBV_TILE_MAXBOX_FWD", 4, 256, 256), mb8 = tile_max_box("UBV_TILE_MAXBOX_FWD", 8, 256, 256);
   const dim3 grid(8 * chunk), blk(256);
   if (k1) {                                               // (the operator's form: f32, Dh = 32 only)
-    if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4, 32, true>), grid, blk, kTWinLds, st, a, chunk, mb4);
-    else hipLaunchKernelGGL((lift_tile_fwd_kernel<8, 32, true>), grid, blk, kTWinLds, st, a, chunk, mb8);
+    if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4, 32, true>), grid, blk, kTWinLds, st, a, chunk, mb4, tile_centre());
+    else hipLaunchKernelGGL((lift_tile_fwd_kernel<8, 32, true>), grid, blk, kTWinLds, st, a, chunk, mb8, tile_centre());
   } else if (dtype == UBV_F32) {
     tile_fwd_launch_t<float, false>(a, P, st, Dh, chunk, mb4, mb8);
   } else if (dtype == UBV_F16) {
@@ -531,8 +581,8 @@ static void tile_bwd_launch_t(const LiftArgs& a, int P, bool bins, int tiles_x, 
   const dim3 grid(8 * chunk), blk(256);
 #define UBV_TILE_BWD(PV, DHV, MB)                                                                                           \
   do {                                                                                                                      \
-    if (bins) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<PV, DHV, true, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, MB); \
-    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<PV, DHV, false, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, MB);     \
+    if (bins) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<PV, DHV, true, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, MB, tile_centre()); \
+    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<PV, DHV, false, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, MB, tile_centre());     \
   } while (0)
   if (Dh == 16) { if (P == 4) UBV_TILE_BWD(4, 16, mb4); else UBV_TILE_BWD(8, 16, mb8); }
   else { if (P == 4) UBV_TILE_BWD(4, 32, mb4); else UBV_TILE_BWD(8, 32, mb8); }
@@ -547,8 +597,8 @@ void tile_bwd_query_launch(const LiftArgs& a, int P, bool bins, int tiles_x, int
   const dim3 grid(8 * chunk), blk(256);
   static const int mb4 = tile_max_box("UBV_TILE_MAXBOX_BWD", 4, 256, 256), mb8 = tile_max_box("UBV_TILE_MAXBOX_BWD", 8, 256, 256);
   if (k1) {                                               // (the operator's backward always bins; f32, Dh = 32 only)
-    if (P == 4) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4, 32, true, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb4);
-    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<8, 32, true, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb8);
+    if (P == 4) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4, 32, true, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb4, tile_centre());
+    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<8, 32, true, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb8, tile_centre());
     return;
   }
   if (dtype == UBV_F32) tile_bwd_launch_t<float, false>(a, P, bins, tiles_x, tiles, st, Dh, chunk, mb4, mb8);

@@ -373,6 +373,14 @@ bool gemm_ws_try(const void* X, long ldx, const void* Wh, const void* Wl, long l
   if (K != 256 && K != 192 && K != 128 && K != 64) return false;
   if (N % 32 != 0 || (N > 256 && N % 256 != 0)) return false;
   if (ldx >= (1L << 26) || ldy >= (1L << 26) || ldw >= (1L << 31) || (act.res_period > 0 && act.res_ld >= (1L << 31))) return false;
+  // stricter than gemm_nt_run's argument checks: this kernel reads the residual / mask rows and both weight halves as
+  // 16-byte vectors and moves X by 16-byte DMA — a sliced or offset operand stays on gemm_nt_kernel
+  {
+    const long ldr_eff = act.res_period > 0 ? act.res_ld : ldy;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    if (!al16(X) || !al16(Wh) || !al16(Wl) || !al16(Y) || (R != nullptr && !al16(R)) || (act.mode == 2 && !al16(act.mask))) return false;
+    if (ldx % 4 != 0 || ldy % 4 != 0 || ldw % 8 != 0 || ((R != nullptr || act.mode == 2) && ldr_eff % 4 != 0)) return false;
+  }
   WsArgs a{};
   a.X = (const float*)X; a.Wh = (const uint16_t*)Wh; a.Wl = (const uint16_t*)Wl;
   a.bias = bias; a.R = (const float*)R; a.mask = (const float*)act.mask; a.Y = (float*)Y;

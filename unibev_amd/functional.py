@@ -199,10 +199,14 @@ class MultiScaleDeformableAttnFunction(Function):
                 gv = torch.empty(value.shape, dtype=torch.float32, device=value.device)
                 ws = _workspace(nws, value.device)
                 with _timed('k1_bwd_grid'):
-                    check(lib().ubv_ms_deform_attn_backward_grid(
+                    rc = lib().ubv_ms_deform_attn_backward_grid(
                         _p(value), _p(loc), _p(aw), _p(go), _p(gv), _p(gloc), _p(gaw), B, S, H, Dh, L, Nq, P, _dt(value),
-                        fh, fw, qh, qw, _p(ws), nws, _stream()), 'ms_deform_attn_backward_grid')
-                return (gv.to(value.dtype), None, None, gloc.to(ctx.in_dtypes[0]), gaw.to(ctx.in_dtypes[1]), None)
+                        fh, fw, qh, qw, _p(ws), nws, _stream())
+                # UBV_ERR_UNSUPPORTED (-3): the plan the forward chose is not available to the backward (include/unibev_hip.h:
+                # "the caller falls back to _backward_planned / _backward") — nothing was launched: take the paths below
+                if rc != -3:
+                    check(rc, 'ms_deform_attn_backward_grid')
+                    return (gv.to(value.dtype), None, None, gloc.to(ctx.in_dtypes[0]), gaw.to(ctx.in_dtypes[1]), None)
             # one level with host-known shape: grad_value on the GRID owner-tile plan — sampling points binned by
             # owner tile, every pixel stored once, no f32 atomics (ubv_ms_deform_attn_backward_planned)
             if L == 1 and ctx.hw is not None and len(ctx.hw) == 1 and _K1_PLAN[0]:
@@ -361,7 +365,24 @@ def bev_lift(value, offlog, ref, num_cams, feat_hw, num_heads, num_points, vis0=
     qw, qh = (query_grid[1], query_grid[0]) if query_grid is not None else (0, 0)
     grid = bool(ref_is_grid) and num_cams == 1 and qw > 0
     geom = (B, num_cams, fh, fw, num_heads, Dh, Nq, num_points, Z, qw, qh, grid)
+    if _STUDY_ROUND[0] is not None and not torch.is_grad_enabled():
+        # precision study (tools/ab/value16_study.py, inference only): WHICH rounding of the value-only 16-bit mode costs
+        # the accuracy — the stored value map ('value': rounded through the type, kept f32), the sampled output ('out')
+        what, dt = _STUDY_ROUND[0]
+        if 'value' in what:
+            value = value.to(dt).to(value.dtype)
+        out = _BevLift.apply(value, offlog, ref, vis0, count, slot_center, visible_lists, geom)
+        return out.to(dt).to(out.dtype) if 'out' in what else out
     return _BevLift.apply(value, offlog, ref, vis0, count, slot_center, visible_lists, geom)
+
+
+_STUDY_ROUND = [None]
+
+
+def set_study_rounding(what=None, dtype=torch.float16):
+    """``what``: None | 'value' | 'out' | 'value+out' (see bev_lift).  Returns the previous setting."""
+    prev, _STUDY_ROUND[0] = _STUDY_ROUND[0], (None if what is None else (what, dtype))
+    return prev
 
 
 # ----------------------------------------------------------------------------------------------- geometry
