@@ -135,7 +135,25 @@ def set_f32_gemm(mode):
     _MFMA_F32 = mode == 'mfma'
     return prev
 _MFMA_WGRAD = os.environ.get('UBV_WGRAD', 'mfma') != 'library'
-_MFMA_16_MAXN = 192          # 16-bit data: the MFMA kernel wins for narrow outputs, the library for wide ones
+# 16-bit data: every Linear (forward and input gradient) on this library's MFMA kernel (round 6: the 16-bit step held 60
+# hipBLASLt `Cijk_*` launches, a sixth of its kernel time).  UBV_MFMA16_MAXN=192 restores round 5's split —
+# the MFMA kernel for narrow outputs, the library for wide ones (A/B: profiles/r06_gemm16.txt)
+_MFMA_16_MAXN = int(os.environ.get('UBV_MFMA16_MAXN', '4096'))
+_WT16 = {}                   # id(16-bit weight buffer) -> (version, transposed copy): the input gradient's operand
+
+
+def _transposed16(w):
+    """w^T [K, N] contiguous for dX = dY . W as ``gemm_nt(dY, w^T)``; one copy per refresh of the shadow weights (their
+    buffers are updated in place: the version counter tells)."""
+    hit = _WT16.get(id(w))
+    if hit is not None and hit[0] == w._version and hit[1].device == w.device and hit[2] is w:
+        return hit[1]
+    if len(_WT16) > 1024:
+        _WT16.clear()
+    with torch.no_grad():
+        wt = w.t().contiguous()
+    _WT16[id(w)] = (w._version, wt, w)
+    return wt
 
 
 _SPLIT_USED = {}            # weight groups the CURRENT pass asked for: key -> parameters
@@ -333,7 +351,7 @@ class _Linear(Function):
                 if wt and go2.dtype == torch.float32:
                     gx = UF.gemm_nt_act(go2, wt[0], wt[1], act=2, mask=a2, p=act[1])
                 elif go2.dtype != torch.float32 and w.dtype == go2.dtype:
-                    gx = UF.gemm_nt_act(go2, w.t().contiguous(), act=2, mask=a2, p=act[1])
+                    gx = UF.gemm_nt_act(go2, _transposed16(w), act=2, mask=a2, p=act[1])
             if gx is None:
                 g = (go2 @ w).to(x_dtype)
                 gx = UF.relu_dropout_grad_raw(g, a2, act[1]) if g.is_cuda else \
@@ -351,6 +369,21 @@ class _Linear(Function):
             own = ga is not None and UF.grad_tag(grad_alias, '_ubv_owned') and \
                 ga.data_ptr() == grad_alias.data_ptr()
             gx = UF.gemm_nt(go2, wt[0], wt[1], residual=ga, out=ga if own else None)
+            if gx is not None:
+                gx = gx.view(xc.shape)
+                if grad_alias is not None and ga is None:
+                    gx = gx + grad_alias.to(x_dtype)
+        if gx is None and ctx.needs_input_grad[0] and go2.is_cuda and go2.dtype != torch.float32 and \
+                w.dtype == go2.dtype == x_dtype and go2.is_contiguous() and w.is_contiguous() and \
+                go2.shape[1] % 32 == 0 and xc.shape[-1] % 32 == 0 and xc.shape[-1] <= _MFMA_16_MAXN:
+            # 16-bit dX = dY . W on this library's MFMA kernel (w^T cached per weight refresh), the residual branch's
+            # gradient added in the epilogue — in place when that tensor was produced for this edge alone
+            ga = None
+            if grad_alias is not None and grad_alias.dtype == go2.dtype:
+                ga = grad_alias.reshape(-1, xc.shape[-1])
+                ga = ga if ga.is_contiguous() else ga.contiguous()
+            own = ga is not None and UF.grad_tag(grad_alias, '_ubv_owned') and ga.data_ptr() == grad_alias.data_ptr()
+            gx = UF.gemm_nt(go2, _transposed16(w), residual=ga, out=ga if own else None)
             if gx is not None:
                 gx = gx.view(xc.shape)
                 if grad_alias is not None and ga is None:
