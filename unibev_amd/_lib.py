@@ -120,9 +120,38 @@ class UniBEVHipError(RuntimeError):
     pass
 
 
+_CALL_HOOK = [None]          # debug.ForeignKernelLog: called with the entry point's name before every call
+
+
+class _Hooked:
+    """The handle with a hook in front of every entry point (debug mode only: ``set_call_hook``)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __getattr__(self, name):
+        fn = getattr(self._h, name)
+        hook = _CALL_HOOK[0]
+        if hook is None or not name.startswith('ubv_'):
+            return fn
+
+        def call(*a):
+            hook(name)
+            return fn(*a)
+        return call
+
+
+def set_call_hook(fn):
+    """Install (None: remove) a function called with the name of every C-ABI entry point about to be called."""
+    prev, _CALL_HOOK[0] = _CALL_HOOK[0], fn
+    return prev
+
+
 def lib():
     """Load (once) and return the ctypes handle; raise loudly if it is absent."""
     global _lib
+    if _lib is not None and _CALL_HOOK[0] is not None:
+        return _Hooked(_lib)
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise UniBEVHipError(

@@ -71,6 +71,7 @@ import os as _os
 # tests/test_bench_gpu.py::test_training_step_gradients_are_reproducible_eagerly_and_replayed runs both modes).
 _QUERY_TABLE = os.environ.get('UBV_QUERY_TABLE', '1') != '0'
 _TWO_STREAMS = [_os.environ.get('UBV_TWO_STREAMS', '1') != '0']
+_REGION_HOOK = [None]       # debug mode (unibev_amd.debug.ForeignKernelLog): called with 'fork' / 'join' / 'bwd_fork' / 'bwd_mark'
 _SIDE_STREAMS = {}
 
 
@@ -423,12 +424,26 @@ class UniBEVTransformer(BaseModule):
             # active streams (three — caller idle + one per encoder — measured the same, and a fourth stream of
             # any kind, e.g. RCCL's, then falls back to the single-stream time; round 5, tools/ab/job_r5p1.sh: the
             # encoders swapped between the streams 149.8 -> 148.9 samples/s, a high-priority side stream -> 115)
+            hook = _REGION_HOOK[0]                  # debug.ForeignKernelLog: where the two-stream windows begin and end
+            if hook is not None:
+                hook('fork')
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 pts_bev_embed = run_pts()
             img_bev_embed = run_img()
             cur.wait_stream(side)
             pts_bev_embed.record_stream(cur)
+            if hook is not None:
+                hook('join')
+                # the backward's window: from the first gradient that enters an encoder to the last one that leaves
+                for t in (img_bev_embed, pts_bev_embed):
+                    if t.requires_grad:
+                        t.register_hook(lambda g, h=hook: h('bwd_fork'))
+                ins = list(bev_queries) if isinstance(bev_queries, list) else [bev_queries]
+                ins += list(img_mlvl_feats) + list(pts_mlvl_feats) + ([bev_pos] if bev_pos is not None else [])
+                for t in ins:
+                    if isinstance(t, torch.Tensor) and t.requires_grad:
+                        t.register_hook(lambda g, h=hook: h('bwd_mark'))
         else:
             if img_mlvl_feats is not None:
                 img_bev_embed = run_img()
