@@ -21,7 +21,7 @@ head.transformer.forced_flags = (1, 1)
 
 
 def step(log=None):
-    for p in params:
+    for p in params + (img or []) + (pts or []):
         p.grad = None
     out = head.forward_bev(img, pts, metas)
     if log is not None:

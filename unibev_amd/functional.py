@@ -258,6 +258,26 @@ def lift_overflow_probe(enable=None):
     _OVF_PROBE = {} if enable else None
 
 
+_REF_CACHE = {}
+
+
+def _ref_contiguous(ref):
+    """f32 contiguous copy of a reference-point tensor.  The encoders hand every layer the same cached (permuted) view
+    of their reference grid; copying it per call is a framework kernel inside the two-stream window, so the copy of a
+    given tensor (storage, layout, version) is made once."""
+    if ref.dtype == torch.float32 and ref.is_contiguous():
+        return ref
+    if ref.requires_grad:
+        return ref.float().contiguous()
+    key = (ref.data_ptr(), tuple(ref.shape), tuple(ref.stride()), ref.dtype, ref._version, ref.device.index)
+    hit = _REF_CACHE.get(key)
+    if hit is None:
+        if len(_REF_CACHE) >= 32:
+            _REF_CACHE.clear()
+        hit = _REF_CACHE[key] = (ref, ref.float().contiguous())        # (the source is kept alive: its address is the key)
+    return hit[1]
+
+
 class _BevLift(Function):
     @staticmethod
     def forward(ctx, value, offlog, ref, vis0, count, center, lists, geom):
@@ -267,7 +287,7 @@ class _BevLift(Function):
             # the kernels read offsets / logits as f32 or in the value's own 16-bit type (autocast)
             lowp = value.dtype != torch.float32 and offlog.dtype == value.dtype
             ol = (offlog if lowp else offlog.float()).contiguous()
-            ref = ref.float().contiguous()
+            ref = _ref_contiguous(ref)
             row = H * P * 3
             assert ol.shape[-1] == row and ol.numel() == B * Nq * row
             assert value.numel() == B * Nc * fh * fw * H * Dh
@@ -437,14 +457,19 @@ class _FlattenEmbed(Function):
             go = grad_out.contiguous()
             gin = torch.empty(N, C, HW, dtype=go.dtype, device=go.device)
             need_emb = (ctx.has[0] and ctx.needs_input_grad[1]) or (ctx.has[1] and ctx.needs_input_grad[2])
-            gemb = torch.zeros(N, C, dtype=torch.float32, device=go.device) if need_emb else None
+            # (accumulator from the step's zero arena, sums by this library's column-sum kernel: torch.zeros / Tensor.sum
+            #  are framework kernels, and this backward runs inside the encoders' two-stream window)
+            gemb = zeros_f32(N * C, go.device).view(N, C) if need_emb else None
             check(lib().ubv_flatten_embed_backward(_p(go), _p(gin), _p(gemb), N, C, HW, _dt(go),
                                                    _stream()), 'flatten_embed_backward')
             ga = gb = None
             if ctx.has[0] and ctx.needs_input_grad[1]:
-                ga = gemb.view(N // ctx.groups, ctx.groups, C).sum(0).to(ctx.emb_dtypes[0])
+                # sum over the N / groups repeats of each group row: column sums of the [N / groups, groups * C] view
+                ga = linear_grad_reduce(gemb.view(N // ctx.groups, ctx.groups * C))[0].view(ctx.groups, C)
+                ga = ga if ga.dtype == ctx.emb_dtypes[0] else ga.to(ctx.emb_dtypes[0])
             if ctx.has[1] and ctx.needs_input_grad[2]:
-                gb = gemb.sum(0).to(ctx.emb_dtypes[1])
+                gb = linear_grad_reduce(gemb)[0]
+                gb = gb if gb.dtype == ctx.emb_dtypes[1] else gb.to(ctx.emb_dtypes[1])
             return gin, ga, gb
 
 
@@ -629,6 +654,7 @@ class _ZeroArena:
 
     def __init__(self):
         self.buf, self.off, self.cap = None, 0, 1 << 16
+        self.used = False
 
     def reset(self):
         if self.buf is not None:
@@ -636,6 +662,7 @@ class _ZeroArena:
         self.buf, self.off = None, 0
 
     def take(self, n, device):
+        self.used = True
         n_al = (n + 63) // 64 * 64                     # 256-byte aligned slices
         if self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
             self.cap = max(self.cap, 4 * n_al)
@@ -660,9 +687,17 @@ def zeros_f32(n, device):
 
 def new_step():
     """Called once per forward pass (``linear.lowp_step_cache``): later backward accumulators come
-    from a fresh zero buffer."""
-    for arena in _ARENAS.values():
+    from a fresh zero buffer — allocated (and zero-filled: the one framework kernel involved) HERE, ahead of the pass and
+    of its two-stream fork, for every arena that was used before, on the caller's stream (the fork orders it before
+    anything the side stream does; the buffer lives until the next ``new_step``, after the join)."""
+    for key, arena in _ARENAS.items():
         arena.reset()
+        if key is not None and arena.used:
+            dev = torch.device('cuda', key[0])
+            arena.buf = torch.zeros(arena.cap, dtype=torch.float32, device=dev)
+            arena.off = 0
+            if torch._C._cuda_getCurrentRawStream(key[0]) != key[1] and not torch.cuda.is_current_stream_capturing():
+                arena.buf.record_stream(torch.cuda.ExternalStream(key[1], device=dev))    # (used on the arena's stream)
     _SEED_STATE[0] = None             # dropout seeds of this pass: one fresh draw from torch's generator
 
 

@@ -233,6 +233,9 @@ class _Linear(Function):
         # every sample of the batch (the Linear of ``query + query_pos`` split into query . W^T + (pos . W^T)[q])
         weights, biases = params[:n], params[n:]
         ctx.act = act
+        # an unused output (the pass-through alias of the last Linear of a chain) must not come back as a zero-filled
+        # gradient: that is a framework fill of the whole activation (66 MB for the LiDAR map) inside the backward
+        ctx.set_materialize_grads(False)
         ctx.rb_rows = None if row_bias is None else row_bias.shape[0]
         w = _cached_lowp(weights, dtype)
         b = _cached_lowp(biases, dtype) if has_bias else None
@@ -305,6 +308,10 @@ class _Linear(Function):
 
     @staticmethod
     def backward(ctx, grad_out, grad_alias=None):
+        if grad_out is None:
+            # (set_materialize_grads(False)) only the pass-through alias was used: x's gradient is the alias' own, nothing
+            # reaches the weights
+            return (grad_alias, None, None, None, None, None, None, *([None] * len(ctx.meta[4])))
         xc, w = ctx.saved_tensors[:2]
         wt = ctx.saved_tensors[2:2 + ctx.n_wt]        # transposed split halves (f32 MFMA path) or ()
         x_dtype, n, has_bias, outs, pdt = ctx.meta
@@ -474,7 +481,10 @@ class _SelfAttnIn(Function):
     def forward(ctx, x, row_bias, wv, bv, wo, bo, wa, ba):
         from . import functional as UF
         split = _split_weights((wv, wo, wa))
-        bias = torch.cat((bv.detach(), bo.detach(), ba.detach())).float()
+        # [bv | bo | ba] from the per-step shadow buffers (refreshed ahead of the pass by one multi-tensor copy): a
+        # torch.cat here is a framework kernel inside the encoders' two-stream window
+        bias = _cached_lowp((bv, bo, ba), torch.float32) if (_ACTIVE and all(isinstance(b, torch.nn.Parameter) for b in (bv, bo, ba))) \
+            else torch.cat((bv.detach(), bo.detach(), ba.detach())).float()
         n2 = wo.shape[0] + wa.shape[0]
         res = UF.gemm_nt_dual(x, split[0], split[1], bias=bias, y2_cols=n2, row_bias=row_bias)
         if res is None:

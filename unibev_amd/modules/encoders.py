@@ -198,8 +198,11 @@ class ImgEncoder(_EncoderBase):
         zs = rp[:, 0, 2].contiguous()
         return self._project(xs, ys, zs, pc_range, img_metas, rp.device, with_visibility)
 
-    def _project(self, xs, ys, zs, pc_range, img_metas, device, with_visibility):
-        l2i = _lidar2img_tensor(img_metas, device)
+    def _project(self, xs, ys, zs, pc_range, img_metas, device, with_visibility, l2i=None):
+        # (``l2i``: the batched matrices when the caller made them already — transformer._encode does, ahead of the
+        #  two-stream fork: stacking per-sample device tensors is a framework kernel)
+        if l2i is None:
+            l2i = _lidar2img_tensor(img_metas, device)
         shape0 = img_metas[0]['img_shape'][0]
         cam, mask, vis0, count = UF.point_sampling(l2i, xs, ys, zs, pc_range,
                                                    (shape0[0], shape0[1]))
@@ -222,7 +225,8 @@ class ImgEncoder(_EncoderBase):
                               lambda: reference_points_3d(bev_h, bev_w, Z, D, bs, dev, dt))
         ref_2d = self._cached(('2d', bev_h, bev_w, bs, dev, dt),
                               lambda: reference_points_2d(bev_h, bev_w, bs, dev, dt))
-        cam, mask, vis0, count = self._project(*axes, self.pc_range, kwargs['img_metas'], dev, True)
+        cam, mask, vis0, count = self._project(*axes, self.pc_range, kwargs['img_metas'], dev, True,
+                                               l2i=kwargs.pop('lidar2img_tensor', None))
         lists = UF.compact_visible(vis0, bev_w)  # once per pass; every layer's backward walks them (tile by tile)
         table = getattr(bev_query, '_ubv_table', None)    # the un-expanded query table (transformer._encode)
         bev_query = bev_query.permute(1, 0, 2)

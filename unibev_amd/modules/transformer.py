@@ -400,10 +400,16 @@ class UniBEVTransformer(BaseModule):
             q_img._ubv_table = bev_queries
         img_bev_embed = pts_bev_embed = None
 
+        l2i = None
+        if img_mlvl_feats is not None and kwargs.get('img_metas') is not None and q_img.is_cuda:
+            from .encoders import _lidar2img_tensor
+            l2i = _lidar2img_tensor(kwargs['img_metas'], q_img.device)     # (ahead of the fork: may stack / upload)
+
         def run_img():
             flat, ss, lsi = self._pre_process_img_feats(img_mlvl_feats, q_img)
+            kw = dict(kwargs, lidar2img_tensor=l2i) if l2i is not None else kwargs
             return self.img_bev_encoder(q_img, flat, flat, bev_h=bev_h, bev_w=bev_w, bev_pos=bev_pos,
-                                        spatial_shapes=ss, level_start_index=lsi, bev_pos_base=pos_base, **kwargs)
+                                        spatial_shapes=ss, level_start_index=lsi, bev_pos_base=pos_base, **kw)
 
         def run_pts():
             flat, ss, lsi = self._pre_process_pts_feats(pts_mlvl_feats, q_pts)
