@@ -465,10 +465,11 @@ class _FlattenEmbed(Function):
             ga = gb = None
             if ctx.has[0] and ctx.needs_input_grad[1]:
                 # sum over the N / groups repeats of each group row: column sums of the [N / groups, groups * C] view
-                ga = linear_grad_reduce(gemb.view(N // ctx.groups, ctx.groups * C))[0].view(ctx.groups, C)
+                # (the slice-sum form: N / groups slices of [groups, C])
+                ga = linear_grad_reduce(None, gemb.view(N // ctx.groups, ctx.groups, C))[1]
                 ga = ga if ga.dtype == ctx.emb_dtypes[0] else ga.to(ctx.emb_dtypes[0])
             if ctx.has[1] and ctx.needs_input_grad[2]:
-                gb = linear_grad_reduce(gemb)[0]
+                gb = linear_grad_reduce(None, gemb.view(N, 1, C))[1].view(C)
                 gb = gb if gb.dtype == ctx.emb_dtypes[1] else gb.to(ctx.emb_dtypes[1])
             return gin, ga, gb
 
