@@ -442,6 +442,13 @@ int ubv_split_weights_batched(int n, const float* const* w, const int* rows, con
  *                                            weight-gradient GEMM (NULL to skip), grad_weight [NK] f32
  * N and NK multiples of 16 bytes' worth of elements, N <= 256 * that.
  */
+/* out[i] = a[i] + b[i], f32, n elements, 16-byte aligned operands (out may alias a or b).  The sum of two gradients of
+ * one tensor — what [ext] torch's autograd engine does with a framework add kernel when a parameter has two consumers
+ * (here: a self-attention's sampling_offsets / attention_weights weights, used by the layer's GEMM and by the folded
+ * positional term, encoder_unibev_detr_img.py:413-420 `query + query_pos`) — as a kernel of this library, for use inside
+ * the two-stream window of the encoders (unibev_amd/debug.py). */
+int ubv_add2_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+
 int ubv_linear_grad_reduce(const void* grad_out, int64_t rows, int N, float* grad_bias,
                            const void* partials, int S, int64_t NK, float* grad_weight, int dtype,
                            void* stream);

@@ -1,0 +1,93 @@
+"""No framework kernel inside the two-stream windows of the encoders.
+
+The image and point-cloud encoders run on two HIP streams (modules/transformer.py) — forward, and again when autograd
+replays the backward on the forward ops' streams.  Every kernel of this library is plain f32 (csrc/Makefile,
+tests/test_build_isa.py) because kernels with packed f32 instructions returned wrong results beside another stream's
+MFMA + VALU kernels (profiles/r05_pk_mfma_hazard.txt); the framework's element-wise kernels carry no such guarantee.
+``unibev_amd.debug.ForeignKernelLog`` records every aten operator that touches device memory between a fork and its
+join, and every C-ABI launch; the training step of the bench's workload must show none of the former."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# The two table-shaped gradients that BOTH encoders produce (BEV query table, positional table) are summed by the
+# autograd engine where the two branches meet: that add is the join itself — it waits for both streams — not a
+# kernel beside the other stream's work.  Nothing else is allowed.
+JOIN_ADDS = {('backward', 'aten.add.Tensor', 'autograd engine', (40000, 256))}
+
+
+def _step_log(dtype=torch.float32):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench as B
+    from unibev_amd.debug import ForeignKernelLog
+    from unibev_amd.modules import transformer as TR
+    dev = torch.device('cuda', 0)
+    prev = torch.cuda.current_stream(dev)
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
+    try:
+        torch.manual_seed(0)
+        head, _ = B.build_head('LC_cnw', dev)
+        head.train()
+        img, pts, metas = B.synth_inputs('LC_cnw', 2, dtype, dev, 0)
+        params = [p for p in head.parameters() if p.requires_grad]
+        cot = torch.randn(200 * 200, 2, 256, device=dev) / 200.0
+        head.transformer.forced_flags = (1, 1)
+
+        def step(log=None):
+            for p in params + img + pts:
+                p.grad = None
+            out = head.forward_bev(img, pts, metas)
+            if log is not None:
+                log.mark('backward')
+            out.backward(cot)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        with ForeignKernelLog(TR._side_stream(dev)) as log:
+            step(log)
+        torch.cuda.synchronize()
+        return log
+    finally:
+        torch.cuda.set_stream(prev)
+
+
+def test_no_framework_kernel_between_fork_and_join():
+    log = _step_log()
+    summary = log.summary()
+    # both windows were seen, both streams were busy in them, with this library's launches
+    assert set(summary) == {'forward', 'backward'}, summary
+    assert summary['forward']['own'] >= 60 and summary['forward']['side'] >= 25, summary
+    assert summary['backward']['own'] >= 100 and summary['backward']['side'] >= 50, summary
+    bad = {k: v for k, v in log.offenders().items() if k not in JOIN_ADDS}
+    assert not bad, 'framework operators inside the two-stream window:\n' + '\n'.join(f'{v} x {k}' for k, v in bad.items())
+    joins = sum(v for k, v in log.offenders().items() if k in JOIN_ADDS)
+    assert joins <= 2, log.offenders()
+
+
+def test_own_add_matches_torch():
+    from unibev_amd import functional as UF
+    g = torch.Generator(device='cpu').manual_seed(5)
+    for n in (4, 64 * 256, 40000 * 96, 1027):
+        a = torch.randn(n, generator=g).cuda()
+        b = torch.randn(n, generator=g).cuda()
+        assert torch.equal(UF.add2(a, b), a + b)
+    a = torch.randn(96, 256, generator=g).cuda()
+    b = torch.randn(96, 256, generator=g).cuda()
+    want = a + b
+    assert UF.add2(a, b, out=a) is a and torch.equal(a, want)
+
+
+def test_fan_out_sums_the_two_gradients_with_the_own_kernel():
+    from unibev_amd import functional as UF
+    w = torch.nn.Parameter(torch.randn(64, 256, device='cuda'))
+    a, b = UF.fan_out(w)
+    assert a._ubv_master is w and b._ubv_master is w and a.data_ptr() == w.data_ptr()
+    ((a * 2.0).sum() + (b * 3.0).sum()).backward()
+    assert torch.equal(w.grad, torch.full_like(w, 5.0))
+    w.grad = None
+    a, b = UF.fan_out(w)
+    (a * 2.0).sum().backward()                   # one consumer only: its gradient passes through
+    assert torch.equal(w.grad, torch.full_like(w, 2.0))

@@ -91,7 +91,42 @@ static void linear_grad_launch(const void* go, long rows, int N, float* gb, cons
                      (const T*)go, rows, N, gb, col_blocks, rpb, (const T*)part, S, NK, gw);
 }
 
+// out = a + b, f32, plain (unpacked) adds: the sum of two gradients of one tensor inside the encoders' two-stream window,
+// where a framework add kernel (packed f32) must not run
+__global__ __launch_bounds__(256) void add2_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                   float* __restrict__ out, long n4, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) {
+    const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+    // (v_add_f32 spelled out: the backend pairs adjacent f32 adds of a float4 into v_pk_add_f32 even without the SLP
+    //  vectoriser, and tests/test_build_isa.py allows no packed f32 instruction in the library)
+    float r[4];
+    const float xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) asm volatile("v_add_f32 %0, %1, %2" : "=v"(r[e]) : "v"(xs[e]), "v"(ys[e]));
+    reinterpret_cast<float4*>(out)[i] = make_float4(r[0], r[1], r[2], r[3]);
+  }
+  if (i == 0)
+    for (long k = 4 * n4; k < n; ++k) {                   // (the tail too: the loop vectoriser would pair these)
+      float r;
+      asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a[k]), "v"(b[k]));
+      out[k] = r;
+    }
+}
+
 }  // namespace ubv
+
+extern "C" int ubv_add2_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(a != nullptr && b != nullptr && out != nullptr && n > 0, "add2: bad arguments");
+  UBV_CHECK_ARG(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                "add2: operands must be 16-byte aligned");
+  const long n4 = n / 4;
+  const long blocks = (n4 > 0 ? n4 : 1) / 256 + 1;
+  hipLaunchKernelGGL(add2_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a, b, out, n4, (long)n);
+  UBV_CHECK_LAUNCH("add2");
+  return UBV_OK;
+}
 
 extern "C" int ubv_linear_grad_reduce(const void* grad_out, int64_t rows, int N, float* grad_bias,
                                       const void* partials, int S, int64_t NK, float* grad_weight,

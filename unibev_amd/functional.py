@@ -434,12 +434,16 @@ def point_sampling(lidar2img, xs, ys, zs, pc_range, img_hw):
 # ----------------------------------------------------------------------------------------------- flatten
 class _FlattenEmbed(Function):
     @staticmethod
-    def forward(ctx, feat, embA, embB):
+    def forward(ctx, feat, embA, embB, row=None):
         with _need_cuda(feat, embA, embB):
             N, C, HW = feat.shape
             feat = feat.contiguous()
             a = None if embA is None else embA.float().contiguous()
-            b = None if embB is None else embB.float().contiguous()
+            # ``row``: embB is a (L, C) table and row ``row`` of it is added (the level embedding): the backward then
+            # returns a table-shaped gradient written by this library — ``table[row]`` outside would come back through
+            # the framework's select_backward (a fill + a copy inside the encoders' two-stream window)
+            ctx.row, ctx.tab_rows = row, (None if row is None else embB.shape[0])
+            b = None if embB is None else (embB if row is None else embB[row]).float().contiguous()
             out = torch.empty(N, HW, C, dtype=feat.dtype, device=feat.device)
             groups = 1 if a is None else a.shape[0]
             check(lib().ubv_flatten_embed_forward(_p(feat), _p(a), groups, _p(b), _p(out), N, C, HW,
@@ -469,14 +473,19 @@ class _FlattenEmbed(Function):
                 ga = linear_grad_reduce(None, gemb.view(N // ctx.groups, ctx.groups, C))[1]
                 ga = ga if ga.dtype == ctx.emb_dtypes[0] else ga.to(ctx.emb_dtypes[0])
             if ctx.has[1] and ctx.needs_input_grad[2]:
-                gb = linear_grad_reduce(None, gemb.view(N, 1, C))[1].view(C)
+                if ctx.row is None:
+                    gb = linear_grad_reduce(None, gemb.view(N, 1, C))[1].view(C)
+                else:
+                    gb = zeros_f32(ctx.tab_rows * C, go.device).view(ctx.tab_rows, C)
+                    linear_grad_reduce(None, gemb.view(N, 1, C), out=gb[ctx.row])
                 gb = gb if gb.dtype == ctx.emb_dtypes[1] else gb.to(ctx.emb_dtypes[1])
-            return gin, ga, gb
+            return gin, ga, gb, None
 
 
-def flatten_embed(feat, embA=None, embB=None):
-    """(N, C, HW) -> (N, HW, C) + embA[n % groups] + embB (``ubv_flatten_embed_forward``)."""
-    return _FlattenEmbed.apply(feat, embA, embB)
+def flatten_embed(feat, embA=None, embB=None, row=None):
+    """(N, C, HW) -> (N, HW, C) + embA[n % groups] + embB (``ubv_flatten_embed_forward``).  ``row``: ``embB`` is an
+    (L, C) table and its row ``row`` is the term."""
+    return _FlattenEmbed.apply(feat, embA, embB, row)
 
 
 # ----------------------------------------------------------------------------------------------- fusion
@@ -972,7 +981,7 @@ def gemm_wgrad(grad_out, x):
 
 # ----------------------------------------------------------------------------------------------- linear grads
 @torch.no_grad()
-def linear_grad_reduce(grad_out=None, partials=None):
+def linear_grad_reduce(grad_out=None, partials=None, out=None):
     """(grad_bias f32 [N] or None, grad_weight f32 [N, K] or None) in one launch
     (``ubv_linear_grad_reduce``): column sums of ``grad_out`` [rows, N] and the sum over the
     split-K slices ``partials`` [S, N, K].  Both inputs must share one dtype."""
@@ -990,11 +999,53 @@ def linear_grad_reduce(grad_out=None, partials=None):
             assert grad_out is None or partials.dtype == grad_out.dtype
             partials = partials.contiguous()
             S, NK = partials.shape[0], partials[0].numel()
-            gw = torch.empty(partials.shape[1:], dtype=torch.float32, device=ref.device)
+            # (``out``: where the slice sum goes — e.g. one row of an arena-zeroed table)
+            gw = out if out is not None else torch.empty(partials.shape[1:], dtype=torch.float32, device=ref.device)
+            assert gw.is_contiguous() and gw.numel() == NK and gw.dtype == torch.float32
             part_p = _p(partials)
         check(lib().ubv_linear_grad_reduce(go_p, rows, N, _p(gb), part_p, S, NK, _p(gw), _dt(ref),
                                            _stream()), 'linear_grad_reduce')
         return gb, gw
+
+
+@torch.no_grad()
+def add2(a, b, out=None):
+    """a + b for two f32 CUDA tensors of one shape on this library's kernel (``ubv_add2_f32``); ``out`` may be ``a``."""
+    with _need_cuda(a, b, out):
+        ac = a if a.is_contiguous() else a.contiguous()
+        bc = b if b.is_contiguous() else b.contiguous()
+        assert ac.dtype == bc.dtype == torch.float32 and ac.shape == bc.shape
+        y = out if out is not None else torch.empty_like(ac)
+        check(lib().ubv_add2_f32(_p(ac), _p(bc), _p(y), ac.numel(), _stream()), 'add2')
+        return y
+
+
+class _FanOut(Function):
+    """Two aliases of one tensor whose gradients are summed by ``add2`` instead of by the autograd engine's framework add:
+    for a parameter with two consumers inside the encoders' two-stream window.  The aliases carry ``_ubv_master`` (the
+    parameter) so that the per-step weight caches of ``unibev_amd.linear`` keep finding their entries."""
+
+    @staticmethod
+    def forward(ctx, w):
+        ctx.set_materialize_grads(False)
+        return w.view_as(w), w.view_as(w)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ga, gb):
+        if ga is None or gb is None:
+            return ga if gb is None else gb
+        if ga.is_cuda and ga.dtype == gb.dtype == torch.float32 and ga.data_ptr() % 16 == 0 and gb.data_ptr() % 16 == 0 \
+                and ga.is_contiguous() and gb.is_contiguous():
+            return add2(ga, gb)
+        return ga + gb
+
+
+def fan_out(w):
+    a, b = _FanOut.apply(w)
+    master = getattr(w, '_ubv_master', w)
+    a._ubv_master = b._ubv_master = master
+    return a, b
 
 
 # ----------------------------------------------------------------------------------------------- voxels

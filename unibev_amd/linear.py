@@ -181,7 +181,13 @@ def _presplit():
             _SPLIT_PASS[tuple(id(p) for p in g)] = out
 
 
+def _masters(params):
+    """Aliases made by ``functional.fan_out`` stand for their parameter in the per-step caches."""
+    return tuple(getattr(p, '_ubv_master', p) for p in params)
+
+
 def _split_weights(weights):
+    weights = _masters(weights)
     key = tuple(id(p) for p in weights)
     hit = _SPLIT_PASS.get(key) if _ACTIVE else None
     if hit is None:
@@ -197,6 +203,7 @@ def _split_weights(weights):
 
 def _cached_lowp(params, dtype):
     """Concatenation (dim 0) of ``params`` in ``dtype``."""
+    params = _masters(params)
     if all(p.dtype == dtype for p in params) and len(params) == 1:
         return params[0]
     key = tuple(id(p) for p in params) + (dtype,)

@@ -159,7 +159,7 @@ class _DeformAttnBase(BaseModule):
         every sample, added in the GEMM epilogue (``encoders._EncoderBase._fold_pos_terms``)."""
         if row_bias is not None:
             assert passthru
-            return linear_cat_pass(query, (self.sampling_offsets.weight, self.attention_weights.weight),
+            return linear_cat_pass(query, self._ol_weights(),
                                    (self.sampling_offsets.bias, self.attention_weights.bias), row_bias=row_bias)
         if _OFFLOG_F32() and query.is_cuda and torch.is_autocast_enabled('cuda'):
             # offsets / logits computed and kept in f32 under autocast (precision knob: a 16-bit
@@ -172,6 +172,13 @@ class _DeformAttnBase(BaseModule):
         fn = linear_cat_pass if passthru else linear_cat
         return fn(query, (self.sampling_offsets.weight, self.attention_weights.weight),
                   (self.sampling_offsets.bias, self.attention_weights.bias))
+
+    def _ol_weights(self):
+        """(sampling_offsets.weight, attention_weights.weight) for this pass' own GEMM: the aliases the encoder's
+        positional fold left for it (``encoders._EncoderBase._fold_pos_terms``: the two consumers of these weights then
+        meet in ``functional.fan_out``'s own add instead of the autograd engine's), else the parameters.  Single use."""
+        al = self.__dict__.pop('_ubv_w_alias', None)
+        return al if al is not None else (self.sampling_offsets.weight, self.attention_weights.weight)
 
     def can_lift(self, value):
         return (self.num_levels == 1 and
@@ -249,9 +256,9 @@ class MultiScaleDeformableAttention(_DeformAttnBase):
                                            self.attention_weights.weight):
                 # value_proj | sampling_offsets | attention_weights in one GEMM (x read once), their input and
                 # weight gradients in one GEMM each
+                wo, wa = self._ol_weights()
                 v, offlog, identity = self_attn_in(x, pos_term, self.value_proj.weight, self.value_proj.bias,
-                                                   self.sampling_offsets.weight, self.sampling_offsets.bias,
-                                                   self.attention_weights.weight, self.attention_weights.bias)
+                                                   wo, self.sampling_offsets.bias, wa, self.attention_weights.bias)
                 v = _store_value(v)
             else:
                 v, alias = self.project_value(x, passthru=True)

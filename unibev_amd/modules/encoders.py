@@ -97,16 +97,29 @@ class _EncoderBase(TransformerLayerSequence):
                 return None
             ws += [att.sampling_offsets.weight, att.attention_weights.weight]
             sizes.append(att.sampling_offsets.weight.shape[0] + att.attention_weights.weight.shape[0])
-        from ..linear import linear_cat
-        # ``cut_after`` = k: the first k layers' terms come from their own GEMM (graph_step.GraphedStep cuts the backward
-        # after layer k: with one GEMM for all layers the upper layers' weights would sit in the lower half's graph)
+        from ..linear import linear_cat_pass
+        # One GEMM per layer, CHAINED through the pass-through alias of the table (``linear.linear_cat_pass``): the layers'
+        # gradients for the table then accumulate in the input-gradient GEMMs' epilogues (as the cross-attentions' value
+        # chain does) and every layer's term is its own tensor — one GEMM for all layers (rounds 3 - 5) came back through
+        # the framework's split / cat backward and a framework add per extra consumer, inside the two-stream window
+        # (unibev_amd/debug.py).  The weights have two consumers — this fold and the layer's own GEMM: they part in
+        # ``functional.fan_out``, whose backward adds the two gradients with this library's kernel.
+        # ``cut_after`` = k: the upper layers' chain starts from a severed leaf of the table (graph_step.GraphedStep cuts
+        # the backward after layer k: the upper layers' weights must not sit in the lower half's graph)
         k = int(getattr(self, 'cut_after', 0) or 0)
-        if 0 < k < len(self.layers):
-            lo = linear_cat(base, ws[:2 * k], [None] * (2 * k))
-            hi = linear_cat(self._sever(base), ws[2 * k:], [None] * (len(ws) - 2 * k))
-            return list(torch.split(lo, sizes[:k], dim=1)) + list(torch.split(hi, sizes[k:], dim=1))
-        terms = linear_cat(base, ws, [None] * len(ws))               # (Nq, sum of sizes), no bias: the layers add theirs
-        return list(torch.split(terms, sizes, dim=1))
+        fan = torch.is_grad_enabled() and all(w.requires_grad for w in ws)
+        terms, alias = [], base
+        for li, layer in enumerate(self.layers):
+            if 0 < k < len(self.layers) and li == k:
+                alias = self._sever(base)
+            so, aw = ws[2 * li], ws[2 * li + 1]
+            if fan:
+                so, so_layer = UF.fan_out(so)
+                aw, aw_layer = UF.fan_out(aw)
+                layer.attentions[0]._ubv_w_alias = (so_layer, aw_layer)
+            t, alias = linear_cat_pass(alias, [so, aw], [None, None])    # (Nq, H*P*3), no bias: the layer adds its own
+            terms.append(t)
+        return terms
 
     def _sever(self, x):
         """``cut_after``: a tensor of the lower layers that the upper layers read is handed to them as a fresh LEAF (no

@@ -215,7 +215,7 @@ class UniBEVTransformer(BaseModule):
             bs, num_cam, c, h, w = feat.shape
             tok = UF.flatten_embed(feat.reshape(bs * num_cam, c, h * w),
                                    self.cams_embeds if self.use_cams_embeds else None,
-                                   self.img_level_embeds[lvl])
+                                   self.img_level_embeds, row=lvl)
             flat.append(tok.view(bs, num_cam, h * w, c))
             shapes.append((h, w))
         flat = flat[0] if len(flat) == 1 else torch.cat(flat, 2)
@@ -232,7 +232,7 @@ class UniBEVTransformer(BaseModule):
             raise ValueError('pts features: the reference path supports exactly one level')
         feat = mlvl_pts_feats[0]
         bs, c, h, w = feat.shape
-        tok = UF.flatten_embed(feat.reshape(bs, c, h * w), None, self.pts_level_embeds[0])
+        tok = UF.flatten_embed(feat.reshape(bs, c, h * w), None, self.pts_level_embeds, row=0)
         spatial_shapes = shapes_tensor([(h, w)], bev_queries.device)
         level_start_index = index_tensor([0], bev_queries.device)
         return tok.permute(1, 0, 2), spatial_shapes, level_start_index
