@@ -107,6 +107,13 @@ class _EncoderBase(TransformerLayerSequence):
         # ``cut_after`` = k: the upper layers' chain starts from a severed leaf of the table (graph_step.GraphedStep cuts
         # the backward after layer k: the upper layers' weights must not sit in the lower half's graph)
         k = int(getattr(self, 'cut_after', 0) or 0)
+        if not _FOLD_CHAIN:                                 # UBV_FOLD_CHAIN=0: round 5's one GEMM for all layers (A/B runs)
+            from ..linear import linear_cat
+            if 0 < k < len(self.layers):
+                lo = linear_cat(base, ws[:2 * k], [None] * (2 * k))
+                hi = linear_cat(self._sever(base), ws[2 * k:], [None] * (len(ws) - 2 * k))
+                return list(torch.split(lo, sizes[:k], dim=1)) + list(torch.split(hi, sizes[k:], dim=1))
+            return list(torch.split(linear_cat(base, ws, [None] * len(ws)), sizes, dim=1))
         fan = torch.is_grad_enabled() and all(w.requires_grad for w in ws)
         terms, alias = [], base
         for li, layer in enumerate(self.layers):
@@ -296,6 +303,7 @@ class PtsEncoder(_EncoderBase):
         return self._run_layers(bev_query, key, value, args, layer_kwargs)
 
 
+_FOLD_CHAIN = os.environ.get('UBV_FOLD_CHAIN', '1') != '0'        # 0: the positional fold as one GEMM for all layers (A/B runs)
 _VALUE_CHAIN = os.environ.get('UBV_VALUE_CHAIN', '1') != '0'      # 0: the layers' feature-map gradients added by autograd (A/B runs)
 _SHARE_FIRST = os.environ.get('UBV_SHARE_FIRST', '1') != '0'     # 0: the first self-attention per sample (A/B runs)
 
