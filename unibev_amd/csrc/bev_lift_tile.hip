@@ -345,6 +345,211 @@ __global__ __launch_bounds__(256) void lift_tile_fwd_kernel(const LiftArgs a, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// Forward, PERSISTENT and software-pipelined (round 6; f32 maps, Dh = 32, module form).  lift_tile_fwd_kernel's block is a
+// chain of two global round trips (offsets / logits / anchors, then the window) in front of its arithmetic, and the four
+// blocks of a CU pass through their phases more or less together (the phases add up).  Here a block stays
+// resident and walks units k = (tile, head) of its XCD's range with three units in flight:
+//     D(k)    corners of unit k from the LDS window            <- arithmetic
+//     B(k+1)  points / box / window geometry of unit k + 1     (its raw operands were requested one iteration ago)
+//     S(k+1)  window of unit k + 1: registers -> LDS           (its loads were requested one iteration ago)
+//     F(k+2)  window loads of unit k + 2 -> registers          (requested now, consumed one iteration later)
+//     R(k+3)  raw operand loads of unit k + 3 -> registers
+// so that both round trips of a unit overlap another unit's corners.  Two barriers per unit, as before: the one inside
+// B (box merge; it also certifies that every wave has finished D(k) before S(k+1) overwrites the window) and the one
+// after S.  UBV_TILE_PIPE=0: lift_tile_fwd_kernel for these instances too (A/B runs).
+template <int PW> struct TileRaw { float2 off[PW], ref[PW]; float lg[PW]; long bq; int b, tile, head; bool valid, live; };
+template <int PW> struct TilePts { float rx[PW], ry[PW], rw[PW]; long bq; int head; bool valid, live; WinGeom g; TileWin tw; };
+
+template <int P>
+__device__ __forceinline__ void pipe_request(const LiftArgs& a, long unit, long end, int li, int pp, TileRaw<P / 4>& r) {
+  constexpr int PW = P / 4;
+  r.live = unit < end;                                    // (block-uniform)
+  const long u = r.live ? unit : end - 1;                 // past the end: the last unit again, never used
+  const int item = (int)(u >> 3);
+  r.head = (int)(u & 7);
+  r.tile = item;
+  int q;
+  r.valid = lift_query(a, item, li, r.b, q);
+  if (!r.valid) q = 0;
+  r.bq = (long)r.b * a.Nq + q;
+  const float* __restrict__ offp = (const float*)a.offsets + r.bq * a.off_stride + r.head * 2 * P;
+  const float* __restrict__ lgp = (const float*)a.logits + r.bq * a.log_stride + r.head * P;
+  const float* __restrict__ rp = a.ref + r.bq * a.Z * 2;
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    const int p = pp + 4 * j;
+    r.off[j] = *reinterpret_cast<const float2*>(offp + 2 * p);
+    r.ref[j] = *reinterpret_cast<const float2*>(rp + (p % a.Z) * 2);
+    r.lg[j] = lgp[p];
+  }
+}
+
+// B: tile_points' arithmetic on operands already in registers + the window geometry.  One barrier (two when the box is
+// over-wide: tile_recentre).
+template <int P>
+__device__ __forceinline__ void pipe_points(const LiftArgs& a, const TileRaw<P / 4>& r, int wv, int lane, int4* wbox,
+                                            float (*cred)[4], int max_box, int centre, TilePts<P / 4>& t) {
+  constexpr int PW = P / 4;
+  const float fwf = (float)a.fw, fhf = (float)a.fh;
+  t.bq = r.bq; t.head = r.head; t.valid = r.valid; t.live = r.live;
+  t.g.b = r.b; t.g.tile = r.tile; t.g.hg = r.head;
+  int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1;
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    const float lx = r.ref[j].x + r.off[j].x / fwf, ly = r.ref[j].y + r.off[j].y / fhf;
+    t.rx[j] = lx * fwf - 0.5f; t.ry[j] = ly * fhf - 0.5f;
+    const Footprint f = footprint_px(t.rx[j], t.ry[j], a.fh, a.fw);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (r.valid && f.w[k] != 0.0f) {
+        x0 = min(x0, f.xc[k & 1]); x1 = max(x1, f.xc[k & 1]);
+        y0 = min(y0, f.yc[k >> 1]); y1 = max(y1, f.yc[k >> 1]);
+      }
+    }
+  }
+  x0 = wave_min_i32(x0); y0 = wave_min_i32(y0); x1 = wave_max_i32(x1); y1 = wave_max_i32(y1);
+  if (lane == 0) wbox[wv] = make_int4(x0, y0, x1, y1);
+  float m = r.lg[0];
+#pragma unroll
+  for (int j = 1; j < PW; ++j) m = fmaxf(m, r.lg[j]);
+  m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0xB1, 0xf, 0xf, true)));
+  m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x4E, 0xf, 0xf, true)));
+  float ssum = 0.0f;
+#pragma unroll
+  for (int j = 0; j < PW; ++j) { t.rw[j] = expf(r.lg[j] - m); ssum += t.rw[j]; }
+  ssum = add_xor<2>(add_xor<1>(ssum));
+#pragma unroll
+  for (int j = 0; j < PW; ++j) t.rw[j] = r.valid ? t.rw[j] / ssum : 0.0f;
+  __syncthreads();
+  int4 bb = box_union(box_union(wbox[0], wbox[1]), box_union(wbox[2], wbox[3]));
+  {
+    float rx1[1][PW], ry1[1][PW];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) { rx1[0][j] = t.rx[j]; ry1[0][j] = t.ry[j]; }
+    tile_recentre<1, PW>(a, bb, rx1, ry1, r.valid, wv, lane, cred, centre);
+  }
+  t.tw = tile_window(a, bb, t.g, max_box);
+}
+
+// F: the window's loads of tile_fill, into registers
+__device__ __forceinline__ void pipe_fill_request(const LiftArgs& a, const WinGeom& g, const TileWin t, uint4 (&v)[8]) {
+  constexpr int rowi = 256;
+  const int tid = threadIdx.x, piece = tid & 7, pxl = tid >> 3;
+  const int dx = pxl & 15, dyl = pxl >> 4;
+  const int cdx = min(dx, max(t.cols - 1, 0));
+  const float* vb = (const float*)a.value + (long)g.b * a.fh * a.fw * rowi + g.hg * 32 + piece * 4;
+  const unsigned off0 = (unsigned)(((g.wy0 + dyl) * a.fw + g.wx0 + cdx) * rowi);
+  const unsigned step = (unsigned)(2 * a.fw * rowi), back = (unsigned)(dyl * a.fw * rowi);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint4 x = make_uint4(0u, 0u, 0u, 0u);
+    if (2 * i < t.rows) {
+      const unsigned o = off0 + (unsigned)i * step - ((2 * i + 1 < t.rows) ? 0u : back);
+      x = *reinterpret_cast<const uint4*>(gather_ptr(vb, o));
+    }
+    v[i] = x;
+  }
+}
+
+// S: registers -> LDS.  Ends with a barrier.
+__device__ __forceinline__ void pipe_fill_store(const TileWin t, const uint4 (&v)[8], unsigned char* __restrict__ win) {
+  const int tid = threadIdx.x, piece = tid & 7, pxl = tid >> 3;
+  const int dx = pxl & 15, dyl = pxl >> 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (2 * i < t.rows)
+      *reinterpret_cast<uint4*>(win + (2 * i + dyl) * kTWinRow + dx * kWinRowB + piece * 16) = v[i];
+  if (t.rows == 0 && tid < 8) *reinterpret_cast<uint4*>(win + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void lift_tile_fwd_pipe_kernel(const LiftArgs a, int chunk, long units, int max_box, int centre) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char win[];
+  constexpr int PW = P / 4, DH = 32, rowi = 256;
+  __shared__ int4 wbox[4];
+  __shared__ float cred[4][4];
+  const int lane = threadIdx.x & 63, wv = wave_in_block();
+  const int li = wv * 16 + (lane >> 2), pp = lane & 3;
+  // XCD x = blockIdx.x % 8 owns units [x chunk, (x + 1) chunk); its blocks take them with stride gridDim.x / 8
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const long stride = gridDim.x >> 3;
+  const long end = min((long)(xcd + 1) * chunk, units);
+  long u = (long)xcd * chunk + slot;
+  if (u >= end) return;
+  TileRaw<PW> raw;
+  TilePts<PW> cur, nxt;
+  uint4 vf[8];
+  // prologue: unit 0 up to its window in LDS, unit 1 up to its window loads, unit 2's raw operands
+  pipe_request<P>(a, u, end, li, pp, raw);
+  pipe_points<P>(a, raw, wv, lane, wbox, cred, max_box, centre, cur);
+  pipe_fill_request(a, cur.g, cur.tw, vf);
+  pipe_request<P>(a, u + stride, end, li, pp, raw);
+  pipe_fill_store(cur.tw, vf, win);
+  pipe_points<P>(a, raw, wv, lane, wbox, cred, max_box, centre, nxt);
+  if (nxt.live) pipe_fill_request(a, nxt.g, nxt.tw, vf);
+  pipe_request<P>(a, u + 2 * stride, end, li, pp, raw);
+  for (;;) {
+    // ---- D(k): the corners of `cur` from the window
+    {
+      const float* vb = (const float*)a.value + (long)cur.g.b * a.fh * a.fw * rowi + cur.head * DH;
+      float acc[DH];
+#pragma unroll
+      for (int i = 0; i < DH; ++i) acc[i] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < PW; ++j) {
+        const Footprint f = footprint_px(cur.rx[j], cur.ry[j], a.fh, a.fw);
+        float c[4];
+        int wr[4];
+        bool miss = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          c[k] = cur.rw[j] * f.w[k];
+          wr[k] = tile_row(f.xc[k & 1], f.yc[k >> 1], cur.g, cur.tw);
+          miss = miss || (wr[k] < 0 && c[k] != 0.0f);
+        }
+        if (__ballot(miss) == 0ull) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) tile_axpy<float, DH>(reinterpret_cast<const float*>(win + (unsigned)max(wr[k], 0)), c[k], acc);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            tile_axpy<float, DH>(reinterpret_cast<const float*>(win + (unsigned)max(wr[k], 0)), wr[k] >= 0 ? c[k] : 0.0f, acc);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bool ms = wr[k] < 0 && c[k] != 0.0f;
+            if (__ballot(ms) != 0ull) {
+              if (ms) tile_axpy<float, DH>(gather_ptr(vb, (unsigned)(f.idx[k] * rowi)), c[k], acc);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < DH; ++i) acc[i] = add_xor<2>(add_xor<1>(acc[i]));
+      if (cur.valid) {
+        constexpr int Q = DH / 4;
+        float o[Q];
+#pragma unroll
+        for (int i = 0; i < Q; ++i) o[i] = pp == 0 ? acc[i] : pp == 1 ? acc[Q + i] : pp == 2 ? acc[2 * Q + i] : acc[3 * Q + i];
+        vec_io<float, Q>::store((float*)a.out + cur.bq * rowi + cur.head * DH + pp * Q, o);
+      }
+    }
+    if (!nxt.live) break;                                 // (block-uniform)
+    u += stride;
+    // ---- B(k+2) first: its barrier certifies that every wave is done with the window of unit k
+    TilePts<PW> nn;
+    pipe_points<P>(a, raw, wv, lane, wbox, cred, max_box, centre, nn);
+    // ---- S(k+1): the window of `nxt` (loads requested one iteration ago)
+    pipe_fill_store(nxt.tw, vf, win);
+    cur = nxt;
+    nxt = nn;
+    // ---- F(k+2), R(k+3)
+    if (nxt.live) pipe_fill_request(a, nxt.g, nxt.tw, vf);
+    pipe_request<P>(a, u + 2 * stride, end, li, pp, raw);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Backward, query side: d(offsets), d(logits) — the forward's block with the query's grad_out row in registers and a
 // dot product per corner instead of an axpy.  BINS: the kernel also appends every point to the bucket of each owner
 // tile that holds one of its corners of non-zero coefficient (what lift_bin_kernel<MODE 0> does, same record format,
@@ -536,6 +741,12 @@ static int tile_max_box(const char* env, int P, int dflt4, int dflt8) {
   return P == 4 ? v4 : v8;
 }
 
+// UBV_TILE_PIPE = blocks per CU of the persistent forward kernel (0: the one-unit-per-block kernel)
+static int tile_pipe() {
+  static const int v = getenv("UBV_TILE_PIPE") ? atoi(getenv("UBV_TILE_PIPE")) : 0;
+  return v;
+}
+
 static int tile_centre() {
   static const int v = getenv("UBV_TILE_CENTER") ? atoi(getenv("UBV_TILE_CENTER")) : 1;
   return v;
@@ -564,6 +775,20 @@ void tile_fwd_launch(const LiftArgs& a, int P, hipStream_t st, bool k1, int Dh, 
   if (k1) {                                               // (the operator's form: f32, Dh = 32 only)
     if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_kernel<4, 32, true>), grid, blk, kTWinLds, st, a, chunk, mb4, tile_centre());
     else hipLaunchKernelGGL((lift_tile_fwd_kernel<8, 32, true>), grid, blk, kTWinLds, st, a, chunk, mb8, tile_centre());
+  } else if (dtype == UBV_F32 && Dh == 32 && tile_pipe() && a.Z >= 1) {
+    // persistent, software-pipelined blocks: `per_cu` per CU (the window's LDS allows 4)
+    static int cus = 0;
+    if (cus == 0) {
+      int dev = 0;
+      hipDeviceProp_t pr;
+      cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
+    }
+    const int per_cu = tile_pipe();
+    long nb = (long)cus * per_cu / 8 * 8;
+    const long need = ((long)chunk) * 8;                  // one block per unit at most
+    if (nb > need) nb = need;
+    if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_pipe_kernel<4>), dim3((unsigned)nb), blk, kTWinLds, st, a, chunk, units, mb4, tile_centre());
+    else hipLaunchKernelGGL((lift_tile_fwd_pipe_kernel<8>), dim3((unsigned)nb), blk, kTWinLds, st, a, chunk, units, mb8, tile_centre());
   } else if (dtype == UBV_F32) {
     tile_fwd_launch_t<float, false>(a, P, st, Dh, chunk, mb4, mb8);
   } else if (dtype == UBV_F16) {
