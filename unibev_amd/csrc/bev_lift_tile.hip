@@ -463,7 +463,54 @@ __device__ __forceinline__ void pipe_fill_store(const TileWin t, const uint4 (&v
   __syncthreads();
 }
 
+// D: the corners of one unit from the LDS window -> its rows of the output
 template <int P>
+__device__ __forceinline__ void pipe_corners(const LiftArgs& a, const TilePts<P / 4>& cur, const unsigned char* __restrict__ win, int pp) {
+  constexpr int PW = P / 4, DH = 32, rowi = 256;
+  const float* vb = (const float*)a.value + (long)cur.g.b * a.fh * a.fw * rowi + cur.head * DH;
+  float acc[DH];
+#pragma unroll
+  for (int i = 0; i < DH; ++i) acc[i] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    const Footprint f = footprint_px(cur.rx[j], cur.ry[j], a.fh, a.fw);
+    float c[4];
+    int wr[4];
+    bool miss = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      c[k] = cur.rw[j] * f.w[k];
+      wr[k] = tile_row(f.xc[k & 1], f.yc[k >> 1], cur.g, cur.tw);
+      miss = miss || (wr[k] < 0 && c[k] != 0.0f);
+    }
+    if (__ballot(miss) == 0ull) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tile_axpy<float, DH>(reinterpret_cast<const float*>(win + (unsigned)max(wr[k], 0)), c[k], acc);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        tile_axpy<float, DH>(reinterpret_cast<const float*>(win + (unsigned)max(wr[k], 0)), wr[k] >= 0 ? c[k] : 0.0f, acc);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool ms = wr[k] < 0 && c[k] != 0.0f;
+        if (__ballot(ms) != 0ull) {
+          if (ms) tile_axpy<float, DH>(gather_ptr(vb, (unsigned)(f.idx[k] * rowi)), c[k], acc);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < DH; ++i) acc[i] = add_xor<2>(add_xor<1>(acc[i]));
+  if (cur.valid) {
+    constexpr int Q = DH / 4;
+    float o[Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) o[i] = pp == 0 ? acc[i] : pp == 1 ? acc[Q + i] : pp == 2 ? acc[2 * Q + i] : acc[3 * Q + i];
+    vec_io<float, Q>::store((float*)a.out + cur.bq * rowi + cur.head * DH + pp * Q, o);
+  }
+}
+
+template <int P, bool LIGHT>
 __global__ __launch_bounds__(256) void lift_tile_fwd_pipe_kernel(const LiftArgs a, int chunk, long units, int max_box, int centre) {
   extern __shared__ __attribute__((aligned(16))) unsigned char win[];
   constexpr int PW = P / 4, DH = 32, rowi = 256;
@@ -480,6 +527,21 @@ __global__ __launch_bounds__(256) void lift_tile_fwd_pipe_kernel(const LiftArgs 
   TileRaw<PW> raw;
   TilePts<PW> cur, nxt;
   uint4 vf[8];
+  if constexpr (LIGHT) {
+    // LIGHT: only the raw operands of the next unit are in flight during the corners (the window's registers do not
+    // live across them: ~100 VGPRs instead of 158 / 199, four blocks per CU stay resident)
+    pipe_request<P>(a, u, end, li, pp, raw);
+    for (;;) {
+      pipe_points<P>(a, raw, wv, lane, wbox, cred, max_box, centre, cur);      // (its barrier: every wave is done with the previous window)
+      pipe_fill_request(a, cur.g, cur.tw, vf);
+      pipe_request<P>(a, u + stride, end, li, pp, raw);
+      pipe_fill_store(cur.tw, vf, win);
+      pipe_corners<P>(a, cur, win, pp);
+      u += stride;
+      if (u >= end) break;                                  // (block-uniform)
+    }
+    return;
+  }
   // prologue: unit 0 up to its window in LDS, unit 1 up to its window loads, unit 2's raw operands
   pipe_request<P>(a, u, end, li, pp, raw);
   pipe_points<P>(a, raw, wv, lane, wbox, cred, max_box, centre, cur);
@@ -490,50 +552,7 @@ __global__ __launch_bounds__(256) void lift_tile_fwd_pipe_kernel(const LiftArgs 
   if (nxt.live) pipe_fill_request(a, nxt.g, nxt.tw, vf);
   pipe_request<P>(a, u + 2 * stride, end, li, pp, raw);
   for (;;) {
-    // ---- D(k): the corners of `cur` from the window
-    {
-      const float* vb = (const float*)a.value + (long)cur.g.b * a.fh * a.fw * rowi + cur.head * DH;
-      float acc[DH];
-#pragma unroll
-      for (int i = 0; i < DH; ++i) acc[i] = 0.0f;
-#pragma unroll
-      for (int j = 0; j < PW; ++j) {
-        const Footprint f = footprint_px(cur.rx[j], cur.ry[j], a.fh, a.fw);
-        float c[4];
-        int wr[4];
-        bool miss = false;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          c[k] = cur.rw[j] * f.w[k];
-          wr[k] = tile_row(f.xc[k & 1], f.yc[k >> 1], cur.g, cur.tw);
-          miss = miss || (wr[k] < 0 && c[k] != 0.0f);
-        }
-        if (__ballot(miss) == 0ull) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) tile_axpy<float, DH>(reinterpret_cast<const float*>(win + (unsigned)max(wr[k], 0)), c[k], acc);
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            tile_axpy<float, DH>(reinterpret_cast<const float*>(win + (unsigned)max(wr[k], 0)), wr[k] >= 0 ? c[k] : 0.0f, acc);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const bool ms = wr[k] < 0 && c[k] != 0.0f;
-            if (__ballot(ms) != 0ull) {
-              if (ms) tile_axpy<float, DH>(gather_ptr(vb, (unsigned)(f.idx[k] * rowi)), c[k], acc);
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < DH; ++i) acc[i] = add_xor<2>(add_xor<1>(acc[i]));
-      if (cur.valid) {
-        constexpr int Q = DH / 4;
-        float o[Q];
-#pragma unroll
-        for (int i = 0; i < Q; ++i) o[i] = pp == 0 ? acc[i] : pp == 1 ? acc[Q + i] : pp == 2 ? acc[2 * Q + i] : acc[3 * Q + i];
-        vec_io<float, Q>::store((float*)a.out + cur.bq * rowi + cur.head * DH + pp * Q, o);
-      }
-    }
+    pipe_corners<P>(a, cur, win, pp);
     if (!nxt.live) break;                                 // (block-uniform)
     u += stride;
     // ---- B(k+2) first: its barrier certifies that every wave is done with the window of unit k
@@ -787,8 +806,14 @@ void tile_fwd_launch(const LiftArgs& a, int P, hipStream_t st, bool k1, int Dh, 
     long nb = (long)cus * per_cu / 8 * 8;
     const long need = ((long)chunk) * 8;                  // one block per unit at most
     if (nb > need) nb = need;
-    if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_pipe_kernel<4>), dim3((unsigned)nb), blk, kTWinLds, st, a, chunk, units, mb4, tile_centre());
-    else hipLaunchKernelGGL((lift_tile_fwd_pipe_kernel<8>), dim3((unsigned)nb), blk, kTWinLds, st, a, chunk, units, mb8, tile_centre());
+    static const int light = getenv("UBV_TILE_PIPE_LIGHT") ? atoi(getenv("UBV_TILE_PIPE_LIGHT")) : 1;
+    if (light) {
+      if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_pipe_kernel<4, true>), dim3((unsigned)nb), blk, kTWinLds, st, a, chunk, units, mb4, tile_centre());
+      else hipLaunchKernelGGL((lift_tile_fwd_pipe_kernel<8, true>), dim3((unsigned)nb), blk, kTWinLds, st, a, chunk, units, mb8, tile_centre());
+    } else {
+      if (P == 4) hipLaunchKernelGGL((lift_tile_fwd_pipe_kernel<4, false>), dim3((unsigned)nb), blk, kTWinLds, st, a, chunk, units, mb4, tile_centre());
+      else hipLaunchKernelGGL((lift_tile_fwd_pipe_kernel<8, false>), dim3((unsigned)nb), blk, kTWinLds, st, a, chunk, units, mb8, tile_centre());
+    }
   } else if (dtype == UBV_F32) {
     tile_fwd_launch_t<float, false>(a, P, st, Dh, chunk, mb4, mb8);
   } else if (dtype == UBV_F16) {
