@@ -91,3 +91,18 @@ def test_fan_out_sums_the_two_gradients_with_the_own_kernel():
     a, b = UF.fan_out(w)
     (a * 2.0).sum().backward()                   # one consumer only: its gradient passes through
     assert torch.equal(w.grad, torch.full_like(w, 2.0))
+
+
+def test_fan_out_pair_adds_adjacent_slices_once():
+    from unibev_amd import functional as UF
+    w1 = torch.nn.Parameter(torch.randn(64, 256, device='cuda'))
+    w2 = torch.nn.Parameter(torch.randn(32, 256, device='cuda'))
+    (a1, b1), (a2, b2) = UF.fan_out_pair(w1, w2)
+    ga = torch.randn(96, 256, device='cuda')
+    gb = torch.randn(96, 256, device='cuda')
+    torch.autograd.backward([a1, a2, b1, b2], [ga[:64], ga[64:], gb[:64], gb[64:]])      # adjacent slices: one add
+    assert torch.equal(w1.grad, (ga + gb)[:64]) and torch.equal(w2.grad, (ga + gb)[64:])
+    w1.grad = w2.grad = None
+    (a1, b1), (a2, b2) = UF.fan_out_pair(w1, w2)
+    torch.autograd.backward([a1, a2, b1, b2], [ga[:64].clone(), ga[64:].clone(), gb[:64].clone(), gb[64:].clone()])
+    assert torch.equal(w1.grad, (ga + gb)[:64]) and torch.equal(w2.grad, (ga + gb)[64:])

@@ -1020,6 +1020,15 @@ def add2(a, b, out=None):
         return y
 
 
+def _sum2(ga, gb):
+    if ga is None or gb is None:
+        return ga if gb is None else gb
+    if ga.is_cuda and ga.dtype == gb.dtype == torch.float32 and ga.data_ptr() % 16 == 0 and gb.data_ptr() % 16 == 0 \
+            and ga.is_contiguous() and gb.is_contiguous():
+        return add2(ga, gb)
+    return ga + gb
+
+
 class _FanOut(Function):
     """Two aliases of one tensor whose gradients are summed by ``add2`` instead of by the autograd engine's framework add:
     for a parameter with two consumers inside the encoders' two-stream window.  The aliases carry ``_ubv_master`` (the
@@ -1033,19 +1042,52 @@ class _FanOut(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, ga, gb):
-        if ga is None or gb is None:
-            return ga if gb is None else gb
-        if ga.is_cuda and ga.dtype == gb.dtype == torch.float32 and ga.data_ptr() % 16 == 0 and gb.data_ptr() % 16 == 0 \
-                and ga.is_contiguous() and gb.is_contiguous():
-            return add2(ga, gb)
-        return ga + gb
+        return _sum2(ga, gb)
+
+
+class _FanOutPair(Function):
+    """``_FanOut`` for two tensors whose gradients usually arrive as adjacent slices of one buffer (the sampling_offsets |
+    attention_weights rows of a fused weight gradient): one ``add2`` over both instead of two."""
+
+    @staticmethod
+    def forward(ctx, w1, w2):
+        ctx.set_materialize_grads(False)
+        return w1.view_as(w1), w1.view_as(w1), w2.view_as(w2), w2.view_as(w2)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ga1, gb1, ga2, gb2):
+        def adjacent(x, y):
+            return x is not None and y is not None and x.is_cuda and x.dtype == y.dtype == torch.float32 and \
+                x.is_contiguous() and y.is_contiguous() and x.data_ptr() + 4 * x.numel() == y.data_ptr() and \
+                x.data_ptr() % 16 == 0
+        if adjacent(ga1, ga2) and adjacent(gb1, gb2):
+            n1, n = ga1.numel(), ga1.numel() + ga2.numel()
+            a = torch.as_strided(ga1, (n,), (1,))           # (both slices: one buffer)
+            b = torch.as_strided(gb1, (n,), (1,))
+            out = add2(a, b)
+            return out[:n1].view_as(ga1), out[n1:].view_as(ga2)
+        return _sum2(ga1, gb1), _sum2(ga2, gb2)
+
+
+def _tag_master(w, *aliases):
+    master = getattr(w, '_ubv_master', w)
+    for t in aliases:
+        t._ubv_master = master
 
 
 def fan_out(w):
     a, b = _FanOut.apply(w)
-    master = getattr(w, '_ubv_master', w)
-    a._ubv_master = b._ubv_master = master
+    _tag_master(w, a, b)
     return a, b
+
+
+def fan_out_pair(w1, w2):
+    """((a1, b1), (a2, b2)): two consumers' aliases of two tensors."""
+    a1, b1, a2, b2 = _FanOutPair.apply(w1, w2)
+    _tag_master(w1, a1, b1)
+    _tag_master(w2, a2, b2)
+    return (a1, b1), (a2, b2)
 
 
 # ----------------------------------------------------------------------------------------------- voxels

@@ -121,8 +121,7 @@ class _EncoderBase(TransformerLayerSequence):
                 alias = self._sever(base)
             so, aw = ws[2 * li], ws[2 * li + 1]
             if fan:
-                so, so_layer = UF.fan_out(so)
-                aw, aw_layer = UF.fan_out(aw)
+                (so, so_layer), (aw, aw_layer) = UF.fan_out_pair(so, aw)
                 layer.attentions[0]._ubv_w_alias = (so_layer, aw_layer)
             t, alias = linear_cat_pass(alias, [so, aw], [None, None])    # (Nq, H*P*3), no bias: the layer adds its own
             terms.append(t)
