@@ -449,6 +449,14 @@ int ubv_split_weights_batched(int n, const float* const* w, const int* rows, con
  * the two-stream window of the encoders (unibev_amd/debug.py). */
 int ubv_add2_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
 
+/* out[r * ld + c] = sum over s < S of slices[s][r * cols + c], f32: the batch sum of S contiguous [rows, cols] blocks
+ * written as a COLUMN SLICE (row stride ld >= cols) of a wider matrix.  The gradient of a term shared by the samples of a
+ * batch — the positional part of `(query + query_pos) . W^T` (encoder_unibev_detr_img.py:413-420), folded into one GEMM
+ * over the positional table for all layers — lands directly in its layer's columns of the fold's gradient matrix, so
+ * that the fold's backward is ONE input-gradient GEMM and ONE weight-gradient pass with no framework cat in front.
+ * cols, ld multiples of 4; 16-byte aligned operands. */
+int ubv_slice_sum_f32(const float* slices, int S, int64_t rows, int cols, float* out, int64_t ld, void* stream);
+
 int ubv_linear_grad_reduce(const void* grad_out, int64_t rows, int N, float* grad_bias,
                            const void* partials, int S, int64_t NK, float* grad_weight, int dtype,
                            void* stream);

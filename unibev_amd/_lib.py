@@ -98,6 +98,7 @@ SIGNATURES = {
     'ubv_split_weight': (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P]),
     'ubv_linear_grad_reduce': (c_int, [_P, c_int64, c_int, _P, _P, c_int, c_int64, _P, c_int, _P]),
     'ubv_add2_f32': (c_int, [_P, _P, _P, c_int64, _P]),
+    'ubv_slice_sum_f32': (c_int, [_P, c_int, c_int64, c_int, _P, c_int64, _P]),
     'ubv_hard_voxelize_workspace': (c_int64, [c_int, c_int, c_int]),
     'ubv_hard_voxelize_batch_workspace': (c_int64, [c_int, c_int, c_int, c_int]),
     'ubv_hard_voxelize_batch': (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, c_int64, c_int, ctypes.POINTER(c_float),

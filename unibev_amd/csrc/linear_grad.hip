@@ -114,7 +114,38 @@ __global__ __launch_bounds__(256) void add2_kernel(const float* __restrict__ a, 
     }
 }
 
+// out[r * ld + c] = sum_s slices[s][r * cols + c]: the batch sum of S row blocks written into a column slice of a wider
+// matrix (the positional fold's gradient slot, encoders._EncoderBase._fold_pos_terms).  One float4 per thread.
+__global__ __launch_bounds__(256) void slice_sum_kernel(const float* __restrict__ slices, int S, long rows, int cols4,
+                                                        float* __restrict__ out, long ld) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cols4) return;
+  const long r = i / cols4;
+  const int c = (int)(i - r * cols4) * 4;
+  const long n = rows * cols4 * 4;
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int s = 0; s < S; ++s) {
+    float a[4];
+    vec_io<float, 4>::load(slices + (long)s * n + i * 4, a);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] += a[k];
+  }
+  *reinterpret_cast<float4*>(out + r * ld + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
 }  // namespace ubv
+
+extern "C" int ubv_slice_sum_f32(const float* slices, int S, int64_t rows, int cols, float* out, int64_t ld, void* stream) {
+  using namespace ubv;
+  UBV_CHECK_ARG(slices != nullptr && out != nullptr && S > 0 && rows > 0 && cols > 0, "slice_sum: bad arguments");
+  UBV_CHECK_ARG(cols % 4 == 0 && ld % 4 == 0 && ld >= cols && ((uintptr_t)slices % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                "slice_sum: cols=%d and the row stride must be multiples of 4 floats, operands 16-byte aligned", cols);
+  const long n4 = rows * (cols / 4);
+  hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, as_stream(stream), slices, S,
+                     (long)rows, cols / 4, out, (long)ld);
+  UBV_CHECK_LAUNCH("slice_sum");
+  return UBV_OK;
+}
 
 extern "C" int ubv_add2_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {
   using namespace ubv;

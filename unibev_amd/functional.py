@@ -1020,6 +1020,18 @@ def add2(a, b, out=None):
         return y
 
 
+@torch.no_grad()
+def slice_sum(slices, out):
+    """out[r, c] = sum_s slices[s, r, c] (``ubv_slice_sum_f32``): ``slices`` f32 contiguous [S, rows, cols]; ``out`` a
+    [rows, cols] view with unit column stride (a column slice of a wider matrix is fine)."""
+    with _need_cuda(slices, out):
+        S, rows, cols = slices.shape
+        assert slices.is_contiguous() and slices.dtype == out.dtype == torch.float32
+        assert out.shape == (rows, cols) and out.stride(1) == 1
+        check(lib().ubv_slice_sum_f32(_p(slices), S, rows, cols, _p(out), out.stride(0), _stream()), 'slice_sum')
+        return out
+
+
 def _sum2(ga, gb):
     if ga is None or gb is None:
         return ga if gb is None else gb

@@ -226,6 +226,89 @@ def _cached_lowp(params, dtype):
     return buf
 
 
+def _row_bias_grad(g3, slot):
+    """d(row_bias) = the sum of grad_out's row blocks g3 [S, R, N] over the samples.  ``slot`` = (G, col0) when the
+    row bias is a column slice of a positional fold's output (``_PosFoldAll``): the sum is written straight into the same
+    columns of the fold's gradient matrix G and that slice is returned — the fold's backward then finds all its gradients
+    in ONE matrix.  This library's kernels only (plain f32 adds: the two-stream window, unibev_amd/debug.py)."""
+    from . import functional as UF
+    if slot is not None and g3.is_cuda and g3.dtype == torch.float32 and g3.is_contiguous() and g3.shape[2] % 4 == 0:
+        G, c0 = slot
+        if G.shape[0] == g3.shape[1] and c0 + g3.shape[2] <= G.shape[1]:
+            return UF.slice_sum(g3, G[:, c0:c0 + g3.shape[2]])
+    if g3.shape[0] == 1:
+        return g3[0]
+    if g3.dtype == torch.float32 and g3.is_cuda and g3.is_contiguous() and g3[0].numel() % 4 == 0:
+        return UF.linear_grad_reduce(None, g3)[1]
+    grb = g3[0] + g3[1]
+    for i in range(2, g3.shape[0]):
+        grb = grb + g3[i]
+    return grb
+
+
+class _PosFoldAll(Function):
+    """The positional terms of ALL layers of an encoder — ``bev_pos . [W_so; W_aw]_l^T`` for every layer l — as ONE GEMM
+    over the (Nq, C) table, returned as per-layer column views of its output; backward: the layers wrote their gradients
+    into the matching columns of ONE matrix (``_row_bias_grad``), so the table's gradient is one input-gradient GEMM and
+    the weights' one weight-gradient pass.  Rounds 3 - 5 had the same GEMMs around ``torch.split``, whose backward is a
+    framework cat (+ a zero fill per unused piece) inside the encoders' two-stream window."""
+
+    @staticmethod
+    def forward(ctx, base, *ws):
+        from . import functional as UF
+        split = _split_weights(ws)
+        terms = UF.gemm_nt(base, split[0], split[1])
+        if terms is None:
+            raise RuntimeError('pos_fold_all: shape outside ubv_gemm_nt')
+        ctx.save_for_backward(base, split[2], split[3])
+        ctx.sizes = [w.shape[0] for w in ws]
+        ctx.G = torch.empty_like(terms)                     # the layers' gradients, column block by column block
+        ctx.set_materialize_grads(False)
+        outs, c = [], 0
+        for i in range(0, len(ws), 2):
+            n = ws[i].shape[0] + ws[i + 1].shape[0]
+            outs.append(terms[:, c:c + n])
+            c += n
+        return tuple(outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gs):
+        from . import functional as UF
+        base, wth, wtl = ctx.saved_tensors
+        G, c = ctx.G, 0
+        for g in gs:                                        # (normally every g IS its column block of G already)
+            n = G.shape[1] // len(gs) if g is None else g.shape[1]
+            blk = G[:, c:c + n]
+            if g is None:
+                blk.zero_()
+            elif g.data_ptr() != blk.data_ptr() or g.stride() != blk.stride():
+                blk.copy_(g)
+            c += n
+        gx = UF.gemm_nt(G, wth, wtl) if ctx.needs_input_grad[0] else None
+        res = UF.gemm_wgrad(G, base)
+        if res is None or (ctx.needs_input_grad[0] and gx is None):
+            raise RuntimeError('pos_fold_all: gradient shape outside the MFMA kernels')
+        gw, grads, off = res[0], [], 0
+        for n in ctx.sizes:
+            grads.append(gw[off:off + n])
+            off += n
+        return (gx, *grads)
+
+
+def pos_fold_all(base, ws):
+    """Per-layer positional terms [(Nq, n_l)] for ws = [W_so_0, W_aw_0, W_so_1, ...] (f32 CUDA); each term carries its
+    gradient slot (``_ubv_grad_slot``) for the consumer's backward."""
+    outs = _PosFoldAll.apply(base, *ws)
+    G = outs[0].grad_fn.G if outs[0].grad_fn is not None and hasattr(outs[0].grad_fn, 'G') else None
+    c = 0
+    for t in outs:
+        if G is not None:
+            t._ubv_grad_slot = (G, c)
+        c += t.shape[1]
+    return list(outs)
+
+
 class _Linear(Function):
     """y = x @ cat(weights)^T + cat(biases).  ``n`` weights followed by ``n`` biases (or none).
 
@@ -244,6 +327,7 @@ class _Linear(Function):
         # gradient: that is a framework fill of the whole activation (66 MB for the LiDAR map) inside the backward
         ctx.set_materialize_grads(False)
         ctx.rb_rows = None if row_bias is None else row_bias.shape[0]
+        ctx.rb_slot = None if row_bias is None else getattr(row_bias, '_ubv_grad_slot', None)
         w = _cached_lowp(weights, dtype)
         b = _cached_lowp(biases, dtype) if has_bias else None
         xc = x.to(dtype)
@@ -346,15 +430,7 @@ class _Linear(Function):
         if ctx.rb_rows is not None and ctx.needs_input_grad[6]:
             # d(row_bias) = sum over the batch of grad_out's row blocks (plain adds: the framework's outer-dimension
             # reduction is slow on this shape, see bricks._ExpandBatch)
-            g3 = go2.reshape(-1, ctx.rb_rows, go2.shape[-1])
-            if g3.shape[0] == 1:
-                grb = g3[0]
-            elif g3.dtype == torch.float32 and g3.is_cuda and g3.is_contiguous() and g3[0].numel() % 4 == 0:
-                grb = UF.linear_grad_reduce(None, g3)[1]    # (this library's slice sum: no packed f32, see _SelfAttnIn)
-            else:
-                grb = g3[0] + g3[1]
-                for i in range(2, g3.shape[0]):
-                    grb = grb + g3[i]
+            grb = _row_bias_grad(go2.reshape(-1, ctx.rb_rows, go2.shape[-1]), ctx.rb_slot)
         gx = None
         if act is not None and act[0] == 'masked_in' and ctx.needs_input_grad[0]:
             assert grad_alias is None, 'linear_after_relu_dropout has no pass-through output'
@@ -498,6 +574,7 @@ class _SelfAttnIn(Function):
             raise RuntimeError('self_attn_in: shape outside ubv_gemm_nt_dual (checked by self_attn_in_supported)')
         ctx.save_for_backward(x, split[2], split[3])
         ctx.rows = row_bias.shape[0]
+        ctx.rb_slot = getattr(row_bias, '_ubv_grad_slot', None)
         ctx.outs = (wv.shape[0], wo.shape[0], wa.shape[0])
         return res[0], res[1], x.view_as(x)
 
@@ -523,18 +600,9 @@ class _SelfAttnIn(Function):
             gx = gx.view(x.shape)
         grb = None
         if ctx.needs_input_grad[1]:
-            g3 = gol2.view(-1, ctx.rows, gol2.shape[-1])
-            if g3.shape[0] == 1:
-                grb = g3[0]
-            elif g3.dtype == torch.float32 and g3.is_cuda and g3.is_contiguous() and g3[0].numel() % 4 == 0:
-                # the sum over the samples by this library's slice reduction: the framework's f32 add kernel holds
-                # packed f32 FMAs, and this runs inside an encoder branch, beside the other stream's MFMA kernels
-                # (DESIGN section 5 "Two streams")
-                grb = UF.linear_grad_reduce(None, g3)[1]
-            else:
-                grb = g3[0] + g3[1]
-                for i in range(2, g3.shape[0]):
-                    grb = grb + g3[i]
+            # (this library's reductions only: the framework's f32 add kernel holds packed f32 FMAs, and this runs inside an
+            #  encoder branch, beside the other stream's MFMA kernels — DESIGN section 5 "Two streams")
+            grb = _row_bias_grad(gol2.view(-1, ctx.rows, gol2.shape[-1]), ctx.rb_slot)
         # weight gradients: two passes over x measured FASTER than the fused ubv_gemm_wgrad_dual (90 vs 113 us back to
         # back at M = 80 000: the kernel is bound by its tiles' MFMA / LDS work, which is the same either way, and
         # the 352-row product takes 85 slabs of 6 tiles where the two take 128 x 4 and 256 x 2); UBV_SELF_IN_WGRAD=dual

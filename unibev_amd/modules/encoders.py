@@ -97,35 +97,35 @@ class _EncoderBase(TransformerLayerSequence):
                 return None
             ws += [att.sampling_offsets.weight, att.attention_weights.weight]
             sizes.append(att.sampling_offsets.weight.shape[0] + att.attention_weights.weight.shape[0])
-        from ..linear import linear_cat_pass
-        # One GEMM per layer, CHAINED through the pass-through alias of the table (``linear.linear_cat_pass``): the layers'
-        # gradients for the table then accumulate in the input-gradient GEMMs' epilogues (as the cross-attentions' value
-        # chain does) and every layer's term is its own tensor — one GEMM for all layers (rounds 3 - 5) came back through
-        # the framework's split / cat backward and a framework add per extra consumer, inside the two-stream window
+        # ONE GEMM over the table for all layers (``linear.pos_fold_all``): every layer's term is a column view of its output
+        # and carries the slot its gradient goes to, so the backward is one input-gradient GEMM + one weight-gradient pass
+        # over ONE gradient matrix — rounds 3 - 5 wrapped the same GEMMs in ``torch.split``, whose backward (a framework
+        # cat, plus one framework add per weight with a second consumer) ran inside the two-stream window
         # (unibev_amd/debug.py).  The weights have two consumers — this fold and the layer's own GEMM: they part in
-        # ``functional.fan_out``, whose backward adds the two gradients with this library's kernel.
-        # ``cut_after`` = k: the upper layers' chain starts from a severed leaf of the table (graph_step.GraphedStep cuts
-        # the backward after layer k: the upper layers' weights must not sit in the lower half's graph)
+        # ``functional.fan_out_pair``, whose backward adds the two gradients with this library's kernel.
+        # ``cut_after`` = k: the upper layers' terms come from their own fold over a severed leaf of the table
+        # (graph_step.GraphedStep cuts the backward after layer k: the upper layers' weights must not sit in the lower
+        # half's graph).  UBV_FOLD_CHAIN=0: round 5's form (A/B runs).
         k = int(getattr(self, 'cut_after', 0) or 0)
-        if not _FOLD_CHAIN:                                 # UBV_FOLD_CHAIN=0: round 5's one GEMM for all layers (A/B runs)
+        if not _FOLD_CHAIN:
             from ..linear import linear_cat
             if 0 < k < len(self.layers):
                 lo = linear_cat(base, ws[:2 * k], [None] * (2 * k))
                 hi = linear_cat(self._sever(base), ws[2 * k:], [None] * (len(ws) - 2 * k))
                 return list(torch.split(lo, sizes[:k], dim=1)) + list(torch.split(hi, sizes[k:], dim=1))
             return list(torch.split(linear_cat(base, ws, [None] * len(ws)), sizes, dim=1))
+        from ..linear import pos_fold_all
         fan = torch.is_grad_enabled() and all(w.requires_grad for w in ws)
-        terms, alias = [], base
+        fold_ws = []
         for li, layer in enumerate(self.layers):
-            if 0 < k < len(self.layers) and li == k:
-                alias = self._sever(base)
             so, aw = ws[2 * li], ws[2 * li + 1]
             if fan:
                 (so, so_layer), (aw, aw_layer) = UF.fan_out_pair(so, aw)
                 layer.attentions[0]._ubv_w_alias = (so_layer, aw_layer)
-            t, alias = linear_cat_pass(alias, [so, aw], [None, None])    # (Nq, H*P*3), no bias: the layer adds its own
-            terms.append(t)
-        return terms
+            fold_ws += [so, aw]
+        if 0 < k < len(self.layers):
+            return pos_fold_all(base, fold_ws[:2 * k]) + pos_fold_all(self._sever(base), fold_ws[2 * k:])
+        return pos_fold_all(base, fold_ws)
 
     def _sever(self, x):
         """``cut_after``: a tensor of the lower layers that the upper layers read is handed to them as a fresh LEAF (no
