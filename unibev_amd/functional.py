@@ -1071,8 +1071,9 @@ class _FanOutPair(Function):
     def backward(ctx, ga1, gb1, ga2, gb2):
         def adjacent(x, y):
             return x is not None and y is not None and x.is_cuda and x.dtype == y.dtype == torch.float32 and \
-                x.is_contiguous() and y.is_contiguous() and x.data_ptr() + 4 * x.numel() == y.data_ptr() and \
-                x.data_ptr() % 16 == 0
+                x.is_contiguous() and y.is_contiguous() and x.data_ptr() % 16 == 0 and \
+                x.untyped_storage().data_ptr() == y.untyped_storage().data_ptr() and \
+                y.storage_offset() == x.storage_offset() + x.numel()        # (slices of ONE buffer, back to back)
         if adjacent(ga1, ga2) and adjacent(gb1, gb2):
             n1, n = ga1.numel(), ga1.numel() + ga2.numel()
             a = torch.as_strided(ga1, (n,), (1,))           # (both slices: one buffer)
