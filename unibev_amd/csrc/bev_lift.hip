@@ -890,6 +890,163 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 3)) void lift_bwd_value_
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// GRID owner tiles from QUERY records (round 6, f32 TILE instances; the query kernel's BINS = 2 mode).  A bucket holds the
+// indices of the (query, head) pairs with a point in the tile — 5x fewer entries than points-in-tile records — and the
+// pair's points come from qpts (written once, coalesced, by the query kernel instead of a 16-byte record per point and
+// owner tile).  Per round of 32 entries, lanes l and l + 32 share an entry and split its P points (as the matrix-core
+// camera kernels do): each builds the footprints of its half, adds the owned corners' coefficients into column l & 31 of
+// A[64 pixels][32 slots] — ONE dword per coefficient, bf16 hi | lo << 16, read-modify-write by the one lane pair that owns
+// the column (the halves take turns: two lanes of a pair may hit one pixel) — and stages its half of the entry's
+// grad_out row.  One MFMA round (K = 32) per 32 ENTRIES where the point-record kernel runs one per 32 POINTS: a fifth of
+// the row gathers, f32 -> bf16 splits, LDS stagings and MFMA rounds; the footprint arithmetic stays (every point of an
+// entry is expanded, about half of them land in the tile).  Exact for any offsets: entries beyond a bucket's capacity and
+// points outside the query block's 8 x 8 neighbourhood of tiles went to the overflow list as point records.
+constexpr int kQStride = 32;                                // dwords per A row (32 slots)
+__device__ __forceinline__ int aq_index(int row, int slot) {
+  // 16-byte chunk c of row r sits at position c ^ (r & 7): the b128 fragment reads of 8 consecutive rows touch 8 bank groups
+  return row * kQStride + ((((slot >> 2) ^ row) & 7) << 2) + (slot & 3);
+}
+
+template <int P>
+__global__ __launch_bounds__(256, 3) void lift_bwd_value_q_kernel(const LiftArgs a, const TileArgs t) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds_all[];
+  constexpr int DH = 32, RB = 2, PH = P / 2, GS = GRow<DH>::kStride;
+  using M = mma_traits<bf16_t>;
+  constexpr int kAWords = 64 * kQStride;                    // dwords of A
+  constexpr int kWaveBytes = kAWords * 4 + 2 * 32 * GS * 2; // A + G_hi + G_lo
+  TileGeom g;
+  if (!tile_decode(a, t, g)) return;
+  const int lane = threadIdx.x & 63, slot = lane & 31, half = lane >> 5;
+  unsigned char* base = reinterpret_cast<unsigned char*>(lds_all) + wave_in_block() * kWaveBytes;
+  uint32_t* A = reinterpret_cast<uint32_t*>(base);
+  uint16_t* g_hi = reinterpret_cast<uint16_t*>(base + kAWords * 4);
+  uint16_t* g_lo = g_hi + 32 * GS;
+  for (int i = lane; i < kWaveBytes / 16; i += 64) reinterpret_cast<uint4*>(base)[i] = make_uint4(0u, 0u, 0u, 0u);
+  f32x16_t acc[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
+  const long row = (long)a.H * DH;
+  const int tiles = t.tiles_x * t.tiles_y;
+  const long bucket = ((long)g.b * a.H + g.h) * tiles + (g.y0 >> 3) * t.tiles_x + (g.x0 >> 3);
+  const int cnt_raw = a.bin_cnt[bucket];
+  const int n = min(cnt_raw, a.cap);
+  const int* __restrict__ qb = reinterpret_cast<const int*>(a.bins) + bucket * a.cap;
+  const float* __restrict__ gbase = (const float*)a.gout + (long)g.b * a.Nq * row + g.h * DH + half * 16;
+  const float* __restrict__ pbase = a.qpts + ((long)g.b * a.Nq * a.H + g.h) * (P * 3) + half * (PH * 3);
+  const int last = max(n - 1, 0);
+  int qn = qb[min(slot, last)];
+  for (int e0 = 0; e0 < n; e0 += 32) {
+    const int q = qn;
+    const bool valid = e0 + slot < n;
+    qn = qb[min(e0 + 32 + slot, last)];                   // next round's entry: in flight during this one
+    // this lane's half of the entry: PH points and 16 channels of its grad_out row
+    float pt[PH * 3];
+    {
+      const float* pp = pbase + (long)q * a.H * (P * 3);
+      if constexpr ((PH * 3) % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < PH * 3; i += 4) {
+          const float4 v = *reinterpret_cast<const float4*>(pp + i);
+          pt[i] = v.x; pt[i + 1] = v.y; pt[i + 2] = v.z; pt[i + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < PH * 3; i += 2) {
+          const float2 v = *reinterpret_cast<const float2*>(pp + i);
+          pt[i] = v.x; pt[i + 1] = v.y;
+        }
+      }
+    }
+    uint4 grow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) grow[i] = reinterpret_cast<const uint4*>(gather_ptr(gbase, (unsigned)q * (unsigned)row))[i];
+    // coefficients: the halves take turns (both lanes of a pair write column `slot`)
+    int lp[PH][4];
+    float cw[PH][4];
+#pragma unroll
+    for (int i = 0; i < PH; ++i) {
+      const Footprint f = footprint_px(pt[3 * i], pt[3 * i + 1], a.fh, a.fw);
+      tile_own(f, pt[3 * i + 2], valid, g, t.tile_w, lp[i], cw[i]);
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      if (half == hh) {
+#pragma unroll
+        for (int i = 0; i < PH; ++i) {
+          uint32_t e[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) e[k] = A[aq_index(max(lp[i][k], 0), slot)];
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (lp[i][k] >= 0) A[aq_index(lp[i][k], slot)] = coef_add(e[k], cw[i][k]);
+        }
+      }
+    }
+    // this lane's 16 channels: f32 -> bf16 hi / lo, into row `slot` of G
+    {
+      const float f[16] = {__uint_as_float(grow[0].x), __uint_as_float(grow[0].y), __uint_as_float(grow[0].z), __uint_as_float(grow[0].w),
+                           __uint_as_float(grow[1].x), __uint_as_float(grow[1].y), __uint_as_float(grow[1].z), __uint_as_float(grow[1].w),
+                           __uint_as_float(grow[2].x), __uint_as_float(grow[2].y), __uint_as_float(grow[2].z), __uint_as_float(grow[2].w),
+                           __uint_as_float(grow[3].x), __uint_as_float(grow[3].y), __uint_as_float(grow[3].z), __uint_as_float(grow[3].w)};
+      uint4 hi[2], lo[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float f8[8] = {f[8 * i], f[8 * i + 1], f[8 * i + 2], f[8 * i + 3], f[8 * i + 4], f[8 * i + 5], f[8 * i + 6], f[8 * i + 7]};
+        split8(f8, hi[i], lo[i]);
+        if (!valid) { hi[i] = make_uint4(0u, 0u, 0u, 0u); lo[i] = hi[i]; }
+      }
+      uint4* dh = reinterpret_cast<uint4*>(g_hi + slot * GS + half * 16);
+      uint4* dl = reinterpret_cast<uint4*>(g_lo + slot * GS + half * 16);
+      dh[0] = hi[0]; dh[1] = hi[1];
+      dl[0] = lo[0]; dl[1] = lo[1];
+    }
+    // Tile += A . G over the 32 slots (one wave: its LDS operations execute in program order), then clear A
+    {
+      const int nn = lane & 31, kg = lane >> 5;
+      const int tr = (kg * 8 + ((lane & 15) >> 2)) * GS + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const uint4 b_hi = tr16_frag(g_hi + kb * 16 * GS + tr, GS);
+        const uint4 b_lo = tr16_frag(g_lo + kb * 16 * GS + tr, GS);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          const int r = rb * 32 + nn, s0 = kb * 16 + kg * 8;
+          const uint4 e0v = *reinterpret_cast<const uint4*>(A + aq_index(r, s0));
+          const uint4 e1v = *reinterpret_cast<const uint4*>(A + aq_index(r, s0 + 4));
+          const uint4 f_hi = make_uint4((e0v.x & 0xffffu) | (e0v.y << 16), (e0v.z & 0xffffu) | (e0v.w << 16),
+                                        (e1v.x & 0xffffu) | (e1v.y << 16), (e1v.z & 0xffffu) | (e1v.w << 16));
+          const uint4 f_lo = make_uint4((e0v.x >> 16) | (e0v.y & 0xffff0000u), (e0v.z >> 16) | (e0v.w & 0xffff0000u),
+                                        (e1v.x >> 16) | (e1v.y & 0xffff0000u), (e1v.z >> 16) | (e1v.w & 0xffff0000u));
+          acc[rb] = M::mma(f_hi, b_hi, acc[rb]);
+          acc[rb] = M::mma(f_lo, b_hi, acc[rb]);
+          acc[rb] = M::mma(f_hi, b_lo, acc[rb]);
+        }
+      }
+      for (int i = lane; i < kAWords / 4; i += 64) reinterpret_cast<uint4*>(A)[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  // ---- store the tile (as lift_bwd_value_kernel: D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+  const long mbase = (long)g.b * a.fh * a.fw * row + g.h * DH;
+  const long tile0 = mbase + ((long)g.y0 * a.fw + g.x0) * row;
+  const int col = lane & 31, lxh = 4 * (lane >> 5);
+  const unsigned lane_off = (unsigned)(lxh * (int)row + col);
+  const unsigned rowstride = (unsigned)(a.fw * (int)row);
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int lx = (r & 3) + lxh, ly = 4 * rb + (r >> 2);
+      if (lx < g.tw && ly < g.th) {
+        const unsigned uo = (unsigned)ly * rowstride + (unsigned)(r & 3) * (unsigned)row;
+        (a.gvalue + tile0 + uo)[lane_off] = acc[rb][r];
+      }
+    }
+  }
+}
+
 #include "bev_lift_maps.inl"
 #include "dcn_owner.inl"
 
@@ -1433,8 +1590,17 @@ static void lift_launch(const LiftArgs& a, const TileArgs& t, int bwd_mode, bool
     {
       ProfScope ps(name("bev_lift_bwd_value_grid"), s2,
                    nb.rec + nb.out + (a.gvalue_lp != nullptr ? nb.value : nb.value_f32));
-      hipLaunchKernelGGL((lift_bwd_value_kernel<T, DH, P, RB>), dim3(8 * t.chunk), dim3(64 * t.waves),
-                         lds, s2, a, t);
+      bool done = false;
+      if constexpr (sizeof(T) == 4 && DH == 32) {
+        if (a.qrec && tile) {                      // the query kernel wrote query records (bev_lift_tile.hip, BINS = 2)
+          const size_t lq = (size_t)t.waves * (64 * kQStride * 4 + 2 * 32 * GRow<32>::kStride * 2);
+          hipLaunchKernelGGL((lift_bwd_value_q_kernel<P>), dim3(8 * t.chunk), dim3(64 * t.waves), lq, s2, a, t);
+          done = true;
+        }
+      }
+      if (!done)
+        hipLaunchKernelGGL((lift_bwd_value_kernel<T, DH, P, RB>), dim3(8 * t.chunk), dim3(64 * t.waves),
+                           lds, s2, a, t);
     }
     if (a.ovf_after)
       hipLaunchKernelGGL((lift_ovf_scatter_kernel<T, DH>), dim3(256), dim3(256), 0, s2, a, t.tiles_x, tiles);
@@ -1673,7 +1839,7 @@ static size_t lift_list_bytes(const LiftArgs& a) {
 }
 // GRID workspace: [tile counters + overflow counter][buckets][overflow records][overflow tiles];
 // the overflow list is sized for the worst case (every point overflowing in all of its <= 4 tiles).
-struct GridWs { size_t cnt_bytes, bins_off, ovf_rec_off, ovf_tile_off, total; long ovf_cap; };
+struct GridWs { size_t cnt_bytes, bins_off, ovf_rec_off, ovf_tile_off, qpts_off, total; long ovf_cap; };
 static GridWs grid_ws(const LiftArgs& a, const TileArgs& t, int P) {
   GridWs w;
   const size_t tiles = (size_t)a.B * a.H * t.tiles_x * t.tiles_y;
@@ -1682,8 +1848,16 @@ static GridWs grid_ws(const LiftArgs& a, const TileArgs& t, int P) {
   w.ovf_cap = 4L * a.B * a.Nq * a.H * P;
   w.ovf_rec_off = w.bins_off + tiles * t.cap * sizeof(float4);
   w.ovf_tile_off = w.ovf_rec_off + (size_t)w.ovf_cap * sizeof(float4);
-  w.total = w.ovf_tile_off + (((size_t)w.ovf_cap * sizeof(int) + 255) & ~(size_t)255);
+  // query records (f32 TILE instances): every (query, head)'s points, 12 bytes each
+  w.qpts_off = w.ovf_tile_off + (((size_t)w.ovf_cap * sizeof(int) + 255) & ~(size_t)255);
+  w.total = w.qpts_off + (((size_t)a.B * a.Nq * a.H * P * 3 * sizeof(float) + 255) & ~(size_t)255);
   return w;
+}
+
+// query records instead of point records: f32 data and f32 grad_value on the TILE plan, module form (UBV_LIFT_QREC=0: off)
+static bool qrec_ok(const LiftArgs& a, int Dh, int P, int dtype) {
+  static const int env = getenv("UBV_LIFT_QREC") ? atoi(getenv("UBV_LIFT_QREC")) : 1;
+  return env != 0 && dtype == UBV_F32 && Dh == 32 && a.gvalue_lp == nullptr && a.ovf_after && tile_ok(a, Dh, P, dtype, true);
 }
 // MAPS workspace: [counts | cursors | n_items] (zeroed per call) [starts][first items][item buckets]
 // [records][slabs].  Records and items are sized for the worst case — every query visible in every
@@ -1781,6 +1955,8 @@ static int lift_run(LiftArgs a, int Dh, int P, int dtype, bool bwd, int ref_is_g
         set_error("bev_lift_backward: memset failed");
         return UBV_ERR_LAUNCH;
       }
+      a.qpts = (float*)((char*)ws + w.qpts_off);
+      a.qrec = qrec_ok(a, Dh, P, dtype) ? 1 : 0;
     }
     if (mode == kPlanMaps) {
       const MapsWs w = maps_ws(a, t, Dh, P);

@@ -23,6 +23,10 @@ struct LiftArgs {
   float4* bins;                                  // [B,H,tiles,cap] (x_pix, y_pix, w/count, query index)
   int cap;                                       // bucket capacity
   int* ovf_n; float4* ovf_rec; int* ovf_tile; int ovf_cap;   // the appends that did not fit
+  // QREC (round 6, f32 TILE instances): the query kernel stores every (query, head)'s points once — qpts [B, Nq, H, P, 3]
+  // (x_pix, y_pix, softmax weight) — and appends the QUERY INDEX to the bucket of each owner tile one of its points
+  // touches (`bins` then holds int32 entries, `cap` of them per tile); lift_bwd_value_q_kernel expands them
+  float* qpts; int qrec;
   int cnt_words;                                 // > 0: the query-gradient kernel (first of the op) zeroes bin_cnt[0 .. cnt_words)
   int ovf_after;                                 // the overflow list is scattered AFTER the owner tiles stored (f32 grad_value)
   int* cam_list; int* cam_n;                     // per-camera compacted visible queries or null

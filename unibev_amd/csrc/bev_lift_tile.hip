@@ -513,7 +513,7 @@ __device__ __forceinline__ void pipe_corners(const LiftArgs& a, const TilePts<P 
 template <int P, bool LIGHT>
 __global__ __launch_bounds__(256) void lift_tile_fwd_pipe_kernel(const LiftArgs a, int chunk, long units, int max_box, int centre) {
   extern __shared__ __attribute__((aligned(16))) unsigned char win[];
-  constexpr int PW = P / 4, DH = 32, rowi = 256;
+  constexpr int PW = P / 4;
   __shared__ int4 wbox[4];
   __shared__ float cred[4][4];
   const int lane = threadIdx.x & 63, wv = wave_in_block();
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void lift_tile_fwd_pipe_kernel(const LiftArgs 
 // tile that holds one of its corners of non-zero coefficient (what lift_bin_kernel<MODE 0> does, same record format,
 // same fixed-capacity buckets + overflow list; see there): ranks inside the wave through LDS counters on an 8x8 torus
 // of tile slots, one returning global atomic per occupied slot.  The caller zeroes the counters.
-template <int P, int DH, bool BINS, bool K1 = false, typename T = float, bool OL16 = false>
+template <int P, int DH, int BINS, bool K1 = false, typename T = float, bool OL16 = false>
 __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs a, int chunk, int tiles_x, int tiles, int max_box, int centre) {
   extern __shared__ __attribute__((aligned(16))) unsigned char win[];
   constexpr int ES = (int)sizeof(T);
@@ -595,12 +595,13 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
   const bool valid = lift_query(a, g.tile, li, b, q);
   if (!valid) q = 0;
   const long bq = (long)b * a.Nq + q;
-  if (BINS && lane < 16) { slot_tile[wv][lane] = -1; slot_cnt[wv][lane] = 0; }
+  if (BINS != 0 && lane < 16) { slot_tile[wv][lane] = -1; slot_cnt[wv][lane] = 0; }
   float rx[HPB][PW], ry[HPB][PW], rw[HPB][PW];
   int4 bb = make_int4(INT_MAX, INT_MAX, -1, -1);
 #pragma unroll
   for (int hh = 0; hh < HPB; ++hh)
     bb = box_union(bb, tile_points<P, true, K1, TO>(a, bq, valid, g.hg * HPB + hh, pp, wv, lane, rx[hh], ry[hh], rw[hh], wbox[hh]));
+  const int qbx0 = max(bb.x, 0) >> 3, qby0 = max(bb.y, 0) >> 3;       // BINS = 2: origin of the block's 8 x 8 neighbourhood of owner tiles
   tile_recentre<HPB, PW>(a, bb, rx, ry, valid, wv, lane, cred, centre);
   const TileWin tw = tile_window(a, bb, g, max_box);
   tile_fill(a, g, tw, g.hg, rowi * ES / 4, win);
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
     gy[j] = (d[2] - d[0]) * hx + (d[3] - d[1]) * f.lx;
     sp = fmaf(rw[hh][j], gw[j], sp);
 
-    if constexpr (BINS) {
+    if constexpr (BINS == 1) {
       // one lane = one point: append it to the bucket of every tile that holds a corner of non-zero coefficient
       const int tile_base = (g.b * a.H + h) * tiles;
       int* __restrict__ cntp = a.bin_cnt + tile_base;
@@ -706,6 +707,99 @@ __global__ __launch_bounds__(256) void lift_tile_bwd_query_kernel(const LiftArgs
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (lead[k] && local[k]) put(tk[k], slot_base[wv][hs[k]] + rank[k]);
+      if (lane < 16) { slot_tile[wv][lane] = -1; slot_cnt[wv][lane] = 0; }
+    }
+  }
+  if constexpr (BINS == 2) {
+    // QUERY records (lift_bwd_value_q_kernel): the points of this (query, head) stored once, the query index appended
+    // to the bucket of every owner tile one of its points touches.  Tiles are addressed relative to the block's box
+    // (every corner of non-zero coefficient lies inside it) on an 8 x 8 grid; a corner beyond it — a box wider than 64
+    // pixels — and the points of an entry that does not fit its bucket go to the overflow list as point records.
+    const int tile_base = (g.b * a.H + h) * tiles;
+    int* __restrict__ cntp = a.bin_cnt + tile_base;
+    int* __restrict__ qbin = reinterpret_cast<int*>(a.bins) + (long)tile_base * a.cap;
+    auto overflow = [&](int j, int tile) {
+      const int o = atomicAdd(a.ovf_n, 1);
+      if (o < a.ovf_cap) { a.ovf_rec[o] = make_float4(rx[hh][j], ry[hh][j], rw[hh][j], __int_as_float(q)); a.ovf_tile[o] = tile_base + tile; }
+    };
+    uint32_t mlo = 0u, mhi = 0u;                           // bit (ty - qby0) * 8 + (tx - qbx0)
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      if (valid) {
+        float* qp = a.qpts + ((bq * a.H + h) * P + (pp + 4 * j)) * 3;
+        qp[0] = rx[hh][j]; qp[1] = ry[hh][j]; qp[2] = rw[hh][j];
+      }
+      const Footprint f = footprint_px(rx[hh][j], ry[hh][j], a.fh, a.fw);
+      int far_t[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        far_t[k] = -1;
+        if (rw[hh][j] != 0.0f && f.w[k] != 0.0f) {
+          const int tx = f.xc[k & 1] >> 3, ty = f.yc[k >> 1] >> 3;
+          const int dx = tx - qbx0, dy = ty - qby0;
+          if ((unsigned)dx < 8u && (unsigned)dy < 8u) {
+            const int bit = dy * 8 + dx;
+            if (bit < 32) mlo |= 1u << bit; else mhi |= 1u << (bit - 32);
+          } else {
+            far_t[k] = ty * tiles_x + tx;
+          }
+        }
+      }
+      // (far tiles: once per point and tile)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bool first = far_t[k] >= 0;
+#pragma unroll
+        for (int k2 = 0; k2 < k; ++k2) first = first && far_t[k2] != far_t[k];
+        if (first) overflow(j, far_t[k]);
+      }
+    }
+    // the quad's tiles: OR over its four lanes, kept by lane pp == 0
+    mlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mlo, 0xB1, 0xf, 0xf, true);
+    mhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mhi, 0xB1, 0xf, 0xf, true);
+    mlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mlo, 0x4E, 0xf, 0xf, true);
+    mhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mhi, 0x4E, 0xf, 0xf, true);
+    uint64_t m = pp == 0 ? ((uint64_t)mhi << 32) | mlo : 0ull;
+    // rounds: every query's next tile.  Ranks inside the wave through the LDS slot counters (4 x 4 torus of tiles, as
+    // the point records did), ONE returning global atomic per occupied slot, all of them in flight together.
+    while (__ballot(m != 0ull) != 0ull) {
+      const bool act = m != 0ull;
+      const int bit = act ? __ffsll((unsigned long long)m) - 1 : 0;
+      m &= m - 1ull;
+      const int tx = qbx0 + (bit & 7), ty = qby0 + (bit >> 3);
+      const int tk = ty * tiles_x + tx, hs = ((ty & 3) << 2) | (tx & 3);
+      bool local = false;
+      int rank = 0, idx = 0;
+      if (act) {
+        volatile int* stp = &slot_tile[wv][hs];
+        if (*stp == -1) *stp = tk;
+        local = *stp == tk;
+        if (local) rank = atomicAdd(&slot_cnt[wv][hs], 1);
+        else idx = atomicAdd(cntp + tk, 1);
+      }
+      if (lane < 16) {
+        const int c = slot_cnt[wv][lane];
+        if (c > 0) slot_base[wv][lane] = atomicAdd(cntp + slot_tile[wv][lane], c);
+      }
+      if (act && local) idx = slot_base[wv][hs] + rank;
+      const bool fits = act && idx < a.cap;
+      if (fits) qbin[(long)tk * a.cap + idx] = q;
+      // an entry that did not fit: the quad's points that touch the tile become point records
+      int ovt = (act && !fits) ? tk : -1;
+      ovt = __builtin_amdgcn_update_dpp(0, ovt, 0x00, 0xf, 0xf, true);       // quad_perm [0, 0, 0, 0]: lane pp == 0's value
+      if (__ballot(ovt >= 0) != 0ull) {
+        if (ovt >= 0) {
+#pragma unroll
+          for (int j = 0; j < PW; ++j) {
+            const Footprint f = footprint_px(rx[hh][j], ry[hh][j], a.fh, a.fw);
+            bool hit = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              hit = hit || (rw[hh][j] != 0.0f && f.w[k] != 0.0f && (f.yc[k >> 1] >> 3) * tiles_x + (f.xc[k & 1] >> 3) == ovt);
+            if (hit) overflow(j, ovt);
+          }
+        }
+      }
       if (lane < 16) { slot_tile[wv][lane] = -1; slot_cnt[wv][lane] = 0; }
     }
   }
@@ -831,8 +925,8 @@ static void tile_bwd_launch_t(const LiftArgs& a, int P, bool bins, int tiles_x, 
   const dim3 grid(8 * chunk), blk(256);
 #define UBV_TILE_BWD(PV, DHV, MB)                                                                                           \
   do {                                                                                                                      \
-    if (bins) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<PV, DHV, true, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, MB, tile_centre()); \
-    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<PV, DHV, false, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, MB, tile_centre());     \
+    if (bins) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<PV, DHV, 1, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, MB, tile_centre()); \
+    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<PV, DHV, 0, false, T, OL16>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, MB, tile_centre());     \
   } while (0)
   if (Dh == 16) { if (P == 4) UBV_TILE_BWD(4, 16, mb4); else UBV_TILE_BWD(8, 16, mb8); }
   else { if (P == 4) UBV_TILE_BWD(4, 32, mb4); else UBV_TILE_BWD(8, 32, mb8); }
@@ -847,8 +941,13 @@ void tile_bwd_query_launch(const LiftArgs& a, int P, bool bins, int tiles_x, int
   const dim3 grid(8 * chunk), blk(256);
   static const int mb4 = tile_max_box("UBV_TILE_MAXBOX_BWD", 4, 256, 256), mb8 = tile_max_box("UBV_TILE_MAXBOX_BWD", 8, 256, 256);
   if (k1) {                                               // (the operator's backward always bins; f32, Dh = 32 only)
-    if (P == 4) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4, 32, true, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb4, tile_centre());
-    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<8, 32, true, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb8, tile_centre());
+    if (P == 4) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4, 32, 1, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb4, tile_centre());
+    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<8, 32, 1, true>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb8, tile_centre());
+    return;
+  }
+  if (dtype == UBV_F32 && a.qrec && bins && Dh == 32) {     // query records (lift_bwd_value_q_kernel)
+    if (P == 4) hipLaunchKernelGGL((lift_tile_bwd_query_kernel<4, 32, 2, false, float, false>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb4, tile_centre());
+    else hipLaunchKernelGGL((lift_tile_bwd_query_kernel<8, 32, 2, false, float, false>), grid, blk, kTWinLds, st, a, chunk, tiles_x, tiles, mb8, tile_centre());
     return;
   }
   if (dtype == UBV_F32) tile_bwd_launch_t<float, false>(a, P, bins, tiles_x, tiles, st, Dh, chunk, mb4, mb8);
