@@ -1854,9 +1854,10 @@ static GridWs grid_ws(const LiftArgs& a, const TileArgs& t, int P) {
   return w;
 }
 
-// query records instead of point records: f32 data and f32 grad_value on the TILE plan, module form (UBV_LIFT_QREC=0: off)
+// query records instead of point records: f32 data and f32 grad_value on the TILE plan, module form.  OFF by default
+// (UBV_LIFT_QREC=1): measured slower — profiles/r06_qrec_experiment.txt
 static bool qrec_ok(const LiftArgs& a, int Dh, int P, int dtype) {
-  static const int env = getenv("UBV_LIFT_QREC") ? atoi(getenv("UBV_LIFT_QREC")) : 1;
+  static const int env = getenv("UBV_LIFT_QREC") ? atoi(getenv("UBV_LIFT_QREC")) : 0;
   return env != 0 && dtype == UBV_F32 && Dh == 32 && a.gvalue_lp == nullptr && a.ovf_after && tile_ok(a, Dh, P, dtype, true);
 }
 // MAPS workspace: [counts | cursors | n_items] (zeroed per call) [starts][first items][item buckets]
