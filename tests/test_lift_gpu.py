@@ -552,3 +552,21 @@ def test_tile_plan_with_every_point_off_the_map_over_poisoned_lds(P, Z):
     np.testing.assert_allclose(out.detach().cpu().numpy(), o_ref.detach().numpy(), rtol=3e-5, atol=3e-5)
     np.testing.assert_allclose(v.grad.cpu().numpy(), v64.grad.numpy(), rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(ol.grad.cpu().numpy(), ol64.grad.numpy(), rtol=2e-4, atol=5e-4)
+
+
+def test_experimental_tile_kernels_stay_parity_green():
+    """The two round-6 kernels that measured slower and are OFF by default — query records for the TILE backward
+    (UBV_LIFT_QREC=1, profiles/r06_qrec_experiment.txt) and the persistent pipelined TILE forward (UBV_TILE_PIPE=4, both
+    forms; profiles/r06_tile_pipe_experiment.txt) — stay correct: the f32 forward / backward parity cases, the owner-tile
+    cases (offsets up to 30 px on small maps: overflow and far-tile paths), the exact-overflow case and the poisoned-LDS
+    case of this file, re-run in a process with the knobs on (they are read once per process)."""
+    import os
+    import subprocess
+    import sys
+    sel = 'fp32_forward_backward or owner_tiles_grid_mode or bins_overflow_is_exact or poisoned_lds or k1_composition'
+    for extra in ({'UBV_LIFT_QREC': '1', 'UBV_TILE_PIPE': '4'}, {'UBV_TILE_PIPE': '3', 'UBV_TILE_PIPE_LIGHT': '0'}):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-m', 'gpu', '-x', '-k', sel,
+                            '-p', 'no:cacheprovider'], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (extra, r.stdout[-2000:])
+        assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-500:]
