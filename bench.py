@@ -735,7 +735,7 @@ def self_launch(args):
     if not args.dry_run:
         assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < args.gpus and not share_gpu():
             raise SystemExit(f'--gpus {args.gpus} but only {have} GPU(s) are visible')
     with socket.socket() as sock:
         sock.bind(('127.0.0.1', 0))
@@ -748,6 +748,11 @@ def self_launch(args):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
     return subprocess.call(cmd, env=env)
+
+
+def share_gpu():
+    """UBV_SHARE_GPU=1 (test hook): ranks beyond the visible GPUs wrap around — N processes on one device."""
+    return os.environ.get('UBV_SHARE_GPU', '0') == '1'
 
 
 def allreduce_algo(args):
@@ -973,6 +978,8 @@ def main():
     if args.dry_run:
         return dry_run(args, rank, world, local)
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    if share_gpu():
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     # everything runs on one non-default stream: HIP-graph capture needs the gradient accumulation of
@@ -982,7 +989,12 @@ def main():
         from unibev_amd.modules import transformer as _tr
         _tr.set_two_streams(False)
     from unibev_amd import dp
-    dp.init_distributed('nccl', device, algo=allreduce_algo(args))   # RCCL over xGMI (no-op for N = 1)
+    # RCCL over xGMI (no-op for N = 1).  TEST HOOK (tests/test_bench_gpu.py): UBV_DIST_BACKEND=gloo + UBV_SHARE_GPU=1 run the
+    # N-rank path of this script — launcher, identical replicas, HIP graphs, the flat-gradient exchange between replays,
+    # max-over-ranks timing, rank 0's line — with N processes on ONE GPU (RCCL refuses two ranks per device; gloo moves
+    # the gradient buffer through the host).  Its samples/s mean nothing; the line says `collective.backend: gloo`.
+    backend = os.environ.get('UBV_DIST_BACKEND', 'nccl')
+    dp.init_distributed(backend, device if backend == 'nccl' else None, algo=allreduce_algo(args))
 
     torch.manual_seed(0)          # identical replicas
     np.random.seed(rank)          # modality dropout is per process, as in the reference

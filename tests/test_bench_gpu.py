@@ -143,6 +143,36 @@ def test_overlapped_exchange_gives_the_gradients_of_the_single_message():
     assert abs(got['split']['sum'] - got['single']['sum']) <= 1e-5 * got['single']['abs'], got
 
 
+@pytest.mark.parametrize('mode', ['single', 'split'])
+def test_two_ranks_run_the_whole_step_on_one_gpu(mode):
+    """The N > 1 path of bench.py END TO END with two ranks — the driver's multi-GPU run is otherwise the first time it
+    executes with more than one: `python bench.py --gpus 2` launches its own two ranks, which build
+    identical replicas, capture their HIP graphs, exchange the flat gradient buffer between replays (one message, or the
+    two segments of the split backward), reduce their timings over the ranks, and rank 0 alone prints the line.  One-GPU
+    box: both ranks share the device and the collective is gloo's (test hooks UBV_SHARE_GPU / UBV_DIST_BACKEND — RCCL
+    refuses two ranks per device); on a box with two GPUs the same test runs over RCCL."""
+    import torch
+    two = torch.cuda.device_count() >= 2
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    if not two:
+        env.update(UBV_SHARE_GPU='1', UBV_DIST_BACKEND='gloo')
+    flags = ['--gpus', '2', '--dtype', 'fp32', '--no-extras', '--no-parity', '--no-kernel-timing', '--params', 'init',
+             '--no-ieee-gemm', '--exchange', mode, '--grad-checksum', '--eval-mode', '--lr', '0', '--extras-file', '']
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1',
+                          '--no-cpu-baseline', *flags], env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = _strict(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['rccl_ranks'] == 2 and d['config']['global_batch'] == 4
+    assert d['config']['gradient_exchange'].startswith(mode) and d['config']['parallelism'] == 'dp2'
+    assert d['config']['collective']['backend'] == ('nccl' if two else 'gloo') and d['config']['collective']['ranks'] == 2
+    assert d['value'] > 0 and d['phases']['gradient_bytes'] > 5e7 and d['phases']['allreduce_ms_per_step'] >= 0
+    # identical replicas, identical inputs per rank seed ... the exchanged gradients are finite and non-trivial
+    ck = d['grad_checksum']
+    assert ck['n'] > 1e7 and ck['l2'] > 0 and ck['l2'] == ck['l2']
+
+
 def test_bench_refuses_a_mismatched_world_and_a_silent_eager_fallback():
     env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29543')
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1'],
