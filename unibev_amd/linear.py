@@ -552,6 +552,9 @@ class _Linear(Function):
         return (gx, None, None, None, None, None, grb, *grads)
 
 
+_SELF_IN_SPLIT_FWD = os.environ.get('UBV_SELF_IN_SPLIT_FWD', '0') != '0'
+
+
 class _SelfAttnIn(Function):
     """The three Linears on the query of a BEV self-attention as ONE GEMM: ``value = x . Wv^T + bv`` and ``offsets |
     logits = x . [Wo; Wa]^T + [bo; ba] + row_bias[q]`` (``ubv_gemm_nt_dual``: x is read once, the two results leave as two
@@ -569,7 +572,20 @@ class _SelfAttnIn(Function):
         bias = _cached_lowp((bv, bo, ba), torch.float32) if (_ACTIVE and all(isinstance(b, torch.nn.Parameter) for b in (bv, bo, ba))) \
             else torch.cat((bv.detach(), bo.detach(), ba.detach())).float()
         n2 = wo.shape[0] + wa.shape[0]
-        res = UF.gemm_nt_dual(x, split[0], split[1], bias=bias, y2_cols=n2, row_bias=row_bias)
+        res = None
+        if _SELF_IN_SPLIT_FWD and wv.shape[0] % 32 == 0 and n2 % 32 == 0 and x.shape[-1] in (64, 128, 192, 256) and \
+                row_bias.stride(1) == 1 and row_bias.stride(0) % 4 == 0 and row_bias.data_ptr() % 16 == 0:
+            # two launches of the weight-stationary GEMM — value (N = 256), then offsets | logits (N = 96) with the
+            # positional term as its row-periodic residual — instead of ONE launch of the tile-per-block dual-output
+            # kernel: x is read twice (the second time from the Infinity Cache), the kernel is the faster one
+            # (UBV_SELF_IN_SPLIT_FWD=0: the dual kernel; A/B in profiles/r06_self_in_split.txt)
+            n1 = wv.shape[0]
+            v = UF.gemm_nt(x, split[0][:n1], split[1][:n1], bias=bias[:n1])
+            ol = UF.gemm_nt(x, split[0][n1:], split[1][n1:], bias=bias[n1:], row_bias=row_bias) if v is not None else None
+            if v is not None and ol is not None:
+                res = (v, ol)
+        if res is None:
+            res = UF.gemm_nt_dual(x, split[0], split[1], bias=bias, y2_cols=n2, row_bias=row_bias)
         if res is None:
             raise RuntimeError('self_attn_in: shape outside ubv_gemm_nt_dual (checked by self_attn_in_supported)')
         ctx.save_for_backward(x, split[2], split[3])
