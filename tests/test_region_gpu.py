@@ -106,3 +106,49 @@ def test_fan_out_pair_adds_adjacent_slices_once():
     (a1, b1), (a2, b2) = UF.fan_out_pair(w1, w2)
     torch.autograd.backward([a1, a2, b1, b2], [ga[:64].clone(), ga[64:].clone(), gb[:64].clone(), gb[64:].clone()])
     assert torch.equal(w1.grad, (ga + gb)[:64]) and torch.equal(w2.grad, (ga + gb)[64:])
+
+
+def test_slice_sum_writes_a_column_slice():
+    """``ubv_slice_sum_f32``: the batch sum of S row blocks written into a column slice of a wider matrix (the positional
+    fold's gradient slot); bit-equal to the same sum in the same order."""
+    from unibev_amd import functional as UF
+    g = torch.Generator(device='cpu').manual_seed(9)
+    for S, rows, cols, ld, c0 in ((2, 40000, 96, 288, 96), (1, 1000, 96, 288, 192), (3, 77, 32, 32, 0)):
+        x = torch.randn(S, rows, cols, generator=g).cuda()
+        G = torch.full((rows, ld), 7.0, device='cuda')
+        out = UF.slice_sum(x, G[:, c0:c0 + cols])
+        want = x[0].clone()
+        for s in range(1, S):
+            want = want + x[s]
+        assert out.data_ptr() == G[:, c0:c0 + cols].data_ptr()
+        assert torch.equal(G[:, c0:c0 + cols], want)
+        keep = torch.ones(ld, dtype=torch.bool)
+        keep[c0:c0 + cols] = False
+        assert bool((G[:, keep.cuda()] == 7.0).all())         # nothing outside the slice is touched
+
+
+def test_pos_fold_all_matches_separate_linears():
+    """``linear.pos_fold_all``: per-layer positional terms from ONE GEMM, their gradients through the slots — equal to the
+    per-layer ``F.linear`` products and their autograd gradients (split-bf16 GEMM tolerance)."""
+    import torch.nn.functional as F
+    from unibev_amd import linear as UL
+    g = torch.Generator(device='cpu').manual_seed(11)
+    R, C, B = 4096, 256, 2
+    base = torch.randn(R, C, generator=g).cuda().requires_grad_()
+    ws = [torch.nn.Parameter(torch.randn(n, C, generator=g).cuda() / 16) for n in (64, 32, 64, 32)]
+    gol = [torch.randn(B, R, 96, generator=g).cuda() for _ in range(2)]
+    with UL.lowp_step_cache():
+        terms = UL.pos_fold_all(base, ws)
+        assert len(terms) == 2 and terms[0].shape == (R, 96) and hasattr(terms[0], '_ubv_grad_slot')
+        # a consumer's backward: the batch sum of its offset | logit gradient goes to the slot
+        gs = [UL._row_bias_grad(gol[i], terms[i]._ubv_grad_slot) for i in range(2)]
+        torch.autograd.backward(terms, gs)
+    ref_base = base.detach().clone().requires_grad_()
+    ref_ws = [w.detach().clone().requires_grad_() for w in ws]
+    ref_terms = [F.linear(ref_base, torch.cat((ref_ws[2 * i], ref_ws[2 * i + 1]))) for i in range(2)]
+    torch.autograd.backward(ref_terms, [gol[i].sum(0) for i in range(2)])
+    for i in range(2):
+        assert float((terms[i] - ref_terms[i]).norm() / ref_terms[i].norm()) < 1e-4
+    assert float((base.grad - ref_base.grad).norm() / ref_base.grad.norm()) < 1e-4
+    for w, rw in zip(ws, ref_ws):
+        assert float((w.grad - rw.grad).norm() / rw.grad.norm()) < 1e-4
