@@ -87,3 +87,47 @@ def test_weight_gradient_kernels_keep_their_closures_in_registers(tmp_path):
             assert 'scratch_' not in m.group(2), f'{m.group(1)} uses scratch memory'
     assert found >= 12, f'only {found} weight-gradient kernels found in the library'
 
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason='llvm-objdump of the ROCm toolchain not found')
+def test_weight_stationary_gemm_stage_issues_exactly_the_counted_memory_instructions(tmp_path):
+    """csrc/gemm_ws.hip waits for its LDS-DMA tiles with a HAND-COUNTED `s_waitcnt vmcnt(PER)`, PER = E + 4 + PPT: a stage
+    of an active wave must issue exactly PPT `global_load_lds_dwordx4` requests, 4 `global_store_dwordx4` and E = 4
+    epilogue-operand loads (EXTRA = 1 / 2; else 0), a stage of a wave without columns exactly its PPT requests — a compiler
+    that split, merged or hoisted one of them would make the kernel under-wait silently.  Checked on the built
+    code: every loop body with ONE barrier (= one stage) of every product instantiation."""
+    so = os.path.join(ROOT, 'unibev_amd', 'libunibev_hip.so')
+    if not os.path.exists(so):
+        import __graft_entry__ as g
+        g.build()
+    shutil.copy(so, tmp_path / 'lib.so')
+    subprocess.run([OBJDUMP, '--offloading', 'lib.so'], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL)
+    seen = 0
+    for f in [f for f in os.listdir(tmp_path) if f.endswith('gfx950')]:
+        out = subprocess.run([OBJDUMP, '-d', f], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        for m in re.finditer(r'^([0-9a-f]+) <(_ZN3ubv14gemm_ws_kernelILi(\d+)ELi(\d)ELi0EEE[^>]*)>:\n(.*?)s_endpgm', out,
+                             flags=re.M | re.S):
+            base, ks, extra = int(m.group(1), 16), int(m.group(3)), int(m.group(4))
+            ppt, e = ks * 16 * 8 // 512, (4 if extra in (1, 2) else 0)
+            ins = []
+            for ln in m.group(5).splitlines():
+                mm = re.match(r'\s*([a-z_0-9]+)\s.*//\s*([0-9A-F]+):', ln)
+                if mm:
+                    t = re.search(r'\+0x([0-9a-f]+)>', ln)
+                    ins.append((int(mm.group(2), 16), mm.group(1), base + int(t.group(1), 16) if t else None))
+            kinds = set()
+            for a, op, tgt in ins:
+                if not (op.startswith('s_cbranch') and tgt is not None and tgt <= a):
+                    continue                                    # (backward branches close loops)
+                seg = [x[1] for x in ins if tgt <= x[0] <= a]
+                if seg.count('s_barrier') != 1:
+                    continue                                    # (an outer loop around several stages)
+                got = (sum(o.startswith('global_load_lds') for o in seg), sum(o.startswith('global_store') for o in seg),
+                       sum(o.startswith('global_load_dword') for o in seg))
+                assert got in ((ppt, 4, e), (ppt, 0, 0)), f'{m.group(2)}: a stage issues {got}, counted ({ppt}, 4, {e})'
+                assert not any(o.startswith('scratch_') or o.startswith('buffer_') for o in seg)
+                kinds.add(got)
+            assert (ppt, 4, e) in kinds and (ppt, 0, 0) in kinds, (m.group(2), kinds)
+            seen += 1
+    assert seen >= 12, f'only {seen} gemm_ws_kernel instantiations found in the library'
