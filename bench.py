@@ -1175,7 +1175,7 @@ def cpu_baseline(args, tcfg, head):
     ncpu = os.cpu_count() or 1
     scan = {}
     if ncpu > 16 and os.environ.get('UBV_CPU_SCAN', '1') != '0':
-        scan = cpu_thread_scan(args, sorted({n for n in (64, ncpu) if 16 < n <= ncpu}), 45.0)
+        scan = cpu_thread_scan(args, sorted({n for n in (64, ncpu) if 16 < n <= ncpu}), 30.0)
     best = max([1.0 / med] + [v['samples_per_s'] for v in scan.values() if 'samples_per_s' in v])
     return {'value': 1.0 / med, 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'cpu': cpu, 'host_cores': ncpu, 'threads_scan': scan, 'best_samples_per_s': best,
