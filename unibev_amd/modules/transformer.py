@@ -384,20 +384,29 @@ class UniBEVTransformer(BaseModule):
             # (hw, bs, C) view of a batch-expanded tensor: cast one sample, keep the expansion
             bev_pos = None if bev_pos is None else \
                 cast_keep_expand(bev_pos.permute(1, 0, 2), adt).permute(1, 0, 2)
+        two = img_mlvl_feats is not None and pts_mlvl_feats is not None and _TWO_STREAMS[0] and \
+            (bev_queries[0] if isinstance(bev_queries, list) else bev_queries).is_cuda
+        pos_img = pos_pts = pos_base
         if self.dual_queries:
             assert isinstance(bev_queries, list)
-            q_img = bev_queries[0].unsqueeze(1).expand(-1, bs, -1)
-            q_pts = bev_queries[1].unsqueeze(1).expand(-1, bs, -1)
+            tab_img, tab_pts = bev_queries[0], bev_queries[1]
         else:
-            q_img = q_pts = bev_queries.unsqueeze(1).expand(-1, bs, -1)
+            tab_img = tab_pts = bev_queries
+            if two and torch.is_grad_enabled() and bev_queries.requires_grad and bev_queries.dtype == torch.float32:
+                # both encoders read ONE query table (and one positional table): each gets its own alias, and the two
+                # gradients meet in functional.fan_out's backward — this library's add — instead of the autograd engine's
+                # framework add at the join of the two streams (unibev_amd/debug.py)
+                tab_img, tab_pts = UF.fan_out(bev_queries)
+        if two and torch.is_grad_enabled() and pos_base is not None and pos_base.requires_grad:
+            pos_img, pos_pts = UF.fan_out(pos_base)
+        q_img = tab_img.unsqueeze(1).expand(-1, bs, -1)
+        q_pts = q_img if tab_pts is tab_img else tab_pts.unsqueeze(1).expand(-1, bs, -1)
         # the encoders' first layer computes its self-attention once for the batch and takes the table
         # itself for that: the attribute rides on the expanded view (a Python attribute, not part of the graph)
-        if not _QUERY_TABLE:
-            pass                                            # (UBV_QUERY_TABLE=0: A/B runs)
-        elif self.dual_queries:
-            q_img._ubv_table, q_pts._ubv_table = bev_queries[0], bev_queries[1]
-        else:
-            q_img._ubv_table = bev_queries
+        if _QUERY_TABLE:                                    # (UBV_QUERY_TABLE=0: A/B runs)
+            q_img._ubv_table = tab_img
+            if q_pts is not q_img:
+                q_pts._ubv_table = tab_pts
         img_bev_embed = pts_bev_embed = None
 
         l2i = None
@@ -409,15 +418,15 @@ class UniBEVTransformer(BaseModule):
             flat, ss, lsi = self._pre_process_img_feats(img_mlvl_feats, q_img)
             kw = dict(kwargs, lidar2img_tensor=l2i) if l2i is not None else kwargs
             return self.img_bev_encoder(q_img, flat, flat, bev_h=bev_h, bev_w=bev_w, bev_pos=bev_pos,
-                                        spatial_shapes=ss, level_start_index=lsi, bev_pos_base=pos_base, **kw)
+                                        spatial_shapes=ss, level_start_index=lsi, bev_pos_base=pos_img, **kw)
 
         def run_pts():
             flat, ss, lsi = self._pre_process_pts_feats(pts_mlvl_feats, q_pts)
             return self.pts_bev_encoder(q_pts, flat, flat, bev_h=bev_h, bev_w=bev_w, bev_pos=bev_pos,
-                                        spatial_shapes=ss, level_start_index=lsi, bev_pos_base=pos_base, **kwargs)
+                                        spatial_shapes=ss, level_start_index=lsi, bev_pos_base=pos_pts, **kwargs)
 
         ref_q = q_img if img_mlvl_feats is not None else q_pts
-        if img_mlvl_feats is not None and pts_mlvl_feats is not None and ref_q.is_cuda and _TWO_STREAMS[0]:
+        if two:
             # The two encoders are independent until the fusion: two HIP streams, forked
             # from and joined into the caller's (autograd replays every backward op on its forward
             # op's stream, so the backward forks the same way).  Most kernels of the path leave part
